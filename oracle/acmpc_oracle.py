@@ -1,0 +1,577 @@
+"""CPU oracle for the ac-mpc rollout-and-cost hot path (TEST INFRASTRUCTURE ONLY).
+
+This module restates, in plain NumPy, the arithmetic of the reference controller
+(`/root/reference/src/acmpc/...`, cited per function as file:line) plus the
+build-defined sampling composition of SURVEY.md section 8 ("mode S" / "mode T").
+It is the checker the HIP path is compared against.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the
+product package (`ac-mpc_amd/`) never does.
+
+Parity status
+-------------
+* Every *ingredient* (waypoints, Frenet transforms, linearisation, QP assembly,
+  kinematic step, nearest waypoint, weighted mean, command selection) is pinned
+  by golden vectors produced by importing the reference itself
+  (`tests/golden/gen_golden.py`).
+* The *composition* "sample N control sequences -> roll out -> cost -> argmin"
+  does not exist in the reference (its MPC is one OSQP QP), so it is
+  BUILD-DEFINED here; it is tied to the reference through the identities
+  `A_eq z = l_eq` and `J - const = 1/2 z'Pz + q'z` checked against the
+  reference-assembled QP matrices.  OSQP itself is absent from this image
+  (un-pinned third-party dependency): QP *solutions* are parity-unpinned.
+
+Numerical specification of the sampling path ("spec order")
+-----------------------------------------------------------
+The float32 variants below fix one operation order with no fused multiply-add
+and no library transcendentals, so that NumPy (here), the C restatement
+(`acmpc_oracle.c`) and the HIP kernels (`-ffp-contract=off`) are bit-identical.
+The float64 variants are the same formulas in double precision with libm
+trigonometry: they measure the fp32 drift, they are not the parity target.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+EPS = 1e-12  # spatial_mpc.py:34, dynamics.py:21, speed_profile.py:114
+
+# Row order of the 7 x n waypoint table (control/paths.py:4-72)
+ROW_X, ROW_Y, ROW_PSI, ROW_KAPPA, ROW_DS, ROW_WIDTH, ROW_V = range(7)
+
+# Width (floats) of one packed coefficient row handed to the kernels
+COEF_STRIDE_S = 12
+COEF_STRIDE_T = 8
+
+# Mode-S coefficient columns
+CS_DS, CS_A21, CS_A31, CS_B31, CS_F3, CS_VREF, CS_KREF, CS_EYLO, CS_EYHI = range(9)
+# Mode-T waypoint columns
+CT_X, CT_Y, CT_COS, CT_SIN, CT_PSI, CT_KREF, CT_VREF, CT_HALF = range(8)
+
+T_MIN = 0.01  # control.py:134  (x_min = [-inf, -inf, 0.01])
+U_SLACK_V = 0.1  # control.py:138-139 (velocity box widened by 0.1)
+
+
+# ---------------------------------------------------------------------------
+# Ingredients pinned by the reference
+# ---------------------------------------------------------------------------
+def wrap_to_pi(angle):
+    """(-pi, pi] wrap used everywhere in the reference (dynamics.py:36, spatial_mpc.py:149-150)."""
+    return np.mod(angle + math.pi, 2.0 * math.pi) - math.pi
+
+
+def construct_waypoints(coords: np.ndarray) -> np.ndarray:
+    """H x 3 `[x, y, width]` -> 7 x n table, n = H-1 (spatial_mpc.py:125-154).
+
+    psi/ds look ahead to the next point, width is taken from the *next* point
+    (:144), kappa is the wrapped heading change from the segment behind divided by
+    ds; the segment "behind" point 0 wraps round to the last point (:135-137) and
+    is then overwritten by kappa[1] (:152).
+    """
+    coords = np.asarray(coords, dtype=np.float64)
+    n = coords.shape[0] - 1
+    xy = coords[:, :2]
+    here = xy[:-1]
+    ahead = xy[1:] - here
+    behind = here - np.concatenate([xy[-1:], xy[:-2]], axis=0)
+    table = np.zeros((7, n))
+    table[ROW_X] = here[:, 0]
+    table[ROW_Y] = here[:, 1]
+    table[ROW_WIDTH] = coords[1:, 2]
+    table[ROW_PSI] = np.arctan2(ahead[:, 1], ahead[:, 0])
+    table[ROW_DS] = np.sqrt(ahead[:, 0] ** 2 + ahead[:, 1] ** 2)
+    heading_behind = np.arctan2(behind[:, 1], behind[:, 0])
+    dpsi = wrap_to_pi(table[ROW_PSI] - heading_behind)
+    kappa = dpsi / (table[ROW_DS] + EPS) + EPS
+    kappa[0] = kappa[1]
+    table[ROW_KAPPA] = kappa
+    return table
+
+
+def t2s(waypoint: Sequence[float], state: Sequence[float]) -> np.ndarray:
+    """Cartesian -> Frenet w.r.t. one waypoint (dynamics.py:23-40)."""
+    xr, yr, psir = waypoint
+    x, y, psi = state
+    e_y = math.cos(psir) * (y - yr) - math.sin(psir) * (x - xr)
+    e_psi = wrap_to_pi(psi - psir)
+    return np.array([e_y, float(e_psi), 0.0])
+
+
+def s2t(table: np.ndarray, states: np.ndarray) -> np.ndarray:
+    """Frenet -> Cartesian for n waypoints at once, returns 3 x n (dynamics.py:42-63)."""
+    e_y = states[:, 0]
+    psi = table[ROW_PSI]
+    return np.stack(
+        [table[ROW_X] - e_y * np.sin(psi), table[ROW_Y] + e_y * np.cos(psi), psi + states[:, 1]]
+    )
+
+
+def linearise(table: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Per-waypoint discrete spatial dynamics f[n,3], A[n,3,3], B[n,3,2] (dynamics.py:65-103)."""
+    ds, kappa, v = table[ROW_DS], table[ROW_KAPPA], table[ROW_V]
+    n = table.shape[1]
+    A = np.tile(np.eye(3), (n, 1, 1))
+    A[:, 0, 1] = ds
+    A[:, 1, 0] = -(kappa**2) * ds
+    A[:, 2, 0] = -kappa / (v * ds + EPS)
+    B = np.zeros((n, 3, 2))
+    B[:, 1, 1] = ds
+    B[:, 2, 0] = -1.0 / (v**2 * ds + EPS)
+    f = np.zeros((n, 3))
+    f[:, 2] = 1.0 / (v * ds + EPS)
+    return f, A, B
+
+
+def vehicle_limits(wheelbase: float, width: float, delta_max: float, v_min: float, v_max: float):
+    """Scalars of SpatialBicycleModel.__init__ (dynamics.py:10-21)."""
+    k_max = np.tan(delta_max) / wheelbase
+    return SimpleNamespace(
+        length=wheelbase,
+        width=width,
+        delta_max=delta_max,
+        margin=width / 2.0,
+        min_u=np.array([v_min, -k_max]),
+        max_u=np.array([v_max, k_max]),
+    )
+
+
+def control_qp(spatial_state: np.ndarray, table: np.ndarray, weights: Dict, limits) -> Dict:
+    """Dense restatement of ControlSolver's QP (control/solvers/control.py:15-79,121-158).
+
+    Decision vector z = [x_0 .. x_n (3 each) ; u_0 .. u_{n-1} (2 each)].
+    Returns P's diagonal, q, dense A ((8n+6) x (5n+3)), l, u.
+    """
+    n = table.shape[1]
+    nx, nu = 3, 2
+    nz = nx * (n + 1) + nu * n
+    Q = np.asarray(weights["step_cost"], dtype=np.float64)
+    R = np.asarray(weights["r_term"], dtype=np.float64)
+    QN = np.asarray(weights["final_cost"], dtype=np.float64)
+    f, A_blk, B_blk = linearise(table)
+    u_ref = np.stack([table[ROW_V], table[ROW_KAPPA]], axis=1)  # n x 2
+
+    # equality rows: -x_0 = -x_init ; A_i x_i - x_{i+1} + B_i u_i = B_i u_ref_i - f_i   (:26-45)
+    A_eq = np.zeros((nx * (n + 1), nz))
+    A_eq[:, : nx * (n + 1)] = -np.eye(nx * (n + 1))
+    for i in range(n):
+        r = nx * (i + 1)
+        A_eq[r : r + nx, nx * i : nx * (i + 1)] += A_blk[i]
+        c = nx * (n + 1) + nu * i
+        A_eq[r : r + nx, c : c + nu] = B_blk[i]
+    uq = (np.einsum("nij,nj->ni", B_blk, u_ref) - f).ravel()
+    l_eq = np.concatenate([-np.asarray(spatial_state, dtype=np.float64), uq])
+
+    # box rows (:47-70,130-144)
+    x_lo = np.tile([-np.inf, -np.inf, T_MIN], n + 1)
+    x_hi = np.tile([np.inf, np.inf, np.inf], n + 1)
+    x_lo[0] = spatial_state[0]
+    x_hi[0] = spatial_state[0]
+    half = table[ROW_WIDTH] / 2.0
+    ey_lo = -half + limits.margin
+    ey_hi = half - limits.margin
+    x_lo[nx::nx] = ey_lo
+    x_hi[nx::nx] = ey_hi
+    x_ref = np.zeros(nx * (n + 1))
+    x_ref[nx::nx] = (ey_lo + ey_hi) / 2.0
+    u_lo = np.tile(limits.min_u, n)
+    u_hi = np.tile(limits.max_u, n)
+    u_lo[0::2] -= U_SLACK_V
+    u_hi[0::2] += U_SLACK_V
+
+    A = np.vstack([A_eq, np.eye(nz)])
+    lower = np.concatenate([l_eq, x_lo, u_lo])
+    upper = np.concatenate([l_eq, x_hi, u_hi])
+    P_diag = np.concatenate([np.tile(Q, n), QN, np.tile(R, n)])
+    q = -np.concatenate([np.tile(Q, n) * x_ref[:-nx], QN * x_ref[-nx:], np.tile(R, n) * u_ref.ravel()])
+    return dict(P_diag=P_diag, q=q, A=A, l=lower, u=upper, x_ref=x_ref, u_ref=u_ref)
+
+
+def speed_profile_qp(table: np.ndarray, constraints: Dict, end_velocity: Optional[float], localised: bool) -> Dict:
+    """Inputs of the speed-profile QP (control/solvers/speed_profile.py:26-59,131-150).
+
+    min 1/2 |v|^2 - v_hi' v   s.t.  a_min <= (v[i+1]-v[i])/(2 ds[i]) <= a_max,  v_min <= v <= v_hi
+    """
+    n = table.shape[1]
+    kappa, ds = table[ROW_KAPPA], table[ROW_DS]
+    v_min, v_max = constraints["v_min"], constraints["v_max"]
+    if localised:
+        v_hi = np.full(n, float(v_max))
+    else:
+        v_dyn = np.sqrt(constraints["ay_max"] / (np.abs(kappa) + EPS))
+        v_dyn[np.abs(kappa) < constraints["ki_min"]] = v_max
+        v_hi = np.maximum(v_min, np.minimum(v_dyn, v_max)) + 2.0
+        if end_velocity is not None:
+            v_hi[-1] = end_velocity
+    D1 = np.zeros((n - 1, n))
+    idx = np.arange(n - 1)
+    D1[idx, idx] = -1.0 / (2.0 * ds[:-1])
+    D1[idx, idx + 1] = 1.0 / (2.0 * ds[:-1])
+    A = np.vstack([D1, np.eye(n)])
+    lower = np.concatenate([np.full(n - 1, float(constraints["a_min"])), np.full(n, float(v_min))])
+    upper = np.concatenate([np.full(n - 1, float(constraints["a_max"])), v_hi])
+    return dict(P_diag=np.ones(n), q=-v_hi, A=A, l=lower, u=upper, v_hi=v_hi)
+
+
+def osqp_restated(P_diag, q, A, l, u, max_iter=4000, rho=0.1, sigma=1e-6, alpha=1.6,
+                  eps_abs=1e-3, eps_rel=1e-3, check_every=25) -> SimpleNamespace:
+    """ADMM of Stellato et al., "OSQP: an operator splitting solver for quadratic programs"
+    (Math. Prog. Comp. 2020), Algorithm 1 - dense, no scaling, no rho adaptation, equality rows
+    get 1e3*rho as in the paper's section 5.2.  `osqp` is a third-party dependency of the reference
+    with no pinned version (requirements.txt:2) and is absent here, so this restates the published
+    algorithm; solutions are parity-UNPINNED and only used as a sanity oracle (is the sampled
+    optimum close to the QP optimum?).  Termination tolerances are OSQP's documented defaults.
+    """
+    P_diag = np.asarray(P_diag, dtype=np.float64)
+    m, nvar = A.shape
+    rho_vec = np.where(l == u, 1e3 * rho, rho)
+    K = np.diag(P_diag + sigma) + A.T @ (rho_vec[:, None] * A)
+    chol = np.linalg.cholesky(K)
+
+    def kkt_solve(rhs):
+        return np.linalg.solve(chol.T, np.linalg.solve(chol, rhs))
+
+    x = np.zeros(nvar)
+    z = np.zeros(m)
+    y = np.zeros(m)
+    status = "maximum iterations reached"
+    it = 0
+    for it in range(1, max_iter + 1):
+        x_t = kkt_solve(sigma * x - q + A.T @ (rho_vec * z - y))
+        z_t = A @ x_t
+        x = alpha * x_t + (1 - alpha) * x
+        z_relaxed = alpha * z_t + (1 - alpha) * z
+        z_new = np.clip(z_relaxed + y / rho_vec, l, u)
+        y = y + rho_vec * (z_relaxed - z_new)
+        z = z_new
+        if it % check_every == 0:
+            Ax = A @ x
+            r_prim = np.max(np.abs(Ax - z))
+            r_dual = np.max(np.abs(P_diag * x + q + A.T @ y))
+            e_prim = eps_abs + eps_rel * max(np.max(np.abs(Ax)), np.max(np.abs(z)))
+            e_dual = eps_abs + eps_rel * max(np.max(np.abs(P_diag * x)), np.max(np.abs(A.T @ y)), np.max(np.abs(q)))
+            if r_prim <= e_prim and r_dual <= e_dual:
+                status = "solved"
+                break
+    return SimpleNamespace(x=x, y=y, info=SimpleNamespace(status=status, iter=it))
+
+
+def kinematic_x_dot(delta, states: np.ndarray, velocity, wheel_base: float) -> np.ndarray:
+    """Rear-axle kinematic bicycle derivative, batched over particles (localiser.py:77-95)."""
+    phi = states[:, 2]
+    out = np.zeros_like(states)
+    out[:, 0] = velocity * np.cos(phi)
+    out[:, 1] = velocity * np.sin(phi)
+    out[:, 2] = velocity * np.tan(delta) / wheel_base
+    return out
+
+
+def nearest_waypoint(points: np.ndarray, track: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Euclidean nearest neighbour, first minimum - what KDTree.query returns (localiser.py:282-289)."""
+    d2 = ((points[:, None, :] - track[None, :, :]) ** 2).sum(axis=2)
+    idx = np.argmin(d2, axis=1)
+    return np.sqrt(d2[np.arange(len(points)), idx]), idx
+
+
+def heading_offset(track: np.ndarray, idx: np.ndarray, headings: np.ndarray) -> np.ndarray:
+    """|wrap(track heading at idx - particle heading)|, index mod (len-1) (localiser.py:291-318)."""
+    m = len(track) - 1
+    here = track[np.mod(idx, m)]
+    nxt = track[np.mod(idx + 1, m)]
+    heading = np.arctan2(nxt[:, 1] - here[:, 1], nxt[:, 0] - here[:, 0])
+    return np.abs((heading - headings + np.pi) % (2 * np.pi) - np.pi)
+
+
+def estimate_location(scores: np.ndarray, states: np.ndarray) -> np.ndarray:
+    """Score-weighted mean with the NaN -> uniform fallback (localiser.py:572-579)."""
+    w = scores.reshape(-1, 1)
+    est = (states[:, :3] * w).sum(axis=0) / w.sum()
+    if np.any(np.isnan(est)):
+        w = np.full_like(w, 1.0 / w.shape[0])
+        est = (states[:, :3] * w).sum(axis=0) / w.sum()
+    return est
+
+
+def select_command(cum_time: np.ndarray, commands: np.ndarray, elapsed: float) -> np.ndarray:
+    """TemporalCommandSelector.get_command (commands.py:20-38) incl. the -1 -> last-row wrap."""
+    d = cum_time - elapsed
+    i = int(np.argmin(np.abs(d)))
+    if d[i] > 0:
+        i -= 1
+    if i >= len(commands):
+        i = len(commands) - 1
+    return commands[i]
+
+
+def interpolate_command(cum_time: np.ndarray, commands: np.ndarray, elapsed: float) -> np.ndarray:
+    """TemporalCommandInterpolator.get_command (commands.py:54-99); `commands` is n x 2."""
+    d = cum_time - elapsed
+    a = int(np.argmin(np.abs(d)))
+    if a == 0 or a == len(commands) - 1:
+        return commands[a]
+    b = a + 1 if d[a] < 0 else a - 1
+    ta, tb = cum_time[a], cum_time[b]
+    return commands[a] * ((tb - elapsed) / (tb - ta)) + commands[b] * ((elapsed - ta) / (tb - ta))
+
+
+def closest_command_index(cum_time: np.ndarray, elapsed: float) -> Tuple[int, float]:
+    """TemporalCommandInterpolator._get_closet_command_index (commands.py:71-74)."""
+    d = cum_time - elapsed
+    i = int(np.argmin(np.abs(d)))
+    return i, float(d[i])
+
+
+def downsample_centreline(centreline: np.ndarray, horizon: int) -> np.ndarray:
+    """500 x 2 perception centreline -> H x 3 reference path (controller.py:256-267)."""
+    step = int(len(centreline) / horizon)
+    pts = centreline[0::step]
+    return np.stack([pts[:, 0], pts[:, 1], np.linspace(10.0, 6.0, horizon)]).T
+
+
+# ---------------------------------------------------------------------------
+# Build-defined sampling composition ("mode S" / "mode T")
+# ---------------------------------------------------------------------------
+def input_box(limits) -> Tuple[np.ndarray, np.ndarray]:
+    """u-box of the QP: [min_u - (0.1, 0), max_u + (0.1, 0)] (control.py:130-139)."""
+    lo = np.array([limits.min_u[0] - U_SLACK_V, limits.min_u[1]])
+    hi = np.array([limits.max_u[0] + U_SLACK_V, limits.max_u[1]])
+    return lo, hi
+
+
+def coefficients_spatial(table: np.ndarray, margin: float) -> np.ndarray:
+    """Mode-S per-step record [ds, a21, a31, b31, f3, v_ref, k_ref, ey_lo, ey_hi, 0,0,0].
+
+    Entries are the non-trivial elements of linearise()'s A, B, f (dynamics.py:65-103) and the
+    corridor bounds of x_{i+1} (control.py:57-60), computed in float64, returned as float32.
+    """
+    f, A, B = linearise(table)
+    n = table.shape[1]
+    c = np.zeros((n, COEF_STRIDE_S))
+    c[:, CS_DS] = A[:, 0, 1]
+    c[:, CS_A21] = A[:, 1, 0]
+    c[:, CS_A31] = A[:, 2, 0]
+    c[:, CS_B31] = B[:, 2, 0]
+    c[:, CS_F3] = f[:, 2]
+    c[:, CS_VREF] = table[ROW_V]
+    c[:, CS_KREF] = table[ROW_KAPPA]
+    c[:, CS_EYLO] = -table[ROW_WIDTH] / 2.0 + margin
+    c[:, CS_EYHI] = table[ROW_WIDTH] / 2.0 - margin
+    return c.astype(np.float32)
+
+
+def coefficients_temporal(table: np.ndarray, margin: float) -> np.ndarray:
+    """Mode-T waypoint record [x, y, cos psi, sin psi, psi, k_ref, v_ref, w/2 - margin] as float32."""
+    n = table.shape[1]
+    c = np.zeros((n, COEF_STRIDE_T))
+    c[:, CT_X] = table[ROW_X]
+    c[:, CT_Y] = table[ROW_Y]
+    c[:, CT_COS] = np.cos(table[ROW_PSI])
+    c[:, CT_SIN] = np.sin(table[ROW_PSI])
+    c[:, CT_PSI] = table[ROW_PSI]
+    c[:, CT_KREF] = table[ROW_KAPPA]
+    c[:, CT_VREF] = table[ROW_V]
+    c[:, CT_HALF] = table[ROW_WIDTH] / 2.0 - margin
+    return c.astype(np.float32)
+
+
+def _quad(w, a):
+    # (w*a)*a  - fixed association, no FMA
+    return (w * a) * a
+
+
+def _hinge2(lo_minus_x, x_minus_hi, zero):
+    v = np.maximum(lo_minus_x, zero) + np.maximum(x_minus_hi, zero)
+    return v * v
+
+
+def rollout_spatial(x0, coef, U, Q, R, QN, u_lo, u_hi, w_bound, dtype=np.float32, return_states=False):
+    """Mode S: x_{i+1} = A_i x_i + B_i (u_i - u_ref_i) + f_i with the a9 cost and bounds.
+
+    x0[3], coef[n,12] (coefficients_spatial), U[N,n,2] = (v, kappa) -> cost[N], viol[N] (0 = feasible)
+    and optionally X[N,n+1,3].  All arithmetic in `dtype`, candidates vectorised, steps sequential.
+    """
+    T = dtype
+    U = np.asarray(U, dtype=T)
+    coef = np.asarray(coef, dtype=T)
+    N, n, _ = U.shape
+    Q, R, QN = (np.asarray(a, dtype=T) for a in (Q, R, QN))
+    u_lo, u_hi = np.asarray(u_lo, dtype=T), np.asarray(u_hi, dtype=T)
+    half, zero, tmin, wb = T(0.5), T(0.0), T(T_MIN), T(w_bound)
+    ey = np.full(N, T(x0[0]), dtype=T)
+    ep = np.full(N, T(x0[1]), dtype=T)
+    t = np.full(N, T(x0[2]), dtype=T)
+    J = np.zeros(N, dtype=T)
+    V = np.zeros(N, dtype=T)
+    X = np.zeros((N, n + 1, 3), dtype=T) if return_states else None
+    for i in range(n):
+        c = coef[i]
+        v, k = U[:, i, 0], U[:, i, 1]
+        if return_states:
+            X[:, i, 0], X[:, i, 1], X[:, i, 2] = ey, ep, t
+        dv = v - c[CS_VREF]
+        dk = k - c[CS_KREF]
+        s = _quad(Q[0], ey)
+        s = s + _quad(Q[1], ep)
+        s = s + _quad(Q[2], t)
+        r = _quad(R[0], dv)
+        r = r + _quad(R[1], dk)
+        J = J + half * (s + r)
+        V = V + _hinge2(u_lo[0] - v, v - u_hi[0], zero)
+        V = V + _hinge2(u_lo[1] - k, k - u_hi[1], zero)
+        ey_n = ey + c[CS_DS] * ep
+        ep_n = (ep + c[CS_A21] * ey) + c[CS_DS] * dk
+        t_n = ((t + c[CS_A31] * ey) + c[CS_B31] * dv) + c[CS_F3]
+        ey, ep, t = ey_n, ep_n, t_n
+        V = V + _hinge2(c[CS_EYLO] - ey, ey - c[CS_EYHI], zero)
+        tv = np.maximum(tmin - t, zero)
+        V = V + tv * tv
+    if return_states:
+        X[:, n, 0], X[:, n, 1], X[:, n, 2] = ey, ep, t
+    s = _quad(QN[0], ey)
+    s = s + _quad(QN[1], ep)
+    s = s + _quad(QN[2], t)
+    J = J + half * s
+    cost = J + wb * V
+    return (cost, V, X) if return_states else (cost, V)
+
+
+# --- spec trigonometry (Cody-Waite reduction + Cephes single-precision minimax polynomials) -------
+TWO_OVER_PI = 0.6366197723675814
+PIO2_HI = 1.5703125  # 8 significant bits: k*PIO2_HI is exact for |k| < 2^16
+PIO2_LO = 4.838267948966e-4  # pi/2 - PIO2_HI
+SIN_C = (-1.6666654611e-1, 8.3321608736e-3, -1.9515295891e-4)
+COS_C = (4.166664568298827e-2, -1.388731625493765e-3, 2.443315711809948e-5)
+PI_F = 3.14159265358979
+TWO_PI_F = 6.28318530717959
+INV_TWO_PI_F = 0.159154943091895
+
+
+def sincos_spec(phi, dtype=np.float32):
+    """sin/cos with a fixed instruction sequence (bit-identical on CPU and GPU in float32)."""
+    T = dtype
+    phi = np.asarray(phi, dtype=T)
+    k = np.rint(phi * T(TWO_OVER_PI))
+    r = (phi - k * T(PIO2_HI)) - k * T(PIO2_LO)
+    r2 = r * r
+    ps = T(SIN_C[1]) + r2 * T(SIN_C[2])
+    ps = T(SIN_C[0]) + r2 * ps
+    s = r + (r * r2) * ps
+    pc = T(COS_C[1]) + r2 * T(COS_C[2])
+    pc = T(COS_C[0]) + r2 * pc
+    c = (T(1.0) - T(0.5) * r2) + (r2 * r2) * pc
+    q = k.astype(np.int64) & 3
+    sin = np.where(q == 0, s, np.where(q == 1, c, np.where(q == 2, -s, -c)))
+    cos = np.where(q == 0, c, np.where(q == 1, -s, np.where(q == 2, -c, s)))
+    return sin.astype(T), cos.astype(T)
+
+
+def wrap_spec(angle, dtype=np.float32):
+    """(-pi, pi] wrap as a - floor(a/2pi)*2pi - pi with a reciprocal multiply (no division)."""
+    T = dtype
+    a = angle + T(PI_F)
+    q = np.floor(a * T(INV_TWO_PI_F))
+    return (a - q * T(TWO_PI_F)) - T(PI_F)
+
+
+def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.float32,
+                     return_states=False, libm_trig=False):
+    """Mode T: Cartesian kinematic Euler rollout (localiser.py:66-95 with phi_dot = v*kappa, kappa =
+    tan(delta)/L), nearest-waypoint projection (first minimum of squared distance, localiser.py:282-289),
+    Frenet errors (dynamics.py:23-40), a9 cost weights and bounds.
+
+    pose0 = (X, Y, phi), wp[n,8] (coefficients_temporal), U[N,n,2] = (v, kappa).
+    """
+    T = dtype
+    U = np.asarray(U, dtype=T)
+    wp = np.asarray(wp, dtype=T)
+    N, n, _ = U.shape
+    Q, R, QN = (np.asarray(a, dtype=T) for a in (Q, R, QN))
+    u_lo, u_hi = np.asarray(u_lo, dtype=T), np.asarray(u_hi, dtype=T)
+    half, zero, wb, dtT = T(0.5), T(0.0), T(w_bound), T(dt)
+    X = np.full(N, T(pose0[0]), dtype=T)
+    Y = np.full(N, T(pose0[1]), dtype=T)
+    phi = np.full(N, T(pose0[2]), dtype=T)
+    J = np.zeros(N, dtype=T)
+    V = np.zeros(N, dtype=T)
+    S = np.zeros((N, n + 1, 3), dtype=T) if return_states else None
+    J_idx = np.zeros((N, n), dtype=np.int32) if return_states else None
+    ey = np.zeros(N, dtype=T)
+    ep = np.zeros(N, dtype=T)
+    if return_states:
+        S[:, 0, 0], S[:, 0, 1], S[:, 0, 2] = X, Y, phi
+    for i in range(n):
+        v, k = U[:, i, 0], U[:, i, 1]
+        if libm_trig:
+            sn, cs = np.sin(phi).astype(T), np.cos(phi).astype(T)
+        else:
+            sn, cs = sincos_spec(phi, T)
+        Xn = X + (v * cs) * dtT
+        Yn = Y + (v * sn) * dtT
+        phin = phi + (v * k) * dtT
+        X, Y, phi = Xn, Yn, phin
+        best = np.full(N, np.inf, dtype=T)
+        j = np.zeros(N, dtype=np.int64)
+        for w in range(n):
+            dx = X - wp[w, CT_X]
+            dy = Y - wp[w, CT_Y]
+            d = dx * dx + dy * dy
+            better = d < best
+            best = np.where(better, d, best)
+            j = np.where(better, w, j)
+        g = wp[j]
+        ey = g[:, CT_COS] * (Y - g[:, CT_Y]) - g[:, CT_SIN] * (X - g[:, CT_X])
+        if libm_trig:
+            ep = wrap_to_pi(phi - g[:, CT_PSI]).astype(T)
+        else:
+            ep = wrap_spec(phi - g[:, CT_PSI], T)
+        dv = v - g[:, CT_VREF]
+        dk = k - g[:, CT_KREF]
+        s = _quad(Q[0], ey)
+        s = s + _quad(Q[1], ep)
+        r = _quad(R[0], dv)
+        r = r + _quad(R[1], dk)
+        J = J + half * (s + r)
+        V = V + _hinge2(u_lo[0] - v, v - u_hi[0], zero)
+        V = V + _hinge2(u_lo[1] - k, k - u_hi[1], zero)
+        V = V + _hinge2((-g[:, CT_HALF]) - ey, ey - g[:, CT_HALF], zero)
+        if return_states:
+            S[:, i + 1, 0], S[:, i + 1, 1], S[:, i + 1, 2] = X, Y, phi
+            J_idx[:, i] = j
+    tN = T(n) * dtT
+    s = _quad(QN[0], ey)
+    s = s + _quad(QN[1], ep)
+    s = s + _quad(QN[2], tN)
+    J = J + half * s
+    cost = J + wb * V
+    return (cost, V, S, J_idx) if return_states else (cost, V)
+
+
+def pick_best(costs: np.ndarray) -> Tuple[int, float]:
+    """argmin with lowest index on ties; non-finite costs rank as +inf (never selected unless all are)."""
+    c = np.where(np.isfinite(costs), costs, np.inf)
+    i = int(np.argmin(c))
+    return i, float(costs[i])
+
+
+def softmin_weights(costs: np.ndarray, lam: float, dtype=np.float32) -> np.ndarray:
+    """exp(-(c - c_min)/lambda); non-finite costs get weight 0."""
+    T = dtype
+    c = np.where(np.isfinite(costs), costs, np.inf).astype(T)
+    return np.exp(-(c - c.min()) / T(lam)).astype(T)
+
+
+def softmin_mean(costs: np.ndarray, U: np.ndarray, lam: float) -> np.ndarray:
+    """Score-weighted mean of the control sequences in a16's form sum(w*u)/sum(w) (localiser.py:572-579),
+    accumulated in float64 so the result does not depend on summation order."""
+    w = softmin_weights(costs, lam).astype(np.float64)
+    return np.tensordot(w, U.astype(np.float64), axes=(0, 0)) / w.sum()
+
+
+def qp_objective(P_diag, q, z):
+    return 0.5 * float(np.dot(P_diag * z, z)) + float(np.dot(q, z))
+
+
+def pack_decision_vector(X: np.ndarray, U: np.ndarray) -> np.ndarray:
+    """[x_0..x_n ; u_0..u_{n-1}] layout of dec.x (control.py:121-158, spatial_mpc.py:193-202)."""
+    return np.concatenate([X.ravel(), U.ravel()])
