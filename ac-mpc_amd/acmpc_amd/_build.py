@@ -1,0 +1,50 @@
+"""Builds libacmpc_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libacmpc_hip.so")
+SOURCES = ("acmpc_kernels.hip", "acmpc_capi.hip")
+HEADERS = ("acmpc_kernels.h", "acmpc_device.h", os.path.join("..", "..", "include", "acmpc.h"))
+
+# -ffp-contract=off: the kernels' float32 arithmetic is specified without fused multiply-add
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Wall", "-Wextra")
+
+
+def find_hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: set HIPCC or install ROCm")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC_DIR, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources into ac-mpc_amd/acmpc_amd/lib/libacmpc_hip.so; returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [find_hipcc(), *HIPCC_FLAGS, *[os.path.join(CSRC_DIR, s) for s in SOURCES], "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

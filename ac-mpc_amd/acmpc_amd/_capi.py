@@ -1,0 +1,241 @@
+"""ctypes binding of include/acmpc.h (the C-ABI drop-in boundary).
+
+The shared library is hand-written HIP for gfx950; there is no CPU implementation behind these calls.  A
+missing library or a missing GPU raises (`EngineError`), it never degrades to another path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _build
+
+OK, EINVAL, EHIP, ENODEVICE, ECAPACITY, ESTATE = 0, -1, -2, -3, -4, -5
+MODE_SPATIAL, MODE_TEMPORAL = 0, 1
+LAYOUT_CANDIDATE_MAJOR, LAYOUT_STEP_MAJOR = 0, 1
+COEF_STRIDE = {MODE_SPATIAL: 12, MODE_TEMPORAL: 8}
+REC_COST, REC_VIOLATION, REC_NFEASIBLE, REC_OWNER, REC_HEADER = 0, 1, 2, 3, 4
+
+
+class EngineError(RuntimeError):
+    """A call into libacmpc_hip failed; `.code` is the ACMPC_E* value."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__("acmpc error %d: %s" % (code, message))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("mode", C.c_int32),
+        ("device", C.c_int32),
+        ("max_problems", C.c_int32),
+        ("max_candidates", C.c_int32),
+        ("max_steps", C.c_int32),
+        ("step_cost", C.c_double * 3),
+        ("r_term", C.c_double * 2),
+        ("final_cost", C.c_double * 3),
+        ("u_min", C.c_double * 2),
+        ("u_max", C.c_double * 2),
+        ("margin", C.c_double),
+        ("wheelbase", C.c_double),
+        ("t_min", C.c_double),
+        ("dt", C.c_double),
+        ("w_bound", C.c_double),
+        ("softmin_lambda", C.c_double),
+    ]
+
+
+_F32P = C.POINTER(C.c_float)
+_F64P = C.POINTER(C.c_double)
+_I32P = C.POINTER(C.c_int32)
+_I64P = C.POINTER(C.c_int64)
+_CTX = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/acmpc.h declares
+SIGNATURES = {
+    "acmpc_version": (C.c_char_p, []),
+    "acmpc_create": (C.c_int, [C.POINTER(Params), C.POINTER(_CTX)]),
+    "acmpc_destroy": (None, [_CTX]),
+    "acmpc_last_error": (C.c_char_p, [_CTX]),
+    "acmpc_set_paths": (C.c_int, [_CTX, _F64P, C.c_int32, C.c_int32]),
+    "acmpc_get_coefficients": (C.c_int, [_CTX, C.c_int32, _F32P, C.c_int32]),
+    "acmpc_record_floats": (C.c_int32, [C.c_int32]),
+    "acmpc_solve": (C.c_int, [_CTX, _F32P, _F32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F32P, _I32P, _F32P]),
+    "acmpc_solve_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acmpc_rollout_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acmpc_finalize_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "acmpc_softmin_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acmpc_sync_tables": (C.c_int, [_CTX, C.c_void_p]),
+    "acmpc_pack_key": (C.c_int64, [C.c_float, C.c_uint32]),
+    "acmpc_key_cost": (C.c_float, [C.c_int64]),
+    "acmpc_key_index": (C.c_uint32, [C.c_int64]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def library_path() -> str:
+    return os.environ.get("ACMPC_HIP_LIBRARY", _build.LIB_PATH)
+
+
+def load_library() -> C.CDLL:
+    """dlopen libacmpc_hip.so and bind every declared symbol.  Raises if the library is absent: build it with
+    `python -m acmpc_amd._build` (or `__graft_entry__.build()`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise EngineError(ENODEVICE, "HIP extension %s is missing - build it with acmpc_amd._build.build_library(); "
+                          "there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _f32(a: np.ndarray):
+    return a.ctypes.data_as(_F32P)
+
+
+def record_floats(n: int) -> int:
+    return REC_HEADER + 2 * n + 3 * (n + 1)
+
+
+def split_record(rec: np.ndarray, n: int):
+    """[cost, violation, n_feasible, owner, u (n x 2), x ((n+1) x 3)] -> dict of views."""
+    u = rec[..., REC_HEADER:REC_HEADER + 2 * n].reshape(rec.shape[:-1] + (n, 2))
+    x = rec[..., REC_HEADER + 2 * n:].reshape(rec.shape[:-1] + (n + 1, 3))
+    return dict(cost=rec[..., REC_COST], violation=rec[..., REC_VIOLATION], n_feasible=rec[..., REC_NFEASIBLE],
+                owner=rec[..., REC_OWNER], u=u, x=x)
+
+
+class Engine:
+    """Owns one acmpc_ctx.  Construction does no device work (fork-safe, controller.py:293-297)."""
+
+    def __init__(self, *, mode: int, max_problems: int, max_candidates: int, max_steps: int, step_cost, r_term,
+                 final_cost, u_min, u_max, margin: float, wheelbase: float, t_min: float = 0.01, dt: float = 0.05,
+                 w_bound: float = 1.0e6, softmin_lambda: float = 1.0, device: int = -1):
+        self._lib = load_library()
+        p = Params()
+        p.struct_size = C.sizeof(Params)
+        p.mode, p.device = mode, device
+        p.max_problems, p.max_candidates, p.max_steps = max_problems, max_candidates, max_steps
+        p.step_cost[:] = [float(v) for v in step_cost]
+        p.r_term[:] = [float(v) for v in r_term]
+        p.final_cost[:] = [float(v) for v in final_cost]
+        p.u_min[:] = [float(v) for v in u_min]
+        p.u_max[:] = [float(v) for v in u_max]
+        p.margin, p.wheelbase, p.t_min, p.dt = float(margin), float(wheelbase), float(t_min), float(dt)
+        p.w_bound, p.softmin_lambda = float(w_bound), float(softmin_lambda)
+        self.params = p
+        self.mode = mode
+        self._ctx = _CTX()
+        rc = self._lib.acmpc_create(C.byref(p), C.byref(self._ctx))
+        if rc != OK:
+            raise EngineError(rc, (self._lib.acmpc_last_error(None) or b"").decode())
+        self.P = 0
+        self.n = 0
+
+    # -- plumbing -----------------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != OK:
+            raise EngineError(rc, (self._lib.acmpc_last_error(self._ctx) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.acmpc_destroy(self._ctx)
+            self._ctx = _CTX()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-only ----------------------------------------------------------------------------------------
+    def set_paths(self, tables: np.ndarray):
+        """tables: [P, 7, n] (or [7, n]) float64 ReferencePath arrays, rows [x, y, psi, kappa, ds, width, v]."""
+        t = np.ascontiguousarray(tables, dtype=np.float64)
+        if t.ndim == 2:
+            t = t[None]
+        if t.ndim != 3 or t.shape[1] != 7:
+            raise ValueError("tables must be [P, 7, n]")
+        self._check(self._lib.acmpc_set_paths(self._ctx, t.ctypes.data_as(_F64P), t.shape[0], t.shape[2]))
+        self.P, self.n = t.shape[0], t.shape[2]
+
+    def coefficients(self, problem: int = 0) -> np.ndarray:
+        out = np.empty((self.n, COEF_STRIDE[self.mode]), dtype=np.float32)
+        self._check(self._lib.acmpc_get_coefficients(self._ctx, problem, _f32(out), out.size))
+        return out
+
+    # -- host-pointer solve -------------------------------------------------------------------------------
+    def solve(self, x0: np.ndarray, U: np.ndarray, layout: int = LAYOUT_CANDIDATE_MAJOR, want_costs: bool = True):
+        """x0 [P,3], U [P,N,n,2] (layout 0) or [P,n,2,N] (layout 1) -> dict(best_idx, costs, record fields)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float32).reshape(-1, 3)
+        U = np.ascontiguousarray(U, dtype=np.float32)
+        if U.ndim == 3:
+            U = U[None]
+        P = x0.shape[0]
+        if layout == LAYOUT_CANDIDATE_MAJOR:
+            _, N, n, two = U.shape
+        else:
+            _, n, two, N = U.shape
+        if two != 2 or U.shape[0] != P:
+            raise ValueError("U has the wrong shape for layout %d" % layout)
+        costs = np.empty((P, N), dtype=np.float32) if want_costs else None
+        best = np.empty(P, dtype=np.int32)
+        rec = np.empty((P, record_floats(n)), dtype=np.float32)
+        self._check(self._lib.acmpc_solve(self._ctx, _f32(x0), _f32(U), P, N, n, layout,
+                                          _f32(costs) if want_costs else None, best.ctypes.data_as(_I32P), _f32(rec)))
+        out = split_record(rec, n)
+        out.update(best_idx=best, costs=costs, records=rec)
+        return out
+
+    # -- device-pointer entry points (pointers are plain integers, e.g. torch.Tensor.data_ptr()) ----------
+    def sync_tables(self, stream: int = 0):
+        self._check(self._lib.acmpc_sync_tables(self._ctx, stream))
+
+    def solve_device(self, d_x0: int, d_U: int, P: int, N: int, n: int, layout: int, d_costs: int, d_keys: int,
+                     d_records: int, stream: int = 0):
+        self._check(self._lib.acmpc_solve_device(self._ctx, d_x0, d_U, P, N, n, layout, d_costs or None,
+                                                 d_keys or None, d_records or None, stream or None))
+
+    def rollout_device(self, d_x0: int, d_U: int, P: int, N: int, n: int, layout: int, index_offset: int,
+                       d_costs: int, d_keys: int, stream: int = 0):
+        self._check(self._lib.acmpc_rollout_device(self._ctx, d_x0, d_U, P, N, n, layout, index_offset,
+                                                   d_costs or None, d_keys, stream or None))
+
+    def finalize_device(self, d_keys: int, d_x0: int, d_U: int, P: int, N: int, n: int, layout: int,
+                        index_offset: int, d_records: int, stream: int = 0):
+        self._check(self._lib.acmpc_finalize_device(self._ctx, d_keys, d_x0, d_U, P, N, n, layout, index_offset,
+                                                    d_records, stream or None))
+
+    def softmin_device(self, d_costs: int, d_keys: int, d_U: int, P: int, N: int, n: int, layout: int, d_mean: int,
+                       d_weight_sum: int = 0, stream: int = 0):
+        self._check(self._lib.acmpc_softmin_device(self._ctx, d_costs, d_keys, d_U, P, N, n, layout, d_mean,
+                                                   d_weight_sum or None, stream or None))
+
+
+def pack_key(cost: float, index: int) -> int:
+    return int(load_library().acmpc_pack_key(float(cost), int(index)))
+
+
+def key_cost(key: int) -> float:
+    return float(load_library().acmpc_key_cost(int(key)))
+
+
+def key_index(key: int) -> int:
+    return int(load_library().acmpc_key_index(int(key)))

@@ -1,0 +1,437 @@
+// C ABI of the rollout-and-cost engine (include/acmpc.h): handle, host-side table preparation, lazy device
+// bring-up, and the launch sequences.  No CPU fallback exists: every compute entry point needs the GPU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/acmpc.h"
+#include "acmpc_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr double kEps = 1e-12;  // dynamics.py:21
+
+}  // namespace
+
+struct acmpc_ctx {
+  acmpc_params prm{};
+  acmpc::Weights w{};
+  int coef_stride = 0;
+
+  // host copy of the packed tables
+  std::vector<float> h_coef;
+  int P_set = 0, n_set = 0;
+  bool tables_dirty = false;
+
+  // device state (created lazily)
+  bool device_ready = false;
+  float* d_coef = nullptr;
+  int64_t* d_partial_keys = nullptr;
+  int* d_partial_feas = nullptr;
+  double* d_soft_partial = nullptr;
+  size_t soft_partial_doubles = 0;
+
+  // staging for the host-pointer entry point (created on its first use)
+  bool staging_ready = false;
+  hipStream_t stream = nullptr;
+  float* d_U = nullptr;
+  float* d_x0 = nullptr;
+  float* d_costs = nullptr;
+  float* d_records = nullptr;
+  int64_t* d_keys = nullptr;
+  int64_t* h_keys = nullptr;  // pinned
+
+  mutable std::string err;
+};
+
+namespace {
+
+int fail(const acmpc_ctx* ctx, int code, const std::string& msg) {
+  if (ctx != nullptr) {
+    ctx->err = msg;
+  } else {
+    g_create_error = msg;
+  }
+  return code;
+}
+
+int fail_hip(const acmpc_ctx* ctx, hipError_t e, const char* what) {
+  const bool nodev = (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver ||
+                      e == hipErrorNotInitialized);
+  return fail(ctx, nodev ? ACMPC_ENODEVICE : ACMPC_EHIP,
+              std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")");
+}
+
+#define ACMPC_HIP(ctx, call)                                   \
+  do {                                                         \
+    const hipError_t e_ = (call);                              \
+    if (e_ != hipSuccess) return fail_hip((ctx), e_, #call);   \
+  } while (0)
+
+int ensure_device(acmpc_ctx* c) {
+  if (c->device_ready) return ACMPC_OK;
+  int count = 0;
+  const hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    return fail(c, ACMPC_ENODEVICE,
+                "no HIP device visible: the rollout path has no CPU fallback (hipGetDeviceCount: " +
+                    std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
+  }
+  if (c->prm.device >= 0) ACMPC_HIP(c, hipSetDevice(c->prm.device));
+  const acmpc_params& p = c->prm;
+  const size_t coef_floats = static_cast<size_t>(p.max_problems) * p.max_steps * c->coef_stride;
+  const size_t partials = static_cast<size_t>(p.max_problems) * acmpc::max_blocks_per_problem(p.max_candidates);
+  c->soft_partial_doubles = static_cast<size_t>(p.max_problems) * acmpc::softmin_chunks(p.max_candidates) *
+                            (4 * static_cast<size_t>(p.max_steps) + 1);
+  ACMPC_HIP(c, hipMalloc(&c->d_coef, coef_floats * sizeof(float)));
+  ACMPC_HIP(c, hipMalloc(&c->d_partial_keys, partials * sizeof(int64_t)));
+  ACMPC_HIP(c, hipMalloc(&c->d_partial_feas, partials * sizeof(int)));
+  ACMPC_HIP(c, hipMalloc(&c->d_soft_partial, c->soft_partial_doubles * sizeof(double)));
+  c->device_ready = true;
+  return ACMPC_OK;
+}
+
+int upload_tables(acmpc_ctx* c, hipStream_t s) {
+  if (c->P_set == 0) return fail(c, ACMPC_ESTATE, "acmpc_set_paths has not been called");
+  if (!c->tables_dirty) return ACMPC_OK;
+  const size_t bytes = static_cast<size_t>(c->P_set) * c->n_set * c->coef_stride * sizeof(float);
+  // pageable source: hipMemcpyAsync stages it before returning, so h_coef may change afterwards
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_coef, c->h_coef.data(), bytes, hipMemcpyHostToDevice, s));
+  c->tables_dirty = false;
+  return ACMPC_OK;
+}
+
+int check_shape(acmpc_ctx* c, int P, int N, int n, int layout) {
+  if (P < 1 || N < 1 || n < 1) return fail(c, ACMPC_EINVAL, "P, N and n must be positive");
+  if (layout != ACMPC_LAYOUT_CANDIDATE_MAJOR && layout != ACMPC_LAYOUT_STEP_MAJOR)
+    return fail(c, ACMPC_EINVAL, "unknown layout");
+  if (P > c->prm.max_problems || N > c->prm.max_candidates || n > c->prm.max_steps) {
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "shape (P=%d, N=%d, n=%d) exceeds the handle's capacity (%d, %d, %d)", P, N, n,
+                  c->prm.max_problems, c->prm.max_candidates, c->prm.max_steps);
+    return fail(c, ACMPC_ECAPACITY, buf);
+  }
+  if (c->P_set == 0) return fail(c, ACMPC_ESTATE, "acmpc_set_paths has not been called");
+  if (P != c->P_set || n != c->n_set) {
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "shape (P=%d, n=%d) does not match the tables set (P=%d, n=%d)", P, n, c->P_set,
+                  c->n_set);
+    return fail(c, ACMPC_EINVAL, buf);
+  }
+  return ACMPC_OK;
+}
+
+int rollout(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int n, int layout, int64_t offset,
+            float* d_costs, hipStream_t s, acmpc::LaunchShape* shape_out) {
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout);
+  acmpc::RolloutArgs a{};
+  a.U = d_U;
+  a.x0 = d_x0;
+  a.coef = c->d_coef;
+  a.costs = d_costs;
+  a.partial_keys = c->d_partial_keys;
+  a.partial_feas = c->d_partial_feas;
+  a.P = P;
+  a.N = N;
+  a.n = n;
+  a.index_offset = offset;
+  a.w = c->w;
+  ACMPC_HIP(c, acmpc::launch_rollout(c->prm.mode, layout, shape, a, s));
+  *shape_out = shape;
+  return ACMPC_OK;
+}
+
+int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const float* d_x0, const float* d_U, int P,
+             int N, int n, int layout, int64_t offset, float* d_records, int blocks_per_problem, hipStream_t s) {
+  acmpc::FinalizeArgs a{};
+  a.U = d_U;
+  a.x0 = d_x0;
+  a.coef = c->d_coef;
+  a.partial_keys = c->d_partial_keys;
+  a.partial_feas = c->d_partial_feas;
+  a.keys_in = d_keys_in;
+  a.keys_out = d_keys_out;
+  a.records = d_records;
+  a.blocks_per_problem = blocks_per_problem;
+  a.P = P;
+  a.N = N;
+  a.n = n;
+  a.index_offset = offset;
+  a.w = c->w;
+  ACMPC_HIP(c, acmpc::launch_finalize(c->prm.mode, layout, a, s));
+  return ACMPC_OK;
+}
+
+int ensure_staging(acmpc_ctx* c) {
+  if (c->staging_ready) return ACMPC_OK;
+  const acmpc_params& p = c->prm;
+  const size_t cand = static_cast<size_t>(p.max_problems) * p.max_candidates;
+  ACMPC_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  ACMPC_HIP(c, hipMalloc(&c->d_U, cand * p.max_steps * 2 * sizeof(float)));
+  ACMPC_HIP(c, hipMalloc(&c->d_x0, static_cast<size_t>(p.max_problems) * 3 * sizeof(float)));
+  ACMPC_HIP(c, hipMalloc(&c->d_costs, cand * sizeof(float)));
+  ACMPC_HIP(c, hipMalloc(&c->d_records,
+                         static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float)));
+  ACMPC_HIP(c, hipMalloc(&c->d_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
+  ACMPC_HIP(c, hipHostMalloc(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t), hipHostMallocDefault));
+  c->staging_ready = true;
+  return ACMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* acmpc_version(void) { return "acmpc-hip 0.1 gfx950"; }
+
+int32_t acmpc_record_floats(int32_t n) { return ACMPC_REC_HEADER + 2 * n + 3 * (n + 1); }
+
+int64_t acmpc_pack_key(float cost, uint32_t index) { return acmpc::pack_key(cost, index); }
+
+float acmpc_key_cost(int64_t key) {
+  const int32_t hi = static_cast<int32_t>(key >> 32);
+  const int32_t bits = (hi >= 0) ? hi : (hi ^ 0x7fffffff);
+  float f;
+  std::memcpy(&f, &bits, sizeof f);
+  return f;
+}
+
+uint32_t acmpc_key_index(int64_t key) { return static_cast<uint32_t>(key & 0xffffffffLL); }
+
+const char* acmpc_last_error(const acmpc_ctx* ctx) { return ctx != nullptr ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
+  if (params == nullptr || out == nullptr) return fail(nullptr, ACMPC_EINVAL, "null argument");
+  *out = nullptr;
+  if (params->struct_size != sizeof(acmpc_params)) return fail(nullptr, ACMPC_EINVAL, "acmpc_params size mismatch");
+  if (params->mode != ACMPC_MODE_SPATIAL && params->mode != ACMPC_MODE_TEMPORAL)
+    return fail(nullptr, ACMPC_EINVAL, "unknown mode");
+  if (params->max_problems < 1 || params->max_candidates < 1 || params->max_steps < 1)
+    return fail(nullptr, ACMPC_EINVAL, "capacities must be positive");
+  if (params->mode == ACMPC_MODE_TEMPORAL && params->max_steps > 4096)
+    return fail(nullptr, ACMPC_EINVAL, "mode T stages the waypoint table in LDS: max_steps <= 4096");
+  acmpc_ctx* c = new (std::nothrow) acmpc_ctx();
+  if (c == nullptr) return fail(nullptr, ACMPC_EINVAL, "out of host memory");
+  c->prm = *params;
+  c->coef_stride = params->mode == ACMPC_MODE_SPATIAL ? ACMPC_COEF_STRIDE_SPATIAL : ACMPC_COEF_STRIDE_TEMPORAL;
+  acmpc::Weights& w = c->w;
+  w.q0 = static_cast<float>(params->step_cost[0]);
+  w.q1 = static_cast<float>(params->step_cost[1]);
+  w.q2 = static_cast<float>(params->step_cost[2]);
+  w.r0 = static_cast<float>(params->r_term[0]);
+  w.r1 = static_cast<float>(params->r_term[1]);
+  w.qn0 = static_cast<float>(params->final_cost[0]);
+  w.qn1 = static_cast<float>(params->final_cost[1]);
+  w.qn2 = static_cast<float>(params->final_cost[2]);
+  w.ulo0 = static_cast<float>(params->u_min[0]);
+  w.ulo1 = static_cast<float>(params->u_min[1]);
+  w.uhi0 = static_cast<float>(params->u_max[0]);
+  w.uhi1 = static_cast<float>(params->u_max[1]);
+  w.tmin = static_cast<float>(params->t_min);
+  w.wbound = static_cast<float>(params->w_bound);
+  w.dt = static_cast<float>(params->dt);
+  *out = c;
+  return ACMPC_OK;
+}
+
+void acmpc_destroy(acmpc_ctx* c) {
+  if (c == nullptr) return;
+  if (c->device_ready || c->staging_ready) {
+    if (c->prm.device >= 0) (void)hipSetDevice(c->prm.device);
+    (void)hipFree(c->d_coef);
+    (void)hipFree(c->d_partial_keys);
+    (void)hipFree(c->d_partial_feas);
+    (void)hipFree(c->d_soft_partial);
+    (void)hipFree(c->d_U);
+    (void)hipFree(c->d_x0);
+    (void)hipFree(c->d_costs);
+    (void)hipFree(c->d_records);
+    (void)hipFree(c->d_keys);
+    if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
+    if (c->stream != nullptr) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+int acmpc_set_paths(acmpc_ctx* c, const double* tables, int32_t P, int32_t n) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (tables == nullptr) return fail(c, ACMPC_EINVAL, "null tables");
+  if (P < 1 || n < 2) return fail(c, ACMPC_EINVAL, "need P >= 1 and n >= 2");
+  if (P > c->prm.max_problems || n > c->prm.max_steps) return fail(c, ACMPC_ECAPACITY, "P or n exceeds capacity");
+  const int stride = c->coef_stride;
+  c->h_coef.assign(static_cast<size_t>(P) * n * stride, 0.0f);
+  const double margin = c->prm.margin;
+  for (int p = 0; p < P; ++p) {
+    const double* t = tables + static_cast<size_t>(p) * 7 * n;
+    const double *x = t, *y = t + n, *psi = t + 2 * n, *kappa = t + 3 * n, *ds = t + 4 * n, *width = t + 5 * n,
+                 *v = t + 6 * n;
+    float* out = c->h_coef.data() + static_cast<size_t>(p) * n * stride;
+    for (int i = 0; i < n; ++i, out += stride) {
+      if (c->prm.mode == ACMPC_MODE_SPATIAL) {
+        // non-trivial entries of A_i, B_i, f_i (dynamics.py:65-103) and the corridor of x_{i+1} (control.py:57-60)
+        const double vds = v[i] * ds[i] + kEps;
+        out[0] = static_cast<float>(ds[i]);
+        out[1] = static_cast<float>(-(kappa[i] * kappa[i]) * ds[i]);
+        out[2] = static_cast<float>(-kappa[i] / vds);
+        out[3] = static_cast<float>(-1.0 / (v[i] * v[i] * ds[i] + kEps));
+        out[4] = static_cast<float>(1.0 / vds);
+        out[5] = static_cast<float>(v[i]);
+        out[6] = static_cast<float>(kappa[i]);
+        out[7] = static_cast<float>(-width[i] / 2.0 + margin);
+        out[8] = static_cast<float>(width[i] / 2.0 - margin);
+      } else {
+        out[0] = static_cast<float>(x[i]);
+        out[1] = static_cast<float>(y[i]);
+        out[2] = static_cast<float>(std::cos(psi[i]));
+        out[3] = static_cast<float>(std::sin(psi[i]));
+        out[4] = static_cast<float>(psi[i]);
+        out[5] = static_cast<float>(kappa[i]);
+        out[6] = static_cast<float>(v[i]);
+        out[7] = static_cast<float>(width[i] / 2.0 - margin);
+      }
+    }
+  }
+  c->P_set = P;
+  c->n_set = n;
+  c->tables_dirty = true;
+  return ACMPC_OK;
+}
+
+int acmpc_get_coefficients(const acmpc_ctx* c, int32_t problem, float* out, int32_t capacity_floats) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (out == nullptr) return fail(c, ACMPC_EINVAL, "null output");
+  if (c->P_set == 0) return fail(c, ACMPC_ESTATE, "acmpc_set_paths has not been called");
+  if (problem < 0 || problem >= c->P_set) return fail(c, ACMPC_EINVAL, "problem index out of range");
+  const size_t count = static_cast<size_t>(c->n_set) * c->coef_stride;
+  if (capacity_floats < static_cast<int64_t>(count)) return fail(c, ACMPC_ECAPACITY, "output buffer too small");
+  std::memcpy(out, c->h_coef.data() + static_cast<size_t>(problem) * count, count * sizeof(float));
+  return ACMPC_OK;
+}
+
+int acmpc_sync_tables(acmpc_ctx* c, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  int rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = upload_tables(c, s);
+  if (rc != ACMPC_OK) return rc;
+  ACMPC_HIP(c, hipStreamSynchronize(s));
+  return ACMPC_OK;
+}
+
+int acmpc_rollout_device(acmpc_ctx* c, const float* d_x0, const float* d_U, int32_t P, int32_t N, int32_t n,
+                         int32_t layout, int64_t index_offset, float* d_costs, int64_t* d_keys, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (d_x0 == nullptr || d_U == nullptr || d_keys == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (index_offset < 0 || index_offset + N > 0xffffffffLL) return fail(c, ACMPC_EINVAL, "global index exceeds 32 bits");
+  int rc = check_shape(c, P, N, n, layout);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = upload_tables(c, s);
+  if (rc != ACMPC_OK) return rc;
+  acmpc::LaunchShape shape;
+  rc = rollout(c, d_x0, d_U, P, N, n, layout, index_offset, d_costs, s, &shape);
+  if (rc != ACMPC_OK) return rc;
+  return finalize(c, nullptr, d_keys, d_x0, d_U, P, N, n, layout, index_offset, nullptr, shape.blocks_per_problem, s);
+}
+
+int acmpc_finalize_device(acmpc_ctx* c, const int64_t* d_keys, const float* d_x0, const float* d_U, int32_t P,
+                          int32_t N, int32_t n, int32_t layout, int64_t index_offset, float* d_records,
+                          void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (d_keys == nullptr || d_x0 == nullptr || d_U == nullptr || d_records == nullptr)
+    return fail(c, ACMPC_EINVAL, "null device pointer");
+  int rc = check_shape(c, P, N, n, layout);
+  if (rc != ACMPC_OK) return rc;
+  if (!c->device_ready) return fail(c, ACMPC_ESTATE, "acmpc_rollout_device must run first");
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout);
+  return finalize(c, d_keys, nullptr, d_x0, d_U, P, N, n, layout, index_offset, d_records, shape.blocks_per_problem,
+                  static_cast<hipStream_t>(stream));
+}
+
+int acmpc_solve_device(acmpc_ctx* c, const float* d_x0, const float* d_U, int32_t P, int32_t N, int32_t n,
+                       int32_t layout, float* d_costs, int64_t* d_keys, float* d_records, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (d_x0 == nullptr || d_U == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (d_keys == nullptr && d_records == nullptr) return fail(c, ACMPC_EINVAL, "need d_keys and/or d_records");
+  int rc = check_shape(c, P, N, n, layout);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = upload_tables(c, s);
+  if (rc != ACMPC_OK) return rc;
+  acmpc::LaunchShape shape;
+  rc = rollout(c, d_x0, d_U, P, N, n, layout, 0, d_costs, s, &shape);
+  if (rc != ACMPC_OK) return rc;
+  return finalize(c, nullptr, d_keys, d_x0, d_U, P, N, n, layout, 0, d_records, shape.blocks_per_problem, s);
+}
+
+int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_t N, int32_t n, int32_t layout,
+                float* costs, int32_t* best_idx, float* records) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (x0 == nullptr || U == nullptr) return fail(c, ACMPC_EINVAL, "null input");
+  int rc = check_shape(c, P, N, n, layout);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_staging(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = c->stream;
+  rc = upload_tables(c, s);
+  if (rc != ACMPC_OK) return rc;
+  const size_t cand = static_cast<size_t>(P) * N;
+  const size_t rec_bytes = static_cast<size_t>(P) * acmpc_record_floats(n) * sizeof(float);
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_U, U, cand * n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+  acmpc::LaunchShape shape;
+  rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, costs != nullptr ? c->d_costs : nullptr, s, &shape);
+  if (rc != ACMPC_OK) return rc;
+  rc = finalize(c, nullptr, c->d_keys, c->d_x0, c->d_U, P, N, n, layout, 0, records != nullptr ? c->d_records : nullptr,
+                shape.blocks_per_problem, s);
+  if (rc != ACMPC_OK) return rc;
+  ACMPC_HIP(c, hipMemcpyAsync(c->h_keys, c->d_keys, static_cast<size_t>(P) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  if (costs != nullptr) ACMPC_HIP(c, hipMemcpyAsync(costs, c->d_costs, cand * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (records != nullptr) ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
+  ACMPC_HIP(c, hipStreamSynchronize(s));
+  if (best_idx != nullptr)
+    for (int p = 0; p < P; ++p) best_idx[p] = static_cast<int32_t>(acmpc_key_index(c->h_keys[p]));
+  return ACMPC_OK;
+}
+
+int acmpc_softmin_device(acmpc_ctx* c, const float* d_costs, const int64_t* d_keys, const float* d_U, int32_t P,
+                         int32_t N, int32_t n, int32_t layout, float* d_mean, double* d_weight_sum, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (d_costs == nullptr || d_keys == nullptr || d_U == nullptr || d_mean == nullptr)
+    return fail(c, ACMPC_EINVAL, "null device pointer");
+  int rc = check_shape(c, P, N, n, layout);
+  if (rc != ACMPC_OK) return rc;
+  if (!(c->prm.softmin_lambda > 0.0)) return fail(c, ACMPC_EINVAL, "softmin_lambda must be positive");
+  rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  acmpc::SoftminArgs a{};
+  a.costs = d_costs;
+  a.keys = d_keys;
+  a.U = d_U;
+  a.partial = c->d_soft_partial;
+  a.mean = d_mean;
+  a.weight_sum = d_weight_sum;
+  a.chunks = acmpc::softmin_chunks(N);
+  a.P = P;
+  a.N = N;
+  a.n = n;
+  a.lambda = static_cast<float>(c->prm.softmin_lambda);
+  ACMPC_HIP(c, acmpc::launch_softmin(layout, a, static_cast<hipStream_t>(stream)));
+  return ACMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,193 @@
+// Device-side arithmetic of the rollout-and-cost path, gfx950 only.
+//
+// Every function here is the float32 "spec order" of DESIGN.md: one fixed association, no FMA contraction
+// (the translation unit is built with -ffp-contract=off and the pragma below), no library transcendentals.
+// That is what makes costs bit-identical to oracle/acmpc_oracle.{py,c}.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace acmpc {
+
+constexpr int kWave = 64;
+constexpr int kCoefS = 12;  // ACMPC_COEF_STRIDE_SPATIAL
+constexpr int kCoefT = 8;   // ACMPC_COEF_STRIDE_TEMPORAL
+
+// Scalars of the cost and the bounds; passed by value in the kernel argument segment, so they live in SGPRs.
+struct Weights {
+  float q0, q1, q2;     // Q   (control.py:126)
+  float r0, r1;         // R   (control.py:127)
+  float qn0, qn1, qn2;  // QN  (control.py:128)
+  float ulo0, ulo1, uhi0, uhi1;  // input box incl. the 0.1 m/s slack (control.py:130-139)
+  float tmin;           // 0.01 (control.py:134)
+  float wbound;
+  float dt;
+};
+
+__device__ __forceinline__ float quad(float w, float a) { return (w * a) * a; }
+
+__device__ __forceinline__ float hinge2(float lo_minus_x, float x_minus_hi) {
+  const float v = fmaxf(lo_minus_x, 0.0f) + fmaxf(x_minus_hi, 0.0f);
+  return v * v;
+}
+
+// ---- mode S --------------------------------------------------------------------------------------------
+// One step of x_{i+1} = A_i x_i + B_i (u_i - u_ref_i) + f_i (dynamics.py:65-103, control.py:26-45) with the
+// stage cost 1/2 (x'Qx + du'R du) (control.py:72-79,151-158) and the squared violation of the input box, the
+// corridor of x_{i+1} (control.py:57-60) and t >= t_min (control.py:134).
+struct StateS {
+  float ey, ep, t, J, V;
+};
+
+__device__ __forceinline__ void step_spatial(StateS& s, const float* __restrict__ c, float v, float k,
+                                             const Weights& w) {
+  const float dv = v - c[5];
+  const float dk = k - c[6];
+  float a = quad(w.q0, s.ey);
+  a = a + quad(w.q1, s.ep);
+  a = a + quad(w.q2, s.t);
+  float r = quad(w.r0, dv);
+  r = r + quad(w.r1, dk);
+  s.J = s.J + 0.5f * (a + r);
+  s.V = s.V + hinge2(w.ulo0 - v, v - w.uhi0);
+  s.V = s.V + hinge2(w.ulo1 - k, k - w.uhi1);
+  const float ds = c[0];
+  const float ey_n = s.ey + ds * s.ep;
+  const float ep_n = (s.ep + c[1] * s.ey) + ds * dk;
+  const float t_n = ((s.t + c[2] * s.ey) + c[3] * dv) + c[4];
+  s.ey = ey_n;
+  s.ep = ep_n;
+  s.t = t_n;
+  s.V = s.V + hinge2(c[7] - s.ey, s.ey - c[8]);
+  const float tv = fmaxf(w.tmin - s.t, 0.0f);
+  s.V = s.V + tv * tv;
+}
+
+__device__ __forceinline__ float finish_spatial(const StateS& s, const Weights& w) {
+  float a = quad(w.qn0, s.ey);
+  a = a + quad(w.qn1, s.ep);
+  a = a + quad(w.qn2, s.t);
+  const float J = s.J + 0.5f * a;
+  return J + w.wbound * s.V;
+}
+
+// ---- mode T --------------------------------------------------------------------------------------------
+// Cody-Waite reduction by pi/2 and the Cephes single-precision minimax polynomials: the same instruction
+// sequence as oracle sincos_spec().
+__device__ __forceinline__ void sincos_spec(float phi, float& sn, float& cs) {
+  const float k = rintf(phi * 0.6366197723675814f);
+  const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
+  const float r2 = r * r;
+  float ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
+  ps = -1.6666654611e-1f + r2 * ps;
+  const float s = r + (r * r2) * ps;
+  float pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
+  pc = 4.166664568298827e-2f + r2 * pc;
+  const float c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
+  const int q = static_cast<int>(k) & 3;
+  sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+  cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+
+__device__ __forceinline__ float wrap_spec(float a) {
+  const float b = a + 3.14159265358979f;
+  const float q = floorf(b * 0.159154943091895f);
+  return (b - q * 6.28318530717959f) - 3.14159265358979f;
+}
+
+struct StateT {
+  float X, Y, phi, ey, ep, J, V;
+};
+
+// `wp` is the waypoint table (kCoefT floats per waypoint); in the rollout kernel it lives in LDS.
+__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, int n, float v, float k,
+                                             const Weights& w) {
+  float sn, cs;
+  sincos_spec(s.phi, sn, cs);
+  // explicit Euler on the rear-axle kinematic bicycle (localiser.py:66-95); phi_dot = v * kappa
+  const float Xn = s.X + (v * cs) * w.dt;
+  const float Yn = s.Y + (v * sn) * w.dt;
+  const float phin = s.phi + (v * k) * w.dt;
+  s.X = Xn;
+  s.Y = Yn;
+  s.phi = phin;
+  // nearest waypoint, first minimum of the squared distance (localiser.py:282-289)
+  float best = __builtin_inff();
+  int j = 0;
+  for (int i = 0; i < n; ++i) {
+    const float dx = s.X - wp[i * kCoefT + 0];
+    const float dy = s.Y - wp[i * kCoefT + 1];
+    const float d = dx * dx + dy * dy;
+    const bool better = d < best;
+    best = better ? d : best;
+    j = better ? i : j;
+  }
+  const float* g = wp + j * kCoefT;
+  // Frenet errors w.r.t. that waypoint (dynamics.py:23-40)
+  s.ey = g[2] * (s.Y - g[1]) - g[3] * (s.X - g[0]);
+  s.ep = wrap_spec(s.phi - g[4]);
+  const float dv = v - g[6];
+  const float dk = k - g[5];
+  float a = quad(w.q0, s.ey);
+  a = a + quad(w.q1, s.ep);
+  float r = quad(w.r0, dv);
+  r = r + quad(w.r1, dk);
+  s.J = s.J + 0.5f * (a + r);
+  s.V = s.V + hinge2(w.ulo0 - v, v - w.uhi0);
+  s.V = s.V + hinge2(w.ulo1 - k, k - w.uhi1);
+  s.V = s.V + hinge2((-g[7]) - s.ey, s.ey - g[7]);
+  return j;
+}
+
+__device__ __forceinline__ float finish_temporal(const StateT& s, int n, const Weights& w) {
+  const float tN = static_cast<float>(n) * w.dt;
+  float a = quad(w.qn0, s.ey);
+  a = a + quad(w.qn1, s.ep);
+  a = a + quad(w.qn2, tN);
+  const float J = s.J + 0.5f * a;
+  return J + w.wbound * s.V;
+}
+
+// ---- (cost, index) keys ---------------------------------------------------------------------------------
+// key = (ordered_int32(cost) << 32) | uint32(index): signed 64-bit order == (cost, index) lexicographic order,
+// so min() is np.argmin's "first minimum".  Non-finite costs rank as +inf.
+__device__ __host__ __forceinline__ int64_t pack_key(float cost, uint32_t index) {
+  union {
+    float f;
+    int32_t i;
+    uint32_t u;
+  } b;
+  b.f = cost;
+  if ((b.u & 0x7f800000u) == 0x7f800000u) b.u = 0x7f800000u;  // inf / nan -> +inf
+  const int32_t hi = (b.i >= 0) ? b.i : (b.i ^ 0x7fffffff);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<int64_t>(index);
+}
+
+constexpr int64_t kKeyMax = INT64_MAX;
+
+__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask) {
+  int lo = static_cast<int>(v & 0xffffffffLL);
+  int hi = static_cast<int>(v >> 32);
+  lo = __shfl_xor(lo, mask, kWave);
+  hi = __shfl_xor(hi, mask, kWave);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+
+__device__ __forceinline__ int64_t wave_min_key(int64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int64_t o = shfl_xor_i64(v, m);
+    v = (o < v) ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+
+}  // namespace acmpc

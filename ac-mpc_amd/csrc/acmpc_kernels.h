@@ -1,0 +1,64 @@
+// Host-callable launchers of the gfx950 kernels (definitions in acmpc_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "acmpc_device.h"
+
+namespace acmpc {
+
+struct RolloutArgs {
+  const float* U;         // control-sample matrix, layout per `layout`
+  const float* x0;        // [P][3]
+  const float* coef;      // [P][n][stride] packed per-step table
+  float* costs;           // [P][N] or nullptr
+  int64_t* partial_keys;  // [P][blocks_per_problem]
+  int* partial_feas;      // [P][blocks_per_problem]
+  int P, N, n;
+  int64_t index_offset;   // global index of local candidate 0
+  Weights w;
+};
+
+struct FinalizeArgs {
+  const float* U;
+  const float* x0;
+  const float* coef;
+  const int64_t* partial_keys;  // used when keys_in == nullptr
+  const int* partial_feas;
+  const int64_t* keys_in;       // [P] global keys (after an all-reduce) or nullptr
+  int64_t* keys_out;            // [P] or nullptr
+  float* records;               // [P][record_floats] or nullptr
+  int blocks_per_problem;
+  int P, N, n;
+  int64_t index_offset;
+  Weights w;
+};
+
+struct SoftminArgs {
+  const float* costs;     // [P][N]
+  const int64_t* keys;    // [P]
+  const float* U;
+  double* partial;        // [P][chunks][2n + 1] workspace
+  float* mean;            // [P][n][2]
+  double* weight_sum;     // [P] or nullptr
+  int chunks;
+  int P, N, n;
+  float lambda;
+};
+
+struct LaunchShape {
+  int block;              // threads per workgroup
+  int cpt;                // candidates per thread
+  int blocks_per_problem;
+};
+
+// Picks workgroup size / candidates per thread for (P, N, layout); pure function, also used to size workspaces.
+LaunchShape choose_shape(int P, int N, int layout);
+int max_blocks_per_problem(int N);
+
+hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s);
+hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
+int softmin_chunks(int N);
+hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s);
+
+}  // namespace acmpc

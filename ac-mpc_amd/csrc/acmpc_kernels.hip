@@ -1,0 +1,495 @@
+// gfx950 kernels of the ac-mpc rollout-and-cost path.
+//
+//   rollout_kernel   one lane = one candidate (or CPT adjacent candidates), steps sequential; the per-step
+//                    table is wave-uniform, so in mode S it is read with scalar loads (SGPRs, no LDS traffic)
+//                    and in mode T - where every lane gathers "its" nearest waypoint - it is staged in LDS once
+//                    per workgroup.  Controls are streamed from HBM exactly once; costs are written once.
+//                    Each workgroup reduces its (cost, index) keys with wave shuffles + LDS and writes ONE
+//                    partial key: no atomics, no pre-zeroed buffers, bitwise reproducible.
+//   finalize_kernel  one wave per problem: min over the partial keys (or takes all-reduced keys), re-rolls the
+//                    winning candidate and writes its record [cost, violation, n_feasible, owner, u, x].
+//   softmin_*        score-weighted mean of the control sequences.
+//
+// Built with -ffp-contract=off: see acmpc_device.h.
+#include "acmpc_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace acmpc {
+
+namespace {
+
+constexpr int kMaxBlock = 256;
+
+template <int CPT>
+struct VecOf;
+template <>
+struct VecOf<1> {
+  using type = float;
+};
+template <>
+struct VecOf<2> {
+  using type = float2;
+};
+template <>
+struct VecOf<4> {
+  using type = float4;
+};
+
+template <int CPT>
+__device__ __forceinline__ void unpack(const typename VecOf<CPT>::type& v, float (&out)[CPT]);
+template <>
+__device__ __forceinline__ void unpack<1>(const float& v, float (&out)[1]) {
+  out[0] = v;
+}
+template <>
+__device__ __forceinline__ void unpack<2>(const float2& v, float (&out)[2]) {
+  out[0] = v.x;
+  out[1] = v.y;
+}
+template <>
+__device__ __forceinline__ void unpack<4>(const float4& v, float (&out)[4]) {
+  out[0] = v.x;
+  out[1] = v.y;
+  out[2] = v.z;
+  out[3] = v.w;
+}
+
+// Controls of CPT adjacent candidates at step i.
+template <int LAYOUT, int CPT>
+__device__ __forceinline__ void load_controls(const float* __restrict__ U, int p, int N, int n, int i, int c0,
+                                              float (&v)[CPT], float (&k)[CPT]) {
+  if constexpr (LAYOUT == 1) {
+    // U[p][i][0|1][c]: lanes read consecutive candidates -> one fully coalesced wave access per component
+    using V = typename VecOf<CPT>::type;
+    const float* row = U + (static_cast<size_t>(p) * n + i) * 2 * static_cast<size_t>(N) + c0;
+    unpack<CPT>(*reinterpret_cast<const V*>(row), v);
+    unpack<CPT>(*reinterpret_cast<const V*>(row + N), k);
+  } else {
+    // U[p][c][i][0|1]: 8-byte (v, kappa) pairs at a row stride of 8n bytes
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const float2 vk = *reinterpret_cast<const float2*>(
+          U + ((static_cast<size_t>(p) * N + c0 + j) * n + i) * 2);
+      v[j] = vk.x;
+      k[j] = vk.y;
+    }
+  }
+}
+
+template <int MODE, int LAYOUT, int CPT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // carve: [0,32) wave keys | [32,48) wave feasible counts | [64, ...) mode-T waypoint table
+  int64_t* s_key = reinterpret_cast<int64_t*>(smem);
+  int* s_feas = reinterpret_cast<int*>(smem + 32);
+  float* s_wp = reinterpret_cast<float*>(smem + 64);
+
+  const int p = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int c0 = (blockIdx.x * BLOCK + tid) * CPT;
+  const bool active = c0 < a.N;  // N % CPT == 0 is guaranteed by the launcher
+  const int n = a.n;
+  const Weights w = a.w;
+  constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+
+  if constexpr (MODE == 1) {
+    for (int e = tid; e < n * kCoefT; e += BLOCK) s_wp[e] = coef[e];
+    __syncthreads();
+  }
+
+  float cost[CPT];
+  bool feas[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    cost[j] = __builtin_inff();
+    feas[j] = false;
+  }
+
+  if (active) {
+    if constexpr (MODE == 0) {
+      StateS st[CPT];
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) st[j] = StateS{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+#pragma unroll 7
+      for (int i = 0; i < n; ++i) {
+        float v[CPT], k[CPT];
+        load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
+        const float* __restrict__ c = coef + i * kCoefS;  // wave-uniform -> scalar loads
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) step_spatial(st[j], c, v[j], k[j], w);
+      }
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        cost[j] = finish_spatial(st[j], w);
+        feas[j] = st[j].V == 0.0f;
+      }
+    } else {
+      StateT st[CPT];
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) st[j] = StateT{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+      for (int i = 0; i < n; ++i) {
+        float v[CPT], k[CPT];
+        load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) step_temporal(st[j], s_wp, n, v[j], k[j], w);
+      }
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        cost[j] = finish_temporal(st[j], n, w);
+        feas[j] = st[j].V == 0.0f;
+      }
+    }
+    if (a.costs != nullptr) {
+      using V = typename VecOf<CPT>::type;
+      float* out = a.costs + static_cast<size_t>(p) * a.N + c0;
+      if constexpr (CPT == 1) {
+        out[0] = cost[0];
+      } else if constexpr (CPT == 2) {
+        *reinterpret_cast<V*>(out) = make_float2(cost[0], cost[1]);
+      } else {
+        *reinterpret_cast<V*>(out) = make_float4(cost[0], cost[1], cost[2], cost[3]);
+      }
+    }
+  }
+
+  // (cost, index) argmin: thread -> wave (shuffles) -> workgroup (LDS) -> one partial per workgroup
+  int64_t key = kKeyMax;
+  int nfeas = 0;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const int64_t kj = pack_key(cost[j], static_cast<uint32_t>(a.index_offset + c0 + j));
+      key = (kj < key) ? kj : key;
+      nfeas += feas[j] ? 1 : 0;
+    }
+  }
+  key = wave_min_key(key);
+  nfeas = wave_sum_int(nfeas);
+  constexpr int kWaves = BLOCK / kWave;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid / kWave;
+  if constexpr (kWaves > 1) {
+    if (lane == 0) {
+      s_key[wave] = key;
+      s_feas[wave] = nfeas;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 1; q < kWaves; ++q) {
+        key = (s_key[q] < key) ? s_key[q] : key;
+        nfeas += s_feas[q];
+      }
+    }
+  }
+  if (tid == 0) {
+    const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;
+    a.partial_keys[slot] = key;
+    a.partial_feas[slot] = nfeas;
+  }
+}
+
+// One wave per problem.
+template <int MODE, int LAYOUT>
+__global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = a.n;
+
+  int nfeas = 0;
+  int64_t key = kKeyMax;
+  for (int b = lane; b < a.blocks_per_problem; b += kWave) {
+    const size_t slot = static_cast<size_t>(p) * a.blocks_per_problem + b;
+    nfeas += a.partial_feas[slot];
+    const int64_t kb = a.partial_keys[slot];
+    key = (kb < key) ? kb : key;
+  }
+  nfeas = wave_sum_int(nfeas);
+  key = wave_min_key(key);
+  if (a.keys_in != nullptr) key = a.keys_in[p];
+  if (a.keys_out != nullptr && lane == 0) a.keys_out[p] = key;
+  if (a.records == nullptr) return;
+
+  const int rec_floats = 4 + 2 * n + 3 * (n + 1);
+  float* __restrict__ rec = a.records + static_cast<size_t>(p) * rec_floats;
+  const int64_t local = static_cast<int64_t>(static_cast<uint32_t>(key & 0xffffffffLL)) - a.index_offset;
+  const bool owner = local >= 0 && local < a.N;
+  if (!owner) {
+    for (int e = lane; e < rec_floats; e += kWave) rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
+    return;
+  }
+  if (lane != 0) return;
+
+  // re-roll the winner with the very same step functions; store u and every state
+  const Weights w = a.w;
+  constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+  const int c = static_cast<int>(local);
+  float* __restrict__ ru = rec + 4;
+  float* __restrict__ rx = rec + 4 + 2 * n;
+  float cost, viol;
+  if constexpr (MODE == 0) {
+    StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+    for (int i = 0; i < n; ++i) {
+      float v[1], k[1];
+      load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, v, k);
+      ru[2 * i] = v[0];
+      ru[2 * i + 1] = k[0];
+      rx[3 * i] = st.ey;
+      rx[3 * i + 1] = st.ep;
+      rx[3 * i + 2] = st.t;
+      step_spatial(st, coef + i * kCoefS, v[0], k[0], w);
+    }
+    rx[3 * n] = st.ey;
+    rx[3 * n + 1] = st.ep;
+    rx[3 * n + 2] = st.t;
+    cost = finish_spatial(st, w);
+    viol = st.V;
+  } else {
+    StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+    rx[0] = st.X;
+    rx[1] = st.Y;
+    rx[2] = st.phi;
+    for (int i = 0; i < n; ++i) {
+      float v[1], k[1];
+      load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, v, k);
+      ru[2 * i] = v[0];
+      ru[2 * i + 1] = k[0];
+      step_temporal(st, coef, n, v[0], k[0], w);
+      rx[3 * (i + 1)] = st.X;
+      rx[3 * (i + 1) + 1] = st.Y;
+      rx[3 * (i + 1) + 2] = st.phi;
+    }
+    cost = finish_temporal(st, n, w);
+    viol = st.V;
+  }
+  rec[0] = cost;
+  rec[1] = viol;
+  rec[2] = static_cast<float>(nfeas);
+  rec[3] = 1.0f;
+}
+
+// ---- softmin-weighted mean -------------------------------------------------------------------------------
+constexpr int kSoftChunk = 4096;  // candidates per workgroup
+constexpr int kSoftBlock = 256;
+
+__device__ __forceinline__ float key_cost(int64_t key) {
+  const int32_t hi = static_cast<int32_t>(key >> 32);
+  union {
+    int32_t i;
+    float f;
+  } b;
+  b.i = (hi >= 0) ? hi : (hi ^ 0x7fffffff);
+  return b.f;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+
+// partial[p][chunk][0] = sum of weights; [1 .. 2n] = weighted sums; [2n+1 .. 4n] = unweighted sums.
+template <int LAYOUT>
+__global__ void __launch_bounds__(kSoftBlock) softmin_partial_kernel(const SoftminArgs a) {
+  __shared__ float s_w[kSoftChunk];
+  __shared__ double s_red[kSoftBlock / kWave];
+  __shared__ double s_acc[2][kSoftBlock];
+  const int p = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n2 = 2 * a.n;
+  const int base = chunk * kSoftChunk;
+  const int count = min(kSoftChunk, a.N - base);
+  const float cmin = key_cost(a.keys[p]);
+  const float* __restrict__ costs = a.costs + static_cast<size_t>(p) * a.N + base;
+  double* __restrict__ out = a.partial + (static_cast<size_t>(p) * a.chunks + chunk) * (2 * n2 + 1);
+
+  double wsum = 0.0;
+  for (int c = tid; c < count; c += kSoftBlock) {
+    const float cost = costs[c];
+    const bool finite = (__float_as_uint(cost) & 0x7f800000u) != 0x7f800000u;
+    const float wt = finite ? expf(-(cost - cmin) / a.lambda) : 0.0f;
+    s_w[c] = wt;
+    wsum += static_cast<double>(wt);
+  }
+  wsum = wave_sum_f64(wsum);
+  if ((tid & (kWave - 1)) == 0) s_red[tid / kWave] = wsum;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int q = 0; q < kSoftBlock / kWave; ++q) t += s_red[q];
+    out[0] = t;
+  }
+
+  if constexpr (LAYOUT == 0) {
+    // rows of 2n floats: thread group g owns rows c = g (mod G); each thread a fixed entry e of the row
+    const int G = kSoftBlock / n2 > 0 ? kSoftBlock / n2 : 1;
+    for (int e0 = 0; e0 < n2; e0 += kSoftBlock) {  // n2 > 256 only for n > 128
+      const int g = tid / n2;
+      const int e = e0 + (tid % n2);
+      double acc = 0.0, plain = 0.0;
+      if (g < G && e < n2) {
+        const float* __restrict__ U = a.U + (static_cast<size_t>(p) * a.N + base) * n2 + e;
+        for (int c = g; c < count; c += G) {
+          const double u = static_cast<double>(U[static_cast<size_t>(c) * n2]);
+          acc += static_cast<double>(s_w[c]) * u;
+          plain += u;
+        }
+      }
+      s_acc[0][tid] = acc;
+      s_acc[1][tid] = plain;
+      __syncthreads();
+      if (tid < n2 && e0 + tid < n2) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int g2 = 0; g2 < G; ++g2) {
+          t0 += s_acc[0][g2 * n2 + tid];
+          t1 += s_acc[1][g2 * n2 + tid];
+        }
+        out[1 + e0 + tid] = t0;
+        out[1 + n2 + e0 + tid] = t1;
+      }
+      __syncthreads();
+    }
+  } else {
+    // U[p][i][comp][N]: thread owns candidates tid, tid + 256, ...; one workgroup reduction per entry
+    for (int e = 0; e < n2; ++e) {
+      const float* __restrict__ U = a.U + (static_cast<size_t>(p) * n2 + e) * a.N + base;
+      double acc = 0.0, plain = 0.0;
+      for (int c = tid; c < count; c += kSoftBlock) {
+        const double u = static_cast<double>(U[c]);
+        acc += static_cast<double>(s_w[c]) * u;
+        plain += u;
+      }
+      acc = wave_sum_f64(acc);
+      plain = wave_sum_f64(plain);
+      if ((tid & (kWave - 1)) == 0) {
+        s_acc[0][tid / kWave] = acc;
+        s_acc[1][tid / kWave] = plain;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int q = 0; q < kSoftBlock / kWave; ++q) {
+          t0 += s_acc[0][q];
+          t1 += s_acc[1][q];
+        }
+        out[1 + e] = t0;
+        out[1 + n2 + e] = t1;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Sums the chunk partials in chunk order; sum(w u)/sum(w), uniform weights when sum(w) is not positive
+// (the NaN fallback of localiser.py:575-578).
+__global__ void __launch_bounds__(kSoftBlock) softmin_final_kernel(const SoftminArgs a) {
+  const int p = blockIdx.x;
+  const int n2 = 2 * a.n;
+  const double* __restrict__ part = a.partial + static_cast<size_t>(p) * a.chunks * (2 * n2 + 1);
+  double wsum = 0.0;
+  for (int q = 0; q < a.chunks; ++q) wsum += part[static_cast<size_t>(q) * (2 * n2 + 1)];
+  const bool usable = wsum > 0.0;
+  for (int e = threadIdx.x; e < n2; e += kSoftBlock) {
+    double acc = 0.0;
+    const int col = usable ? 1 + e : 1 + n2 + e;
+    for (int q = 0; q < a.chunks; ++q) acc += part[static_cast<size_t>(q) * (2 * n2 + 1) + col];
+    a.mean[static_cast<size_t>(p) * n2 + e] =
+        static_cast<float>(acc / (usable ? wsum : static_cast<double>(a.N)));
+  }
+  if (threadIdx.x == 0 && a.weight_sum != nullptr) a.weight_sum[p] = wsum;
+}
+
+template <int MODE, int LAYOUT, int CPT, int BLOCK>
+hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s) {
+  const dim3 grid(shape.blocks_per_problem, args.P);
+  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * kCoefT * sizeof(float) : 0);
+  hipLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK>), grid, dim3(BLOCK), lds, s, args);
+  return hipGetLastError();
+}
+
+template <int MODE, int LAYOUT>
+hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s) {
+  if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 64>(shape, args, s);
+  if (shape.block == 256 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 256>(shape, args, s);
+  if constexpr (LAYOUT == 1) {
+    if (shape.block == 256 && shape.cpt == 2) return launch_rollout_t<MODE, LAYOUT, 2, 256>(shape, args, s);
+    if (shape.block == 256 && shape.cpt == 4) return launch_rollout_t<MODE, LAYOUT, 4, 256>(shape, args, s);
+  }
+  return hipErrorInvalidConfiguration;
+}
+
+}  // namespace
+
+int max_blocks_per_problem(int N) { return (N + kWave - 1) / kWave; }
+
+LaunchShape choose_shape(int P, int N, int layout) {
+  // Fill 256 CUs first (small batches: 64-thread workgroups, one candidate per lane), then widen the
+  // per-lane work so that each wave load moves 16 B per lane (large step-major batches).
+  LaunchShape s;
+  const long long total = static_cast<long long>(P) * N;
+  if (total <= 256LL * 64 * 8) {
+    s.block = 64;
+    s.cpt = 1;
+  } else if (layout == 1 && N % 4 == 0 && total >= 256LL * 256 * 4 * 4) {
+    s.block = 256;
+    s.cpt = 4;
+  } else if (layout == 1 && N % 2 == 0 && total >= 256LL * 256 * 2 * 4) {
+    s.block = 256;
+    s.cpt = 2;
+  } else {
+    s.block = 256;
+    s.cpt = 1;
+  }
+  const int per_block = s.block * s.cpt;
+  s.blocks_per_problem = (N + per_block - 1) / per_block;
+  return s;
+}
+
+hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s) {
+  if (mode == 0 && layout == 0) return launch_rollout_ml<0, 0>(shape, args, s);
+  if (mode == 0 && layout == 1) return launch_rollout_ml<0, 1>(shape, args, s);
+  if (mode == 1 && layout == 0) return launch_rollout_ml<1, 0>(shape, args, s);
+  if (mode == 1 && layout == 1) return launch_rollout_ml<1, 1>(shape, args, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s) {
+  const dim3 grid(args.P), block(kWave);
+  if (mode == 0 && layout == 0) {
+    hipLaunchKernelGGL((finalize_kernel<0, 0>), grid, block, 0, s, args);
+  } else if (mode == 0 && layout == 1) {
+    hipLaunchKernelGGL((finalize_kernel<0, 1>), grid, block, 0, s, args);
+  } else if (mode == 1 && layout == 0) {
+    hipLaunchKernelGGL((finalize_kernel<1, 0>), grid, block, 0, s, args);
+  } else if (mode == 1 && layout == 1) {
+    hipLaunchKernelGGL((finalize_kernel<1, 1>), grid, block, 0, s, args);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+int softmin_chunks(int N) { return (N + kSoftChunk - 1) / kSoftChunk; }
+
+hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s) {
+  const dim3 grid(args.chunks, args.P);
+  if (layout == 0) {
+    hipLaunchKernelGGL((softmin_partial_kernel<0>), grid, dim3(kSoftBlock), 0, s, args);
+  } else if (layout == 1) {
+    hipLaunchKernelGGL((softmin_partial_kernel<1>), grid, dim3(kSoftBlock), 0, s, args);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(softmin_final_kernel, dim3(args.P), dim3(kSoftBlock), 0, s, args);
+  return hipGetLastError();
+}
+
+}  // namespace acmpc

@@ -1,0 +1,168 @@
+/*
+ * acmpc.h - C ABI of the MI355X (gfx950) rollout-and-cost engine for the ac-mpc controller.
+ *
+ * This is the drop-in boundary of SURVEY.md section 8(b).  The reference is pure Python, so there is no
+ * FFI to bind to; each entry point names the reference interface whose work it takes over
+ * (paths relative to /root/reference/).  Host code stays Python and calls these through ctypes
+ * (`ac-mpc_amd/acmpc_amd/_capi.py`; reference-side stub in INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ACMPC_E* code; no exception crosses the ABI;
+ *     `acmpc_last_error()` gives the message of the last failure on that handle;
+ *   - a handle is not thread-safe; buffers passed in are only read for the duration of the call;
+ *   - `acmpc_create`, `acmpc_set_paths` and `acmpc_get_coefficients` do no device work: the reference builds
+ *     its MPC objects in the parent process and then forks the ControlProcess
+ *     (src/acmpc/control/controller.py:94-100,293-297), so the HIP context is created lazily on the first call
+ *     that needs the GPU, in whichever process makes it;
+ *   - "n" is the number of control steps = horizon - 1 = len(ReferencePath)
+ *     (src/acmpc/control/spatial_mpc.py:133-134), "N" the number of candidate control sequences per problem,
+ *     "P" the number of independent problems (poses) evaluated by one launch;
+ *   - a candidate is n pairs (v, kappa): the decision variables u of the reference QP
+ *     (src/acmpc/control/solvers/control.py:26-28); steering angle = atan(kappa * wheelbase)
+ *     (spatial_mpc.py:195-196).
+ *
+ * Arithmetic is float32 in a fixed operation order with no FMA contraction, so that results are
+ * bit-identical to oracle/acmpc_oracle.{py,c}.
+ */
+#ifndef ACMPC_H
+#define ACMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACMPC_OK 0
+#define ACMPC_EINVAL (-1)    /* bad argument (null pointer, size out of range, unknown mode/layout)      */
+#define ACMPC_EHIP (-2)      /* a HIP runtime call failed; message carries hipGetErrorString             */
+#define ACMPC_ENODEVICE (-3) /* no usable GPU / HIP runtime: the product path never falls back to the CPU */
+#define ACMPC_ECAPACITY (-4) /* P, N or n exceeds what the handle was created for                         */
+#define ACMPC_ESTATE (-5)    /* call order violated (e.g. solve before set_paths)                          */
+
+/* Rollout model. */
+#define ACMPC_MODE_SPATIAL 0  /* x_{i+1} = A_i x_i + B_i (u_i - u_ref_i) + f_i, x = (e_y, e_psi, t):
+                                 dynamics.py:65-103 + control.py:26-45 ("mode S")                        */
+#define ACMPC_MODE_TEMPORAL 1 /* Cartesian kinematic Euler step (localisation/localiser.py:66-95) with
+                                 nearest-waypoint Frenet projection (localiser.py:282-289, dynamics.py:23-40)
+                                 ("mode T")                                                               */
+
+/* Memory layout of the control-sample matrix U. */
+#define ACMPC_LAYOUT_CANDIDATE_MAJOR 0 /* U[P][N][n][2]  - what NumPy host code naturally holds          */
+#define ACMPC_LAYOUT_STEP_MAJOR 1      /* U[P][n][2][N]  - what an on-device sampler writes; lane-coalesced */
+
+/* Width in floats of one row of the packed per-step tables returned by acmpc_get_coefficients. */
+#define ACMPC_COEF_STRIDE_SPATIAL 12  /* ds, a21, a31, b31, f3, v_ref, k_ref, ey_lo, ey_hi, 0, 0, 0 */
+#define ACMPC_COEF_STRIDE_TEMPORAL 8  /* x, y, cos psi, sin psi, psi, k_ref, v_ref, w/2 - margin     */
+
+/* Header floats of a winner record (see acmpc_record_floats). */
+#define ACMPC_REC_COST 0
+#define ACMPC_REC_VIOLATION 1
+#define ACMPC_REC_NFEASIBLE 2
+#define ACMPC_REC_OWNER 3
+#define ACMPC_REC_HEADER 4
+
+typedef struct acmpc_ctx acmpc_ctx;
+
+/* Everything SpatialMPC.__init__ / ControlSolver.__setup / SpatialBicycleModel.__init__ hold as scalars
+ * (spatial_mpc.py:21-58, control.py:108-158, dynamics.py:10-21). */
+typedef struct acmpc_params {
+  uint32_t struct_size;  /* sizeof(acmpc_params), for ABI checking                                   */
+  int32_t mode;          /* ACMPC_MODE_*                                                              */
+  int32_t device;        /* HIP device ordinal                                                        */
+  int32_t max_problems;  /* capacity P                                                                */
+  int32_t max_candidates;/* capacity N (per problem)                                                  */
+  int32_t max_steps;     /* capacity n                                                                */
+  /* real-valued fields are doubles so that Python floats cross the ABI exactly; the device gets float32 */
+  double step_cost[3];   /* Q  = diag(step_cost)  on (e_y, e_psi, t)     control.py:126               */
+  double r_term[2];      /* R  = diag(r_term)     on (v, kappa)          control.py:127               */
+  double final_cost[3];  /* QN = diag(final_cost)                        control.py:128               */
+  double u_min[2];       /* QP input box: min_u - (0.1, 0)               control.py:130-139           */
+  double u_max[2];       /*               max_u + (0.1, 0)                                           */
+  double margin;         /* vehicle width / 2                            dynamics.py:14               */
+  double wheelbase;      /* L                                            dynamics.py:11               */
+  double t_min;          /* lower bound on the time state, 0.01          control.py:134               */
+  double dt;             /* mode T Euler step [s]                                                     */
+  double w_bound;        /* penalty weight on squared bound violation (build parameter, default 1e6)  */
+  double softmin_lambda; /* temperature of the softmin-weighted mean (build parameter)                */
+} acmpc_params;
+
+/* Replaces: SpatialMPC.__init__ + ControlSolver.__setup (spatial_mpc.py:21-58, control.py:108-158).
+ * Allocates host state only. */
+int acmpc_create(const acmpc_params* params, acmpc_ctx** out);
+void acmpc_destroy(acmpc_ctx* ctx);
+
+/* Message of the last failing call on `ctx` (or of the last failing acmpc_create when ctx is NULL). */
+const char* acmpc_last_error(const acmpc_ctx* ctx);
+
+/* Replaces: ControlSolver._update_references + _update_problem_bounds (control.py:26-33,47-70), i.e.
+ * SpatialBicycleModel.linearise (dynamics.py:65-103) and the corridor bounds, for P reference paths at once.
+ * `tables` is P consecutive 7 x n float64 ReferencePath arrays in the reference's row order
+ * [x, y, psi, kappa, ds, width, v] (control/paths.py:4-72).  Coefficients are computed in float64 on the host,
+ * stored as float32, and uploaded by the next device call.  No device work. */
+int acmpc_set_paths(acmpc_ctx* ctx, const double* tables, int32_t P, int32_t n);
+
+/* Copies the packed float32 table of problem `problem` (n rows of ACMPC_COEF_STRIDE_* floats) to `out`.
+ * Host only; lets CPU tests pin the host-side arithmetic against the oracle. */
+int acmpc_get_coefficients(const acmpc_ctx* ctx, int32_t problem, float* out, int32_t capacity_floats);
+
+/* Floats in one winner record: ACMPC_REC_HEADER + 2 n + 3 (n + 1) =
+ *   [cost, violation, n_feasible, owner, u_0 .. u_{n-1} (2 each), x_0 .. x_n (3 each)]
+ * x is (e_y, e_psi, t) in mode S and (X, Y, phi) in mode T.  The u / x blocks are what
+ * spatial_mpc.py:193-202 slices out of OSQP's dec.x ([x_0..x_n ; u_0..u_{n-1}], control.py:121-158). */
+int32_t acmpc_record_floats(int32_t n);
+
+/* Replaces: ControlSolver.solve (control.py:15-24) for host-resident inputs - one blocking call doing H2D,
+ * rollout + cost + argmin, and D2H.
+ *   x0        [P][3]   mode S: t2s(...) output (e_y, e_psi, t) (dynamics.py:23-40); mode T: pose (X, Y, phi)
+ *   U         control-sample matrix in `layout`
+ *   costs     [P][N] or NULL
+ *   best_idx  [P] index of the cheapest candidate (lowest index on ties; non-finite costs rank last)
+ *   records   [P][acmpc_record_floats(n)] or NULL
+ */
+int acmpc_solve(acmpc_ctx* ctx, const float* x0, const float* U, int32_t P, int32_t N, int32_t n,
+                int32_t layout, float* costs, int32_t* best_idx, float* records);
+
+/* Same work with every buffer already resident in device memory, asynchronous on `stream`
+ * (a hipStream_t, NULL = the null stream).  `d_keys` [P] receives the packed (cost, index) keys - see
+ * acmpc_rollout_device - and `d_records` [P][acmpc_record_floats(n)] the winner records. */
+int acmpc_solve_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, int32_t P, int32_t N, int32_t n,
+                       int32_t layout, float* d_costs, int64_t* d_keys, float* d_records, void* stream);
+
+/* Sharded form: each rank rolls out its own N candidates whose global indices start at
+ * `index_offset`, and gets per-problem keys
+ *     key = (ordered_int32(cost) << 32) | uint32(global index)
+ * that order like (cost, index) under signed 64-bit comparison, so ONE RCCL all-reduce(MIN) over `d_keys`
+ * yields the global argmin with lowest-index tie-breaking.  acmpc_finalize_device then writes the winner's
+ * record on the rank that owns it and zeros elsewhere (owner flag 0), plus every rank's feasible count, so an
+ * all-reduce(SUM) of the records gives every rank the selected controls. */
+int acmpc_rollout_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, int32_t P, int32_t N, int32_t n,
+                         int32_t layout, int64_t index_offset, float* d_costs, int64_t* d_keys, void* stream);
+int acmpc_finalize_device(acmpc_ctx* ctx, const int64_t* d_keys, const float* d_x0, const float* d_U, int32_t P,
+                          int32_t N, int32_t n, int32_t layout, int64_t index_offset, float* d_records,
+                          void* stream);
+
+/* Softmin-weighted mean control sequence, sum_c w_c U_c / sum_c w_c with w_c = exp(-(cost_c - min)/lambda)
+ * (the weighted-reduction form of localiser.py:572-579).  `d_costs` [P][N] and `d_keys` [P] come from a
+ * previous rollout; `d_mean` [P][n][2] (float32), `d_weight_sum` [P] (float64) or NULL.  Partial sums are
+ * combined in a fixed order: results are bitwise reproducible. */
+int acmpc_softmin_device(acmpc_ctx* ctx, const float* d_costs, const int64_t* d_keys, const float* d_U,
+                         int32_t P, int32_t N, int32_t n, int32_t layout, float* d_mean, double* d_weight_sum,
+                         void* stream);
+
+/* Uploads pending tables now (otherwise done by the next device call) and blocks until resident, so that a
+ * timed region contains no host-to-device traffic. */
+int acmpc_sync_tables(acmpc_ctx* ctx, void* stream);
+
+/* Key helpers (host side; same packing as the kernels). */
+int64_t acmpc_pack_key(float cost, uint32_t index);
+float acmpc_key_cost(int64_t key);
+uint32_t acmpc_key_index(int64_t key);
+
+/* Library identification: "acmpc-hip <version> gfx950". */
+const char* acmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACMPC_H */

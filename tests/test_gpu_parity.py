@@ -1,0 +1,121 @@
+"""HIP path vs the oracle through the C ABI (needs an MI355X: `pytest -m gpu`).
+
+Bar (BASELINE.json north_star): per-candidate costs within 1e-4, selected control within 1e-5, argmin index
+bit-identical.  The implementation is specified to be bit-identical to the oracle's float32 path, so the checks
+below assert exact equality, which is stronger.
+"""
+import numpy as np
+import pytest
+
+import acmpc_oracle as orc
+from test_support import engine_kwargs, make_problem
+
+pytestmark = pytest.mark.gpu
+
+LAYOUT_CM, LAYOUT_SM = 0, 1
+
+
+def _oracle(problem, coef, mode, states=False):
+    cfg = problem["cfg"]
+    args = (coef, problem["U"], cfg["step_cost"], cfg["r_term"], cfg["final_cost"], problem["u_lo"], problem["u_hi"],
+            1.0e6)
+    if mode == 0:
+        return orc.rollout_spatial(problem["x0"], *args, dtype=np.float32, return_states=states)
+    return orc.rollout_temporal(problem["pose0"], *args, 0.05, dtype=np.float32, return_states=states)
+
+
+def _engine(problems, mode, N, n):
+    from acmpc_amd import Engine
+    eng = Engine(**engine_kwargs(problems[0], mode, len(problems), N, n))
+    eng.set_paths(np.stack([p["table"] for p in problems]))
+    return eng
+
+
+def _as_layout(U, layout):
+    # U [P,N,n,2] -> requested layout
+    return U if layout == LAYOUT_CM else np.ascontiguousarray(U.transpose(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("layout", [LAYOUT_CM, LAYOUT_SM])
+@pytest.mark.parametrize("track,H,N,P", [
+    ("monza", 20, 128, 1),      # BASELINE config 1 shape
+    ("monza", 50, 4096, 1),     # config 2
+    ("spa", 50, 1000, 3),       # ragged N (not a multiple of 64), several problems
+    ("nordschleife", 80, 520, 2),
+    ("silverstone", 50, 1, 1),  # single candidate
+    ("monza", 50, 67, 5),
+])
+def test_costs_argmin_and_winner_record(mode, layout, track, H, N, P):
+    n = H - 1
+    if mode == 1 and N > 1024:
+        N = 1024  # the NumPy mode-T oracle is O(N n^2)
+    problems = [make_problem(orc, track, H, N, seed=10 * P + p) for p in range(P)]
+    eng = _engine(problems, mode, N, n)
+    x0 = np.stack([p["x0"] if mode == 0 else p["pose0"] for p in problems])
+    U = np.stack([p["U"] for p in problems])
+    out = eng.solve(x0, _as_layout(U, layout), layout=layout)
+    for p, prob in enumerate(problems):
+        coef = eng.coefficients(p)
+        cost, viol, X = _oracle(prob, coef, mode, states=True)[:3]
+        np.testing.assert_array_equal(out["costs"][p], cost, err_msg="per-candidate costs")
+        best, best_cost = orc.pick_best(cost)
+        assert out["best_idx"][p] == best
+        assert out["cost"][p] == np.float32(best_cost)
+        assert out["violation"][p] == viol[best]
+        assert out["n_feasible"][p] == np.count_nonzero(viol == 0)
+        assert out["owner"][p] == 1.0
+        np.testing.assert_array_equal(out["u"][p], prob["U"][best])
+        np.testing.assert_array_equal(out["x"][p], X[best])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_large_step_major_batch_uses_vector_loads(mode):
+    """P*N large enough for the 4-candidates-per-lane kernel; properties that need no O(N) oracle run:
+    the winner's cost equals min(costs), the record re-rolls to the same cost, and a sampled subset matches."""
+    H, N, P = 50, 8192, 40
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 8, seed=77 + p) for p in range(P)]
+    rng = np.random.default_rng(5)
+    u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems])
+    U = (u_ref[:, None] + rng.standard_normal((P, N, n, 2)) * np.array([2.0, 0.01])).astype(np.float32)
+    eng = _engine(problems, mode, N, n)
+    x0 = np.stack([p["x0"] if mode == 0 else p["pose0"] for p in problems])
+    out = eng.solve(x0, _as_layout(U, LAYOUT_SM), layout=LAYOUT_SM)
+    out_cm = eng.solve(x0, U, layout=LAYOUT_CM)
+    np.testing.assert_array_equal(out["costs"], out_cm["costs"])  # layout must not change a single bit
+    np.testing.assert_array_equal(out["best_idx"], out_cm["best_idx"])
+    for p in range(P):
+        best, best_cost = orc.pick_best(out["costs"][p])
+        assert out["best_idx"][p] == best and out["cost"][p] == np.float32(best_cost)
+        np.testing.assert_array_equal(out["u"][p], U[p, best])
+    sub = rng.choice(N, 256 if mode == 0 else 64, replace=False)
+    for p in (0, P - 1):
+        prob = dict(problems[p], U=U[p, sub])
+        cost = _oracle(prob, eng.coefficients(p), mode)[0]
+        np.testing.assert_array_equal(out["costs"][p, sub], cost)
+
+
+def test_nonfinite_costs_rank_last():
+    prob = make_problem(orc, "monza", 20, 64, seed=3)
+    prob["U"][5, 3, 0] = np.nan
+    prob["U"][9, 0, 1] = np.inf
+    eng = _engine([prob], 0, 64, 19)
+    out = eng.solve(prob["x0"][None], prob["U"][None])
+    cost = _oracle(prob, eng.coefficients(0), 0)[0]
+    assert not np.isfinite(out["costs"][0, 5]) and not np.isfinite(out["costs"][0, 9])
+    assert out["best_idx"][0] == orc.pick_best(cost)[0]
+    assert out["best_idx"][0] not in (5, 9)
+
+
+def test_capacity_and_state_errors():
+    from acmpc_amd import Engine, EngineError
+    prob = make_problem(orc, "monza", 20, 16, seed=1)
+    eng = Engine(**engine_kwargs(prob, 0, 1, 16, 19))
+    with pytest.raises(EngineError) as e:
+        eng.solve(prob["x0"][None], prob["U"][None])
+    assert e.value.code == -5  # ACMPC_ESTATE: no tables yet
+    eng.set_paths(prob["table"])
+    with pytest.raises(EngineError) as e:
+        eng.solve(prob["x0"][None], np.zeros((1, 32, 19, 2), np.float32))
+    assert e.value.code == -4  # ACMPC_ECAPACITY
