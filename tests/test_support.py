@@ -53,7 +53,8 @@ def local_path(H: int, seed: int, length: float = 150.0) -> np.ndarray:
 def make_problem(orc, track: str, H: int, N: int, seed: int, sigma=(2.0, 0.01)):
     """Returns dict(table, limits, weights, x0_spatial, pose0, U[N,n,2], u_lo, u_hi) for one problem."""
     cfg = RACING[track]
-    cons = cfg["speed_profile_constraints"]
+    # the control process overwrites v_max with the reference speed every tick (controller.py:241-243)
+    cons = dict(cfg["speed_profile_constraints"], v_max=float(cfg["unlocalised_max_speed"]))
     rng = np.random.default_rng(1000 + seed)
     coords = local_path(H, seed)
     table = orc.construct_waypoints(coords)
@@ -65,7 +66,8 @@ def make_problem(orc, track: str, H: int, N: int, seed: int, sigma=(2.0, 0.01)):
     x0 = orc.t2s(table[:3, 0], pose0)
     n = H - 1
     u_ref = np.stack([table[orc.ROW_V], table[orc.ROW_KAPPA]], axis=1)
-    U = u_ref[None] + rng.standard_normal((N, n, 2)) * np.asarray(sigma)
+    spread = rng.uniform(0.02, 1.0, (N, 1, 1))  # per-candidate noise scale: a mix of feasible and infeasible
+    U = u_ref[None] + rng.standard_normal((N, n, 2)) * np.asarray(sigma) * spread
     u_lo, u_hi = orc.input_box(limits)
     U = np.clip(U, u_lo, u_hi)
     if N > 3:  # a few candidates outside the box so that the violation branch is exercised
