@@ -216,11 +216,11 @@ class Engine:
     def rollout_device(self, d_x0: int, d_U: int, P: int, N: int, n: int, layout: int, index_offset: int,
                        d_costs: int, d_keys: int, stream: int = 0):
         self._check(self._lib.acmpc_rollout_device(self._ctx, d_x0, d_U, P, N, n, layout, index_offset,
-                                                   d_costs or None, d_keys, stream or None))
+                                                   d_costs or None, d_keys or None, stream or None))
 
     def finalize_device(self, d_keys: int, d_x0: int, d_U: int, P: int, N: int, n: int, layout: int,
                         index_offset: int, d_records: int, stream: int = 0):
-        self._check(self._lib.acmpc_finalize_device(self._ctx, d_keys, d_x0, d_U, P, N, n, layout, index_offset,
+        self._check(self._lib.acmpc_finalize_device(self._ctx, d_keys or None, d_x0, d_U, P, N, n, layout, index_offset,
                                                     d_records, stream or None))
 
     def softmin_device(self, d_costs: int, d_keys: int, d_U: int, P: int, N: int, n: int, layout: int, d_mean: int,

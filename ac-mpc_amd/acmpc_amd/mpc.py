@@ -1,0 +1,139 @@
+"""`SpatialMPC` and `build_mpc` with the reference's Python surface
+(/root/reference/src/acmpc/control/spatial_mpc.py:20-217, control/controller.py:19-29): same constructor, same
+`get_control(reference_path, is_localised=False, offset=0.0) -> None`, same read-after-call attributes
+(`projected_control`, `current_prediction`, `cum_time`, `times`, `accelerations`, `steer_rates`, `reference_path`,
+`speed_profile`, `infeasibility_counter`, `MPC_horizon`, `delta_max`, `model`, `speed_profile_constraints`), so it
+drops into the ACI control loop's `ControlProcess` unchanged.  The optimisation inside is the GPU
+rollout-and-cost engine (`sampling_solver.ControlSolver`) instead of OSQP.
+"""
+from __future__ import annotations
+
+import copy
+import logging
+import math
+from typing import Dict
+
+import numpy as np
+
+from .bicycle_model import SpatialBicycleModel, wrap_angle
+from .reference_path import ReferencePath
+from .sampling_solver import SOLVED, ControlSolver
+from .speed_profile import LocalisedSpeedProfileSolver, SpeedProfileSolver
+
+logger = logging.getLogger("acmpc_amd")
+
+MAX_SOLVER_ITERATIONS_MAP = 40000
+MAX_SOLVER_ITERATIONS = 4000
+
+
+def waypoint_table(waypoint_coordinates: np.ndarray, eps: float = 1e-12) -> np.ndarray:
+    """H x 3 `[x, y, width]` -> 7 x n table with n = H - 1 (what spatial_mpc.py:125-154 computes).
+
+    Heading and spacing come from the segment to the next point, the width is the next point's, curvature is
+    the wrapped heading change against the previous segment over the spacing.  The previous segment of point 0
+    closes the loop to the last point; its curvature is then replaced by point 1's, as the reference does."""
+    pts = np.asarray(waypoint_coordinates, dtype=np.float64)
+    xy = pts[:, :2]
+    n = len(pts) - 1
+    seg_ahead = xy[1:] - xy[:-1]
+    seg_behind = xy[:-1] - np.roll(xy, 1, axis=0)[:-1]
+    table = np.zeros((7, n))
+    table[0], table[1] = xy[:-1, 0], xy[:-1, 1]
+    table[2] = np.arctan2(seg_ahead[:, 1], seg_ahead[:, 0])
+    table[4] = np.linalg.norm(seg_ahead, axis=1)
+    table[5] = pts[1:, 2]
+    turn = wrap_angle(table[2] - np.arctan2(seg_behind[:, 1], seg_behind[:, 0]))
+    table[3] = turn / (table[4] + eps) + eps
+    table[3, 0] = table[3, 1]
+    return table
+
+
+class SpatialMPC:
+    def __init__(self, config: Dict, model: SpatialBicycleModel):
+        self.MPC_horizon = config["horizon"]
+        self.model = model
+        self.nx, self.nu = 3, 2
+        self._eps = 1e-12
+        self.speed_profile_constraints = config["speed_profile_constraints"]  # live dict, mutated by the caller
+        self.ay_max = self.speed_profile_constraints["ay_max"]
+        self.delta_max = model.delta_max
+        self.current_prediction = None
+        self.infeasibility_counter = 0
+        self.cum_time = np.zeros(1)
+        self.projected_control = np.zeros((self.nu, self.MPC_horizon))
+        solver_config = copy.deepcopy(config)
+        solver_config["max_iterations"] = MAX_SOLVER_ITERATIONS
+        self._control_solver = ControlSolver(solver_config, model)
+        profile_config = {
+            "control_horizon": self.MPC_horizon - 1,
+            "max_iterations": MAX_SOLVER_ITERATIONS,
+            "constraints": self.speed_profile_constraints,
+        }
+        self._speed_profile_solver = SpeedProfileSolver(profile_config)
+        self._localised_speed_profile_solver = LocalisedSpeedProfileSolver(profile_config)
+
+    # -- speed profiles -----------------------------------------------------------------------------------
+    def compute_map_speed_profile(self, reference_path: ReferencePath, ay_max: float, a_min: float) -> ReferencePath:
+        """Whole-lap profile at race start (spatial_mpc.py:60-87): own solver sized to the lap."""
+        constraints = copy.deepcopy(self.speed_profile_constraints)
+        constraints.update(a_min=a_min, ay_max=ay_max)
+        solver = SpeedProfileSolver({"control_horizon": len(reference_path),
+                                     "max_iterations": MAX_SOLVER_ITERATIONS_MAP, "constraints": constraints})
+        return self._compute_speed_profile(solver, reference_path)
+
+    def compute_speed_profile(self, reference_path: ReferencePath, is_localised: bool = False,
+                              end_vel=None) -> ReferencePath:
+        solver = self._localised_speed_profile_solver if is_localised else self._speed_profile_solver
+        return self._compute_speed_profile(solver, reference_path, end_vel)
+
+    def _compute_speed_profile(self, solver, reference_path: ReferencePath, end_vel=None) -> ReferencePath:
+        dec = solver.solve(reference_path, end_vel)
+        if dec.info.status == "solved":
+            reference_path.velocities = dec.x
+            self.speed_profile = dec.x
+        else:  # keep whatever velocities the path already carries (spatial_mpc.py:119-122)
+            logger.warning("Infeasible speed profile (%s); keeping previous velocities", dec.info.status)
+        return reference_path
+
+    # -- waypoints / prediction ---------------------------------------------------------------------------
+    def construct_waypoints(self, waypoint_coordinates: np.ndarray) -> ReferencePath:
+        return ReferencePath.from_table(waypoint_table(waypoint_coordinates, self._eps))
+
+    def update_prediction(self, spatial_state_prediction: np.ndarray, reference_path: ReferencePath) -> np.ndarray:
+        """Predicted Frenet states -> n x 2 Cartesian points (spatial_mpc.py:156-168)."""
+        return self.model.s2t(reference_path, spatial_state_prediction)[:-1].T
+
+    # -- the entry point ----------------------------------------------------------------------------------
+    def get_control(self, reference_path: np.ndarray, is_localised: bool = False, offset: float = 0.0):
+        """One MPC solve for an H x 3 reference path given in the vehicle frame (car at the origin, heading +y,
+        laterally displaced by `offset`).  Returns None; results are left in attributes."""
+        n = self.MPC_horizon - 1
+        path = self.construct_waypoints(reference_path)
+        path = self.compute_speed_profile(path, is_localised,
+                                          end_vel=self.speed_profile_constraints["end_velocity"])
+        spatial_state = self.model.t2s(path.get_state(0), np.array([offset, 0.0, math.pi / 2]))
+        dec = self._control_solver.solve(spatial_state, path)
+
+        if dec.info.status != SOLVED:
+            # keep the previous plan, count the failure (spatial_mpc.py:212-217)
+            logger.warning("Infeasible problem! Failed %d time(s).", self.infeasibility_counter)
+            self.infeasibility_counter += 1
+            return
+
+        controls = np.array(dec.x[-n * self.nu:]).reshape(n, self.nu)
+        self.projected_control = np.array([controls[:, 0], np.arctan(controls[:, 1] * self.model.length)])
+        states = np.reshape(dec.x[: n * self.nx], (n, self.nx))
+        self.current_prediction = self.update_prediction(states, path)
+        self.reference_path = path
+        self.cum_time = states[:, 2]
+        self.times = np.diff(states[:, 2])
+        self.accelerations = np.diff(states[:, 0]) / self.times
+        self.steer_rates = np.diff(states[:, 1]) / self.times
+        self.infeasibility_counter = 0
+
+
+def build_mpc(control_config: Dict, vehicle_data) -> SpatialMPC:
+    """Same factory as controller.py:19-29."""
+    limits = control_config["speed_profile_constraints"]
+    model = SpatialBicycleModel(vehicle_data, {"max": limits["v_max"], "min": limits["v_min"]})
+    return SpatialMPC(control_config, model)

@@ -1,0 +1,104 @@
+"""`ControlSolver` with the reference's seam - `solve(spatial_state, reference_path) -> obj` with `obj.x` laid out
+`[x_0 .. x_n ; u_0 .. u_{n-1}]` and `obj.info.status == "solved"` on success
+(/root/reference/src/acmpc/control/solvers/control.py:15-24, spatial_mpc.py:191-202) - but instead of assembling a
+sparse QP for OSQP it scores batches of candidate control sequences on the GPU: every candidate is rolled through
+the same linearised spatial bicycle model the QP has as equality rows, costed with the QP's own P, q and checked
+against the QP's own box rows (`csrc/acmpc_device.h`), and the cheapest one wins.
+
+A few refinement rounds (sample around the incumbent, shrink the spread) take the sampled optimum close to the QP
+optimum; the rounds, the candidate count and the spread are build parameters read from optional config keys
+(`n_candidates`, `sampling_rounds`, `sampling_sigma`, `sampling_seed`, `w_bound`).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict
+
+import numpy as np
+
+from . import _capi
+from .reference_path import ReferencePath
+
+SOLVED = "solved"
+INFEASIBLE = "primal infeasible"
+
+
+def smooth_basis(n: int, knots: int) -> np.ndarray:
+    """[n, knots] raised-cosine bumps: perturbations built from them are smooth along the horizon."""
+    centres = np.linspace(0.0, n - 1.0, knots)
+    width = (n - 1.0) / max(knots - 1, 1)
+    d = np.abs(np.arange(n)[:, None] - centres[None, :]) / width
+    return np.where(d < 1.0, 0.5 * (1.0 + np.cos(np.pi * d)), 0.0)
+
+
+class ControlSolver:
+    def __init__(self, config: Dict, model):
+        self._dynamics_model = model
+        self._n_horizon = config["horizon"] - 1
+        self._max_iterations = config.get("max_iterations", 4000)
+        self._n_candidates = int(config.get("n_candidates", 4096))
+        self._rounds = int(config.get("sampling_rounds", 4))
+        self._sigma = np.asarray(config.get("sampling_sigma", (3.0, 0.01)), dtype=np.float64)
+        self._rng = np.random.default_rng(config.get("sampling_seed", 0))
+        self._basis = smooth_basis(self._n_horizon, int(config.get("sampling_knots", 8)))
+        self._Q = np.asarray(config["step_cost"], dtype=np.float64)
+        self._R = np.asarray(config["r_term"], dtype=np.float64)
+        self._QN = np.asarray(config["final_cost"], dtype=np.float64)
+        self._w_bound = float(config.get("w_bound", 1.0e6))
+        self._incumbent = None
+        self._engine = None  # built on first solve: the input box follows the live velocity limits
+
+    # QP input box, widened by 0.1 m/s like the reference (control.py:130-139)
+    def _input_box(self):
+        lo = np.array([self._dynamics_model.min_u[0] - 0.1, self._dynamics_model.min_u[1]])
+        hi = np.array([self._dynamics_model.max_u[0] + 0.1, self._dynamics_model.max_u[1]])
+        return lo, hi
+
+    def _ensure_engine(self):
+        lo, hi = self._input_box()
+        if self._engine is None or not (np.array_equal(lo, self._box[0]) and np.array_equal(hi, self._box[1])):
+            if self._engine is not None:
+                self._engine.close()
+            self._box = (lo, hi)
+            self._engine = _capi.Engine(
+                mode=_capi.MODE_SPATIAL, max_problems=1, max_candidates=self._n_candidates,
+                max_steps=self._n_horizon, step_cost=self._Q, r_term=self._R, final_cost=self._QN, u_min=lo,
+                u_max=hi, margin=self._dynamics_model.margin, wheelbase=self._dynamics_model.length,
+                w_bound=self._w_bound)
+        return self._engine
+
+    def _sample(self, centre: np.ndarray, u_ref: np.ndarray, scale: float) -> np.ndarray:
+        N, n = self._n_candidates, self._n_horizon
+        lo, hi = self._box
+        z = self._rng.standard_normal((N, self._basis.shape[1], 2))
+        U = centre[None] + np.einsum("nk,ckd->cnd", self._basis, z) * (self._sigma * scale)
+        np.clip(U, lo, hi, out=U)
+        U[0] = centre
+        if N > 1:
+            U[1] = np.clip(u_ref, lo, hi)
+        return U.astype(np.float32)
+
+    def solve(self, spatial_state: np.ndarray, reference_path: ReferencePath) -> SimpleNamespace:
+        engine = self._ensure_engine()
+        n = self._n_horizon
+        engine.set_paths(reference_path.table)
+        u_ref = np.stack([reference_path.velocities, reference_path.kappas], axis=1)
+        centre = self._incumbent if self._incumbent is not None and self._incumbent.shape == u_ref.shape else u_ref
+        x0 = np.asarray(spatial_state, dtype=np.float32)[None]
+        best = None
+        for r in range(self._rounds):
+            U = self._sample(centre, u_ref, 0.5**r)
+            out = engine.solve(x0, U[None], layout=_capi.LAYOUT_CANDIDATE_MAJOR, want_costs=False)
+            if best is None or out["cost"][0] < best["cost"][0]:
+                best = out
+            centre = best["u"][0].astype(np.float64)
+        u_star = best["u"][0].astype(np.float64)
+        x_star = best["x"][0].astype(np.float64)
+        self._incumbent = u_star
+        # accept a residual bound violation the way the reference's solver does: within eps_abs + eps_rel * |z|
+        tolerance = 1e-3 + 1e-3 * max(np.abs(x_star).max(), np.abs(u_star).max())
+        violation = float(best["violation"][0])
+        status = SOLVED if violation <= n * tolerance**2 else INFEASIBLE
+        info = SimpleNamespace(status=status, obj_val=float(best["cost"][0]), violation=violation,
+                               n_feasible=int(best["n_feasible"][0]), iter=self._rounds)
+        return SimpleNamespace(x=np.concatenate([x_star.ravel(), u_star.ravel()]), info=info)

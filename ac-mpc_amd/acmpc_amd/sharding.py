@@ -1,0 +1,76 @@
+"""Multi-GPU form of one solve: candidates are independent, so each rank (one process per
+GPU) rolls out its own contiguous slice and the ranks meet once, in an all-reduce(MIN) over the per-problem packed
+(cost, global index) keys - RCCL over xGMI when the tensors live on the GPU (`backend="nccl"` is RCCL on ROCm),
+gloo on the CPU in tests.  The rank that owns the winning candidate then contributes its record (selected
+controls + predicted states) to an all-reduce(SUM) in which every other rank adds zeros, so the result is exact
+and every rank ends with the same plan.  Payloads are O(P) keys and O(P n) floats: latency-bound, so a single
+flat collective each, no ring pipelining or bucketing.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous slice [offset, offset + count) of `total` candidates owned by `rank`; the first
+    `total % world_size` ranks hold one extra."""
+    base, extra = divmod(total, world_size)
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def global_select(local_keys: torch.Tensor, make_records: Callable[[torch.Tensor], torch.Tensor],
+                  group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """local_keys: int64 [P], this rank's best key per problem.  Returns (global_keys [P], records [P, R]).
+
+    `make_records(global_keys)` must return this rank's [P, R] float32 records: the winner's record where this
+    rank owns the winning index, zeros elsewhere (column 2 always carries the local feasible count)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local_keys, op=dist.ReduceOp.MIN, group=group)
+        records = make_records(local_keys)
+        dist.all_reduce(records, op=dist.ReduceOp.SUM, group=group)
+    else:
+        records = make_records(local_keys)
+    return local_keys, records
+
+
+class ShardedRollout:
+    """Binds an `Engine` to this rank's slice of the candidates.  All tensors are torch CUDA tensors; the engine
+    is handed raw pointers and the current stream, RCCL runs on the same stream through torch.distributed."""
+
+    def __init__(self, engine, n_problems: int, n_local: int, n_steps: int, layout: int, index_offset: int,
+                 device: torch.device, group: Optional[dist.ProcessGroup] = None, want_costs: bool = True):
+        from ._capi import record_floats
+
+        self.engine, self.group = engine, group
+        self.P, self.N, self.n, self.layout, self.offset = n_problems, n_local, n_steps, layout, index_offset
+        self.keys = torch.empty(n_problems, dtype=torch.int64, device=device)
+        self.records = torch.empty(n_problems, record_floats(n_steps), dtype=torch.float32, device=device)
+        self.costs = torch.empty(n_problems, n_local, dtype=torch.float32, device=device) if want_costs else None
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def rollout(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
+        """The dominant kernel alone: controls in, costs and per-workgroup partial keys out."""
+        self.engine.rollout_device(x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n, self.layout, self.offset,
+                                   self.costs.data_ptr() if self.costs is not None else 0,
+                                   self.keys.data_ptr() if self.distributed else 0, stream)
+
+    def select(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
+        """argmin across workgroups (and across ranks), then the winner's record."""
+        if self.distributed:
+            dist.all_reduce(self.keys, op=dist.ReduceOp.MIN, group=self.group)
+            self.engine.finalize_device(self.keys.data_ptr(), x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n,
+                                        self.layout, self.offset, self.records.data_ptr(), stream)
+            dist.all_reduce(self.records, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.engine.finalize_device(0, x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n, self.layout,
+                                        self.offset, self.records.data_ptr(), stream)
+        return self.records
+
+    def step(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
+        self.rollout(x0, U, stream)
+        return self.select(x0, U, stream)

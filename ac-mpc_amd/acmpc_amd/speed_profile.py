@@ -1,0 +1,71 @@
+"""Curvature-limited reference speed for every waypoint - the interface of the reference's
+`SpeedProfileSolver` / `LocalisedSpeedProfileSolver` (/root/reference/src/acmpc/control/solvers/speed_profile.py).
+
+The problem is the reference's:  min 1/2 |v|^2 - v_hi'v  subject to
+    a_min <= (v[i+1] - v[i]) / (2 ds[i]) <= a_max        (speed_profile.py:47-51)
+    v_min <= v <= v_hi                                    (speed_profile.py:45)
+with v_hi the curvature-limited ceiling sqrt(ay_max / |kappa|) clipped to [v_min, v_max] plus 2 m/s, and the
+last entry forced to the end velocity (speed_profile.py:26-43).  It is solved on the host by `qp.solve_qp`
+instead of the `osqp` package.  `constraints` is held by reference: the control process rewrites its "v_max"
+every tick (controller.py:241-243) and the next solve must see it.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import qp
+from .reference_path import ReferencePath
+
+
+class SpeedProfileSolver:
+    def __init__(self, config: Dict):
+        self._n_horizon = config["control_horizon"]
+        self._max_iterations = config["max_iterations"]
+        self._constraints = config["constraints"]
+        self._eps = 1e-12
+        self._warm = None
+
+    # -- the QP's data ------------------------------------------------------------------------------------
+    def velocity_ceiling(self, reference_path: ReferencePath, end_velocity: Optional[float]) -> np.ndarray:
+        c = self._constraints
+        curvature = np.abs(reference_path.kappas)
+        ceiling = np.sqrt(c["ay_max"] / (curvature + self._eps))
+        ceiling[curvature < c["ki_min"]] = c["v_max"]
+        ceiling = np.maximum(c["v_min"], np.minimum(ceiling, c["v_max"])) + 2.0
+        if end_velocity is not None:
+            ceiling[-1] = end_velocity
+        return ceiling
+
+    def problem(self, reference_path: ReferencePath, end_velocity: Optional[float] = None) -> Dict:
+        """P (diagonal), q, A, l, u of the speed-profile QP."""
+        n = self._n_horizon
+        c = self._constraints
+        ceiling = self.velocity_ceiling(reference_path, end_velocity)
+        gain = 1.0 / (2.0 * reference_path.distances[:-1])
+        A = np.zeros((2 * n - 1, n))
+        rows = np.arange(n - 1)
+        A[rows, rows] = -gain
+        A[rows, rows + 1] = gain
+        A[n - 1 + np.arange(n), np.arange(n)] = 1.0
+        lower = np.concatenate([np.full(n - 1, float(c["a_min"])), np.full(n, float(c["v_min"]))])
+        upper = np.concatenate([np.full(n - 1, float(c["a_max"])), ceiling])
+        return dict(P_diag=np.ones(n), q=-ceiling, A=A, l=lower, u=upper, v_hi=ceiling)
+
+    def solve(self, reference_path: ReferencePath, end_velocity: Optional[float] = None) -> SimpleNamespace:
+        prob = self.problem(reference_path, end_velocity)
+        warm = self._warm if self._warm is not None and self._warm[0].shape == prob["q"].shape else (None, None)
+        result = qp.solve_qp(prob["P_diag"], prob["q"], prob["A"], prob["l"], prob["u"],
+                             max_iter=self._max_iterations, x0=warm[0], y0=warm[1])
+        if result.info.status == qp.SOLVED:
+            self._warm = (result.x, result.y)
+        return result
+
+
+class LocalisedSpeedProfileSolver(SpeedProfileSolver):
+    """Once localised the ceiling is the map-derived reference speed itself (speed_profile.py:131-150)."""
+
+    def velocity_ceiling(self, reference_path: ReferencePath, end_velocity: Optional[float]) -> np.ndarray:
+        return np.full(self._n_horizon, float(self._constraints["v_max"]))

@@ -1,0 +1,157 @@
+"""Synthetic inputs for benchmarks and tests.  The reference ships no maps, vehicle data or recordings (they
+are network assets, scripts/download_assets.sh), so circuits are seeded closed curves at the reference's map
+resolution (0.5 m, mapping/map_maker.py:203; 9.5 m wide, agent.py:288) with builder-supplied nominal lengths,
+and the per-track weights/constraints are the reference's `configs/<track>.yaml` `racing.control` blocks.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .mpc import waypoint_table
+from .reference_path import ReferencePath
+from .speed_profile import SpeedProfileSolver
+
+# nominal lap lengths [m] (builder-supplied, not from the reference) and generator seeds
+TRACKS = {"monza": (5793.0, 0), "spa": (7004.0, 1), "nordschleife": (25378.0, 2), "silverstone": (5891.0, 3)}
+
+# configs/<track>.yaml:67-81
+RACING_CONTROL = {
+    "monza": dict(horizon=50, unlocalised_max_speed=28,
+                  speed_profile_constraints=dict(v_min=8.0, v_max=84.0, a_min=-1.3, a_max=1.0, ay_max=5.5,
+                                                 ki_min=0.005, end_velocity=14.0),
+                  step_cost=[4.0e-3, 5.0e-2, 0.0], r_term=[1.0e-2, 10.0], final_cost=[1.0, 0.0, 0.1]),
+    "spa": dict(horizon=50, unlocalised_max_speed=8.0,
+                speed_profile_constraints=dict(v_min=5.0, v_max=84.0, a_min=-1.0, a_max=1.0, ay_max=4.0,
+                                               ki_min=0.003, end_velocity=20.0),
+                step_cost=[1.0e-3, 0.0, 0.0], r_term=[1.0e-2, 10.0], final_cost=[1.0, 0.0, 0.1]),
+    "nordschleife": dict(horizon=50, unlocalised_max_speed=20,
+                         speed_profile_constraints=dict(v_min=12.0, v_max=84.0, a_min=-1.0, a_max=1.0,
+                                                        ay_max=3.0, ki_min=0.0, end_velocity=14.0),
+                         step_cost=[2.0e-4, 0.0, 0.0], r_term=[1.0e-2, 10.0], final_cost=[1.0, 0.0, 0.1]),
+    "silverstone": dict(horizon=50, unlocalised_max_speed=32.0,
+                        speed_profile_constraints=dict(v_min=8.0, v_max=84.0, a_min=-1.0, a_max=1.0,
+                                                       ay_max=5.0, ki_min=0.003, end_velocity=20.0),
+                        step_cost=[2.0e-3, 5.0e-2, 0.0], r_term=[1.0e-2, 10.0], final_cost=[1.0, 0.0, 0.1]),
+}
+
+# placeholder vehicle (the reference's vehicle file is a network asset): wheelbase, width [m], max steer [rad]
+VEHICLE = SimpleNamespace(wheelbase=2.65, width=1.94, delta_max=0.30)
+
+BEV_LOOKAHEAD_M = 150.0      # perception/tracks.py:14
+CENTRELINE_POINTS = 500      # perception centreline length (controller.py:102-108)
+
+
+class PlaceholderVehicle:
+    """Duck-type of ace.steering.SteeringGeometry as the model uses it (dynamics.py:11-13)."""
+
+    def __init__(self, spec=VEHICLE):
+        self.vehicle_data = SimpleNamespace(wheelbase=spec.wheelbase, width=spec.width)
+        self._delta_max = spec.delta_max
+
+    def max_steering_angle(self) -> float:
+        return self._delta_max
+
+
+def synthetic_track(name: str, spacing: float = 0.5, width: float = 9.5) -> Dict[str, np.ndarray]:
+    """Closed circuit {centre, left, right} (each M x 2) in the format of utils/load.py:9-35."""
+    length, seed = TRACKS[name]
+    rng = np.random.default_rng(seed)
+    theta = np.linspace(0.0, 2 * np.pi, 20001)[:-1]
+    radius = np.ones_like(theta)
+    for k in range(2, 9):
+        radius += rng.uniform(0.02, 0.12) / (k - 1) * np.cos(k * theta + rng.uniform(0, 2 * np.pi))
+    curve = np.stack([1.35 * radius * np.cos(theta), radius * np.sin(theta)], axis=1)
+    closed = np.vstack([curve, curve[:1]])
+    arc = np.concatenate([[0.0], np.cumsum(np.linalg.norm(np.diff(closed, axis=0), axis=1))])
+    closed *= length / arc[-1]
+    arc *= length / arc[-1]
+    s = np.arange(0.0, length, spacing)
+    centre = np.stack([np.interp(s, arc, closed[:, 0]), np.interp(s, arc, closed[:, 1])], axis=1)
+    tangent = np.roll(centre, -1, axis=0) - np.roll(centre, 1, axis=0)
+    tangent /= np.linalg.norm(tangent, axis=1, keepdims=True)
+    normal = np.stack([-tangent[:, 1], tangent[:, 0]], axis=1)
+    return dict(centre=centre, left=centre + 0.5 * width * normal, right=centre - 0.5 * width * normal,
+                spacing=spacing)
+
+
+def local_centreline(track: Dict[str, np.ndarray], index: int, lateral_offset: float = 0.0) -> np.ndarray:
+    """The next 150 m of centreline seen from the pose at `index`, in the vehicle frame (car at the origin,
+    heading +y), resampled to 500 points - what perception publishes."""
+    centre = track["centre"]
+    count = int(round(BEV_LOOKAHEAD_M / track["spacing"])) + 1
+    window = centre[(index + np.arange(count)) % len(centre)]
+    heading = np.arctan2(*(window[1] - window[0])[::-1])
+    rot = np.pi / 2 - heading
+    c, s = np.cos(rot), np.sin(rot)
+    local = (window - window[0]) @ np.array([[c, s], [-s, c]])
+    local[:, 0] -= lateral_offset
+    t = np.linspace(0, count - 1, CENTRELINE_POINTS)
+    return np.stack([np.interp(t, np.arange(count), local[:, 0]), np.interp(t, np.arange(count), local[:, 1])],
+                    axis=1).astype(np.float32)
+
+
+def reference_path_from_centreline(centreline: np.ndarray, horizon: int) -> np.ndarray:
+    """500 x 2 centreline -> H x 3 path with widths linspace(10, 6, H) (controller.py:256-267)."""
+    stride = int(len(centreline) / horizon)
+    picked = centreline[0::stride]
+    return np.stack([picked[:, 0], picked[:, 1], np.linspace(10.0, 6.0, horizon)]).T
+
+
+def problem_batch(track_name: str, n_problems: int, horizon: int, seed: int = 0) -> SimpleNamespace:
+    """P poses spread round the circuit -> tables [P,7,n] (with a solved speed profile), Frenet start states
+    [P,3] (mode S), Cartesian poses [P,3] (mode T) and the model/weights they were built with."""
+    from .bicycle_model import SpatialBicycleModel
+
+    cfg = RACING_CONTROL[track_name]
+    # the control process overwrites v_max with the reference speed every tick (controller.py:241-243)
+    cons = dict(cfg["speed_profile_constraints"], v_max=float(cfg["unlocalised_max_speed"]))
+    model = SpatialBicycleModel(PlaceholderVehicle(), {"min": cons["v_min"], "max": cons["v_max"]})
+    track = synthetic_track(track_name)
+    rng = np.random.default_rng(seed)
+    n = horizon - 1
+    solver = SpeedProfileSolver({"control_horizon": n, "max_iterations": 4000, "constraints": cons})
+    tables = np.zeros((n_problems, 7, n))
+    x0 = np.zeros((n_problems, 3), dtype=np.float32)
+    pose0 = np.zeros((n_problems, 3), dtype=np.float32)
+    starts = (np.linspace(0, len(track["centre"]), n_problems, endpoint=False)).astype(int)
+    for p, index in enumerate(starts):
+        offset = float(rng.uniform(-0.5, 0.5))
+        coords = reference_path_from_centreline(local_centreline(track, int(index)), horizon)
+        path = ReferencePath.from_table(waypoint_table(coords))
+        dec = solver.solve(path, cons["end_velocity"])
+        path.velocities = dec.x if dec.info.status == "solved" else np.clip(
+            solver.velocity_ceiling(path, cons["end_velocity"]) - 2.0, cons["v_min"], cons["v_max"])
+        tables[p] = path.table
+        pose = np.array([offset, 0.0, np.pi / 2])
+        x0[p] = model.t2s(path.get_state(0), pose)
+        pose0[p] = pose
+    u_lo = np.array([model.min_u[0] - 0.1, model.min_u[1]])
+    u_hi = np.array([model.max_u[0] + 0.1, model.max_u[1]])
+    return SimpleNamespace(track=track_name, cfg=cfg, constraints=cons, model=model, tables=tables, x0=x0,
+                           pose0=pose0, u_lo=u_lo, u_hi=u_hi, n=n, horizon=horizon)
+
+
+def engine_kwargs(batch: SimpleNamespace, mode: int, max_candidates: int, **extra) -> Dict:
+    kw = dict(mode=mode, max_problems=batch.tables.shape[0], max_candidates=max_candidates, max_steps=batch.n,
+              step_cost=batch.cfg["step_cost"], r_term=batch.cfg["r_term"], final_cost=batch.cfg["final_cost"],
+              u_min=batch.u_lo, u_max=batch.u_hi, margin=batch.model.margin, wheelbase=batch.model.length,
+              t_min=0.01, dt=0.05, w_bound=1.0e6, softmin_lambda=0.5)
+    kw.update(extra)
+    return kw
+
+
+def sample_candidates(batch: SimpleNamespace, n_candidates: int, seed: int, sigma: Tuple[float, float] = (2.0, 0.01),
+                      layout: int = 0) -> np.ndarray:
+    """U = u_ref + sigma * N(0,1) clipped to the input box, candidate 0 = u_ref exactly.
+    Returned float32 as [P,N,n,2] (layout 0) or [P,n,2,N] (layout 1)."""
+    rng = np.random.default_rng(seed)
+    P, n = batch.tables.shape[0], batch.n
+    u_ref = np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2)  # [P,n,2]
+    U = u_ref[:, None] + rng.standard_normal((P, n_candidates, n, 2)) * np.asarray(sigma)
+    np.clip(U, batch.u_lo, batch.u_hi, out=U)
+    U[:, 0] = np.clip(u_ref, batch.u_lo, batch.u_hi)
+    U = U.astype(np.float32)
+    return U if layout == 0 else np.ascontiguousarray(U.transpose(0, 2, 3, 1))

@@ -329,7 +329,7 @@ int acmpc_sync_tables(acmpc_ctx* c, void* stream) {
 int acmpc_rollout_device(acmpc_ctx* c, const float* d_x0, const float* d_U, int32_t P, int32_t N, int32_t n,
                          int32_t layout, int64_t index_offset, float* d_costs, int64_t* d_keys, void* stream) {
   if (c == nullptr) return ACMPC_EINVAL;
-  if (d_x0 == nullptr || d_U == nullptr || d_keys == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (d_x0 == nullptr || d_U == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
   if (index_offset < 0 || index_offset + N > 0xffffffffLL) return fail(c, ACMPC_EINVAL, "global index exceeds 32 bits");
   int rc = check_shape(c, P, N, n, layout);
   if (rc != ACMPC_OK) return rc;
@@ -340,7 +340,7 @@ int acmpc_rollout_device(acmpc_ctx* c, const float* d_x0, const float* d_U, int3
   if (rc != ACMPC_OK) return rc;
   acmpc::LaunchShape shape;
   rc = rollout(c, d_x0, d_U, P, N, n, layout, index_offset, d_costs, s, &shape);
-  if (rc != ACMPC_OK) return rc;
+  if (rc != ACMPC_OK || d_keys == nullptr) return rc;
   return finalize(c, nullptr, d_keys, d_x0, d_U, P, N, n, layout, index_offset, nullptr, shape.blocks_per_problem, s);
 }
 
@@ -348,8 +348,7 @@ int acmpc_finalize_device(acmpc_ctx* c, const int64_t* d_keys, const float* d_x0
                           int32_t N, int32_t n, int32_t layout, int64_t index_offset, float* d_records,
                           void* stream) {
   if (c == nullptr) return ACMPC_EINVAL;
-  if (d_keys == nullptr || d_x0 == nullptr || d_U == nullptr || d_records == nullptr)
-    return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (d_x0 == nullptr || d_U == nullptr || d_records == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
   int rc = check_shape(c, P, N, n, layout);
   if (rc != ACMPC_OK) return rc;
   if (!c->device_ready) return fail(c, ACMPC_ESTATE, "acmpc_rollout_device must run first");

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Benchmark of the rollout-and-cost hot path (contract: see the task statement / DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM: P poses round
+the synthetic Monza circuit x 4 096 candidate control sequences x horizon 50 (BASELINE.json configs[1], batched
+over poses so that one launch fills the GPU), i.e. rollout through the bicycle model + per-step cost + argmin +
+winner record for every pose.  With N > 1 every rank (one process per GPU) evaluates its own 4 096 candidates of
+every pose (weak scaling) and the ranks meet in one RCCL all-reduce(MIN) of the packed (cost, index) keys plus the
+all-reduce(SUM) that distributes the winners' records.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ac-mpc_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--track", default="monza", choices=["monza", "spa", "nordschleife", "silverstone"])
+    ap.add_argument("--horizon", type=int, default=50)
+    ap.add_argument("--candidates", type=int, default=4096, help="candidates per pose per GPU")
+    ap.add_argument("--poses", type=int, default=256, help="independent solves batched into one launch")
+    ap.add_argument("--mode", default="S", choices=["S", "T"], help="S: spatial bicycle model, T: Cartesian + NN search")
+    ap.add_argument("--layout", type=int, default=1, help="0: U[P][N][n][2], 1: U[P][n][2][N]")
+    ap.add_argument("--buffers", type=int, default=2, help="distinct control matrices cycled through (HBM-cold reads)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--single-solve", action="store_true", help="also time one 4096-candidate solve per launch")
+    return ap.parse_args()
+
+
+def make_controls(batch, P, N, n, layout, device, seed):
+    """u_ref + sigma * N(0,1), clipped to the input box, candidate 0 = u_ref, generated on
+    the device with a seeded generator so no 400 MB host buffer is needed."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    u_ref = torch.tensor(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=torch.float32,
+                         device=device)  # [P,n,2]
+    lo = torch.tensor(batch.u_lo, dtype=torch.float32, device=device)
+    hi = torch.tensor(batch.u_hi, dtype=torch.float32, device=device)
+    sigma = torch.tensor([2.0, 0.01], dtype=torch.float32, device=device)
+    if layout == 1:
+        U = torch.randn(P, n, 2, N, generator=g, device=device, dtype=torch.float32)
+        U = U * sigma.view(1, 1, 2, 1) + u_ref.view(P, n, 2, 1)
+        U = torch.maximum(torch.minimum(U, hi.view(1, 1, 2, 1)), lo.view(1, 1, 2, 1))
+        U[:, :, :, 0] = torch.maximum(torch.minimum(u_ref, hi), lo)
+    else:
+        U = torch.randn(P, N, n, 2, generator=g, device=device, dtype=torch.float32)
+        U = U * sigma + u_ref.view(P, 1, n, 2)
+        U = torch.maximum(torch.minimum(U, hi), lo)
+        U[:, 0] = torch.maximum(torch.minimum(u_ref, hi), lo)
+    return U.contiguous()
+
+
+def cpu_baseline(batch, mode, U_dev, layout, N, n, gpu_costs, seconds):
+    """The oracle's C restatement (oracle/acmpc_oracle.c, OpenMP over candidates) timed on this box's host cores
+    on a bounded sample of the same workload: the first poses of the batch, repeated until ~`seconds` of CPU
+    work.  Also re-checks parity of the sample (costs bit-identical to the GPU's)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    sample = min(8, U_dev.shape[0])
+    U = U_dev[:sample].cpu().numpy()
+    cfg = batch.cfg
+    w = c_oracle.make_weights(cfg["step_cost"], cfg["r_term"], cfg["final_cost"], batch.u_lo, batch.u_hi, 1.0e6)
+    x0 = batch.x0 if mode == 0 else batch.pose0
+
+    def one_pass(check):
+        for p in range(sample):
+            cost, _ = c_oracle.rollout(mode, x0[p], batch.coef_host[p], U[p], layout, w)
+            c_oracle.argmin(cost)
+            if check and not np.array_equal(cost, gpu_costs[p]):
+                raise SystemExit("bench: GPU costs differ from the oracle on pose %d" % p)
+
+    one_pass(check=True)
+    t0 = time.perf_counter()
+    one_pass(check=False)
+    probe = time.perf_counter() - t0
+    repeats = max(1, int(seconds / max(probe, 1e-6)))
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        one_pass(check=False)
+    elapsed = time.perf_counter() - t0
+    return {
+        "value": sample * N * repeats / elapsed,
+        "unit": "candidate-trajectories/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d poses x %d candidates x horizon %d of the same batch, %d passes, %.1f s; oracle/acmpc_oracle.c "
+                  "(gcc -O2, OpenMP over candidates), costs checked bit-identical to the GPU's" %
+                  (sample, N, n + 1, repeats, elapsed),
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
+              file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench: no GPU visible - the rollout path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from acmpc_amd import Engine, workloads
+    from acmpc_amd.sharding import ShardedRollout
+
+    mode = 0 if args.mode == "S" else 1
+    P, N, H = args.poses, args.candidates, args.horizon
+    n = H - 1
+    batch = workloads.problem_batch(args.track, P, H, seed=0)
+    engine = Engine(**workloads.engine_kwargs(batch, mode, N, device=local_rank))
+    engine.set_paths(batch.tables)
+    batch.coef_host = [engine.coefficients(p) for p in range(min(8, P))]
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.sync_tables(stream)
+    x0 = torch.tensor(batch.x0 if mode == 0 else batch.pose0, device=device)
+    # every rank draws its own candidates (different seed); global index = rank * N + local index
+    controls = [make_controls(batch, P, N, n, args.layout, device, seed=1000 * b + rank) for b in range(args.buffers)]
+    shard = ShardedRollout(engine, P, N, n, args.layout, index_offset=rank * N, device=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        shard.step(x0, controls[i % args.buffers], stream)
+    barrier()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        U = controls[i % args.buffers]
+        starts[i].record()          # HIP events on the stream the kernel is launched on
+        shard.rollout(x0, U, stream)
+        stops[i].record()
+        shard.select(x0, U, stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, stops)]))
+
+    if rank == 0:
+        algorithmic_bytes = P * N * (8 * n + 4)  # 8n B of controls read + 4 B of cost written
+        achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+        total_candidates = P * N * world
+        out = {
+            "metric": "candidate-trajectories/sec (horizon=%d)" % H,
+            "value": total_candidates * args.steps / elapsed,
+            "unit": "candidate-trajectories/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s (synthetic circuit): %d candidates x horizon %d per solve per GPU, %d solves (poses) "
+                            "batched per launch; mode %s rollout + cost + argmin + winner record"
+                            % (args.track, N, H, P, args.mode),
+                "candidates_per_solve_per_gpu": N, "solves_per_step": P, "horizon": H, "mode": args.mode,
+                "layout": "U[P][n][2][N]" if args.layout == 1 else "U[P][N][n][2]",
+                "parallelism": "candidate-sharded x%d" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            gpu_costs = shard.costs[:8].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
+            out["cpu_baseline"] = cpu_baseline(batch, mode, controls[(args.steps - 1) % args.buffers], args.layout, N,
+                                               n, gpu_costs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

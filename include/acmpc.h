@@ -135,7 +135,9 @@ int acmpc_solve_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, int3
  * that order like (cost, index) under signed 64-bit comparison, so ONE RCCL all-reduce(MIN) over `d_keys`
  * yields the global argmin with lowest-index tie-breaking.  acmpc_finalize_device then writes the winner's
  * record on the rank that owns it and zeros elsewhere (owner flag 0), plus every rank's feasible count, so an
- * all-reduce(SUM) of the records gives every rank the selected controls. */
+ * all-reduce(SUM) of the records gives every rank the selected controls.
+ * `d_keys` may be NULL in both calls on a single GPU: the rollout then leaves its per-workgroup partial keys in
+ * the handle and the finalize step reduces those itself (two launches in total - what acmpc_solve_device does). */
 int acmpc_rollout_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, int32_t P, int32_t N, int32_t n,
                          int32_t layout, int64_t index_offset, float* d_costs, int64_t* d_keys, void* stream);
 int acmpc_finalize_device(acmpc_ctx* ctx, const int64_t* d_keys, const float* d_x0, const float* d_U, int32_t P,

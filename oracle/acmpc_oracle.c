@@ -1,0 +1,180 @@
+/*
+ * acmpc_oracle.c - scalar C restatement of the sampling composition (TEST INFRASTRUCTURE ONLY).
+ *
+ * Same float32 "spec order" as oracle/acmpc_oracle.py (rollout_spatial / rollout_temporal): one fixed
+ * association, no FMA contraction (-ffp-contract=off), no libm transcendentals in the rollouts.  It exists to
+ * (a) cross-check the NumPy oracle bit-for-bit at sizes NumPy finishes slowly, and (b) serve as the CPU baseline
+ * ("port") that bench.py times beside the GPU.  Nothing under ac-mpc_amd/ links or loads it.
+ *
+ * Reference arithmetic restated (paths relative to /root/reference/src/acmpc/):
+ *   step_spatial  : x_{i+1} = A_i x_i + B_i (u_i - u_ref_i) + f_i     control/dynamics.py:65-103,
+ *                   cost 1/2 (x'Qx + du'R du), bounds                  control/solvers/control.py:26-79,121-158
+ *   step_temporal : kinematic Euler step                               localisation/localiser.py:66-95
+ *                   nearest waypoint (first minimum)                   localisation/localiser.py:282-289
+ *                   Frenet errors                                      control/dynamics.py:23-40
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp -shared)
+ */
+#include <math.h>
+#include <stdint.h>
+
+#define CS 12 /* floats per mode-S row: ds, a21, a31, b31, f3, v_ref, k_ref, ey_lo, ey_hi, 0, 0, 0 */
+#define CT 8  /* floats per mode-T row: x, y, cos psi, sin psi, psi, k_ref, v_ref, w/2 - margin    */
+
+typedef struct {
+  float q[3], r[2], qn[3], ulo[2], uhi[2], tmin, wbound, dt;
+} oracle_weights;
+
+static inline float quad(float w, float a) { return (w * a) * a; }
+
+static inline float hinge2(float lo_minus_x, float x_minus_hi) {
+  const float v = fmaxf(lo_minus_x, 0.0f) + fmaxf(x_minus_hi, 0.0f);
+  return v * v;
+}
+
+static inline void fetch(const float* U, int layout, int64_t N, int n, int64_t c, int i, float* v, float* k) {
+  if (layout == 0) { /* U[N][n][2] */
+    const float* p = U + (c * n + i) * 2;
+    *v = p[0];
+    *k = p[1];
+  } else { /* U[n][2][N] */
+    *v = U[((int64_t)i * 2) * N + c];
+    *k = U[((int64_t)i * 2 + 1) * N + c];
+  }
+}
+
+/* costs[N], viol[N]; states (optional) [N][n+1][3].  Returns nothing; threads over candidates. */
+void acmpc_oracle_rollout_spatial(const float* x0, const float* coef, const float* U, int layout, int64_t N, int n,
+                                  const oracle_weights* w, float* costs, float* viol, float* states) {
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < N; ++c) {
+    float ey = x0[0], ep = x0[1], t = x0[2], J = 0.0f, V = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      const float* k_ = coef + (int64_t)i * CS;
+      float v, k;
+      fetch(U, layout, N, n, c, i, &v, &k);
+      if (states) {
+        float* s = states + (c * (n + 1) + i) * 3;
+        s[0] = ey, s[1] = ep, s[2] = t;
+      }
+      const float dv = v - k_[5];
+      const float dk = k - k_[6];
+      float a = quad(w->q[0], ey);
+      a = a + quad(w->q[1], ep);
+      a = a + quad(w->q[2], t);
+      float r = quad(w->r[0], dv);
+      r = r + quad(w->r[1], dk);
+      J = J + 0.5f * (a + r);
+      V = V + hinge2(w->ulo[0] - v, v - w->uhi[0]);
+      V = V + hinge2(w->ulo[1] - k, k - w->uhi[1]);
+      const float ey_n = ey + k_[0] * ep;
+      const float ep_n = (ep + k_[1] * ey) + k_[0] * dk;
+      const float t_n = ((t + k_[2] * ey) + k_[3] * dv) + k_[4];
+      ey = ey_n, ep = ep_n, t = t_n;
+      V = V + hinge2(k_[7] - ey, ey - k_[8]);
+      const float tv = fmaxf(w->tmin - t, 0.0f);
+      V = V + tv * tv;
+    }
+    if (states) {
+      float* s = states + (c * (n + 1) + n) * 3;
+      s[0] = ey, s[1] = ep, s[2] = t;
+    }
+    float a = quad(w->qn[0], ey);
+    a = a + quad(w->qn[1], ep);
+    a = a + quad(w->qn[2], t);
+    J = J + 0.5f * a;
+    costs[c] = J + w->wbound * V;
+    viol[c] = V;
+  }
+}
+
+static inline void sincos_spec(float phi, float* sn, float* cs) {
+  const float k = rintf(phi * 0.6366197723675814f);
+  const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
+  const float r2 = r * r;
+  float ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
+  ps = -1.6666654611e-1f + r2 * ps;
+  const float s = r + (r * r2) * ps;
+  float pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
+  pc = 4.166664568298827e-2f + r2 * pc;
+  const float c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
+  const int q = (int)k & 3;
+  *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+  *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+
+static inline float wrap_spec(float a) {
+  const float b = a + 3.14159265358979f;
+  const float q = floorf(b * 0.159154943091895f);
+  return (b - q * 6.28318530717959f) - 3.14159265358979f;
+}
+
+void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const float* U, int layout, int64_t N, int n,
+                                   const oracle_weights* w, float* costs, float* viol, float* states) {
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < N; ++c) {
+    float X = pose0[0], Y = pose0[1], phi = pose0[2], ey = 0.0f, ep = 0.0f, J = 0.0f, V = 0.0f;
+    if (states) {
+      float* s = states + c * (n + 1) * 3;
+      s[0] = X, s[1] = Y, s[2] = phi;
+    }
+    for (int i = 0; i < n; ++i) {
+      float v, k, sn, cs;
+      fetch(U, layout, N, n, c, i, &v, &k);
+      sincos_spec(phi, &sn, &cs);
+      const float Xn = X + (v * cs) * w->dt;
+      const float Yn = Y + (v * sn) * w->dt;
+      const float phin = phi + (v * k) * w->dt;
+      X = Xn, Y = Yn, phi = phin;
+      float best = INFINITY;
+      int j = 0;
+      for (int m = 0; m < n; ++m) {
+        const float dx = X - wp[m * CT + 0];
+        const float dy = Y - wp[m * CT + 1];
+        const float d = dx * dx + dy * dy;
+        if (d < best) {
+          best = d;
+          j = m;
+        }
+      }
+      const float* g = wp + j * CT;
+      ey = g[2] * (Y - g[1]) - g[3] * (X - g[0]);
+      ep = wrap_spec(phi - g[4]);
+      const float dv = v - g[6];
+      const float dk = k - g[5];
+      float a = quad(w->q[0], ey);
+      a = a + quad(w->q[1], ep);
+      float r = quad(w->r[0], dv);
+      r = r + quad(w->r[1], dk);
+      J = J + 0.5f * (a + r);
+      V = V + hinge2(w->ulo[0] - v, v - w->uhi[0]);
+      V = V + hinge2(w->ulo[1] - k, k - w->uhi[1]);
+      V = V + hinge2((-g[7]) - ey, ey - g[7]);
+      if (states) {
+        float* s = states + (c * (n + 1) + i + 1) * 3;
+        s[0] = X, s[1] = Y, s[2] = phi;
+      }
+    }
+    const float tN = (float)n * w->dt;
+    float a = quad(w->qn[0], ey);
+    a = a + quad(w->qn[1], ep);
+    a = a + quad(w->qn[2], tN);
+    J = J + 0.5f * a;
+    costs[c] = J + w->wbound * V;
+    viol[c] = V;
+  }
+}
+
+/* first minimum; non-finite costs rank as +inf */
+int64_t acmpc_oracle_argmin(const float* costs, int64_t N) {
+  int64_t best = 0;
+  float bc = INFINITY;
+  for (int64_t c = 0; c < N; ++c) {
+    const float v = isfinite(costs[c]) ? costs[c] : INFINITY;
+    if (v < bc) {
+      bc = v;
+      best = c;
+    }
+  }
+  return best;
+}

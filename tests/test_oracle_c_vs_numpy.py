@@ -1,0 +1,37 @@
+"""The two restatements of the sampling composition (NumPy and C) must agree bit-for-bit (not GPU)."""
+import numpy as np
+import pytest
+
+import acmpc_oracle as orc
+import c_oracle
+from test_support import make_problem
+
+
+@pytest.mark.parametrize("track,H,N", [("monza", 20, 128), ("monza", 50, 777), ("nordschleife", 80, 300)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_c_matches_numpy(track, H, N, mode):
+    prob = make_problem(orc, track, H, N, seed=H + N)
+    cfg = prob["cfg"]
+    w = c_oracle.make_weights(cfg["step_cost"], cfg["r_term"], cfg["final_cost"], prob["u_lo"], prob["u_hi"], 1.0e6)
+    args = (prob["U"], cfg["step_cost"], cfg["r_term"], cfg["final_cost"], prob["u_lo"], prob["u_hi"], 1.0e6)
+    if mode == 0:
+        coef = orc.coefficients_spatial(prob["table"], prob["limits"].margin)
+        want = orc.rollout_spatial(prob["x0"], coef, *args, dtype=np.float32, return_states=True)
+        x0 = prob["x0"]
+    else:
+        coef = orc.coefficients_temporal(prob["table"], prob["limits"].margin)
+        want = orc.rollout_temporal(prob["pose0"], coef, *args, 0.05, dtype=np.float32, return_states=True)
+        x0 = prob["pose0"]
+    for layout in (0, 1):
+        U = prob["U"] if layout == 0 else np.ascontiguousarray(prob["U"].transpose(1, 2, 0))
+        cost, viol, states = c_oracle.rollout(mode, x0, coef, U, layout, w, return_states=True)
+        np.testing.assert_array_equal(cost, want[0])
+        np.testing.assert_array_equal(viol, want[1])
+        np.testing.assert_array_equal(states, want[2])
+    assert c_oracle.argmin(want[0]) == orc.pick_best(want[0])[0]
+
+
+def test_argmin_first_minimum_and_nonfinite():
+    c = np.array([3.0, np.nan, 1.0, 1.0, np.inf, -np.inf], dtype=np.float32)
+    assert orc.pick_best(c)[0] == 2 and c_oracle.argmin(c) == 2
+    assert orc.pick_best(np.array([np.nan, np.inf], dtype=np.float32))[0] == 0
