@@ -77,9 +77,10 @@ def synthetic_track(name: str, spacing: float = 0.5, width: float = 9.5) -> Dict
                 spacing=spacing)
 
 
-def local_centreline(track: Dict[str, np.ndarray], index: int, lateral_offset: float = 0.0) -> np.ndarray:
+def local_centreline(track: Dict[str, np.ndarray], index: int, lateral_offset: float = 0.0,
+                     points: int = CENTRELINE_POINTS) -> np.ndarray:
     """The next 150 m of centreline seen from the pose at `index`, in the vehicle frame (car at the origin,
-    heading +y), resampled to 500 points - what perception publishes."""
+    heading +y), resampled to `points` (500) points - what perception publishes."""
     centre = track["centre"]
     count = int(round(BEV_LOOKAHEAD_M / track["spacing"])) + 1
     window = centre[(index + np.arange(count)) % len(centre)]
@@ -88,15 +89,18 @@ def local_centreline(track: Dict[str, np.ndarray], index: int, lateral_offset: f
     c, s = np.cos(rot), np.sin(rot)
     local = (window - window[0]) @ np.array([[c, s], [-s, c]])
     local[:, 0] -= lateral_offset
-    t = np.linspace(0, count - 1, CENTRELINE_POINTS)
+    t = np.linspace(0, count - 1, points)
     return np.stack([np.interp(t, np.arange(count), local[:, 0]), np.interp(t, np.arange(count), local[:, 1])],
                     axis=1).astype(np.float32)
 
 
 def reference_path_from_centreline(centreline: np.ndarray, horizon: int) -> np.ndarray:
-    """500 x 2 centreline -> H x 3 path with widths linspace(10, 6, H) (controller.py:256-267)."""
+    """500 x 2 centreline -> H x 3 path with widths linspace(10, 6, H) (controller.py:256-267).  Like the
+    reference this needs len(centreline)/horizon rows to come out at exactly H (true for its horizons 50, 100)."""
     stride = int(len(centreline) / horizon)
     picked = centreline[0::stride]
+    if len(picked) != horizon:
+        raise ValueError("a %d-point centreline does not downsample to horizon %d" % (len(centreline), horizon))
     return np.stack([picked[:, 0], picked[:, 1], np.linspace(10.0, 6.0, horizon)]).T
 
 
@@ -119,7 +123,9 @@ def problem_batch(track_name: str, n_problems: int, horizon: int, seed: int = 0)
     starts = (np.linspace(0, len(track["centre"]), n_problems, endpoint=False)).astype(int)
     for p, index in enumerate(starts):
         offset = float(rng.uniform(-0.5, 0.5))
-        coords = reference_path_from_centreline(local_centreline(track, int(index)), horizon)
+        # horizons that do not divide 500 (e.g. 80) get the nearest centreline length that does downsample
+        points = horizon * (CENTRELINE_POINTS // horizon)
+        coords = reference_path_from_centreline(local_centreline(track, int(index), points=points), horizon)
         path = ReferencePath.from_table(waypoint_table(coords))
         dec = solver.solve(path, cons["end_velocity"])
         path.velocities = dec.x if dec.info.status == "solved" else np.clip(

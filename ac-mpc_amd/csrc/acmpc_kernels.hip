@@ -214,35 +214,39 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   if (a.records == nullptr) return;
 
   const int rec_floats = 4 + 2 * n + 3 * (n + 1);
-  float* __restrict__ rec = a.records + static_cast<size_t>(p) * rec_floats;
+  float* rec = a.records + static_cast<size_t>(p) * rec_floats;
   const int64_t local = static_cast<int64_t>(static_cast<uint32_t>(key & 0xffffffffLL)) - a.index_offset;
   const bool owner = local >= 0 && local < a.N;
   if (!owner) {
     for (int e = lane; e < rec_floats; e += kWave) rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
     return;
   }
-  if (lane != 0) return;
-
-  // re-roll the winner with the very same step functions; store u and every state
+  // All lanes fetch the winner's controls at once (one pass of parallel loads instead of n dependent ones) and
+  // park them in the record; lane 0 then re-rolls the candidate from there with the very same step functions.
   const Weights w = a.w;
   constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
   const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
   const int c = static_cast<int>(local);
-  float* __restrict__ ru = rec + 4;
-  float* __restrict__ rx = rec + 4 + 2 * n;
+  float* ru = rec + 4;
+  float* rx = rec + 4 + 2 * n;
+  for (int i = lane; i < n; i += kWave) {
+    float v[1], k[1];
+    load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, v, k);
+    ru[2 * i] = v[0];
+    ru[2 * i + 1] = k[0];
+  }
+  __syncthreads();  // one wave: orders the record stores above before lane 0's loads below
+  if (lane != 0) return;
+
   float cost, viol;
   if constexpr (MODE == 0) {
     StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
     for (int i = 0; i < n; ++i) {
-      float v[1], k[1];
-      load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, v, k);
-      ru[2 * i] = v[0];
-      ru[2 * i + 1] = k[0];
       rx[3 * i] = st.ey;
       rx[3 * i + 1] = st.ep;
       rx[3 * i + 2] = st.t;
-      step_spatial(st, coef + i * kCoefS, v[0], k[0], w);
+      step_spatial(st, coef + i * kCoefS, ru[2 * i], ru[2 * i + 1], w);
     }
     rx[3 * n] = st.ey;
     rx[3 * n + 1] = st.ep;
@@ -255,11 +259,7 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
     rx[1] = st.Y;
     rx[2] = st.phi;
     for (int i = 0; i < n; ++i) {
-      float v[1], k[1];
-      load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, v, k);
-      ru[2 * i] = v[0];
-      ru[2 * i + 1] = k[0];
-      step_temporal(st, coef, n, v[0], k[0], w);
+      step_temporal(st, coef, n, ru[2 * i], ru[2 * i + 1], w);
       rx[3 * (i + 1)] = st.X;
       rx[3 * (i + 1) + 1] = st.Y;
       rx[3 * (i + 1) + 2] = st.phi;

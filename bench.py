@@ -78,8 +78,9 @@ def cpu_baseline(batch, mode, U_dev, layout, N, n, gpu_costs, seconds):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
 
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # the one-GPU box gives this job 16 host cores; never more threads than cores we may run on
+    cores = min(16, len(os.sched_getaffinity(0)))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     sample = min(8, U_dev.shape[0])
     U = U_dev[:sample].cpu().numpy()
     cfg = batch.cfg
@@ -94,13 +95,11 @@ def cpu_baseline(batch, mode, U_dev, layout, N, n, gpu_costs, seconds):
                 raise SystemExit("bench: GPU costs differ from the oracle on pose %d" % p)
 
     one_pass(check=True)
+    repeats = 0
     t0 = time.perf_counter()
-    one_pass(check=False)
-    probe = time.perf_counter() - t0
-    repeats = max(1, int(seconds / max(probe, 1e-6)))
-    t0 = time.perf_counter()
-    for _ in range(repeats):
+    while time.perf_counter() - t0 < seconds:
         one_pass(check=False)
+        repeats += 1
     elapsed = time.perf_counter() - t0
     return {
         "value": sample * N * repeats / elapsed,
