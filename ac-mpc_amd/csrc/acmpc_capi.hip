@@ -215,8 +215,8 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
     return fail(nullptr, ACMPC_EINVAL, "unknown mode");
   if (params->max_problems < 1 || params->max_candidates < 1 || params->max_steps < 1)
     return fail(nullptr, ACMPC_EINVAL, "capacities must be positive");
-  if (params->mode == ACMPC_MODE_TEMPORAL && params->max_steps > 4096)
-    return fail(nullptr, ACMPC_EINVAL, "mode T stages the waypoint table in LDS: max_steps <= 4096");
+  if (params->max_steps > 1024)
+    return fail(nullptr, ACMPC_EINVAL, "the waypoint table and the winner record are staged in LDS: max_steps <= 1024");
   acmpc_ctx* c = new (std::nothrow) acmpc_ctx();
   if (c == nullptr) return fail(nullptr, ACMPC_EINVAL, "out of host memory");
   c->prm = *params;

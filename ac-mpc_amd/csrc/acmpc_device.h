@@ -29,7 +29,8 @@ struct Weights {
 __device__ __forceinline__ float quad(float w, float a) { return (w * a) * a; }
 
 __device__ __forceinline__ float hinge2(float lo_minus_x, float x_minus_hi) {
-  const float v = fmaxf(lo_minus_x, 0.0f) + fmaxf(x_minus_hi, 0.0f);
+  // at most one side of a (non-degenerate) interval can be violated: one v_max3_f32
+  const float v = fmaxf(fmaxf(lo_minus_x, x_minus_hi), 0.0f);
   return v * v;
 }
 

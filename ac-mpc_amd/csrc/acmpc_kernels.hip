@@ -13,6 +13,9 @@
 // Built with -ffp-contract=off: see acmpc_device.h.
 #include "acmpc_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace acmpc {
@@ -192,9 +195,11 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   }
 }
 
-// One wave per problem.
+// One wave per problem.  LDS holds the winner's controls and states while lane 0 re-rolls it, so the sequential
+// part touches no global memory; the record is then written by all lanes.
 template <int MODE, int LAYOUT>
 __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_rec[];  // [4 + 2n + 3(n+1)] record image
   const int p = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = a.n;
@@ -214,63 +219,63 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   if (a.records == nullptr) return;
 
   const int rec_floats = 4 + 2 * n + 3 * (n + 1);
-  float* rec = a.records + static_cast<size_t>(p) * rec_floats;
+  float* __restrict__ rec = a.records + static_cast<size_t>(p) * rec_floats;
   const int64_t local = static_cast<int64_t>(static_cast<uint32_t>(key & 0xffffffffLL)) - a.index_offset;
-  const bool owner = local >= 0 && local < a.N;
+  const bool owner = local >= 0 && local < a.N;  // wave-uniform
   if (!owner) {
     for (int e = lane; e < rec_floats; e += kWave) rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
     return;
   }
-  // All lanes fetch the winner's controls at once (one pass of parallel loads instead of n dependent ones) and
-  // park them in the record; lane 0 then re-rolls the candidate from there with the very same step functions.
+
   const Weights w = a.w;
   constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
   const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
   const int c = static_cast<int>(local);
-  float* ru = rec + 4;
-  float* rx = rec + 4 + 2 * n;
+  float* su = s_rec + 4;
+  float* sx = s_rec + 4 + 2 * n;
+  // all lanes fetch the winner's controls at once: one round of parallel loads instead of n dependent ones
   for (int i = lane; i < n; i += kWave) {
     float v[1], k[1];
     load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, v, k);
-    ru[2 * i] = v[0];
-    ru[2 * i + 1] = k[0];
+    su[2 * i] = v[0];
+    su[2 * i + 1] = k[0];
   }
-  __syncthreads();  // one wave: orders the record stores above before lane 0's loads below
-  if (lane != 0) return;
-
-  float cost, viol;
-  if constexpr (MODE == 0) {
-    StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
-    for (int i = 0; i < n; ++i) {
-      rx[3 * i] = st.ey;
-      rx[3 * i + 1] = st.ep;
-      rx[3 * i + 2] = st.t;
-      step_spatial(st, coef + i * kCoefS, ru[2 * i], ru[2 * i + 1], w);
+  __syncthreads();
+  if (lane == 0) {
+    // the very same step functions as the rollout kernel -> the same bits
+    if constexpr (MODE == 0) {
+      StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+      for (int i = 0; i < n; ++i) {
+        sx[3 * i] = st.ey;
+        sx[3 * i + 1] = st.ep;
+        sx[3 * i + 2] = st.t;
+        step_spatial(st, coef + i * kCoefS, su[2 * i], su[2 * i + 1], w);
+      }
+      sx[3 * n] = st.ey;
+      sx[3 * n + 1] = st.ep;
+      sx[3 * n + 2] = st.t;
+      s_rec[0] = finish_spatial(st, w);
+      s_rec[1] = st.V;
+    } else {
+      StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+      sx[0] = st.X;
+      sx[1] = st.Y;
+      sx[2] = st.phi;
+      for (int i = 0; i < n; ++i) {
+        step_temporal(st, coef, n, su[2 * i], su[2 * i + 1], w);
+        sx[3 * (i + 1)] = st.X;
+        sx[3 * (i + 1) + 1] = st.Y;
+        sx[3 * (i + 1) + 2] = st.phi;
+      }
+      s_rec[0] = finish_temporal(st, n, w);
+      s_rec[1] = st.V;
     }
-    rx[3 * n] = st.ey;
-    rx[3 * n + 1] = st.ep;
-    rx[3 * n + 2] = st.t;
-    cost = finish_spatial(st, w);
-    viol = st.V;
-  } else {
-    StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
-    rx[0] = st.X;
-    rx[1] = st.Y;
-    rx[2] = st.phi;
-    for (int i = 0; i < n; ++i) {
-      step_temporal(st, coef, n, ru[2 * i], ru[2 * i + 1], w);
-      rx[3 * (i + 1)] = st.X;
-      rx[3 * (i + 1) + 1] = st.Y;
-      rx[3 * (i + 1) + 2] = st.phi;
-    }
-    cost = finish_temporal(st, n, w);
-    viol = st.V;
+    s_rec[2] = static_cast<float>(nfeas);
+    s_rec[3] = 1.0f;
   }
-  rec[0] = cost;
-  rec[1] = viol;
-  rec[2] = static_cast<float>(nfeas);
-  rec[3] = 1.0f;
+  __syncthreads();
+  for (int e = lane; e < rec_floats; e += kWave) rec[e] = s_rec[e];
 }
 
 // ---- softmin-weighted mean -------------------------------------------------------------------------------
@@ -433,13 +438,22 @@ LaunchShape choose_shape(int P, int N, int layout) {
   // per-lane work so that each wave load moves 16 B per lane (large step-major batches).
   LaunchShape s;
   const long long total = static_cast<long long>(P) * N;
-  if (total <= 256LL * 64 * 8) {
+  // tuning override for experiments: ACMPC_SHAPE="<block>,<cpt>"
+  int fb = 0, fc = 0;
+  if (const char* env = std::getenv("ACMPC_SHAPE")) {
+    if (std::sscanf(env, "%d,%d", &fb, &fc) != 2) fb = fc = 0;
+    if (!((fb == 64 && fc == 1) || (fb == 256 && (fc == 1 || (layout == 1 && (fc == 2 || fc == 4) && N % fc == 0)))))
+      fb = fc = 0;
+  }
+  if (fb != 0) {
+    s.block = fb;
+    s.cpt = fc;
+  } else if (total <= 256LL * 64 * 8) {
     s.block = 64;
     s.cpt = 1;
-  } else if (layout == 1 && N % 4 == 0 && total >= 256LL * 256 * 4 * 4) {
-    s.block = 256;
-    s.cpt = 4;
-  } else if (layout == 1 && N % 2 == 0 && total >= 256LL * 256 * 2 * 4) {
+  } else if (layout == 1 && N % 2 == 0 && total >= 256LL * 2048 * 2) {
+    // >= 8 waves per SIMD on every CU even at two candidates per lane (43 VGPRs); four per lane measured slower
+    // (70 VGPRs, half the waves: 97 us vs 78 us on 256 x 4096 x 49)
     s.block = 256;
     s.cpt = 2;
   } else {
@@ -461,14 +475,15 @@ hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const 
 
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s) {
   const dim3 grid(args.P), block(kWave);
+  const size_t lds = static_cast<size_t>(4 + 2 * args.n + 3 * (args.n + 1)) * sizeof(float);
   if (mode == 0 && layout == 0) {
-    hipLaunchKernelGGL((finalize_kernel<0, 0>), grid, block, 0, s, args);
+    hipLaunchKernelGGL((finalize_kernel<0, 0>), grid, block, lds, s, args);
   } else if (mode == 0 && layout == 1) {
-    hipLaunchKernelGGL((finalize_kernel<0, 1>), grid, block, 0, s, args);
+    hipLaunchKernelGGL((finalize_kernel<0, 1>), grid, block, lds, s, args);
   } else if (mode == 1 && layout == 0) {
-    hipLaunchKernelGGL((finalize_kernel<1, 0>), grid, block, 0, s, args);
+    hipLaunchKernelGGL((finalize_kernel<1, 0>), grid, block, lds, s, args);
   } else if (mode == 1 && layout == 1) {
-    hipLaunchKernelGGL((finalize_kernel<1, 1>), grid, block, 0, s, args);
+    hipLaunchKernelGGL((finalize_kernel<1, 1>), grid, block, lds, s, args);
   } else {
     return hipErrorInvalidValue;
   }

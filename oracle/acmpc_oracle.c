@@ -28,7 +28,7 @@ typedef struct {
 static inline float quad(float w, float a) { return (w * a) * a; }
 
 static inline float hinge2(float lo_minus_x, float x_minus_hi) {
-  const float v = fmaxf(lo_minus_x, 0.0f) + fmaxf(x_minus_hi, 0.0f);
+  const float v = fmaxf(fmaxf(lo_minus_x, x_minus_hi), 0.0f);
   return v * v;
 }
 

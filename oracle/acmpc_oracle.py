@@ -381,7 +381,8 @@ def _quad(w, a):
 
 
 def _hinge2(lo_minus_x, x_minus_hi, zero):
-    v = np.maximum(lo_minus_x, zero) + np.maximum(x_minus_hi, zero)
+    # distance outside [lo, hi]: at most one side of a non-degenerate interval can be violated
+    v = np.maximum(np.maximum(lo_minus_x, x_minus_hi), zero)
     return v * v
 
 
