@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(kSoftBlock) softmin_partial_kernel(const Softm
         const float* __restrict__ U = a.U + (static_cast<size_t>(p) * a.N + base) * n2 + e;
         for (int c = g; c < count; c += G) {
           const double u = static_cast<double>(U[static_cast<size_t>(c) * n2]);
-          acc += static_cast<double>(s_w[c]) * u;
+          const double wt = static_cast<double>(s_w[c]);
+          if (wt != 0.0) acc += wt * u;  // a zero-weight (non-finite cost) candidate is excluded, NaN controls too
           plain += u;
         }
       }
@@ -367,7 +368,8 @@ __global__ void __launch_bounds__(kSoftBlock) softmin_partial_kernel(const Softm
       double acc = 0.0, plain = 0.0;
       for (int c = tid; c < count; c += kSoftBlock) {
         const double u = static_cast<double>(U[c]);
-        acc += static_cast<double>(s_w[c]) * u;
+        const double wt = static_cast<double>(s_w[c]);
+        if (wt != 0.0) acc += wt * u;
         plain += u;
       }
       acc = wave_sum_f64(acc);

@@ -1,0 +1,104 @@
+"""C-ABI library: loads, exports every declared symbol, host-side table preparation matches the oracle (no GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import acmpc_oracle as orc
+from test_support import engine_kwargs, make_problem
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "acmpc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(acmpc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from acmpc_amd import _capi
+    lib = _capi.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), "libacmpc_hip.so does not export %s" % name
+    assert set(declared) == set(_capi.SIGNATURES), "ctypes binding and header disagree"
+    assert lib.acmpc_version().startswith(b"acmpc-hip")
+
+
+def test_params_struct_matches_header_layout():
+    import ctypes
+    from acmpc_amd import _capi
+    # 6 x 4-byte ints then 18 doubles, no padding surprises
+    assert ctypes.sizeof(_capi.Params) == 24 + 18 * 8
+    assert _capi.record_floats(49) == _capi.load_library().acmpc_record_floats(49) == 4 + 98 + 150
+
+
+@pytest.mark.parametrize("track,H", [("monza", 20), ("monza", 50), ("nordschleife", 80), ("spa", 50)])
+def test_host_tables_match_oracle(track, H):
+    """acmpc_set_paths restates linearise() + the corridor bounds (dynamics.py:65-103, control.py:57-60) in C++
+    double precision: the packed float32 rows must equal the oracle's bit for bit (mode S) and to one ulp in the
+    cos/sin columns of mode T (libm vs NumPy)."""
+    from acmpc_amd import Engine
+    probs = [make_problem(orc, track, H, 4, seed=s) for s in range(3)]
+    n = H - 1
+    tables = np.stack([p["table"] for p in probs])
+    eng = Engine(**engine_kwargs(probs[0], 0, 3, 4, n))
+    eng.set_paths(tables)
+    for p, prob in enumerate(probs):
+        np.testing.assert_array_equal(eng.coefficients(p), orc.coefficients_spatial(prob["table"], prob["limits"].margin))
+    eng = Engine(**engine_kwargs(probs[0], 1, 3, 4, n))
+    eng.set_paths(tables)
+    for p, prob in enumerate(probs):
+        got, want = eng.coefficients(p), orc.coefficients_temporal(prob["table"], prob["limits"].margin)
+        exact = [orc.CT_X, orc.CT_Y, orc.CT_PSI, orc.CT_KREF, orc.CT_VREF, orc.CT_HALF]
+        np.testing.assert_array_equal(got[:, exact], want[:, exact])
+        np.testing.assert_allclose(got[:, [orc.CT_COS, orc.CT_SIN]], want[:, [orc.CT_COS, orc.CT_SIN]], rtol=0,
+                                   atol=6e-8)
+
+
+def test_key_packing_orders_like_cost_then_index():
+    from acmpc_amd import _capi
+    rng = np.random.default_rng(0)
+    costs = np.concatenate([rng.normal(0, 10, 200), [0.0, -0.0, 1e-30, -1e-30, np.inf, 3.0, 3.0]]).astype(np.float32)
+    idx = rng.integers(0, 2**32 - 1, len(costs), dtype=np.uint64)
+    keys = [_capi.pack_key(c, int(i)) for c, i in zip(costs, idx)]
+    order = sorted(range(len(costs)), key=lambda j: keys[j])
+    want = sorted(range(len(costs)), key=lambda j: (float(costs[j]) + 0.0 if costs[j] != 0 else
+                                                    (-0.0 if np.signbit(costs[j]) else 0.0), int(idx[j])))
+    # -0.0 orders just below +0.0 in the key; otherwise (cost, index) lexicographic
+    assert [(float(costs[j]), int(idx[j])) for j in order if costs[j] != 0] == \
+           [(float(costs[j]), int(idx[j])) for j in want if costs[j] != 0]
+    for c, i, k in zip(costs, idx, keys):
+        assert _capi.key_index(k) == int(i)
+        assert _capi.key_cost(k) == c or (np.isnan(c) and np.isinf(_capi.key_cost(k)))
+    assert _capi.key_cost(_capi.pack_key(float("nan"), 7)) == np.inf
+    assert _capi.key_cost(_capi.pack_key(float("-inf"), 7)) == np.inf  # every non-finite cost ranks last
+    assert _capi.pack_key(1.0, 5) < _capi.pack_key(1.0, 6) < _capi.pack_key(np.nextafter(np.float32(1), 2), 0)
+    assert _capi.pack_key(-2.0, 9) < _capi.pack_key(-1.0, 0) < _capi.pack_key(0.0, 0)
+
+
+def test_errors_without_device_or_tables():
+    """Host-only error paths; on a box without a GPU the compute call must fail loudly (ENODEVICE), never fall
+    back to a CPU path."""
+    import torch
+    from acmpc_amd import Engine, EngineError
+    prob = make_problem(orc, "monza", 20, 8, seed=0)
+    with pytest.raises(EngineError):
+        Engine(**engine_kwargs(prob, 7, 1, 8, 19))  # unknown mode
+    with pytest.raises(EngineError):
+        Engine(**engine_kwargs(prob, 0, 1, 8, 5000))  # max_steps beyond the LDS staging limit
+    eng = Engine(**engine_kwargs(prob, 0, 1, 8, 19))
+    with pytest.raises(EngineError) as e:
+        eng.coefficients(0)
+    assert e.value.code == -5
+    with pytest.raises(EngineError) as e:
+        eng.set_paths(np.zeros((2, 7, 19)))
+    assert e.value.code == -4
+    eng.set_paths(prob["table"])
+    if not torch.cuda.is_available():
+        with pytest.raises(EngineError) as e:
+            eng.solve(prob["x0"][None], prob["U"][None])
+        assert e.value.code == -3 and "no CPU fallback" in str(e.value)

@@ -1,0 +1,99 @@
+"""Drop-in controller on the GPU: `build_mpc(...).get_control(...)` with the reference's call pattern."""
+import numpy as np
+import pytest
+
+import acmpc_oracle as orc
+from test_support import RACING, PlaceholderVehicle
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_path(H, kind):
+    s = np.linspace(0, 120.0, H)
+    x = {"straight": 0 * s, "curve": 0.004 * s**2, "chicane": 6.0 / (1 + np.exp(-0.1 * (s - 60)))}[kind]
+    return np.stack([x, s, np.linspace(10.0, 6.0, H)], axis=1)
+
+
+@pytest.mark.parametrize("kind", ["straight", "curve", "chicane"])
+def test_get_control_fills_the_reference_attributes(kind):
+    import copy
+    from acmpc_amd.mpc import build_mpc
+    cfg = copy.deepcopy(RACING["monza"])
+    cfg["speed_profile_constraints"]["v_max"] = 28.0  # what controller.py:241-243 writes before each solve
+    mpc = build_mpc(cfg, PlaceholderVehicle())
+    H, n = 50, 49
+    ret = mpc.get_control(_reference_path(H, kind), is_localised=False, offset=0.3)
+    assert ret is None and mpc.infeasibility_counter == 0
+    assert mpc.projected_control.shape == (2, n)           # [v; delta], spatial_mpc.py:195-200
+    assert mpc.current_prediction.shape == (n, 2)          # s2t(...)[:-1] drops the psi ROW, spatial_mpc.py:167-168
+    assert mpc.cum_time.shape == (n,) and mpc.times.shape == (n - 1,)
+    assert np.all(np.abs(mpc.projected_control[1]) <= mpc.delta_max + 1e-6)
+    assert np.all(mpc.projected_control[0] >= 8.0 - 0.1 - 1e-4) and np.all(mpc.projected_control[0] <= 28.1 + 1e-4)
+    assert np.all(np.diff(mpc.cum_time) > 0)               # time advances along the horizon
+    assert len(mpc.reference_path) == n and mpc.speed_profile.shape == (n,)
+    # the published plan is exactly one of the rollouts: re-roll it with the oracle and compare the states
+    path = mpc.reference_path
+    coef = orc.coefficients_spatial(path.table, mpc.model.margin)
+    u = np.stack([mpc.projected_control[0], np.tan(mpc.projected_control[1]) / mpc.model.length], axis=1)
+    lo, hi = orc.input_box(mpc.model)
+    x0 = mpc.model.t2s(path.get_state(0), np.array([0.3, 0.0, np.pi / 2]))
+    _, viol, X = orc.rollout_spatial(x0.astype(np.float32), coef, u[None], cfg["step_cost"], cfg["r_term"],
+                                     cfg["final_cost"], lo, hi, 1e6, dtype=np.float64, return_states=True)
+    np.testing.assert_allclose(X[0, :n, 2], mpc.cum_time, rtol=1e-4, atol=1e-5)
+    # a second solve warm-starts from the first and must not get worse
+    first_cost = mpc._control_solver._incumbent.copy()
+    mpc.get_control(_reference_path(H, kind), is_localised=False, offset=0.3)
+    assert mpc.infeasibility_counter == 0 and first_cost.shape == (n, 2)
+
+
+def test_sampled_optimum_approaches_the_qp_optimum():
+    """Sanity, not parity (QP solutions are unpinned): on the reference's own QP - built by the oracle's
+    restatement of control.py and solved by the oracle's ADMM - the sampled plan's objective must come close to
+    the QP optimum and never beat it by more than the solver tolerance."""
+    import copy
+    from acmpc_amd.mpc import build_mpc
+    cfg = copy.deepcopy(RACING["monza"])
+    cfg["speed_profile_constraints"]["v_max"] = 28.0
+    cfg.update(n_candidates=8192, sampling_rounds=6)
+    mpc = build_mpc(cfg, PlaceholderVehicle())
+    H, n = 50, 49
+    mpc.get_control(_reference_path(H, "curve"), offset=0.2)
+    assert mpc.infeasibility_counter == 0
+    path = mpc.reference_path
+    x0 = mpc.model.t2s(path.get_state(0), np.array([0.2, 0.0, np.pi / 2]))
+    qp = orc.control_qp(x0, path.table, cfg, mpc.model)
+    # the reference pins t_0 = 0 by equality while boxing t >= 0.01 (control.py:134 vs :67): drop x_0's box rows
+    n_eq = 3 * (n + 1)
+    keep = np.r_[0:n_eq, n_eq + 3:len(qp["l"])]
+    ref = orc.osqp_restated(qp["P_diag"], qp["q"], qp["A"][keep], qp["l"][keep], qp["u"][keep], max_iter=20000,
+                            eps_abs=1e-5, eps_rel=1e-5)
+    u = np.stack([mpc.projected_control[0], np.tan(mpc.projected_control[1]) / mpc.model.length], axis=1)
+    lo, hi = orc.input_box(mpc.model)
+    coef = orc.coefficients_spatial(path.table, mpc.model.margin).astype(np.float64)
+    cost, viol, X = orc.rollout_spatial(x0, coef, u[None], cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi,
+                                        0.0, dtype=np.float64, return_states=True)
+    z = orc.pack_decision_vector(X[0], u)
+    j_sampled = orc.qp_objective(qp["P_diag"], qp["q"], z)
+    j_qp = orc.qp_objective(qp["P_diag"], qp["q"], ref.x)
+    spread = abs(j_qp) + 1.0
+    assert j_sampled >= j_qp - 1e-2 * spread, "a feasible rollout cannot beat the QP optimum"
+    assert j_sampled <= j_qp + 0.25 * spread, "sampled plan too far from the QP optimum: %g vs %g" % (j_sampled, j_qp)
+
+
+def test_infeasible_problem_keeps_previous_controls():
+    """Reference behaviour on solver failure (spatial_mpc.py:212-217): keep the old plan, bump the counter."""
+    import copy
+    from acmpc_amd.mpc import build_mpc
+    cfg = copy.deepcopy(RACING["monza"])
+    cfg["speed_profile_constraints"]["v_max"] = 28.0
+    mpc = build_mpc(cfg, PlaceholderVehicle())
+    H = 50
+    mpc.get_control(_reference_path(H, "straight"))
+    plan = mpc.projected_control.copy()
+    narrow = _reference_path(H, "straight")
+    narrow[:, 2] = 1.0  # corridor narrower than the car: no candidate can satisfy the e_y bounds
+    mpc.get_control(narrow)
+    assert mpc.infeasibility_counter == 1
+    np.testing.assert_array_equal(mpc.projected_control, plan)
+    mpc.get_control(narrow)
+    assert mpc.infeasibility_counter == 2

@@ -1,0 +1,125 @@
+"""Sharded entry points on one GPU (needs an MI355X).  The RCCL collectives themselves need >1 GPU; what can be
+proven on one card is everything around them: keys carry global indices, finalize writes the record only on the
+owning shard, and the reduction of per-shard results equals the unsharded solve bit for bit."""
+import numpy as np
+import pytest
+
+import acmpc_oracle as orc
+from test_support import engine_kwargs, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_two_shards_on_one_gpu_equal_the_full_solve(mode, layout):
+    import torch
+    from acmpc_amd import Engine, _capi
+    P, H, total = 3, 50, 1536
+    n = H - 1
+    problems = [make_problem(orc, "silverstone", H, total, seed=90 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    x0 = torch.tensor(np.stack([p["x0"] if mode == 0 else p["pose0"] for p in problems]), device=dev)
+    U_full = np.stack([p["U"] for p in problems])  # [P,N,n,2]
+    stream = torch.cuda.current_stream().cuda_stream
+    R = _capi.record_floats(n)
+
+    full = Engine(**engine_kwargs(problems[0], mode, P, total, n))
+    full.set_paths(np.stack([p["table"] for p in problems]))
+    want = full.solve(x0.cpu().numpy(), U_full if layout == 0 else np.ascontiguousarray(U_full.transpose(0, 2, 3, 1)),
+                      layout=layout)
+
+    shards = [(0, 1000), (1000, 536)]  # uneven on purpose
+    keys, recs, costs = [], [], []
+    engines = []
+    for offset, count in shards:
+        eng = Engine(**engine_kwargs(problems[0], mode, P, count, n))
+        eng.set_paths(np.stack([p["table"] for p in problems]))
+        U = U_full[:, offset:offset + count]
+        U = torch.tensor(U if layout == 0 else np.ascontiguousarray(U.transpose(0, 2, 3, 1)), device=dev)
+        k = torch.empty(P, dtype=torch.int64, device=dev)
+        c = torch.empty(P, count, dtype=torch.float32, device=dev)
+        eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, count, n, layout, offset, c.data_ptr(), k.data_ptr(), stream)
+        engines.append((eng, U, offset, count))
+        keys.append(k)
+        costs.append(c)
+    gkeys = torch.minimum(keys[0], keys[1])  # what all-reduce(MIN) computes
+    for eng, U, offset, count in engines:
+        r = torch.empty(P, R, dtype=torch.float32, device=dev)
+        eng.finalize_device(gkeys.data_ptr(), x0.data_ptr(), U.data_ptr(), P, count, n, layout, offset, r.data_ptr(),
+                            stream)
+        recs.append(r)
+    torch.cuda.synchronize()
+    owners = torch.stack([r[:, _capi.REC_OWNER] for r in recs]).cpu().numpy()
+    assert (owners.sum(axis=0) == 1).all(), "exactly one shard owns each winner"
+    total_rec = (recs[0] + recs[1]).cpu().numpy()  # what all-reduce(SUM) computes
+    np.testing.assert_array_equal(total_rec, want["records"])
+    np.testing.assert_array_equal(np.concatenate([c.cpu().numpy() for c in costs], axis=1), want["costs"])
+    for p in range(P):
+        assert _capi.key_index(int(gkeys[p])) == want["best_idx"][p]
+        assert _capi.key_cost(int(gkeys[p])) == want["cost"][p]
+
+
+def test_sharded_rollout_class_with_a_one_rank_process_group():
+    """ShardedRollout end to end over torch.distributed's nccl (= RCCL) backend with world_size 1: the collective
+    calls execute on the GPU tensors, the result must equal Engine.solve."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from acmpc_amd import Engine
+    from acmpc_amd.sharding import ShardedRollout
+    P, H, N = 4, 50, 2048
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, N, seed=120 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
+        eng.set_paths(np.stack([p["table"] for p in problems]))
+        x0_h = np.stack([p["x0"] for p in problems])
+        U_h = np.ascontiguousarray(np.stack([p["U"] for p in problems]).transpose(0, 2, 3, 1))
+        want = eng.solve(x0_h, U_h, layout=1)
+        shard = ShardedRollout(eng, P, N, n, 1, index_offset=0, device=dev)
+        shard.distributed = True  # force the collective path although world_size == 1
+        x0, U = torch.tensor(x0_h, device=dev), torch.tensor(U_h, device=dev)
+        rec = shard.step(x0, U, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(rec.cpu().numpy(), want["records"])
+        np.testing.assert_array_equal(shard.costs.cpu().numpy(), want["costs"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("N,H", [(5000, 50), (300, 20)])
+def test_softmin_weighted_mean(layout, N, H):
+    import torch
+    from acmpc_amd import Engine
+    P, n = 2, H - 1
+    problems = [make_problem(orc, "monza", H, N, seed=200 + p) for p in range(P)]
+    problems[1]["U"][7, 2, 0] = np.nan  # a non-finite candidate must get weight 0
+    dev = torch.device("cuda", 0)
+    eng = Engine(**engine_kwargs(problems[0], 0, P, N, n, softmin_lambda=0.5))
+    eng.set_paths(np.stack([p["table"] for p in problems]))
+    U_h = np.stack([p["U"] for p in problems])
+    U = torch.tensor(U_h if layout == 0 else np.ascontiguousarray(U_h.transpose(0, 2, 3, 1)), device=dev)
+    x0 = torch.tensor(np.stack([p["x0"] for p in problems]), device=dev)
+    costs = torch.empty(P, N, device=dev)
+    keys = torch.empty(P, dtype=torch.int64, device=dev)
+    mean = torch.empty(P, n, 2, device=dev)
+    wsum = torch.empty(P, dtype=torch.float64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, layout, 0, costs.data_ptr(), keys.data_ptr(), s)
+    eng.softmin_device(costs.data_ptr(), keys.data_ptr(), U.data_ptr(), P, N, n, layout, mean.data_ptr(),
+                       wsum.data_ptr(), s)
+    torch.cuda.synchronize()
+    for p in range(P):
+        c = costs[p].cpu().numpy()
+        Up = np.where(np.isfinite(U_h[p]), U_h[p], 0.0)  # weight 0 x NaN control: excluded, as on the device
+        w = orc.softmin_weights(c, 0.5).astype(np.float64)
+        want = np.tensordot(w, Up.astype(np.float64), axes=(0, 0)) / w.sum()
+        got = mean[p].cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(wsum[p].item(), w.sum(), rtol=1e-5)

@@ -1,0 +1,134 @@
+"""Host-side mirror of the reference's controller interface, against golden vectors from the reference (no GPU)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import acmpc_oracle as orc
+from test_support import RACING, PlaceholderVehicle
+
+
+def _model(track="monza"):
+    from acmpc_amd.bicycle_model import SpatialBicycleModel
+    c = RACING[track]["speed_profile_constraints"]
+    return SpatialBicycleModel(PlaceholderVehicle(), {"min": c["v_min"], "max": c["v_max"]})
+
+
+def test_waypoint_table(golden, golden_cases):
+    from acmpc_amd.mpc import waypoint_table
+    for key in golden_cases:
+        np.testing.assert_allclose(waypoint_table(golden[key + "/coords"]), golden[key + "/table_no_v"], rtol=0,
+                                   atol=1e-12, err_msg=key)
+
+
+def test_reference_path_views():
+    from acmpc_amd.reference_path import ReferencePath
+    path = ReferencePath(5)
+    path.xs, path.kappas, path.velocities = np.arange(5), 0.1, [1, 2, 3, 4, 5]
+    assert len(path) == 5 and path.table.shape == (7, 5)
+    np.testing.assert_array_equal(path.table[0], np.arange(5))
+    np.testing.assert_array_equal(path.table[3], np.full(5, 0.1))
+    np.testing.assert_array_equal(path.table[6], [1, 2, 3, 4, 5])
+    path.psis[2] = 0.5  # views are writable
+    np.testing.assert_array_equal(path.get_state(2), [2.0, 0.0, 0.5])
+
+
+def test_bicycle_model_against_reference(golden, golden_cases):
+    from acmpc_amd.reference_path import ReferencePath
+    model = _model()
+    lim = golden[golden_cases[0] + "/limits"]
+    assert (model.length, model.width, model.delta_max, model.margin) == tuple(lim[:4])
+    np.testing.assert_array_equal(model.min_u, lim[4:6])
+    np.testing.assert_array_equal(model.max_u, lim[6:8])
+    got = np.array([model.t2s(w, s) for w, s in zip(golden["t2s/waypoints"], golden["t2s/states"])])
+    np.testing.assert_allclose(got, golden["t2s/out"], rtol=0, atol=1e-12)
+    for key in golden_cases[::3]:
+        path = ReferencePath.from_table(golden[key + "/table"])
+        f, A, B = model.linearise(path)
+        np.testing.assert_allclose(f, golden[key + "/lin_f"], rtol=1e-14)
+        np.testing.assert_allclose(A, golden[key + "/lin_A"], rtol=1e-14)
+        np.testing.assert_allclose(B, golden[key + "/lin_B"], rtol=1e-14)
+        np.testing.assert_allclose(model.s2t(path, golden[key + "/s2t_states"]), golden[key + "/s2t_out"], rtol=0,
+                                   atol=1e-12)
+
+
+def test_speed_profile_problem_matches_reference_inputs(golden, golden_cases):
+    from acmpc_amd.reference_path import ReferencePath
+    from acmpc_amd.speed_profile import LocalisedSpeedProfileSolver, SpeedProfileSolver
+    for key in golden_cases[::2]:
+        cons = RACING[key.split("_")[0]]["speed_profile_constraints"]
+        path = ReferencePath.from_table(golden[key + "/table_no_v"])
+        for cls, tag in ((SpeedProfileSolver, "sp0_"), (LocalisedSpeedProfileSolver, "sp1_")):
+            solver = cls({"control_horizon": len(path), "max_iterations": 4000, "constraints": cons})
+            prob = solver.problem(path, cons["end_velocity"])
+            for name in ("q", "A", "l", "u"):
+                np.testing.assert_allclose(prob[name], golden[key + "/" + tag + name], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("key", ["monza_H50_chicane_90", "monza_H50_hairpin_10", "spa_H50_chicane_70"])
+def test_speed_profile_solution_satisfies_kkt(golden, key):
+    """QP solutions are parity-unpinned (osqp absent), so optimality is certified solver-independently: primal
+    feasibility, dual signs and stationarity at a tight tolerance."""
+    from acmpc_amd import qp
+    from acmpc_amd.reference_path import ReferencePath
+    from acmpc_amd.speed_profile import SpeedProfileSolver
+    cons = RACING[key.split("_")[0]]["speed_profile_constraints"]
+    path = ReferencePath.from_table(golden[key + "/table_no_v"])
+    solver = SpeedProfileSolver({"control_horizon": len(path), "max_iterations": 4000, "constraints": cons})
+    prob = solver.problem(path, cons["end_velocity"])
+    res = qp.solve_qp(prob["P_diag"], prob["q"], prob["A"], prob["l"], prob["u"], max_iter=100000, eps_abs=1e-9,
+                      eps_rel=1e-9)
+    assert res.info.status == "solved"
+    Ax = prob["A"] @ res.x
+    assert (Ax >= prob["l"] - 1e-6).all() and (Ax <= prob["u"] + 1e-6).all()
+    np.testing.assert_allclose(prob["P_diag"] * res.x + prob["q"] + prob["A"].T @ res.y, 0, atol=1e-6)
+    assert (res.y[Ax < prob["u"] - 1e-5] <= 1e-6).all()  # y > 0 only on active upper bounds
+    assert (res.y[Ax > prob["l"] + 1e-5] >= -1e-6).all()  # y < 0 only on active lower bounds
+    # and the default-tolerance solve the controller uses reports "solved" within OSQP's own criterion
+    assert solver.solve(path, cons["end_velocity"]).info.status == "solved"
+    # the oracle's independent restatement of the same published algorithm agrees
+    ref = orc.osqp_restated(prob["P_diag"], prob["q"], prob["A"], prob["l"], prob["u"], max_iter=200000, eps_abs=1e-9,
+                            eps_rel=1e-9, check_every=50)
+    if ref.info.status == "solved":
+        np.testing.assert_allclose(res.x, ref.x, atol=1e-4)
+
+
+def test_command_selection_against_reference(golden):
+    from acmpc_amd.command_selection import TemporalCommandInterpolator, TemporalCommandSelector
+    holder = SimpleNamespace(control_cumtime=golden["cmd/cum_time"], control_inputs=golden["cmd/commands"])
+    selector = TemporalCommandSelector(holder)
+    for t, want in zip(golden["cmd/elapsed"], golden["cmd/selected"]):
+        np.testing.assert_array_equal(selector(t), want)
+    interp = TemporalCommandInterpolator(SimpleNamespace(control_cumtime=golden["cmd/interp_b_cum_time"],
+                                                         control_inputs=golden["cmd/interp_b_commands"]))
+    expected = np.array([[17, -0.03], [4.2, 0.12], [-2.0, 0.02], [-0.5, 0.21], [6.9, 0.01], [-2.0, 0.02]])
+    for t, want, ref in zip(golden["cmd/interp_b_elapsed"], expected, golden["cmd/interp_b_out"]):
+        np.testing.assert_allclose(interp(t), want, atol=1e-7)
+        np.testing.assert_allclose(interp(t), ref, atol=1e-14)
+    interp = TemporalCommandInterpolator(SimpleNamespace(control_cumtime=golden["cmd/interp_a_cum_time"],
+                                                         control_inputs=np.zeros((2, 10))))
+    for t, i_ref in zip(golden["cmd/interp_a_elapsed"], golden["cmd/interp_a_index"]):
+        assert interp._get_closet_command_index(t)[0] == i_ref
+
+
+def test_workload_downsample_matches_reference(golden):
+    from acmpc_amd import workloads
+    for H in (20, 50, 100):
+        got = workloads.reference_path_from_centreline(golden["downsample/centreline"], H)
+        np.testing.assert_array_equal(got, golden["downsample/H%d" % H])
+    with pytest.raises(ValueError):
+        workloads.reference_path_from_centreline(golden["downsample/centreline"], 80)
+
+
+def test_build_mpc_constructs_without_touching_the_gpu():
+    """The reference builds its MPCs in the parent and forks (controller.py:293-297): construction must not
+    create a HIP context - checked by building one here, where there may be no GPU at all."""
+    from acmpc_amd.mpc import SpatialMPC, build_mpc
+    mpc = build_mpc(RACING["monza"], PlaceholderVehicle())
+    assert isinstance(mpc, SpatialMPC)
+    assert mpc.MPC_horizon == 50 and mpc.delta_max == 0.30 and mpc.projected_control.shape == (2, 50)
+    assert mpc.speed_profile_constraints is RACING["monza"]["speed_profile_constraints"]  # live dict, not a copy
+    path = mpc.construct_waypoints(np.stack([np.zeros(50), np.linspace(0, 150, 50), np.full(50, 8.0)], axis=1))
+    assert len(path) == 49 and np.allclose(path.psis, np.pi / 2)
+    out = mpc.compute_speed_profile(path, False, end_vel=14.0)
+    assert out is path and out.velocities.min() > 7.9 and hasattr(mpc, "speed_profile")

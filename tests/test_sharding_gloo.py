@@ -1,0 +1,104 @@
+"""N > 1 path on CPU: two gloo ranks each hold half of the candidates; the all-reduce(MIN) of packed keys plus
+the all-reduce(SUM) of owner-masked records must reproduce the single-process answer.  The local evaluator is the
+oracle here (there is no GPU in this container); on the GPU the same `global_select` runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out_dir):
+    for p in (os.path.join(ROOT, "ac-mpc_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import acmpc_oracle as orc
+    from acmpc_amd import _capi
+    from acmpc_amd.sharding import global_select, shard_range
+    from test_support import make_problem
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, H = 3, 20
+    n = H - 1
+    R = _capi.record_floats(n)
+    problems = [make_problem(orc, "monza", H, total, seed=50 + p) for p in range(P)]
+    offset, count = shard_range(total, rank, world)
+    local = []
+    for prob in problems:
+        cfg = prob["cfg"]
+        coef = orc.coefficients_spatial(prob["table"], prob["limits"].margin)
+        U = prob["U"][offset:offset + count]
+        cost, viol, X = orc.rollout_spatial(prob["x0"], coef, U, cfg["step_cost"], cfg["r_term"], cfg["final_cost"],
+                                            prob["u_lo"], prob["u_hi"], 1e6, dtype=np.float32, return_states=True)
+        local.append((cost, viol, X, U))
+    keys = torch.tensor([_capi.pack_key(c[0][orc.pick_best(c[0])[0]], offset + orc.pick_best(c[0])[0]) for c in local],
+                        dtype=torch.int64)
+
+    def make_records(global_keys):
+        rec = torch.zeros(P, R)
+        for p, (cost, viol, X, U) in enumerate(local):
+            rec[p, _capi.REC_NFEASIBLE] = float(np.count_nonzero(viol == 0))
+            j = _capi.key_index(int(global_keys[p])) - offset
+            if 0 <= j < count:
+                rec[p, _capi.REC_COST], rec[p, _capi.REC_VIOLATION] = float(cost[j]), float(viol[j])
+                rec[p, _capi.REC_OWNER] = 1.0
+                rec[p, _capi.REC_HEADER:_capi.REC_HEADER + 2 * n] = torch.from_numpy(U[j].ravel())
+                rec[p, _capi.REC_HEADER + 2 * n:] = torch.from_numpy(X[j].ravel())
+        return rec
+
+    gkeys, records = global_select(keys, make_records)
+    np.save(os.path.join(out_dir, "keys_%d.npy" % rank), gkeys.numpy())
+    np.save(os.path.join(out_dir, "records_%d.npy" % rank), records.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [256, 257])
+def test_two_rank_selection_equals_single_process(tmp_path, total):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import acmpc_oracle as orc
+    from acmpc_amd import _capi
+    from test_support import make_problem
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    keys = [np.load(tmp_path / ("keys_%d.npy" % r)) for r in range(world)]
+    recs = [np.load(tmp_path / ("records_%d.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(keys[0], keys[1])
+    np.testing.assert_array_equal(recs[0], recs[1])
+    P, H = 3, 20
+    n = H - 1
+    for p in range(P):
+        prob = make_problem(orc, "monza", H, total, seed=50 + p)
+        cfg = prob["cfg"]
+        coef = orc.coefficients_spatial(prob["table"], prob["limits"].margin)
+        cost, viol, X = orc.rollout_spatial(prob["x0"], coef, prob["U"], cfg["step_cost"], cfg["r_term"],
+                                            cfg["final_cost"], prob["u_lo"], prob["u_hi"], 1e6, dtype=np.float32,
+                                            return_states=True)
+        best, _ = orc.pick_best(cost)
+        assert _capi.key_index(int(keys[0][p])) == best
+        out = _capi.split_record(recs[0][p], n)
+        assert out["owner"] == 1.0 and out["cost"] == cost[best] and out["n_feasible"] == np.count_nonzero(viol == 0)
+        np.testing.assert_array_equal(out["u"], prob["U"][best])
+        np.testing.assert_array_equal(out["x"], X[best])
+
+
+def test_shard_range_partitions_exactly():
+    from acmpc_amd.sharding import shard_range
+    for total in (1, 7, 4096, 262144, 262145):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (o1, c1), (o2, _) in zip(spans, spans[1:]):
+                assert o1 + c1 == o2
