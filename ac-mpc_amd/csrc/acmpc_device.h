@@ -102,31 +102,39 @@ struct StateT {
   float X, Y, phi, ey, ep, J, V;
 };
 
-// `wp` is the waypoint table (kCoefT floats per waypoint); in the rollout kernel it lives in LDS.
-__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, int n, float v, float k,
-                                             const Weights& w) {
+// explicit Euler on the rear-axle kinematic bicycle (localiser.py:66-95); phi_dot = v * kappa
+__device__ __forceinline__ void temporal_advance(StateT& s, float v, float k, const Weights& w) {
   float sn, cs;
   sincos_spec(s.phi, sn, cs);
-  // explicit Euler on the rear-axle kinematic bicycle (localiser.py:66-95); phi_dot = v * kappa
   const float Xn = s.X + (v * cs) * w.dt;
   const float Yn = s.Y + (v * sn) * w.dt;
   const float phin = s.phi + (v * k) * w.dt;
   s.X = Xn;
   s.Y = Yn;
   s.phi = phin;
-  // nearest waypoint, first minimum of the squared distance (localiser.py:282-289)
+}
+
+__device__ __forceinline__ float dist2(float X, float Y, float wx, float wy) {
+  const float dx = X - wx;
+  const float dy = Y - wy;
+  return dx * dx + dy * dy;
+}
+
+// nearest waypoint, first minimum of the squared distance (localiser.py:282-289); one lane scans the table
+__device__ __forceinline__ int temporal_nearest(const StateT& s, const float* wp, int n) {
   float best = __builtin_inff();
   int j = 0;
   for (int i = 0; i < n; ++i) {
-    const float dx = s.X - wp[i * kCoefT + 0];
-    const float dy = s.Y - wp[i * kCoefT + 1];
-    const float d = dx * dx + dy * dy;
+    const float d = dist2(s.X, s.Y, wp[i * kCoefT + 0], wp[i * kCoefT + 1]);
     const bool better = d < best;
     best = better ? d : best;
     j = better ? i : j;
   }
-  const float* g = wp + j * kCoefT;
-  // Frenet errors w.r.t. that waypoint (dynamics.py:23-40)
+  return j;
+}
+
+// Frenet errors w.r.t. waypoint row g (dynamics.py:23-40), stage cost and bound violations
+__device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v, float k, const Weights& w) {
   s.ey = g[2] * (s.Y - g[1]) - g[3] * (s.X - g[0]);
   s.ep = wrap_spec(s.phi - g[4]);
   const float dv = v - g[6];
@@ -139,6 +147,14 @@ __device__ __forceinline__ int step_temporal(StateT& s, const float* wp, int n, 
   s.V = s.V + hinge2(w.ulo0 - v, v - w.uhi0);
   s.V = s.V + hinge2(w.ulo1 - k, k - w.uhi1);
   s.V = s.V + hinge2((-g[7]) - s.ey, s.ey - g[7]);
+}
+
+// `wp` is the waypoint table (kCoefT floats per waypoint); in the rollout kernel it lives in LDS.
+__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, int n, float v, float k,
+                                             const Weights& w) {
+  temporal_advance(s, v, k, w);
+  const int j = temporal_nearest(s, wp, n);
+  temporal_cost(s, wp + j * kCoefT, v, k, w);
   return j;
 }
 

@@ -195,8 +195,14 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   }
 }
 
-// One wave per problem.  LDS holds the winner's controls and states while lane 0 re-rolls it, so the sequential
-// part touches no global memory; the record is then written by all lanes.
+// One wave per problem.  The winner is re-rolled by the whole wave in lock-step: lane l fetches step l's controls
+// and table row (one round of parallel loads), each step's inputs are then broadcast with v_readlane (SGPRs), so
+// the sequential chain touches no memory at all; every lane carries the same state and the record image is
+// assembled in LDS and written out by all lanes.  Same step functions as the rollout kernel -> same bits.
+__device__ __forceinline__ float bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 template <int MODE, int LAYOUT>
 __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_rec[];  // [4 + 2n + 3(n+1)] record image
@@ -234,43 +240,98 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   const int c = static_cast<int>(local);
   float* su = s_rec + 4;
   float* sx = s_rec + 4 + 2 * n;
-  // all lanes fetch the winner's controls at once: one round of parallel loads instead of n dependent ones
-  for (int i = lane; i < n; i += kWave) {
-    float v[1], k[1];
-    load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, v, k);
-    su[2 * i] = v[0];
-    su[2 * i + 1] = k[0];
-  }
-  __syncthreads();
-  if (lane == 0) {
-    // the very same step functions as the rollout kernel -> the same bits
-    if constexpr (MODE == 0) {
-      StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
-      for (int i = 0; i < n; ++i) {
-        sx[3 * i] = st.ey;
-        sx[3 * i + 1] = st.ep;
-        sx[3 * i + 2] = st.t;
-        step_spatial(st, coef + i * kCoefS, su[2 * i], su[2 * i + 1], w);
+
+  if constexpr (MODE == 0) {
+    StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+    for (int base = 0; base < n; base += kWave) {
+      const int mine = base + lane;
+      float v[1] = {0.0f}, k[1] = {0.0f};
+      float row[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (mine < n) {
+        load_controls<LAYOUT, 1>(a.U, p, a.N, n, mine, c, v, k);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) row[q] = coef[mine * kCoefS + q];
+        su[2 * mine] = v[0];
+        su[2 * mine + 1] = k[0];
       }
+      const int steps = min(kWave, n - base);
+      for (int i = 0; i < steps; ++i) {
+        float cr[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cr[q] = bcast(row[q], i);
+        if (lane == i) {
+          sx[3 * (base + i)] = st.ey;
+          sx[3 * (base + i) + 1] = st.ep;
+          sx[3 * (base + i) + 2] = st.t;
+        }
+        step_spatial(st, cr, bcast(v[0], i), bcast(k[0], i), w);
+      }
+    }
+    if (lane == 0) {
       sx[3 * n] = st.ey;
       sx[3 * n + 1] = st.ep;
       sx[3 * n + 2] = st.t;
       s_rec[0] = finish_spatial(st, w);
       s_rec[1] = st.V;
-    } else {
-      StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  } else {
+    StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+    // waypoint table -> LDS (behind the record image); each lane also keeps "its" waypoint's (x, y) in registers
+    float* s_wp = s_rec + ((rec_floats + 3) & ~3);
+    for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
+    if (lane == 0) {
       sx[0] = st.X;
       sx[1] = st.Y;
       sx[2] = st.phi;
-      for (int i = 0; i < n; ++i) {
-        step_temporal(st, coef, n, su[2 * i], su[2 * i + 1], w);
-        sx[3 * (i + 1)] = st.X;
-        sx[3 * (i + 1) + 1] = st.Y;
-        sx[3 * (i + 1) + 2] = st.phi;
+    }
+    __syncthreads();
+    const float my_x = (lane < n) ? s_wp[lane * kCoefT + 0] : 0.0f;
+    const float my_y = (lane < n) ? s_wp[lane * kCoefT + 1] : 0.0f;
+    for (int base = 0; base < n; base += kWave) {
+      const int mine = base + lane;
+      float v[1] = {0.0f}, k[1] = {0.0f};
+      if (mine < n) {
+        load_controls<LAYOUT, 1>(a.U, p, a.N, n, mine, c, v, k);
+        su[2 * mine] = v[0];
+        su[2 * mine + 1] = k[0];
       }
+      const int steps = min(kWave, n - base);
+      for (int i = 0; i < steps; ++i) {
+        const float vi = bcast(v[0], i), ki = bcast(k[0], i);
+        temporal_advance(st, vi, ki, w);
+        // nearest waypoint with the lanes scanning the table side by side; (distance, index) keys keep the
+        // first minimum exactly like the one-lane scan of the rollout kernel
+        float best = (lane < n) ? dist2(st.X, st.Y, my_x, my_y) : __builtin_inff();
+        int j = lane;
+        for (int m = lane + kWave; m < n; m += kWave) {
+          const float d = dist2(st.X, st.Y, s_wp[m * kCoefT + 0], s_wp[m * kCoefT + 1]);
+          const bool better = d < best;
+          best = better ? d : best;
+          j = better ? m : j;
+        }
+#pragma unroll
+        for (int mask = 32; mask >= 1; mask >>= 1) {
+          const float ob = __shfl_xor(best, mask, kWave);
+          const int oj = __shfl_xor(j, mask, kWave);
+          const bool take = (ob < best) || (ob == best && oj < j);
+          best = take ? ob : best;
+          j = take ? oj : j;
+        }
+        j = __builtin_amdgcn_readfirstlane(j);
+        temporal_cost(st, s_wp + j * kCoefT, vi, ki, w);
+        if (lane == 0) {
+          sx[3 * (base + i + 1)] = st.X;
+          sx[3 * (base + i + 1) + 1] = st.Y;
+          sx[3 * (base + i + 1) + 2] = st.phi;
+        }
+      }
+    }
+    if (lane == 0) {
       s_rec[0] = finish_temporal(st, n, w);
       s_rec[1] = st.V;
     }
+  }
+  if (lane == 0) {
     s_rec[2] = static_cast<float>(nfeas);
     s_rec[3] = 1.0f;
   }
@@ -477,7 +538,9 @@ hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const 
 
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s) {
   const dim3 grid(args.P), block(kWave);
-  const size_t lds = static_cast<size_t>(4 + 2 * args.n + 3 * (args.n + 1)) * sizeof(float);
+  // record image, then (mode T) the waypoint table
+  const size_t rec_floats = static_cast<size_t>(4 + 2 * args.n + 3 * (args.n + 1));
+  const size_t lds = (((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? args.n * kCoefT : 0)) * sizeof(float);
   if (mode == 0 && layout == 0) {
     hipLaunchKernelGGL((finalize_kernel<0, 0>), grid, block, lds, s, args);
   } else if (mode == 0 && layout == 1) {

@@ -44,7 +44,8 @@ def parse_args():
     ap.add_argument("--buffers", type=int, default=2, help="distinct control matrices cycled through (HBM-cold reads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--single-solve", action="store_true", help="also time one 4096-candidate solve per launch")
+    ap.add_argument("--no-single-solve", action="store_true",
+                    help="skip the extra 'single_solve' block (one 4096-candidate problem per launch: latency)")
     return ap.parse_args()
 
 
@@ -110,6 +111,74 @@ def cpu_baseline(batch, mode, U_dev, layout, N, n, gpu_costs, seconds):
                   "(gcc -O2, OpenMP over candidates), costs checked bit-identical to the GPU's" %
                   (sample, N, n + 1, repeats, elapsed),
     }
+
+
+def latest_traffic(algorithmic_bytes, kernel_name):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary for this exact workload
+    (profiles/*_summary.json, produced by tools/profile.sh + tools/summarize_profile.py: separate --pmc passes,
+    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None when no matching profile exists."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            summary = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if summary.get("algorithmic_bytes_per_launch") == algorithmic_bytes and \
+                kernel_name in summary.get("dominant_kernel", "") and "hbm_traffic_bytes_per_launch" in summary:
+            best = (summary["hbm_traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
+    return best
+
+
+def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300):
+    """BASELINE.json configs[1] as ONE problem per call (the closed-loop shape): device-resident solve latency
+    (rollout + argmin + winner record, HIP events) and the host-pointer acmpc_solve (H2D + kernels + D2H)."""
+    n = H - 1
+    batch = workloads.problem_batch(track, 1, H, seed=1)
+    eng = Engine(**workloads.engine_kwargs(batch, mode, N, device=device.index))
+    eng.set_paths(batch.tables)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.sync_tables(stream)
+    U = make_controls(batch, 1, N, n, layout, device, seed=7)
+    x0 = torch.tensor(batch.x0 if mode == 0 else batch.pose0, device=device)
+    from acmpc_amd._capi import record_floats
+    keys = torch.empty(1, dtype=torch.int64, device=device)
+    rec = torch.empty(1, record_floats(n), device=device)
+    costs = torch.empty(1, N, device=device)
+
+    def call():
+        eng.solve_device(x0.data_ptr(), U.data_ptr(), 1, N, n, layout, costs.data_ptr(), keys.data_ptr(),
+                         rec.data_ptr(), stream)
+
+    for _ in range(20):
+        call()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        call()
+        b.record()
+    torch.cuda.synchronize()
+    dev_us = np.array([a.elapsed_time(b) for a, b in ev]) * 1e3
+    U_host, x0_host = U.cpu().numpy(), x0.cpu().numpy()
+    wall = []
+    for _ in range(20):
+        eng.solve(x0_host, U_host, layout=layout, want_costs=False)
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        eng.solve(x0_host, U_host, layout=layout, want_costs=False)
+        wall.append((time.perf_counter() - t0) * 1e6)
+    wall = np.array(wall)
+    out = {
+        "workload": "%s: 1 solve x %d candidates x horizon %d per call" % (track, N, H),
+        "device_resident_us_p50": float(np.percentile(dev_us, 50)), "device_resident_us_p99": float(np.percentile(dev_us, 99)),
+        "device_resident_traj_per_s": N / (np.percentile(dev_us, 50) * 1e-6),
+        "host_pointer_us_p50": float(np.percentile(wall, 50)), "host_pointer_us_p99": float(np.percentile(wall, 99)),
+        "host_pointer_traj_per_s": N / (np.percentile(wall, 50) * 1e-6),
+        "note": "host-pointer figures include PCIe H2D of the %.1f MB control matrix and D2H of the record" % (U_host.nbytes / 1e6),
+    }
+    eng.close()
+    return out
 
 
 def main():
@@ -200,6 +269,11 @@ def main():
                 "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms,
             },
         }
+        traffic = latest_traffic(algorithmic_bytes, "rollout_kernel<%d, %d" % (mode, args.layout))
+        if traffic is not None:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic
+        if world == 1 and not args.no_single_solve:
+            out["single_solve"] = single_solve(workloads, Engine, args.track, H, N, mode, args.layout, device)
         if world == 1 and not args.no_cpu_baseline:
             gpu_costs = shard.costs[:8].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
             out["cpu_baseline"] = cpu_baseline(batch, mode, controls[(args.steps - 1) % args.buffers], args.layout, N,
