@@ -75,6 +75,8 @@ SIGNATURES = {
     "acmpc_softmin_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acmpc_sync_tables": (C.c_int, [_CTX, C.c_void_p]),
+    "acmpc_profile_enable": (C.c_int, [_CTX, C.c_int32]),
+    "acmpc_profile_collect": (C.c_int, [_CTX, _F32P, C.c_int32, _I32P]),
     "acmpc_pack_key": (C.c_int64, [C.c_float, C.c_uint32]),
     "acmpc_key_cost": (C.c_float, [C.c_int64]),
     "acmpc_key_index": (C.c_uint32, [C.c_int64]),
@@ -207,6 +209,19 @@ class Engine:
     # -- device-pointer entry points (pointers are plain integers, e.g. torch.Tensor.data_ptr()) ----------
     def sync_tables(self, stream: int = 0):
         self._check(self._lib.acmpc_sync_tables(self._ctx, stream))
+
+    def profile_enable(self, capacity: int):
+        """Attach event pairs to the next `capacity` rollout launches (no extra packets on the stream)."""
+        self._check(self._lib.acmpc_profile_enable(self._ctx, capacity))
+        self._profile_capacity = capacity
+
+    def profile_collect(self) -> np.ndarray:
+        """Durations [ms] of the rollout launches timed since the last enable/collect; re-arms the pairs."""
+        cap = getattr(self, "_profile_capacity", 0)
+        out = np.empty(max(cap, 1), dtype=np.float32)
+        count = C.c_int32(0)
+        self._check(self._lib.acmpc_profile_collect(self._ctx, _f32(out), cap, C.byref(count)))
+        return out[:count.value].copy()
 
     def solve_device(self, d_x0: int, d_U: int, P: int, N: int, n: int, layout: int, d_costs: int, d_keys: int,
                      d_records: int, stream: int = 0):

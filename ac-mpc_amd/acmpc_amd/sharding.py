@@ -74,3 +74,54 @@ class ShardedRollout:
     def step(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
         self.rollout(x0, U, stream)
         return self.select(x0, U, stream)
+
+
+class PipelinedRollout:
+    """Two-deep software pipeline over independent batches: the dominant rollout kernels run back to back on the
+    caller's stream while argmin / winner record (and, with several ranks, the two small collectives) of the
+    previous batch run on a side stream.  Each pipeline slot has its own `Engine`, so the per-workgroup partial
+    keys of batch i are never overwritten before batch i's finalize has read them (the main stream waits for the
+    slot's previous finalize before reusing it)."""
+
+    def __init__(self, engines, n_problems: int, n_local: int, n_steps: int, layout: int, index_offset: int,
+                 device: torch.device, group: Optional[dist.ProcessGroup] = None, want_costs: bool = True):
+        self.slots = [ShardedRollout(e, n_problems, n_local, n_steps, layout, index_offset, device, group, want_costs)
+                      for e in engines]
+        self.side = torch.cuda.Stream(device=device)
+        self.rolled = [torch.cuda.Event() for _ in self.slots]
+        self.selected = [torch.cuda.Event() for _ in self.slots]
+        self.count = 0
+        self._main = None
+
+    def bind_stream(self, stream: "torch.cuda.Stream"):
+        """Fix the launch stream once instead of looking it up every step."""
+        self._main = stream
+
+    def step(self, x0: torch.Tensor, U: torch.Tensor, before_rollout=None, after_rollout=None) -> "ShardedRollout":
+        """Enqueue one batch; returns the slot whose `.records` / `.costs` will hold its results once the side
+        stream has drained (call `drain()` before reading them on the host or from the main stream).
+        `before_rollout` / `after_rollout` are optional timing events recorded on the launch stream around the
+        rollout kernel.  The host side of a step is seven driver calls, kept lean on purpose: at ~80 us of GPU
+        work per step the Python launch path is otherwise the bottleneck."""
+        i = self.count % len(self.slots)
+        slot = self.slots[i]
+        main = self._main if self._main is not None else torch.cuda.current_stream()
+        if self.count >= len(self.slots):
+            main.wait_event(self.selected[i])          # slot free again: its previous finalize has read the partials
+        if before_rollout is not None:
+            before_rollout.record(main)
+        slot.rollout(x0, U, main.cuda_stream)
+        done = after_rollout if after_rollout is not None else self.rolled[i]
+        done.record(main)
+        self.side.wait_event(done)
+        if slot.distributed:
+            with torch.cuda.stream(self.side):         # torch.distributed enqueues on the current stream
+                slot.select(x0, U, self.side.cuda_stream)
+        else:
+            slot.select(x0, U, self.side.cuda_stream)
+        self.selected[i].record(self.side)
+        self.count += 1
+        return slot
+
+    def drain(self):
+        torch.cuda.current_stream().wait_stream(self.side)

@@ -48,6 +48,10 @@ struct acmpc_ctx {
   int64_t* d_keys = nullptr;
   int64_t* h_keys = nullptr;  // pinned
 
+  // optional timing of the rollout dispatches (acmpc_profile_*): event pairs attached to the launches
+  std::vector<hipEvent_t> prof_start, prof_stop;
+  size_t prof_used = 0;
+
   mutable std::string err;
 };
 
@@ -143,7 +147,13 @@ int rollout(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int
   a.n = n;
   a.index_offset = offset;
   a.w = c->w;
-  ACMPC_HIP(c, acmpc::launch_rollout(c->prm.mode, layout, shape, a, s));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof_used < c->prof_start.size()) {
+    e0 = c->prof_start[c->prof_used];
+    e1 = c->prof_stop[c->prof_used];
+    ++c->prof_used;
+  }
+  ACMPC_HIP(c, acmpc::launch_rollout(c->prm.mode, layout, shape, a, s, e0, e1));
   *shape_out = shape;
   return ACMPC_OK;
 }
@@ -256,6 +266,8 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_keys);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
     if (c->stream != nullptr) (void)hipStreamDestroy(c->stream);
+    for (hipEvent_t e : c->prof_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->prof_stop) (void)hipEventDestroy(e);
   }
   delete c;
 }
@@ -404,6 +416,42 @@ int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_
   ACMPC_HIP(c, hipStreamSynchronize(s));
   if (best_idx != nullptr)
     for (int p = 0; p < P; ++p) best_idx[p] = static_cast<int32_t>(acmpc_key_index(c->h_keys[p]));
+  return ACMPC_OK;
+}
+
+int acmpc_profile_enable(acmpc_ctx* c, int32_t capacity) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (capacity < 0) return fail(c, ACMPC_EINVAL, "negative capacity");
+  const int rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  while (static_cast<int32_t>(c->prof_start.size()) < capacity) {
+    hipEvent_t e0, e1;
+    ACMPC_HIP(c, hipEventCreate(&e0));
+    ACMPC_HIP(c, hipEventCreate(&e1));
+    c->prof_start.push_back(e0);
+    c->prof_stop.push_back(e1);
+  }
+  while (static_cast<int32_t>(c->prof_start.size()) > capacity) {
+    (void)hipEventDestroy(c->prof_start.back());
+    (void)hipEventDestroy(c->prof_stop.back());
+    c->prof_start.pop_back();
+    c->prof_stop.pop_back();
+  }
+  c->prof_used = 0;
+  return ACMPC_OK;
+}
+
+int acmpc_profile_collect(acmpc_ctx* c, float* out_ms, int32_t capacity, int32_t* count) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (out_ms == nullptr || count == nullptr) return fail(c, ACMPC_EINVAL, "null output");
+  const int32_t used = static_cast<int32_t>(c->prof_used);
+  const int32_t take = used < capacity ? used : capacity;
+  for (int32_t i = 0; i < take; ++i) {
+    ACMPC_HIP(c, hipEventSynchronize(c->prof_stop[i]));
+    ACMPC_HIP(c, hipEventElapsedTime(&out_ms[i], c->prof_start[i], c->prof_stop[i]));
+  }
+  *count = take;
+  c->prof_used = 0;
   return ACMPC_OK;
 }
 

@@ -56,7 +56,10 @@ struct LaunchShape {
 LaunchShape choose_shape(int P, int N, int layout);
 int max_blocks_per_problem(int N);
 
-hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s);
+// `start`/`stop` (both or neither) are attached to the dispatch itself (hipExtLaunchKernel): the kernel's own begin
+// and end timestamps, with no marker packets added to the stream.
+hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
+                          hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
 int softmin_chunks(int N);
 hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s);

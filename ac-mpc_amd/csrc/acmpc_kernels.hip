@@ -13,6 +13,8 @@
 // Built with -ffp-contract=off: see acmpc_device.h.
 #include "acmpc_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -24,6 +26,9 @@ namespace {
 
 constexpr int kMaxBlock = 256;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int CPT>
 struct VecOf;
 template <>
@@ -32,30 +37,21 @@ struct VecOf<1> {
 };
 template <>
 struct VecOf<2> {
-  using type = float2;
+  using type = f32x2;
 };
 template <>
 struct VecOf<4> {
-  using type = float4;
+  using type = f32x4;
 };
 
 template <int CPT>
-__device__ __forceinline__ void unpack(const typename VecOf<CPT>::type& v, float (&out)[CPT]);
-template <>
-__device__ __forceinline__ void unpack<1>(const float& v, float (&out)[1]) {
-  out[0] = v;
-}
-template <>
-__device__ __forceinline__ void unpack<2>(const float2& v, float (&out)[2]) {
-  out[0] = v.x;
-  out[1] = v.y;
-}
-template <>
-__device__ __forceinline__ void unpack<4>(const float4& v, float (&out)[4]) {
-  out[0] = v.x;
-  out[1] = v.y;
-  out[2] = v.z;
-  out[3] = v.w;
+__device__ __forceinline__ void unpack(const typename VecOf<CPT>::type& v, float (&out)[CPT]) {
+  if constexpr (CPT == 1) {
+    out[0] = v;
+  } else {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) out[j] = v[j];
+  }
 }
 
 // Controls of CPT adjacent candidates at step i.
@@ -66,16 +62,15 @@ __device__ __forceinline__ void load_controls(const float* __restrict__ U, int p
     // U[p][i][0|1][c]: lanes read consecutive candidates -> one fully coalesced wave access per component
     using V = typename VecOf<CPT>::type;
     const float* row = U + (static_cast<size_t>(p) * n + i) * 2 * static_cast<size_t>(N) + c0;
-    unpack<CPT>(*reinterpret_cast<const V*>(row), v);
-    unpack<CPT>(*reinterpret_cast<const V*>(row + N), k);
+    unpack<CPT>(__builtin_nontemporal_load(reinterpret_cast<const V*>(row)), v);
+    unpack<CPT>(__builtin_nontemporal_load(reinterpret_cast<const V*>(row + N)), k);
   } else {
     // U[p][c][i][0|1]: 8-byte (v, kappa) pairs at a row stride of 8n bytes
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-      const float2 vk = *reinterpret_cast<const float2*>(
-          U + ((static_cast<size_t>(p) * N + c0 + j) * n + i) * 2);
-      v[j] = vk.x;
-      k[j] = vk.y;
+      const f32x2 vk = *reinterpret_cast<const f32x2*>(U + ((static_cast<size_t>(p) * N + c0 + j) * n + i) * 2);
+      v[j] = vk[0];
+      k[j] = vk[1];
     }
   }
 }
@@ -150,10 +145,11 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
       float* out = a.costs + static_cast<size_t>(p) * a.N + c0;
       if constexpr (CPT == 1) {
         out[0] = cost[0];
-      } else if constexpr (CPT == 2) {
-        *reinterpret_cast<V*>(out) = make_float2(cost[0], cost[1]);
       } else {
-        *reinterpret_cast<V*>(out) = make_float4(cost[0], cost[1], cost[2], cost[3]);
+        V packed;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) packed[j] = cost[j];
+        *reinterpret_cast<V*>(out) = packed;
       }
     }
   }
@@ -242,37 +238,77 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   float* sx = s_rec + 4 + 2 * n;
 
   if constexpr (MODE == 0) {
-    StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+    // Re-roll split by dependence: only the 9-operation state recurrence is sequential (run by the whole wave in
+    // lock-step on broadcast inputs); everything that hangs off a state - stage cost, the four bound terms - is
+    // evaluated by lane i for step i in parallel, and the partial results are then accumulated in step order so
+    // that J and V see exactly the additions of step_spatial(), in the same order.
+    float ey = x0[0], ep = x0[1], t = x0[2], J = 0.0f, V = 0.0f;
     for (int base = 0; base < n; base += kWave) {
       const int mine = base + lane;
+      const bool valid = mine < n;
       float v[1] = {0.0f}, k[1] = {0.0f};
       float row[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-      if (mine < n) {
+      if (valid) {
         load_controls<LAYOUT, 1>(a.U, p, a.N, n, mine, c, v, k);
 #pragma unroll
         for (int q = 0; q < 9; ++q) row[q] = coef[mine * kCoefS + q];
         su[2 * mine] = v[0];
         su[2 * mine + 1] = k[0];
       }
+      const float dv = v[0] - row[5];
+      const float dk = k[0] - row[6];
+      const float term_ep = row[0] * dk;   // ds * dk
+      const float term_t = row[3] * dv;    // b31 * dv
+      float r = quad(w.r0, dv);
+      r = r + quad(w.r1, dk);
+      const float hu0 = hinge2(w.ulo0 - v[0], v[0] - w.uhi0);
+      const float hu1 = hinge2(w.ulo1 - k[0], k[0] - w.uhi1);
+      float my_ey = 0.0f, my_ep = 0.0f, my_t = 0.0f, nx_ey = 0.0f, nx_t = 0.0f;
       const int steps = min(kWave, n - base);
       for (int i = 0; i < steps; ++i) {
-        float cr[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) cr[q] = bcast(row[q], i);
+        const float b_ds = bcast(row[0], i), b_a21 = bcast(row[1], i), b_a31 = bcast(row[2], i);
+        const float b_f3 = bcast(row[4], i), b_te = bcast(term_ep, i), b_tt = bcast(term_t, i);
+        const float ey_n = ey + b_ds * ep;
+        const float ep_n = (ep + b_a21 * ey) + b_te;
+        const float t_n = ((t + b_a31 * ey) + b_tt) + b_f3;
         if (lane == i) {
-          sx[3 * (base + i)] = st.ey;
-          sx[3 * (base + i) + 1] = st.ep;
-          sx[3 * (base + i) + 2] = st.t;
+          my_ey = ey;
+          my_ep = ep;
+          my_t = t;
+          nx_ey = ey_n;
+          nx_t = t_n;
         }
-        step_spatial(st, cr, bcast(v[0], i), bcast(k[0], i), w);
+        ey = ey_n;
+        ep = ep_n;
+        t = t_n;
+      }
+      float q = quad(w.q0, my_ey);
+      q = q + quad(w.q1, my_ep);
+      q = q + quad(w.q2, my_t);
+      const float stage = 0.5f * (q + r);
+      const float hc = hinge2(row[7] - nx_ey, nx_ey - row[8]);
+      const float tv = fmaxf(w.tmin - nx_t, 0.0f);
+      const float ht = tv * tv;
+      if (valid) {
+        sx[3 * mine] = my_ey;
+        sx[3 * mine + 1] = my_ep;
+        sx[3 * mine + 2] = my_t;
+      }
+      for (int i = 0; i < steps; ++i) {
+        J = J + bcast(stage, i);
+        V = V + bcast(hu0, i);
+        V = V + bcast(hu1, i);
+        V = V + bcast(hc, i);
+        V = V + bcast(ht, i);
       }
     }
     if (lane == 0) {
-      sx[3 * n] = st.ey;
-      sx[3 * n + 1] = st.ep;
-      sx[3 * n + 2] = st.t;
+      sx[3 * n] = ey;
+      sx[3 * n + 1] = ep;
+      sx[3 * n + 2] = t;
+      const StateS st{ey, ep, t, J, V};
       s_rec[0] = finish_spatial(st, w);
-      s_rec[1] = st.V;
+      s_rec[1] = V;
     }
   } else {
     StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
@@ -474,20 +510,27 @@ __global__ void __launch_bounds__(kSoftBlock) softmin_final_kernel(const Softmin
 }
 
 template <int MODE, int LAYOUT, int CPT, int BLOCK>
-hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s) {
+hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
+                            hipEvent_t e1) {
   const dim3 grid(shape.blocks_per_problem, args.P);
   const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * kCoefT * sizeof(float) : 0);
-  hipLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK>), grid, dim3(BLOCK), lds, s, args);
+  if (e0 != nullptr && e1 != nullptr) {
+    hipExtLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK>), grid, dim3(BLOCK),
+                          static_cast<std::uint32_t>(lds), s, e0, e1, 0, args);
+  } else {
+    hipLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK>), grid, dim3(BLOCK), lds, s, args);
+  }
   return hipGetLastError();
 }
 
 template <int MODE, int LAYOUT>
-hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s) {
-  if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 64>(shape, args, s);
-  if (shape.block == 256 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 256>(shape, args, s);
+hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
+                             hipEvent_t e1) {
+  if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 64>(shape, args, s, e0, e1);
+  if (shape.block == 256 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 256>(shape, args, s, e0, e1);
   if constexpr (LAYOUT == 1) {
-    if (shape.block == 256 && shape.cpt == 2) return launch_rollout_t<MODE, LAYOUT, 2, 256>(shape, args, s);
-    if (shape.block == 256 && shape.cpt == 4) return launch_rollout_t<MODE, LAYOUT, 4, 256>(shape, args, s);
+    if (shape.block == 256 && shape.cpt == 2) return launch_rollout_t<MODE, LAYOUT, 2, 256>(shape, args, s, e0, e1);
+    if (shape.block == 256 && shape.cpt == 4) return launch_rollout_t<MODE, LAYOUT, 4, 256>(shape, args, s, e0, e1);
   }
   return hipErrorInvalidConfiguration;
 }
@@ -528,11 +571,12 @@ LaunchShape choose_shape(int P, int N, int layout) {
   return s;
 }
 
-hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s) {
-  if (mode == 0 && layout == 0) return launch_rollout_ml<0, 0>(shape, args, s);
-  if (mode == 0 && layout == 1) return launch_rollout_ml<0, 1>(shape, args, s);
-  if (mode == 1 && layout == 0) return launch_rollout_ml<1, 0>(shape, args, s);
-  if (mode == 1 && layout == 1) return launch_rollout_ml<1, 1>(shape, args, s);
+hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
+                          hipEvent_t e0, hipEvent_t e1) {
+  if (mode == 0 && layout == 0) return launch_rollout_ml<0, 0>(shape, args, s, e0, e1);
+  if (mode == 0 && layout == 1) return launch_rollout_ml<0, 1>(shape, args, s, e0, e1);
+  if (mode == 1 && layout == 0) return launch_rollout_ml<1, 0>(shape, args, s, e0, e1);
+  if (mode == 1 && layout == 1) return launch_rollout_ml<1, 1>(shape, args, s, e0, e1);
   return hipErrorInvalidValue;
 }
 

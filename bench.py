@@ -38,10 +38,15 @@ def parse_args():
     ap.add_argument("--track", default="monza", choices=["monza", "spa", "nordschleife", "silverstone"])
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--candidates", type=int, default=4096, help="candidates per pose per GPU")
-    ap.add_argument("--poses", type=int, default=256, help="independent solves batched into one launch")
+    ap.add_argument("--poses", type=int, default=1024, help="independent solves batched into one launch")
     ap.add_argument("--mode", default="S", choices=["S", "T"], help="S: spatial bicycle model, T: Cartesian + NN search")
     ap.add_argument("--layout", type=int, default=1, help="0: U[P][N][n][2], 1: U[P][n][2][N]")
     ap.add_argument("--buffers", type=int, default=2, help="distinct control matrices cycled through (HBM-cold reads)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap argmin/record of batch i (side stream) with the rollout of batch i+1; measured "
+                         "slower than plain stream order on MI355X (cross-queue dependencies cost ~10 us each)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="(diagnostic) attach no events to the rollout launches; roofline fields become null")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-single-solve", action="store_true",
@@ -197,21 +202,46 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     from acmpc_amd import Engine, workloads
-    from acmpc_amd.sharding import ShardedRollout
+    from acmpc_amd.sharding import PipelinedRollout, ShardedRollout
 
     mode = 0 if args.mode == "S" else 1
     P, N, H = args.poses, args.candidates, args.horizon
     n = H - 1
-    batch = workloads.problem_batch(args.track, P, H, seed=0)
-    engine = Engine(**workloads.engine_kwargs(batch, mode, N, device=local_rank))
-    engine.set_paths(batch.tables)
-    batch.coef_host = [engine.coefficients(p) for p in range(min(8, P))]
+    # at most 256 distinct poses round the circuit (each needs a host-side speed-profile QP); beyond that the
+    # poses repeat with independent candidate sets
+    batch = workloads.problem_batch(args.track, min(P, 256), H, seed=0)
+    if P > 256:
+        reps = (P + 255) // 256
+        batch.tables = np.tile(batch.tables, (reps, 1, 1))[:P]
+        batch.x0 = np.tile(batch.x0, (reps, 1))[:P]
+        batch.pose0 = np.tile(batch.pose0, (reps, 1))[:P]
     stream = torch.cuda.current_stream().cuda_stream
-    engine.sync_tables(stream)
+    engines = []
+    for _ in range(2 if args.pipeline else 1):   # one handle per pipeline slot (own partial-key buffers)
+        engine = Engine(**workloads.engine_kwargs(batch, mode, N, device=local_rank))
+        engine.set_paths(batch.tables)
+        engine.sync_tables(stream)
+        engines.append(engine)
+    batch.coef_host = [engines[0].coefficients(p) for p in range(min(8, P))]
     x0 = torch.tensor(batch.x0 if mode == 0 else batch.pose0, device=device)
     # every rank draws its own candidates (different seed); global index = rank * N + local index
     controls = [make_controls(batch, P, N, n, args.layout, device, seed=1000 * b + rank) for b in range(args.buffers)]
-    shard = ShardedRollout(engine, P, N, n, args.layout, index_offset=rank * N, device=device)
+    if not args.pipeline:
+        class _Serial:  # rollout and argmin/record back to back on the launch stream
+            def __init__(self):
+                self.slot = ShardedRollout(engines[0], P, N, n, args.layout, index_offset=rank * N, device=device)
+
+            def step(self, x0_, U_):
+                self.slot.step(x0_, U_, stream)
+                return self.slot
+
+            def drain(self):
+                pass
+
+        pipe = _Serial()
+    else:
+        pipe = PipelinedRollout(engines, P, N, n, args.layout, index_offset=rank * N, device=device)
+        pipe.bind_stream(torch.cuda.current_stream())
 
     def barrier():
         if world > 1:
@@ -219,24 +249,32 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        shard.step(x0, controls[i % args.buffers], stream)
+        pipe.step(x0, controls[i % args.buffers])
+    pipe.drain()
     barrier()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # HIP event pairs attached to every rollout dispatch of the timed region (hipExtLaunchKernel through
+    # acmpc_profile_enable): the kernel's own begin/end on its launch stream, no marker packets between launches
+    per_engine = (args.steps + len(engines) - 1) // len(engines)
+    for engine in engines:
+        engine.profile_enable(0 if args.no_kernel_timing else per_engine)
     t0 = time.perf_counter()
+    last = None
     for i in range(args.steps):
-        U = controls[i % args.buffers]
-        starts[i].record()          # HIP events on the stream the kernel is launched on
-        shard.rollout(x0, U, stream)
-        stops[i].record()
-        shard.select(x0, U, stream)
+        last = pipe.step(x0, controls[i % args.buffers])
+    host_enqueue = time.perf_counter() - t0   # (diagnostic) time the host needed to enqueue all steps
+    pipe.drain()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, stops)]))
+    kernel_times = np.concatenate([engine.profile_collect() for engine in engines])
+    if args.no_kernel_timing:
+        kernel_ms = float("nan")
+    else:
+        assert len(kernel_times) == args.steps, "every rollout launch of the timed region carries an event pair"
+        kernel_ms = float(kernel_times.mean())
 
     if rank == 0:
         algorithmic_bytes = P * N * (8 * n + 4)  # 8n B of controls read + 4 B of cost written
@@ -257,17 +295,19 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s (synthetic circuit): %d candidates x horizon %d per solve per GPU, %d solves (poses) "
-                            "batched per launch; mode %s rollout + cost + argmin + winner record"
-                            % (args.track, N, H, P, args.mode),
+                            "batched per launch (%d distinct poses); mode %s rollout + cost + argmin + winner record"
+                            % (args.track, N, H, P, min(P, 256), args.mode),
                 "candidates_per_solve_per_gpu": N, "solves_per_step": P, "horizon": H, "mode": args.mode,
                 "layout": "U[P][n][2][N]" if args.layout == 1 else "U[P][N][n][2]",
                 "parallelism": "candidate-sharded x%d" % world,
+                "pipeline": "argmin/record of batch i overlaps rollout of batch i+1" if args.pipeline else "none (stream order)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms,
             },
+            "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
         }
         traffic = latest_traffic(algorithmic_bytes, "rollout_kernel<%d, %d" % (mode, args.layout))
         if traffic is not None:
@@ -275,7 +315,7 @@ def main():
         if world == 1 and not args.no_single_solve:
             out["single_solve"] = single_solve(workloads, Engine, args.track, H, N, mode, args.layout, device)
         if world == 1 and not args.no_cpu_baseline:
-            gpu_costs = shard.costs[:8].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
+            gpu_costs = last.costs[:8].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
             out["cpu_baseline"] = cpu_baseline(batch, mode, controls[(args.steps - 1) % args.buffers], args.layout, N,
                                                n, gpu_costs, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -156,6 +156,13 @@ int acmpc_softmin_device(acmpc_ctx* ctx, const float* d_costs, const int64_t* d_
  * timed region contains no host-to-device traffic. */
 int acmpc_sync_tables(acmpc_ctx* ctx, void* stream);
 
+/* Measurement hooks.  After acmpc_profile_enable(ctx, K) the next K rollout launches of this handle carry a HIP
+ * event pair attached to the dispatch itself (hipExtLaunchKernel: the kernel's own begin/end timestamps on the
+ * stream it is launched on, no marker packets between launches); acmpc_profile_collect waits for them, writes the
+ * per-launch durations in milliseconds and re-arms the K pairs.  K = 0 disables. */
+int acmpc_profile_enable(acmpc_ctx* ctx, int32_t capacity);
+int acmpc_profile_collect(acmpc_ctx* ctx, float* out_ms, int32_t capacity, int32_t* count);
+
 /* Key helpers (host side; same packing as the kernels). */
 int64_t acmpc_pack_key(float cost, uint32_t index);
 float acmpc_key_cost(int64_t key);
