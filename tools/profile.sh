@@ -10,9 +10,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline $*"
+BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-single-solve $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
-SHORT="python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline $*"
+SHORT="python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-single-solve $*"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
   --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- $SHORT > /dev/null 2> "$OUT/pmc_sq.err"
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $SHORT > /dev/null 2> "$OUT/pmc_fetch.err"

@@ -32,13 +32,13 @@ def main():
     counters = collections.defaultdict(list)
     for path in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
-            if needle in r["Kernel_Name"]:
+            if r["Kernel_Name"] == dom["Name"]:
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
     mean = {k: sum(v) / len(v) for k, v in counters.items()}
     bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
     summary = {
         "tag": tag,
-        "command": "python bench.py --steps 200 --warmup 20 (plain) / --steps 50 --warmup 10 under rocprofv3",
+        "command": "python bench.py --steps 200 --warmup 20: plain run, and the same under rocprofv3 --kernel-trace --stats; --pmc passes with --steps 8",
         "dominant_kernel": dom["Name"],
         "calls": int(dom["Calls"]),
         "average_ns": float(dom["AverageNs"]),
@@ -59,6 +59,14 @@ def main():
     summary["achieved_GBps_rocprof"] = summary["algorithmic_bytes_per_launch"] / summary["average_ns"]
     summary["frac_of_8TBps_rocprof"] = summary["achieved_GBps_rocprof"] / 8000.0
     summary["bench_kernel_ms_hip_events"] = bench["roofline"]["kernel_ms"]
+    traced = os.path.join(src, "bench_trace.json")
+    if os.path.exists(traced):
+        t = json.loads(open(traced).read().strip().splitlines()[-1])
+        # the same process, the same launches: HIP events vs rocprofv3's own dispatch timestamps
+        summary["hip_events_kernel_ms_under_rocprof"] = t["roofline"]["kernel_ms"]
+        summary["note"] = ("rocprofv3 slows the run (lower clocks under the profiler, MI355X_MICROARCH.md 'DVFS "
+                           "give-back' item 2): compare average_ns with hip_events_kernel_ms_under_rocprof (same "
+                           "process); bench_kernel_ms_hip_events is the un-profiled run")
     json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
     json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
