@@ -36,6 +36,8 @@ class Params(C.Structure):
         ("max_problems", C.c_int32),
         ("max_candidates", C.c_int32),
         ("max_steps", C.c_int32),
+        ("nn_back", C.c_int32),
+        ("nn_ahead", C.c_int32),
         ("step_cost", C.c_double * 3),
         ("r_term", C.c_double * 2),
         ("final_cost", C.c_double * 3),
@@ -129,12 +131,15 @@ class Engine:
 
     def __init__(self, *, mode: int, max_problems: int, max_candidates: int, max_steps: int, step_cost, r_term,
                  final_cost, u_min, u_max, margin: float, wheelbase: float, t_min: float = 0.01, dt: float = 0.05,
-                 w_bound: float = 1.0e6, softmin_lambda: float = 1.0, device: int = -1):
+                 w_bound: float = 1.0e6, softmin_lambda: float = 1.0, device: int = -1, nn_window=None):
+        """`nn_window=(back, ahead)` restricts mode T's nearest-waypoint search to that many waypoints round the
+        previous step's nearest index; None = exhaustive scan."""
         self._lib = load_library()
         p = Params()
         p.struct_size = C.sizeof(Params)
         p.mode, p.device = mode, device
         p.max_problems, p.max_candidates, p.max_steps = max_problems, max_candidates, max_steps
+        p.nn_back, p.nn_ahead = (-1, -1) if nn_window is None else (int(nn_window[0]), int(nn_window[1]))
         p.step_cost[:] = [float(v) for v in step_cost]
         p.r_term[:] = [float(v) for v in r_term]
         p.final_cost[:] = [float(v) for v in final_cost]

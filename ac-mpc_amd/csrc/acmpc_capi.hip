@@ -225,6 +225,8 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
     return fail(nullptr, ACMPC_EINVAL, "unknown mode");
   if (params->max_problems < 1 || params->max_candidates < 1 || params->max_steps < 1)
     return fail(nullptr, ACMPC_EINVAL, "capacities must be positive");
+  if (params->nn_ahead >= 0 && (params->nn_back < 0 || params->nn_back + params->nn_ahead + 1 > 64))
+    return fail(nullptr, ACMPC_EINVAL, "nearest-waypoint window: need nn_back >= 0 and at most 64 waypoints");
   if (params->max_steps > 1024)
     return fail(nullptr, ACMPC_EINVAL, "the waypoint table and the winner record are staged in LDS: max_steps <= 1024");
   acmpc_ctx* c = new (std::nothrow) acmpc_ctx();
@@ -247,6 +249,8 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
   w.tmin = static_cast<float>(params->t_min);
   w.wbound = static_cast<float>(params->w_bound);
   w.dt = static_cast<float>(params->dt);
+  w.nn_back = params->nn_back;
+  w.nn_ahead = params->nn_ahead;
   *out = c;
   return ACMPC_OK;
 }

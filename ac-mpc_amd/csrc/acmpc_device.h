@@ -24,6 +24,7 @@ struct Weights {
   float tmin;           // 0.01 (control.py:134)
   float wbound;
   float dt;
+  int nn_back, nn_ahead;  // mode T search window round the previous nearest index; nn_ahead < 0 = exhaustive
 };
 
 __device__ __forceinline__ float quad(float w, float a) { return (w * a) * a; }
@@ -133,6 +134,27 @@ __device__ __forceinline__ int temporal_nearest(const StateT& s, const float* wp
   return j;
 }
 
+// The same search restricted to [j_prev - back, j_prev + ahead] (clipped to the table): progress along the path is
+// monotone and at most about one waypoint per step, so a short window finds the global minimum on every realistic
+// input at a fraction of the ALU work (tests check equality with the exhaustive scan).  Fixed trip count, lanes
+// whose window is clipped mask the tail.
+__device__ __forceinline__ int temporal_nearest_window(const StateT& s, const float* wp, int n, int j_prev,
+                                                       int back, int ahead) {
+  const int lo = max(j_prev - back, 0);
+  const int hi = min(j_prev + ahead, n - 1);
+  float best = __builtin_inff();
+  int j = lo;
+  const int trips = back + ahead + 1;
+  for (int m = 0; m < trips; ++m) {
+    const int i = min(lo + m, hi);  // the clipped tail re-reads `hi`: equal distance, never "better"
+    const float d = dist2(s.X, s.Y, wp[i * kCoefT + 0], wp[i * kCoefT + 1]);
+    const bool better = d < best;
+    best = better ? d : best;
+    j = better ? i : j;
+  }
+  return j;
+}
+
 // Frenet errors w.r.t. waypoint row g (dynamics.py:23-40), stage cost and bound violations
 __device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v, float k, const Weights& w) {
   s.ey = g[2] * (s.Y - g[1]) - g[3] * (s.X - g[0]);
@@ -151,9 +173,10 @@ __device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v
 
 // `wp` is the waypoint table (kCoefT floats per waypoint); in the rollout kernel it lives in LDS.
 __device__ __forceinline__ int step_temporal(StateT& s, const float* wp, int n, float v, float k,
-                                             const Weights& w) {
+                                             const Weights& w, int j_prev) {
   temporal_advance(s, v, k, w);
-  const int j = temporal_nearest(s, wp, n);
+  const int j = (w.nn_ahead < 0) ? temporal_nearest(s, wp, n)
+                                 : temporal_nearest_window(s, wp, n, j_prev, w.nn_back, w.nn_ahead);
   temporal_cost(s, wp + j * kCoefT, v, k, w);
   return j;
 }

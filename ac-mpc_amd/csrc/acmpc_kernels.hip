@@ -128,11 +128,14 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
       StateT st[CPT];
 #pragma unroll
       for (int j = 0; j < CPT; ++j) st[j] = StateT{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+      int nearest[CPT];
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) nearest[j] = 0;
       for (int i = 0; i < n; ++i) {
         float v[CPT], k[CPT];
         load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) step_temporal(st[j], s_wp, n, v[j], k[j], w);
+        for (int j = 0; j < CPT; ++j) nearest[j] = step_temporal(st[j], s_wp, n, v[j], k[j], w, nearest[j]);
       }
 #pragma unroll
       for (int j = 0; j < CPT; ++j) {
@@ -323,6 +326,7 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
     __syncthreads();
     const float my_x = (lane < n) ? s_wp[lane * kCoefT + 0] : 0.0f;
     const float my_y = (lane < n) ? s_wp[lane * kCoefT + 1] : 0.0f;
+    int j_prev = 0;
     for (int base = 0; base < n; base += kWave) {
       const int mine = base + lane;
       float v[1] = {0.0f}, k[1] = {0.0f};
@@ -337,10 +341,14 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
         temporal_advance(st, vi, ki, w);
         // nearest waypoint with the lanes scanning the table side by side; (distance, index) keys keep the
         // first minimum exactly like the one-lane scan of the rollout kernel
-        float best = (lane < n) ? dist2(st.X, st.Y, my_x, my_y) : __builtin_inff();
+        // (a search window, when configured, only masks out the waypoints outside it)
+        const int win_lo = (w.nn_ahead < 0) ? 0 : max(j_prev - w.nn_back, 0);
+        const int win_hi = (w.nn_ahead < 0) ? n - 1 : min(j_prev + w.nn_ahead, n - 1);
+        float best = (lane >= win_lo && lane <= win_hi) ? dist2(st.X, st.Y, my_x, my_y) : __builtin_inff();
         int j = lane;
-        for (int m = lane + kWave; m < n; m += kWave) {
-          const float d = dist2(st.X, st.Y, s_wp[m * kCoefT + 0], s_wp[m * kCoefT + 1]);
+        for (int m = lane + kWave; m <= win_hi; m += kWave) {
+          const float d = (m >= win_lo) ? dist2(st.X, st.Y, s_wp[m * kCoefT + 0], s_wp[m * kCoefT + 1])
+                                        : __builtin_inff();
           const bool better = d < best;
           best = better ? d : best;
           j = better ? m : j;
@@ -354,6 +362,7 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
           j = take ? oj : j;
         }
         j = __builtin_amdgcn_readfirstlane(j);
+        j_prev = j;
         temporal_cost(st, s_wp + j * kCoefT, vi, ki, w);
         if (lane == 0) {
           sx[3 * (base + i + 1)] = st.X;

@@ -23,6 +23,7 @@
 
 typedef struct {
   float q[3], r[2], qn[3], ulo[2], uhi[2], tmin, wbound, dt;
+  int nn_back, nn_ahead; /* mode T search window round the previous nearest index; nn_ahead < 0 = exhaustive */
 } oracle_weights;
 
 static inline float quad(float w, float a) { return (w * a) * a; }
@@ -88,6 +89,64 @@ void acmpc_oracle_rollout_spatial(const float* x0, const float* coef, const floa
   }
 }
 
+/* Same arithmetic as acmpc_oracle_rollout_spatial for the step-major layout U[n][2][N], organised so that the
+ * compiler can vectorise across candidates (blocks of VB candidates advance through the steps together).  This is
+ * the form bench.py times as the CPU baseline; results are bit-identical to the scalar form (IEEE single, no FMA). */
+/* a > b ? a : b equals fmaxf(a, b) whenever b is not NaN - true at both call sites (b is x - hi with the same x
+ * as a, or the constant 0) - and unlike fmaxf it vectorises without -ffinite-math-only */
+static inline float max2(float a, float b) { return a > b ? a : b; }
+static inline float hinge2v(float lo_minus_x, float x_minus_hi) {
+  const float v = max2(max2(lo_minus_x, x_minus_hi), 0.0f);
+  return v * v;
+}
+
+#define VB 64
+void acmpc_oracle_rollout_spatial_blocked(const float* x0, const float* coef, const float* U, int64_t N, int n,
+                                          const oracle_weights* w, float* costs, float* viol) {
+  const int64_t blocks = (N + VB - 1) / VB;
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < blocks; ++b) {
+    const int64_t c0 = b * VB;
+    const int m = (int)((N - c0) < VB ? (N - c0) : VB);
+    float ey[VB], ep[VB], t[VB], J[VB], V[VB];
+    for (int j = 0; j < VB; ++j) ey[j] = x0[0], ep[j] = x0[1], t[j] = x0[2], J[j] = 0.0f, V[j] = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      const float* k_ = coef + (int64_t)i * CS;
+      const float* vrow = U + ((int64_t)i * 2) * N + c0;
+      const float* krow = vrow + N;
+#pragma omp simd
+      for (int j = 0; j < m; ++j) {
+        const float v = vrow[j], k = krow[j];
+        const float dv = v - k_[5];
+        const float dk = k - k_[6];
+        float a = quad(w->q[0], ey[j]);
+        a = a + quad(w->q[1], ep[j]);
+        a = a + quad(w->q[2], t[j]);
+        float r = quad(w->r[0], dv);
+        r = r + quad(w->r[1], dk);
+        J[j] = J[j] + 0.5f * (a + r);
+        float Vj = V[j] + hinge2v(w->ulo[0] - v, v - w->uhi[0]);
+        Vj = Vj + hinge2v(w->ulo[1] - k, k - w->uhi[1]);
+        const float ey_n = ey[j] + k_[0] * ep[j];
+        const float ep_n = (ep[j] + k_[1] * ey[j]) + k_[0] * dk;
+        const float t_n = ((t[j] + k_[2] * ey[j]) + k_[3] * dv) + k_[4];
+        ey[j] = ey_n, ep[j] = ep_n, t[j] = t_n;
+        Vj = Vj + hinge2v(k_[7] - ey_n, ey_n - k_[8]);
+        const float tv = max2(w->tmin - t_n, 0.0f);
+        V[j] = Vj + tv * tv;
+      }
+    }
+    for (int j = 0; j < m; ++j) {
+      float a = quad(w->qn[0], ey[j]);
+      a = a + quad(w->qn[1], ep[j]);
+      a = a + quad(w->qn[2], t[j]);
+      const float Jf = J[j] + 0.5f * a;
+      costs[c0 + j] = Jf + w->wbound * V[j];
+      viol[c0 + j] = V[j];
+    }
+  }
+}
+
 static inline void sincos_spec(float phi, float* sn, float* cs) {
   const float k = rintf(phi * 0.6366197723675814f);
   const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
@@ -114,6 +173,7 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
 #pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < N; ++c) {
     float X = pose0[0], Y = pose0[1], phi = pose0[2], ey = 0.0f, ep = 0.0f, J = 0.0f, V = 0.0f;
+    int j_prev = 0;
     if (states) {
       float* s = states + c * (n + 1) * 3;
       s[0] = X, s[1] = Y, s[2] = phi;
@@ -128,7 +188,13 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       X = Xn, Y = Yn, phi = phin;
       float best = INFINITY;
       int j = 0;
-      for (int m = 0; m < n; ++m) {
+      int lo = 0, hi = n - 1;
+      if (w->nn_ahead >= 0) {
+        lo = j_prev - w->nn_back < 0 ? 0 : j_prev - w->nn_back;
+        hi = j_prev + w->nn_ahead > n - 1 ? n - 1 : j_prev + w->nn_ahead;
+        j = lo;
+      }
+      for (int m = lo; m <= hi; ++m) {
         const float dx = X - wp[m * CT + 0];
         const float dy = Y - wp[m * CT + 1];
         const float d = dx * dx + dy * dy;
@@ -137,6 +203,7 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
           j = m;
         }
       }
+      j_prev = j;
       const float* g = wp + j * CT;
       ey = g[2] * (Y - g[1]) - g[3] * (X - g[0]);
       ep = wrap_spec(phi - g[4]);

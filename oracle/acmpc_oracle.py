@@ -476,12 +476,15 @@ def wrap_spec(angle, dtype=np.float32):
 
 
 def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.float32,
-                     return_states=False, libm_trig=False):
+                     return_states=False, libm_trig=False, nn_window=None):
     """Mode T: Cartesian kinematic Euler rollout (localiser.py:66-95 with phi_dot = v*kappa, kappa =
     tan(delta)/L), nearest-waypoint projection (first minimum of squared distance, localiser.py:282-289),
     Frenet errors (dynamics.py:23-40), a9 cost weights and bounds.
 
     pose0 = (X, Y, phi), wp[n,8] (coefficients_temporal), U[N,n,2] = (v, kappa).
+    nn_window = (back, ahead): search only waypoints [j_prev - back, j_prev + ahead] (clipped; j_prev = previous
+    step's nearest index, 0 at the start) instead of all n - a build-defined shortcut, equal to the exhaustive
+    search whenever progress along the path is slower than the window (checked in tests).
     """
     T = dtype
     U = np.asarray(U, dtype=T)
@@ -499,6 +502,7 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
     J_idx = np.zeros((N, n), dtype=np.int32) if return_states else None
     ey = np.zeros(N, dtype=T)
     ep = np.zeros(N, dtype=T)
+    j_prev = np.zeros(N, dtype=np.int64)
     if return_states:
         S[:, 0, 0], S[:, 0, 1], S[:, 0, 2] = X, Y, phi
     for i in range(n):
@@ -512,14 +516,29 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
         phin = phi + (v * k) * dtT
         X, Y, phi = Xn, Yn, phin
         best = np.full(N, np.inf, dtype=T)
-        j = np.zeros(N, dtype=np.int64)
-        for w in range(n):
-            dx = X - wp[w, CT_X]
-            dy = Y - wp[w, CT_Y]
-            d = dx * dx + dy * dy
-            better = d < best
-            best = np.where(better, d, best)
-            j = np.where(better, w, j)
+        if nn_window is None:
+            j = np.zeros(N, dtype=np.int64)
+            for w in range(n):
+                dx = X - wp[w, CT_X]
+                dy = Y - wp[w, CT_Y]
+                d = dx * dx + dy * dy
+                better = d < best
+                best = np.where(better, d, best)
+                j = np.where(better, w, j)
+        else:
+            back, ahead = nn_window
+            lo = np.maximum(j_prev - back, 0)
+            hi = np.minimum(j_prev + ahead, n - 1)
+            j = lo.copy()
+            for m in range(back + ahead + 1):
+                w = np.minimum(lo + m, hi)
+                dx = X - wp[w, CT_X]
+                dy = Y - wp[w, CT_Y]
+                d = dx * dx + dy * dy
+                better = d < best
+                best = np.where(better, d, best)
+                j = np.where(better, w, j)
+        j_prev = j
         g = wp[j]
         ey = g[:, CT_COS] * (Y - g[:, CT_Y]) - g[:, CT_SIN] * (X - g[:, CT_X])
         if libm_trig:

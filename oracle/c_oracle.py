@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(HERE, "libacmpc_oracle.so")
 
 class Weights(C.Structure):
     _fields_ = [("q", C.c_float * 3), ("r", C.c_float * 2), ("qn", C.c_float * 3), ("ulo", C.c_float * 2),
-                ("uhi", C.c_float * 2), ("tmin", C.c_float), ("wbound", C.c_float), ("dt", C.c_float)]
+                ("uhi", C.c_float * 2), ("tmin", C.c_float), ("wbound", C.c_float), ("dt", C.c_float),
+                ("nn_back", C.c_int), ("nn_ahead", C.c_int)]
 
 
 _lib = None
@@ -33,12 +34,14 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(_lib, name)
             fn.restype = None
             fn.argtypes = [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.POINTER(Weights), fp, fp, fp]
+        _lib.acmpc_oracle_rollout_spatial_blocked.restype = None
+        _lib.acmpc_oracle_rollout_spatial_blocked.argtypes = [fp, fp, fp, C.c_int64, C.c_int, C.POINTER(Weights), fp, fp]
         _lib.acmpc_oracle_argmin.restype = C.c_int64
         _lib.acmpc_oracle_argmin.argtypes = [fp, C.c_int64]
     return _lib
 
 
-def make_weights(Q, R, QN, u_lo, u_hi, w_bound, dt=0.05, t_min=0.01) -> Weights:
+def make_weights(Q, R, QN, u_lo, u_hi, w_bound, dt=0.05, t_min=0.01, nn_window=None) -> Weights:
     w = Weights()
     w.q[:] = [float(np.float32(v)) for v in Q]
     w.r[:] = [float(np.float32(v)) for v in R]
@@ -46,6 +49,7 @@ def make_weights(Q, R, QN, u_lo, u_hi, w_bound, dt=0.05, t_min=0.01) -> Weights:
     w.ulo[:] = [float(np.float32(v)) for v in u_lo]
     w.uhi[:] = [float(np.float32(v)) for v in u_hi]
     w.tmin, w.wbound, w.dt = t_min, w_bound, dt
+    w.nn_back, w.nn_ahead = (-1, -1) if nn_window is None else nn_window
     return w
 
 
@@ -64,6 +68,21 @@ def rollout(mode: int, x0, coef, U, layout: int, weights: Weights, return_states
     fn(x0.ctypes.data_as(fp), coef.ctypes.data_as(fp), U.ctypes.data_as(fp), layout, N, n, C.byref(weights),
        costs.ctypes.data_as(fp), viol.ctypes.data_as(fp), states.ctypes.data_as(fp) if return_states else None)
     return (costs, viol, states) if return_states else (costs, viol)
+
+
+def rollout_spatial_blocked(x0, coef, U_step_major, weights: Weights):
+    """Vectorisable form of the mode-S rollout for U[n][2][N] (bit-identical to `rollout(0, ..., layout=1)`)."""
+    lib = load()
+    fp = C.POINTER(C.c_float)
+    x0 = np.ascontiguousarray(x0, dtype=np.float32)
+    coef = np.ascontiguousarray(coef, dtype=np.float32)
+    U = np.ascontiguousarray(U_step_major, dtype=np.float32)
+    n, N = U.shape[0], U.shape[2]
+    costs = np.empty(N, dtype=np.float32)
+    viol = np.empty(N, dtype=np.float32)
+    lib.acmpc_oracle_rollout_spatial_blocked(x0.ctypes.data_as(fp), coef.ctypes.data_as(fp), U.ctypes.data_as(fp), N, n,
+                                             C.byref(weights), costs.ctypes.data_as(fp), viol.ctypes.data_as(fp))
+    return costs, viol
 
 
 def argmin(costs: np.ndarray) -> int:

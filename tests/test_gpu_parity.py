@@ -119,3 +119,28 @@ def test_capacity_and_state_errors():
     with pytest.raises(EngineError) as e:
         eng.solve(prob["x0"][None], np.zeros((1, 32, 19, 2), np.float32))
     assert e.value.code == -4  # ACMPC_ECAPACITY
+
+
+@pytest.mark.parametrize("layout", [LAYOUT_CM, LAYOUT_SM])
+@pytest.mark.parametrize("window", [(2, 5), (1, 2)])
+def test_mode_t_windowed_nearest_search(layout, window):
+    """Mode T with nn_window: bit-identical to the oracle's windowed spec (also where the window is too short to
+    find the global nearest waypoint - the spec, not the outcome, is what must match)."""
+    from acmpc_amd import Engine
+    H, N, P = 50, 777, 2
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, N, seed=300 + p) for p in range(P)]
+    eng = Engine(**engine_kwargs(problems[0], 1, P, N, n, nn_window=window))
+    eng.set_paths(np.stack([p["table"] for p in problems]))
+    x0 = np.stack([p["pose0"] for p in problems])
+    U = np.stack([p["U"] for p in problems])
+    out = eng.solve(x0, _as_layout(U, layout), layout=layout)
+    for p, prob in enumerate(problems):
+        cfg = prob["cfg"]
+        cost, viol, S, _ = orc.rollout_temporal(prob["pose0"], eng.coefficients(p), prob["U"], cfg["step_cost"],
+                                                cfg["r_term"], cfg["final_cost"], prob["u_lo"], prob["u_hi"], 1.0e6,
+                                                0.05, dtype=np.float32, return_states=True, nn_window=window)
+        np.testing.assert_array_equal(out["costs"][p], cost)
+        best = orc.pick_best(cost)[0]
+        assert out["best_idx"][p] == best and out["violation"][p] == viol[best]
+        np.testing.assert_array_equal(out["x"][p], S[best])

@@ -18,7 +18,9 @@ from bench import make_controls  # noqa: E402
 
 
 def run(spec, iters=30):
-    mode_s, layout, P, N, H = spec.split(",")
+    parts = spec.split(",")
+    window = (int(parts[5]), int(parts[6])) if len(parts) > 5 else None
+    mode_s, layout, P, N, H = parts[:5]
     mode, layout, P, N, H = (0 if mode_s == "S" else 1), int(layout), int(P), int(N), int(H)
     n = H - 1
     device = torch.device("cuda", 0)
@@ -27,7 +29,7 @@ def run(spec, iters=30):
     base.tables = np.tile(base.tables, (reps, 1, 1))[:P]
     base.x0 = np.tile(base.x0, (reps, 1))[:P]
     base.pose0 = np.tile(base.pose0, (reps, 1))[:P]
-    eng = Engine(**workloads.engine_kwargs(base, mode, N, device=0))
+    eng = Engine(**workloads.engine_kwargs(base, mode, N, device=0, nn_window=window))
     eng.set_paths(base.tables)
     stream = torch.cuda.current_stream().cuda_stream
     eng.sync_tables(stream)
