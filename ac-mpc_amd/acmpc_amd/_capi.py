@@ -77,6 +77,12 @@ SIGNATURES = {
     "acmpc_softmin_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acmpc_sync_tables": (C.c_int, [_CTX, C.c_void_p]),
+    "acmpc_sample_device": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
+                                      C.c_void_p, C.c_void_p]),
+    "acmpc_optimize": (C.c_int, [_CTX, _F32P, _F32P, _F32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F64P,
+                                 C.c_double, C.c_uint64, _F32P]),
+    "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "acmpc_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "acmpc_profile_collect": (C.c_int, [_CTX, _F32P, C.c_int32, _I32P]),
     "acmpc_pack_key": (C.c_int64, [C.c_float, C.c_uint32]),
@@ -215,6 +221,31 @@ class Engine:
     def sync_tables(self, stream: int = 0):
         self._check(self._lib.acmpc_sync_tables(self._ctx, stream))
 
+    def sample_device(self, d_centre: int, centre_stride: int, d_u_ref: int, P: int, N: int, n: int, layout: int,
+                      index_offset: int, sigma, seed: int, round_: int, d_U: int, stream: int = 0):
+        self._check(self._lib.acmpc_sample_device(self._ctx, d_centre, centre_stride, d_u_ref or None, P, N, n, layout,
+                                                  index_offset, float(sigma[0]), float(sigma[1]), seed, round_, d_U,
+                                                  stream or None))
+
+    def optimize(self, x0: np.ndarray, centre: np.ndarray, u_ref, n_candidates: int, rounds: int, sigma,
+                 shrink: float = 0.5, seed: int = 0):
+        """Sampling optimisation entirely on the device; x0 [P,3], centre/u_ref [P,n,2] -> record fields."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float32).reshape(-1, 3)
+        centre = np.ascontiguousarray(centre, dtype=np.float32)
+        if centre.ndim == 2:
+            centre = centre[None]
+        P, n = centre.shape[0], centre.shape[1]
+        ref = None
+        if u_ref is not None:
+            ref = np.ascontiguousarray(u_ref, dtype=np.float32).reshape(P, n, 2)
+        sig = (C.c_double * 2)(float(sigma[0]), float(sigma[1]))
+        rec = np.empty((P, record_floats(n)), dtype=np.float32)
+        self._check(self._lib.acmpc_optimize(self._ctx, _f32(x0), _f32(centre), _f32(ref) if ref is not None else None,
+                                             P, n_candidates, n, rounds, sig, float(shrink), seed, _f32(rec)))
+        out = split_record(rec, n)
+        out["records"] = rec
+        return out
+
     def profile_enable(self, capacity: int):
         """Attach event pairs to the next `capacity` rollout launches (no extra packets on the stream)."""
         self._check(self._lib.acmpc_profile_enable(self._ctx, capacity))
@@ -247,6 +278,14 @@ class Engine:
                        d_weight_sum: int = 0, stream: int = 0):
         self._check(self._lib.acmpc_softmin_device(self._ctx, d_costs, d_keys, d_U, P, N, n, layout, d_mean,
                                                    d_weight_sum or None, stream or None))
+
+
+def philox4x32(counter, key) -> np.ndarray:
+    ctr = (C.c_uint32 * 4)(*[int(v) for v in counter])
+    k = (C.c_uint32 * 2)(*[int(v) for v in key])
+    out = (C.c_uint32 * 4)()
+    load_library().acmpc_philox4x32(ctr, k, out)
+    return np.array(list(out), dtype=np.uint32)
 
 
 def pack_key(cost: float, index: int) -> int:

@@ -6,8 +6,9 @@ the same linearised spatial bicycle model the QP has as equality rows, costed wi
 against the QP's own box rows (`csrc/acmpc_device.h`), and the cheapest one wins.
 
 A few refinement rounds (sample around the incumbent, shrink the spread) take the sampled optimum close to the QP
-optimum; the rounds, the candidate count and the spread are build parameters read from optional config keys
-(`n_candidates`, `sampling_rounds`, `sampling_sigma`, `sampling_seed`, `w_bound`).
+optimum.  Candidates are generated on the device too (Philox counters, smooth perturbations - `acmpc_optimize`), so
+one solve is a single host round trip.  The rounds, the candidate count and the spread are build parameters read
+from optional config keys (`n_candidates`, `sampling_rounds`, `sampling_sigma`, `sampling_seed`, `w_bound`).
 """
 from __future__ import annotations
 
@@ -23,14 +24,6 @@ SOLVED = "solved"
 INFEASIBLE = "primal infeasible"
 
 
-def smooth_basis(n: int, knots: int) -> np.ndarray:
-    """[n, knots] raised-cosine bumps: perturbations built from them are smooth along the horizon."""
-    centres = np.linspace(0.0, n - 1.0, knots)
-    width = (n - 1.0) / max(knots - 1, 1)
-    d = np.abs(np.arange(n)[:, None] - centres[None, :]) / width
-    return np.where(d < 1.0, 0.5 * (1.0 + np.cos(np.pi * d)), 0.0)
-
-
 class ControlSolver:
     def __init__(self, config: Dict, model):
         self._dynamics_model = model
@@ -39,8 +32,8 @@ class ControlSolver:
         self._n_candidates = int(config.get("n_candidates", 4096))
         self._rounds = int(config.get("sampling_rounds", 4))
         self._sigma = np.asarray(config.get("sampling_sigma", (3.0, 0.01)), dtype=np.float64)
-        self._rng = np.random.default_rng(config.get("sampling_seed", 0))
-        self._basis = smooth_basis(self._n_horizon, int(config.get("sampling_knots", 8)))
+        self._seed = int(config.get("sampling_seed", 0))
+        self._solves = 0
         self._Q = np.asarray(config["step_cost"], dtype=np.float64)
         self._R = np.asarray(config["r_term"], dtype=np.float64)
         self._QN = np.asarray(config["final_cost"], dtype=np.float64)
@@ -67,31 +60,19 @@ class ControlSolver:
                 w_bound=self._w_bound)
         return self._engine
 
-    def _sample(self, centre: np.ndarray, u_ref: np.ndarray, scale: float) -> np.ndarray:
-        N, n = self._n_candidates, self._n_horizon
-        lo, hi = self._box
-        z = self._rng.standard_normal((N, self._basis.shape[1], 2))
-        U = centre[None] + np.einsum("nk,ckd->cnd", self._basis, z) * (self._sigma * scale)
-        np.clip(U, lo, hi, out=U)
-        U[0] = centre
-        if N > 1:
-            U[1] = np.clip(u_ref, lo, hi)
-        return U.astype(np.float32)
-
     def solve(self, spatial_state: np.ndarray, reference_path: ReferencePath) -> SimpleNamespace:
         engine = self._ensure_engine()
         n = self._n_horizon
         engine.set_paths(reference_path.table)
-        u_ref = np.stack([reference_path.velocities, reference_path.kappas], axis=1)
-        centre = self._incumbent if self._incumbent is not None and self._incumbent.shape == u_ref.shape else u_ref
-        x0 = np.asarray(spatial_state, dtype=np.float32)[None]
-        best = None
-        for r in range(self._rounds):
-            U = self._sample(centre, u_ref, 0.5**r)
-            out = engine.solve(x0, U[None], layout=_capi.LAYOUT_CANDIDATE_MAJOR, want_costs=False)
-            if best is None or out["cost"][0] < best["cost"][0]:
-                best = out
-            centre = best["u"][0].astype(np.float64)
+        lo, hi = self._box
+        u_ref = np.clip(np.stack([reference_path.velocities, reference_path.kappas], axis=1), lo, hi)
+        warm = self._incumbent is not None and self._incumbent.shape == u_ref.shape
+        centre = self._incumbent if warm else u_ref
+        self._solves += 1
+        # sample -> rollout + cost -> argmin, `rounds` times, entirely on the device (acmpc_optimize)
+        best = engine.optimize(np.asarray(spatial_state, dtype=np.float32)[None], centre[None], u_ref[None],
+                               self._n_candidates, self._rounds, self._sigma, shrink=0.5,
+                               seed=self._seed + self._solves)
         u_star = best["u"][0].astype(np.float64)
         x_star = best["x"][0].astype(np.float64)
         self._incumbent = u_star

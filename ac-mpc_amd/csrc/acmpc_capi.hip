@@ -38,6 +38,12 @@ struct acmpc_ctx {
   double* d_soft_partial = nullptr;
   size_t soft_partial_doubles = 0;
 
+  // sampler: per-step (left knot, weight) table, uploaded when n changes
+  float* d_segments = nullptr;
+  int segments_n = 0;
+  float* d_centre = nullptr;  // [P][n][2] staging of acmpc_optimize (first round's centre, then u_ref)
+  float* d_uref = nullptr;
+
   // staging for the host-pointer entry point (created on its first use)
   bool staging_ready = false;
   hipStream_t stream = nullptr;
@@ -98,6 +104,7 @@ int ensure_device(acmpc_ctx* c) {
   ACMPC_HIP(c, hipMalloc(&c->d_partial_keys, partials * sizeof(int64_t)));
   ACMPC_HIP(c, hipMalloc(&c->d_partial_feas, partials * sizeof(int)));
   ACMPC_HIP(c, hipMalloc(&c->d_soft_partial, c->soft_partial_doubles * sizeof(double)));
+  ACMPC_HIP(c, hipMalloc(&c->d_segments, static_cast<size_t>(p.max_steps) * 2 * sizeof(float)));
   c->device_ready = true;
   return ACMPC_OK;
 }
@@ -179,10 +186,59 @@ int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const 
   return ACMPC_OK;
 }
 
+// raised-cosine blend between kSampleKnots knots spread evenly over the n steps
+int upload_segments(acmpc_ctx* c, int n, hipStream_t s) {
+  if (c->segments_n == n) return ACMPC_OK;
+  std::vector<float> seg(static_cast<size_t>(n) * 2);
+  const double width = static_cast<double>(n - 1) / (acmpc::kSampleKnots - 1);
+  for (int i = 0; i < n; ++i) {
+    const double pos = (n > 1) ? i / width : 0.0;
+    int k0 = static_cast<int>(std::floor(pos));
+    if (k0 > acmpc::kSampleKnots - 2) k0 = acmpc::kSampleKnots - 2;
+    const double frac = pos - k0;
+    seg[2 * i] = static_cast<float>(k0);
+    seg[2 * i + 1] = static_cast<float>(0.5 * (1.0 + std::cos(3.14159265358979323846 * frac)));
+  }
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_segments, seg.data(), seg.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  ACMPC_HIP(c, hipStreamSynchronize(s));  // `seg` is a local
+  c->segments_n = n;
+  return ACMPC_OK;
+}
+
+int sample(acmpc_ctx* c, const float* d_centre, int centre_stride, const float* d_uref, int P, int N, int n,
+           int layout, int64_t offset, double sigma_v, double sigma_k, uint64_t seed, uint32_t round, float* d_U,
+           hipStream_t s) {
+  const int rc = upload_segments(c, n, s);
+  if (rc != ACMPC_OK) return rc;
+  acmpc::SampleArgs a{};
+  a.centre = d_centre;
+  a.u_ref = d_uref;
+  a.segments = c->d_segments;
+  a.U = d_U;
+  a.centre_stride = centre_stride;
+  a.P = P;
+  a.N = N;
+  a.n = n;
+  a.index_offset = offset;
+  a.seed_lo = static_cast<uint32_t>(seed);
+  a.seed_hi = static_cast<uint32_t>(seed >> 32);
+  a.round = round;
+  a.sigma_v = static_cast<float>(sigma_v);
+  a.sigma_k = static_cast<float>(sigma_k);
+  a.ulo0 = c->w.ulo0;
+  a.ulo1 = c->w.ulo1;
+  a.uhi0 = c->w.uhi0;
+  a.uhi1 = c->w.uhi1;
+  ACMPC_HIP(c, acmpc::launch_sample(layout, a, s));
+  return ACMPC_OK;
+}
+
 int ensure_staging(acmpc_ctx* c) {
   if (c->staging_ready) return ACMPC_OK;
   const acmpc_params& p = c->prm;
   const size_t cand = static_cast<size_t>(p.max_problems) * p.max_candidates;
+  ACMPC_HIP(c, hipMalloc(&c->d_centre, static_cast<size_t>(p.max_problems) * p.max_steps * 2 * sizeof(float)));
+  ACMPC_HIP(c, hipMalloc(&c->d_uref, static_cast<size_t>(p.max_problems) * p.max_steps * 2 * sizeof(float)));
   ACMPC_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   ACMPC_HIP(c, hipMalloc(&c->d_U, cand * p.max_steps * 2 * sizeof(float)));
   ACMPC_HIP(c, hipMalloc(&c->d_x0, static_cast<size_t>(p.max_problems) * 3 * sizeof(float)));
@@ -263,6 +319,9 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_partial_keys);
     (void)hipFree(c->d_partial_feas);
     (void)hipFree(c->d_soft_partial);
+    (void)hipFree(c->d_segments);
+    (void)hipFree(c->d_centre);
+    (void)hipFree(c->d_uref);
     (void)hipFree(c->d_U);
     (void)hipFree(c->d_x0);
     (void)hipFree(c->d_costs);
@@ -420,6 +479,66 @@ int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_
   ACMPC_HIP(c, hipStreamSynchronize(s));
   if (best_idx != nullptr)
     for (int p = 0; p < P; ++p) best_idx[p] = static_cast<int32_t>(acmpc_key_index(c->h_keys[p]));
+  return ACMPC_OK;
+}
+
+void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+  acmpc::philox4x32_10(counter, key, out);
+}
+
+int acmpc_sample_device(acmpc_ctx* c, const float* d_centre, int32_t centre_stride, const float* d_u_ref, int32_t P,
+                        int32_t N, int32_t n, int32_t layout, int64_t index_offset, double sigma_v, double sigma_kappa,
+                        uint64_t seed, uint32_t round, float* d_U, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (d_centre == nullptr || d_U == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (centre_stride < 2 * n) return fail(c, ACMPC_EINVAL, "centre_stride must be at least 2 n");
+  if (index_offset < 0 || index_offset + N > 0xffffffffLL) return fail(c, ACMPC_EINVAL, "global index exceeds 32 bits");
+  int rc = check_shape(c, P, N, n, layout);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  return sample(c, d_centre, centre_stride, d_u_ref, P, N, n, layout, index_offset, sigma_v, sigma_kappa, seed, round,
+                d_U, static_cast<hipStream_t>(stream));
+}
+
+int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const float* u_ref, int32_t P, int32_t N,
+                   int32_t n, int32_t rounds, const double sigma[2], double shrink, uint64_t seed, float* records) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (x0 == nullptr || centre == nullptr || sigma == nullptr || records == nullptr)
+    return fail(c, ACMPC_EINVAL, "null argument");
+  if (rounds < 1) return fail(c, ACMPC_EINVAL, "rounds must be positive");
+  const int layout = ACMPC_LAYOUT_STEP_MAJOR;
+  int rc = check_shape(c, P, N, n, layout);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_staging(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = c->stream;
+  rc = upload_tables(c, s);
+  if (rc != ACMPC_OK) return rc;
+  const size_t path_bytes = static_cast<size_t>(P) * n * 2 * sizeof(float);
+  const int rec_floats = acmpc_record_floats(n);
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_centre, centre, path_bytes, hipMemcpyHostToDevice, s));
+  if (u_ref != nullptr) ACMPC_HIP(c, hipMemcpyAsync(c->d_uref, u_ref, path_bytes, hipMemcpyHostToDevice, s));
+  double scale = 1.0;
+  for (int r = 0; r < rounds; ++r, scale *= shrink) {
+    // round 0 samples round the caller's centre, later rounds round the incumbent = the u block of the records
+    const float* d_c = (r == 0) ? c->d_centre : c->d_records + ACMPC_REC_HEADER;
+    const int stride = (r == 0) ? 2 * n : rec_floats;
+    rc = sample(c, d_c, stride, u_ref != nullptr ? c->d_uref : nullptr, P, N, n, layout, 0, sigma[0] * scale,
+                sigma[1] * scale, seed, static_cast<uint32_t>(r), c->d_U, s);
+    if (rc != ACMPC_OK) return rc;
+    acmpc::LaunchShape shape;
+    rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, nullptr, s, &shape);
+    if (rc != ACMPC_OK) return rc;
+    rc = finalize(c, nullptr, nullptr, c->d_x0, c->d_U, P, N, n, layout, 0, c->d_records, shape.blocks_per_problem, s);
+    if (rc != ACMPC_OK) return rc;
+  }
+  ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, static_cast<size_t>(P) * rec_floats * sizeof(float),
+                              hipMemcpyDeviceToHost, s));
+  ACMPC_HIP(c, hipStreamSynchronize(s));
   return ACMPC_OK;
 }
 

@@ -190,6 +190,46 @@ __device__ __forceinline__ float finish_temporal(const StateT& s, int n, const W
   return J + w.wbound * s.V;
 }
 
+// ---- candidate sampling ------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based, so candidate c
+// of problem p in round r is the same numbers on every rank and in every launch shape.
+__device__ __host__ __forceinline__ void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = static_cast<uint32_t>(p1);
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = static_cast<uint32_t>(p0);
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+// 32 random bits -> uniform in (0, 1): 24 bits, centred, never 0 or 1
+__device__ __forceinline__ float uniform_open(uint32_t bits) {
+  return static_cast<float>(bits >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
+}
+
+// Box-Muller on two uniforms -> two standard normals
+__device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float& z1) {
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.28318530717958647692f * u2, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
 // ---- (cost, index) keys ---------------------------------------------------------------------------------
 // key = (ordered_int32(cost) << 32) | uint32(index): signed 64-bit order == (cost, index) lexicographic order,
 // so min() is np.argmin's "first minimum".  Non-finite costs rank as +inf.

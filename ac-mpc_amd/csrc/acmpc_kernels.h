@@ -46,6 +46,21 @@ struct SoftminArgs {
   float lambda;
 };
 
+constexpr int kSampleKnots = 8;  // raised-cosine knots along the horizon
+
+struct SampleArgs {
+  const float* centre;     // [P] x centre_stride floats, first 2n of each = (v, kappa) per step
+  const float* u_ref;      // [P][n][2] or nullptr: becomes candidate 1
+  const float* segments;   // [n][2]: knot index (as float) and weight of that knot, the next knot gets 1 - weight
+  float* U;                // out, layout per `layout`
+  int centre_stride;
+  int P, N, n;
+  int64_t index_offset;    // global index of local candidate 0 (the counter of the generator)
+  uint32_t seed_lo, seed_hi, round;
+  float sigma_v, sigma_k;  // spread of this round
+  float ulo0, ulo1, uhi0, uhi1;
+};
+
 struct LaunchShape {
   int block;              // threads per workgroup
   int cpt;                // candidates per thread
@@ -61,6 +76,7 @@ int max_blocks_per_problem(int N);
 hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                           hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
+hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s);
 int softmin_chunks(int N);
 hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s);
 

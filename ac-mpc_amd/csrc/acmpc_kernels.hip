@@ -384,6 +384,63 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   for (int e = lane; e < rec_floats; e += kWave) rec[e] = s_rec[e];
 }
 
+// ---- candidate sampling ------------------------------------------------------------------------------------
+// U_c = clip(centre + a_c * sigma * (smooth noise)), one lane per candidate.  The noise is a raised-cosine blend of
+// kSampleKnots x 2 standard normals per candidate (smooth along the horizon), a_c cycles through 8 amplitude
+// levels, candidate 0 is the centre itself (so a round can never lose the incumbent) and candidate 1 the reference
+// controls.  Philox counters are (global candidate, problem, round, draw): reproducible on any rank.
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
+  const int p = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.N) return;
+  const int n = a.n;
+  const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
+  float z[kSampleKnots][2];
+  const uint32_t key[2] = {a.seed_lo, a.seed_hi};
+#pragma unroll
+  for (int q = 0; q < kSampleKnots / 2; ++q) {
+    const uint32_t ctr[4] = {gidx, static_cast<uint32_t>(p), a.round, static_cast<uint32_t>(q)};
+    uint32_t r[4];
+    philox4x32_10(ctr, key, r);
+    box_muller(uniform_open(r[0]), uniform_open(r[1]), z[2 * q][0], z[2 * q][1]);
+    box_muller(uniform_open(r[2]), uniform_open(r[3]), z[2 * q + 1][0], z[2 * q + 1][1]);
+  }
+  float amp = static_cast<float>((gidx & 7u) + 1u) * 0.125f;
+  if (gidx == 0u) amp = 0.0f;
+  const bool use_ref = (gidx == 1u) && (a.u_ref != nullptr);
+  const float sv = a.sigma_v * amp, sk = a.sigma_k * amp;
+  const float* __restrict__ centre = a.centre + static_cast<size_t>(p) * a.centre_stride;
+  const float* __restrict__ ref = use_ref ? a.u_ref + static_cast<size_t>(p) * n * 2 : centre;
+  int i = 0;
+#pragma unroll
+  for (int knot = 0; knot < kSampleKnots; ++knot) {
+    const float z0v = z[knot][0], z0k = z[knot][1];
+    const float z1v = z[knot + 1 < kSampleKnots ? knot + 1 : knot][0];
+    const float z1k = z[knot + 1 < kSampleKnots ? knot + 1 : knot][1];
+    // steps whose left knot is `knot` (segments[] is wave-uniform: scalar loads)
+    while (i < n && static_cast<int>(a.segments[2 * i]) == knot) {
+      const float w0 = a.segments[2 * i + 1];
+      const float w1 = 1.0f - w0;
+      float v = ref[2 * i] + (use_ref ? 0.0f : sv * (w0 * z0v + w1 * z1v));
+      float k = ref[2 * i + 1] + (use_ref ? 0.0f : sk * (w0 * z0k + w1 * z1k));
+      v = fminf(fmaxf(v, a.ulo0), a.uhi0);
+      k = fminf(fmaxf(k, a.ulo1), a.uhi1);
+      if constexpr (LAYOUT == 1) {
+        float* row = a.U + (static_cast<size_t>(p) * n + i) * 2 * static_cast<size_t>(a.N) + c;
+        row[0] = v;
+        row[a.N] = k;
+      } else {
+        f32x2 vk;
+        vk[0] = v;
+        vk[1] = k;
+        *reinterpret_cast<f32x2*>(a.U + ((static_cast<size_t>(p) * a.N + c) * n + i) * 2) = vk;
+      }
+      ++i;
+    }
+  }
+}
+
 // ---- softmin-weighted mean -------------------------------------------------------------------------------
 constexpr int kSoftChunk = 4096;  // candidates per workgroup
 constexpr int kSoftBlock = 256;
@@ -602,6 +659,18 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
     hipLaunchKernelGGL((finalize_kernel<1, 0>), grid, block, lds, s, args);
   } else if (mode == 1 && layout == 1) {
     hipLaunchKernelGGL((finalize_kernel<1, 1>), grid, block, lds, s, args);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
+  const dim3 grid((args.N + 255) / 256, args.P);
+  if (layout == 0) {
+    hipLaunchKernelGGL((sample_kernel<0>), grid, dim3(256), 0, s, args);
+  } else if (layout == 1) {
+    hipLaunchKernelGGL((sample_kernel<1>), grid, dim3(256), 0, s, args);
   } else {
     return hipErrorInvalidValue;
   }

@@ -159,6 +159,27 @@ int acmpc_softmin_device(acmpc_ctx* ctx, const float* d_costs, const int64_t* d_
  * timed region contains no host-to-device traffic. */
 int acmpc_sync_tables(acmpc_ctx* ctx, void* stream);
 
+/* On-device candidate generation.  Candidate c of problem p is
+ *     U_c = clip(centre_p + a_c * (sigma_v, sigma_kappa) * smooth_noise_c, input box),   a_c = ((c mod 8) + 1) / 8,
+ * smooth_noise = raised-cosine blend along the horizon of 8 x 2 standard normals drawn with Philox4x32-10 at
+ * counter (global candidate index, problem, round, draw) and key = seed, so every rank regenerates the same
+ * candidate from its index alone.  Candidate 0 is the centre itself, candidate 1 is `d_u_ref` when given.
+ * `d_centre` holds P rows of `centre_stride` floats whose first 2n are (v, kappa) per step - the u block of a
+ * winner record qualifies (centre_stride = acmpc_record_floats(n), pointer = records + ACMPC_REC_HEADER). */
+int acmpc_sample_device(acmpc_ctx* ctx, const float* d_centre, int32_t centre_stride, const float* d_u_ref,
+                        int32_t P, int32_t N, int32_t n, int32_t layout, int64_t index_offset, double sigma_v,
+                        double sigma_kappa, uint64_t seed, uint32_t round, float* d_U, void* stream);
+
+/* Replaces: ControlSolver.solve (control.py:15-24) end to end on the device - `rounds` rounds of
+ * sample -> rollout + cost -> argmin, each round sampling round the previous winner with the spread shrunk by
+ * `shrink`, one host round trip in total (x0, centre, u_ref up; the final records down).  Host pointers:
+ * x0 [P][3], centre [P][n][2], u_ref [P][n][2] or NULL, sigma[2], records [P][acmpc_record_floats(n)]. */
+int acmpc_optimize(acmpc_ctx* ctx, const float* x0, const float* centre, const float* u_ref, int32_t P, int32_t N,
+                   int32_t n, int32_t rounds, const double sigma[2], double shrink, uint64_t seed, float* records);
+
+/* The generator itself, on the host (same code as the kernels): lets tests pin the integer stream. */
+void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+
 /* Measurement hooks.  After acmpc_profile_enable(ctx, K) the next K rollout launches of this handle carry a HIP
  * event pair attached to the dispatch itself (hipExtLaunchKernel: the kernel's own begin/end timestamps on the
  * stream it is launched on, no marker packets between launches); acmpc_profile_collect waits for them, writes the

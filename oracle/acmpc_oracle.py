@@ -595,3 +595,74 @@ def qp_objective(P_diag, q, z):
 def pack_decision_vector(X: np.ndarray, U: np.ndarray) -> np.ndarray:
     """[x_0..x_n ; u_0..u_{n-1}] layout of dec.x (control.py:121-158, spatial_mpc.py:193-202)."""
     return np.concatenate([X.ravel(), U.ravel()])
+
+
+# ---------------------------------------------------------------------------
+# On-device candidate generation (build-defined; SURVEY.md section 8f #3)
+# ---------------------------------------------------------------------------
+PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+SAMPLE_KNOTS = 8
+
+
+def philox4x32_10(counter: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """Philox4x32-10 of Salmon, Moraes, Dror & Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11),
+    vectorised: counter [..., 4] uint32, key [..., 2] uint32 -> [..., 4] uint32.  Integer arithmetic: exact."""
+    c = np.asarray(counter, dtype=np.uint64) & 0xFFFFFFFF
+    k = np.asarray(key, dtype=np.uint64) & 0xFFFFFFFF
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = k[..., 0].copy(), k[..., 1].copy()
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(PHILOX_M0) * c0
+        p1 = np.uint64(PHILOX_M1) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & mask
+        n3 = p0 & mask
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(PHILOX_W0)) & mask
+        k1 = (k1 + np.uint64(PHILOX_W1)) & mask
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def sample_segments(n: int) -> np.ndarray:
+    """Per step: (left knot, weight of the left knot); the next knot gets 1 - weight (raised cosine)."""
+    width = (n - 1) / (SAMPLE_KNOTS - 1)
+    pos = np.arange(n) / width
+    k0 = np.minimum(np.floor(pos), SAMPLE_KNOTS - 2)
+    w0 = 0.5 * (1.0 + np.cos(np.pi * (pos - k0)))
+    return np.stack([k0, w0], axis=1).astype(np.float32)
+
+
+def sample_candidates(centre, u_ref, n_candidates, index_offset, problem, round_, seed, sigma, u_lo, u_hi):
+    """Restates csrc sample_kernel for ONE problem in float64 (the device uses float32 with library log/sin/cos,
+    so agreement is to ~1e-6 relative, not bitwise).  centre/u_ref [n,2] -> U [N,n,2]."""
+    centre = np.asarray(centre, dtype=np.float32).astype(np.float64)
+    n = centre.shape[0]
+    gidx = (np.arange(n_candidates, dtype=np.uint64) + np.uint64(index_offset)).astype(np.uint32)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    z = np.zeros((n_candidates, SAMPLE_KNOTS, 2))
+    for q in range(SAMPLE_KNOTS // 2):
+        ctr = np.stack([gidx, np.full_like(gidx, problem), np.full_like(gidx, round_), np.full_like(gidx, q)], axis=1)
+        r = philox4x32_10(ctr, np.broadcast_to(key, (n_candidates, 2)))
+        u = ((r >> 8).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)).astype(np.float64)
+        for half in range(2):
+            rad = np.sqrt(-2.0 * np.log(u[:, 2 * half]))
+            ang = 2.0 * np.pi * u[:, 2 * half + 1]
+            z[:, 2 * q + half, 0] = rad * np.cos(ang)
+            z[:, 2 * q + half, 1] = rad * np.sin(ang)
+    seg = sample_segments(n).astype(np.float64)
+    k0 = seg[:, 0].astype(int)
+    w0 = seg[:, 1]
+    k1 = np.minimum(k0 + 1, SAMPLE_KNOTS - 1)
+    noise = w0[None, :, None] * z[:, k0, :] + (1.0 - w0)[None, :, None] * z[:, k1, :]   # [N,n,2]
+    amp = ((gidx & 7) + 1).astype(np.float64) * 0.125
+    amp[gidx == 0] = 0.0
+    sig = np.asarray(sigma, dtype=np.float32).astype(np.float64)
+    U = centre[None] + amp[:, None, None] * sig[None, None, :] * noise
+    if u_ref is not None:
+        U[gidx == 1] = np.asarray(u_ref, dtype=np.float32).astype(np.float64)
+    lo = np.asarray(u_lo, dtype=np.float32).astype(np.float64)
+    hi = np.asarray(u_hi, dtype=np.float32).astype(np.float64)
+    return np.clip(U, lo, hi)

@@ -102,3 +102,23 @@ def test_errors_without_device_or_tables():
         with pytest.raises(EngineError) as e:
             eng.solve(prob["x0"][None], prob["U"][None])
         assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_philox_known_answers_and_oracle_agreement():
+    """Random123's published known-answer vectors for philox4x32-10, and library == NumPy restatement."""
+    from acmpc_amd import _capi
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, want in kat:
+        np.testing.assert_array_equal(_capi.philox4x32(ctr, key), np.array(want, dtype=np.uint32))
+        np.testing.assert_array_equal(orc.philox4x32_10(np.array(ctr), np.array(key)), np.array(want, dtype=np.uint32))
+    rng = np.random.default_rng(3)
+    ctr = rng.integers(0, 2**32, (50, 4), dtype=np.uint64)
+    key = rng.integers(0, 2**32, (50, 2), dtype=np.uint64)
+    got = orc.philox4x32_10(ctr, key)
+    for i in range(50):
+        np.testing.assert_array_equal(_capi.philox4x32(ctr[i], key[i]), got[i])

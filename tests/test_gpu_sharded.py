@@ -123,3 +123,78 @@ def test_softmin_weighted_mean(layout, N, H):
         got = mean[p].cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(wsum[p].item(), w.sum(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_device_sampler_matches_its_restatement(layout):
+    """acmpc_sample_device vs the oracle's float64 restatement (integer stream exact, transform to 1e-6),
+    structural guarantees, and regeneration of a shard from indices alone."""
+    import torch
+    from acmpc_amd import Engine
+    P, H, N = 2, 50, 1000
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 4, seed=400 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
+    eng.set_paths(np.stack([p["table"] for p in problems]))
+    u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]).astype(np.float32)
+    centre = (u_ref + np.array([-1.0, 0.002], dtype=np.float32)).astype(np.float32)
+    d_centre, d_ref = torch.tensor(centre, device=dev), torch.tensor(u_ref, device=dev)
+    shape = (P, N, n, 2) if layout == 0 else (P, n, 2, N)
+    U = torch.empty(shape, device=dev)
+    sigma, seed, rnd = (3.0, 0.01), 0x1234567899, 2
+    s = torch.cuda.current_stream().cuda_stream
+    eng.sample_device(d_centre.data_ptr(), 2 * n, d_ref.data_ptr(), P, N, n, layout, 0, sigma, seed, rnd, U.data_ptr(), s)
+    torch.cuda.synchronize()
+    got = U.cpu().numpy() if layout == 0 else U.cpu().numpy().transpose(0, 3, 1, 2)
+    lo, hi = problems[0]["u_lo"], problems[0]["u_hi"]
+    for p in range(P):
+        want = orc.sample_candidates(centre[p], u_ref[p], N, 0, p, rnd, seed, sigma, lo, hi)
+        np.testing.assert_allclose(got[p], want, rtol=3e-6, atol=3e-6)
+        np.testing.assert_array_equal(got[p, 0], np.clip(centre[p], lo.astype(np.float32), hi.astype(np.float32)))
+        np.testing.assert_array_equal(got[p, 1], np.clip(u_ref[p], lo.astype(np.float32), hi.astype(np.float32)))
+        assert (got[p] >= lo.astype(np.float32)).all() and (got[p] <= hi.astype(np.float32)).all()
+    # perturbations are smooth along the horizon and grow with the amplitude level
+    dev_k = got[0, 8:, :, 1] - np.clip(centre[0, :, 1], lo[1], hi[1])
+    assert np.abs(np.diff(dev_k, axis=1)).mean() < 0.25 * np.abs(dev_k).mean()
+    # a shard regenerates exactly the candidates its global indices name
+    part = torch.empty((P, 300, n, 2) if layout == 0 else (P, n, 2, 300), device=dev)
+    eng.sample_device(d_centre.data_ptr(), 2 * n, d_ref.data_ptr(), P, 300, n, layout, 500, sigma, seed, rnd,
+                      part.data_ptr(), s)
+    torch.cuda.synchronize()
+    got_part = part.cpu().numpy() if layout == 0 else part.cpu().numpy().transpose(0, 3, 1, 2)
+    np.testing.assert_array_equal(got_part, got[:, 500:800])
+
+
+def test_optimize_equals_the_manual_round_loop():
+    """acmpc_optimize == sample_device -> solve_device per round with the incumbent fed back, bit for bit; and the
+    winner's cost never increases from round to round."""
+    import torch
+    from acmpc_amd import Engine, _capi
+    P, H, N, rounds = 3, 50, 2048, 4
+    n = H - 1
+    problems = [make_problem(orc, "silverstone", H, 4, seed=500 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
+    eng.set_paths(np.stack([p["table"] for p in problems]))
+    u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]).astype(np.float32)
+    x0 = np.stack([p["x0"] for p in problems])
+    sigma, seed = (3.0, 0.01), 42
+    out = eng.optimize(x0, u_ref, u_ref, N, rounds, sigma, shrink=0.5, seed=seed)
+    R = _capi.record_floats(n)
+    d_x0, d_ref = torch.tensor(x0, device=dev), torch.tensor(u_ref, device=dev)
+    U = torch.empty(P, n, 2, N, device=dev)
+    rec = torch.empty(P, R, device=dev)
+    keys = torch.empty(P, dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    costs = []
+    for r in range(rounds):
+        centre_ptr, stride = (d_ref.data_ptr(), 2 * n) if r == 0 else (rec.data_ptr() + 4 * _capi.REC_HEADER, R)
+        eng.sample_device(centre_ptr, stride, d_ref.data_ptr(), P, N, n, 1, 0, (sigma[0] * 0.5**r, sigma[1] * 0.5**r),
+                          seed, r, U.data_ptr(), s)
+        eng.solve_device(d_x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, keys.data_ptr(), rec.data_ptr(), s)
+        torch.cuda.synchronize()
+        costs.append(rec[:, 0].cpu().numpy().copy())
+    np.testing.assert_array_equal(out["records"], rec.cpu().numpy())
+    for a, b in zip(costs, costs[1:]):
+        assert (b <= a).all()
