@@ -189,6 +189,38 @@ def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300
     return out
 
 
+def closed_loop_replay(workloads, track_name="silverstone", poses=2000):
+    """BASELINE.json configs[4]: the drop-in controller (`build_mpc(...).get_control`) against consecutive poses
+    along the synthetic Silverstone circuit - one full MPC solve per pose (waypoints, host speed-profile QP,
+    4 rounds x 4 096 candidates sampled, rolled out and reduced on the GPU) - wall-clock p50/p99 per solve."""
+    import copy
+    from acmpc_amd.mpc import build_mpc
+
+    cfg = copy.deepcopy(workloads.RACING_CONTROL[track_name])
+    cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])  # controller.py:241-243
+    mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
+    track = workloads.synthetic_track(track_name)
+    H = cfg["horizon"]
+    stride = 2  # 1 m between consecutive poses at 0.5 m map spacing (~30 m/s at 30 Hz perception)
+    paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * stride) % len(track["centre"])), H)
+             for i in range(poses + 20)]
+    for p in paths[:20]:
+        mpc.get_control(p)
+    wall = np.empty(poses)
+    for i, p in enumerate(paths[20:]):
+        t0 = time.perf_counter()
+        mpc.get_control(p)
+        wall[i] = time.perf_counter() - t0
+    return {
+        "workload": "%s (synthetic circuit): %d consecutive poses, SpatialMPC.get_control per pose, horizon %d, "
+                    "%d candidates x %d rounds" % (track_name, poses, H, mpc._control_solver._n_candidates,
+                                                    mpc._control_solver._rounds),
+        "solve_ms_p50": float(np.percentile(wall, 50) * 1e3), "solve_ms_p99": float(np.percentile(wall, 99) * 1e3),
+        "solve_ms_max": float(wall.max() * 1e3), "sustainable_hz": float(1.0 / np.percentile(wall, 99)),
+        "infeasible_solves": int(mpc.infeasibility_counter),
+    }
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -317,6 +349,7 @@ def main():
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic
         if world == 1 and not args.no_single_solve:
             out["single_solve"] = single_solve(workloads, Engine, args.track, H, N, mode, args.layout, device)
+            out["closed_loop_replay"] = closed_loop_replay(workloads)
         if world == 1 and not args.no_cpu_baseline:
             gpu_costs = last.costs[:8].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
             out["cpu_baseline"] = cpu_baseline(batch, mode, controls[(args.steps - 1) % args.buffers], args.layout, N,

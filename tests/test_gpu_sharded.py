@@ -198,3 +198,46 @@ def test_optimize_equals_the_manual_round_loop():
     np.testing.assert_array_equal(out["records"], rec.cpu().numpy())
     for a, b in zip(costs, costs[1:]):
         assert (b <= a).all()
+
+
+def test_profile_hooks_and_pipelined_rollout():
+    """acmpc_profile_enable/collect time exactly the launches they were armed for, and the pipelined (side-stream)
+    driver produces the same records as plain stream order."""
+    import torch
+    from acmpc_amd import Engine
+    from acmpc_amd.sharding import PipelinedRollout, ShardedRollout
+    P, H, N = 8, 50, 4096
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 4, seed=600 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    tables = np.stack([p["table"] for p in problems])
+    x0 = torch.tensor(np.stack([p["x0"] for p in problems]), device=dev)
+    rng = np.random.default_rng(0)
+    Us = [torch.tensor((rng.standard_normal((P, n, 2, N)) * np.array([2.0, 0.01])[None, None, :, None]
+                        + np.array([20.0, 0.0])[None, None, :, None]).astype(np.float32), device=dev) for _ in range(3)]
+    engines = []
+    for _ in range(2):
+        eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
+        eng.set_paths(tables)
+        engines.append(eng)
+    stream = torch.cuda.current_stream()
+    serial = ShardedRollout(engines[0], P, N, n, 1, 0, dev)
+    engines[0].profile_enable(2)
+    want = []
+    for U in Us:
+        want.append(serial.step(x0, U, stream.cuda_stream).clone())
+    torch.cuda.synchronize()
+    times = engines[0].profile_collect()
+    assert times.shape == (2,) and (times > 0).all() and (times < 5.0).all()  # armed for 2 of the 3 launches
+    assert engines[0].profile_collect().shape == (0,)
+    engines[0].profile_enable(0)
+    pipe = PipelinedRollout(engines, P, N, n, 1, 0, dev)
+    pipe.bind_stream(stream)
+    got = []
+    for U in Us:
+        slot = pipe.step(x0, U)
+        pipe.drain()
+        torch.cuda.synchronize()
+        got.append(slot.records.clone())
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
