@@ -80,6 +80,9 @@ SIGNATURES = {
     "acmpc_sample_device": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
                                       C.c_void_p, C.c_void_p]),
+    "acmpc_finalize_sampled_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
+                                                C.c_uint32, C.c_void_p, C.c_void_p]),
     "acmpc_optimize": (C.c_int, [_CTX, _F32P, _F32P, _F32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F64P,
                                  C.c_double, C.c_uint64, _F32P]),
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -226,6 +229,12 @@ class Engine:
         self._check(self._lib.acmpc_sample_device(self._ctx, d_centre, centre_stride, d_u_ref or None, P, N, n, layout,
                                                   index_offset, float(sigma[0]), float(sigma[1]), seed, round_, d_U,
                                                   stream or None))
+
+    def finalize_sampled_device(self, d_keys: int, d_x0: int, d_centre: int, centre_stride: int, d_u_ref: int, P: int,
+                                N: int, n: int, sigma, seed: int, round_: int, d_records: int, stream: int = 0):
+        self._check(self._lib.acmpc_finalize_sampled_device(self._ctx, d_keys or None, d_x0, d_centre, centre_stride,
+                                                            d_u_ref or None, P, N, n, float(sigma[0]), float(sigma[1]),
+                                                            seed, round_, d_records, stream or None))
 
     def optimize(self, x0: np.ndarray, centre: np.ndarray, u_ref, n_candidates: int, rounds: int, sigma,
                  shrink: float = 0.5, seed: int = 0):

@@ -38,6 +38,15 @@ def global_select(local_keys: torch.Tensor, make_records: Callable[[torch.Tensor
     return local_keys, records
 
 
+def global_select_sampled(local_keys: torch.Tensor, regenerate_records: Callable[[torch.Tensor], torch.Tensor],
+                          group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Single-collective form for counter-based candidates: all-reduce(MIN) the keys, then EVERY rank rebuilds the
+    winners' records from the global indices in the keys (`regenerate_records(global_keys) -> [P, R]`)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local_keys, op=dist.ReduceOp.MIN, group=group)
+    return local_keys, regenerate_records(local_keys)
+
+
 class ShardedRollout:
     """Binds an `Engine` to this rank's slice of the candidates.  All tensors are torch CUDA tensors; the engine
     is handed raw pointers and the current stream, RCCL runs on the same stream through torch.distributed."""
@@ -52,6 +61,22 @@ class ShardedRollout:
         self.records = torch.empty(n_problems, record_floats(n_steps), dtype=torch.float32, device=device)
         self.costs = torch.empty(n_problems, n_local, dtype=torch.float32, device=device) if want_costs else None
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.sampler = None
+
+    def use_sampler(self, centre: torch.Tensor, u_ref: Optional[torch.Tensor], sigma, seed: int, round_: int = 0):
+        """Declare that the control matrices handed to rollout()/select() were produced by `sample()` with these
+        parameters.  select() then re-draws each winner from the global index in its key on EVERY rank
+        (acmpc_finalize_sampled_device): ONE all-reduce(MIN) of the keys per step, no record exchange."""
+        self.sampler = dict(centre=centre, u_ref=u_ref, sigma=tuple(sigma), seed=int(seed), round=int(round_))
+
+    def sample(self, U: torch.Tensor, stream: int, seed: Optional[int] = None, round_: Optional[int] = None):
+        """Fill `U` with this rank's slice of the candidates (global indices offset .. offset + N)."""
+        sp = self.sampler
+        self.engine.sample_device(sp["centre"].data_ptr(), sp["centre"].shape[-2] * 2 if sp["centre"].dim() == 3
+                                  else sp["centre"].shape[-1], sp["u_ref"].data_ptr() if sp["u_ref"] is not None else 0,
+                                  self.P, self.N, self.n, self.layout, self.offset, sp["sigma"],
+                                  sp["seed"] if seed is None else seed, sp["round"] if round_ is None else round_,
+                                  U.data_ptr(), stream)
 
     def rollout(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
         """The dominant kernel alone: controls in, costs and per-workgroup partial keys out."""
@@ -59,8 +84,22 @@ class ShardedRollout:
                                    self.costs.data_ptr() if self.costs is not None else 0,
                                    self.keys.data_ptr() if self.distributed else 0, stream)
 
-    def select(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
+    def select(self, x0: torch.Tensor, U: torch.Tensor, stream: int, seed: Optional[int] = None,
+               round_: Optional[int] = None):
         """argmin across workgroups (and across ranks), then the winner's record."""
+        if self.sampler is not None:
+            sp = self.sampler
+            if self.distributed:
+                dist.all_reduce(self.keys, op=dist.ReduceOp.MIN, group=self.group)   # the only collective
+            centre = sp["centre"]
+            stride = centre.shape[-2] * 2 if centre.dim() == 3 else centre.shape[-1]
+            self.engine.finalize_sampled_device(self.keys.data_ptr() if self.distributed else 0, x0.data_ptr(),
+                                                centre.data_ptr(), stride,
+                                                sp["u_ref"].data_ptr() if sp["u_ref"] is not None else 0, self.P, self.N,
+                                                self.n, sp["sigma"], sp["seed"] if seed is None else seed,
+                                                sp["round"] if round_ is None else round_, self.records.data_ptr(),
+                                                stream)
+            return self.records
         if self.distributed:
             dist.all_reduce(self.keys, op=dist.ReduceOp.MIN, group=self.group)
             self.engine.finalize_device(self.keys.data_ptr(), x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n,

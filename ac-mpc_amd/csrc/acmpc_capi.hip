@@ -165,9 +165,24 @@ int rollout(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int
   return ACMPC_OK;
 }
 
+struct Regenerate {
+  const float* d_centre;
+  int centre_stride;
+  const float* d_uref;
+  acmpc::SampleSpec spec;
+};
+
 int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const float* d_x0, const float* d_U, int P,
-             int N, int n, int layout, int64_t offset, float* d_records, int blocks_per_problem, hipStream_t s) {
+             int N, int n, int layout, int64_t offset, float* d_records, int blocks_per_problem, hipStream_t s,
+             const Regenerate* regen = nullptr) {
   acmpc::FinalizeArgs a{};
+  if (regen != nullptr) {
+    a.regenerate = true;
+    a.centre = regen->d_centre;
+    a.centre_stride = regen->centre_stride;
+    a.u_ref = regen->d_uref;
+    a.spec = regen->spec;
+  }
   a.U = d_U;
   a.x0 = d_x0;
   a.coef = c->d_coef;
@@ -205,6 +220,21 @@ int upload_segments(acmpc_ctx* c, int n, hipStream_t s) {
   return ACMPC_OK;
 }
 
+acmpc::SampleSpec make_spec(const acmpc_ctx* c, double sigma_v, double sigma_k, uint64_t seed, uint32_t round) {
+  acmpc::SampleSpec sp{};
+  sp.segments = c->d_segments;
+  sp.seed_lo = static_cast<uint32_t>(seed);
+  sp.seed_hi = static_cast<uint32_t>(seed >> 32);
+  sp.round = round;
+  sp.sigma_v = static_cast<float>(sigma_v);
+  sp.sigma_k = static_cast<float>(sigma_k);
+  sp.ulo0 = c->w.ulo0;
+  sp.ulo1 = c->w.ulo1;
+  sp.uhi0 = c->w.uhi0;
+  sp.uhi1 = c->w.uhi1;
+  return sp;
+}
+
 int sample(acmpc_ctx* c, const float* d_centre, int centre_stride, const float* d_uref, int P, int N, int n,
            int layout, int64_t offset, double sigma_v, double sigma_k, uint64_t seed, uint32_t round, float* d_U,
            hipStream_t s) {
@@ -213,22 +243,13 @@ int sample(acmpc_ctx* c, const float* d_centre, int centre_stride, const float* 
   acmpc::SampleArgs a{};
   a.centre = d_centre;
   a.u_ref = d_uref;
-  a.segments = c->d_segments;
   a.U = d_U;
   a.centre_stride = centre_stride;
   a.P = P;
   a.N = N;
   a.n = n;
   a.index_offset = offset;
-  a.seed_lo = static_cast<uint32_t>(seed);
-  a.seed_hi = static_cast<uint32_t>(seed >> 32);
-  a.round = round;
-  a.sigma_v = static_cast<float>(sigma_v);
-  a.sigma_k = static_cast<float>(sigma_k);
-  a.ulo0 = c->w.ulo0;
-  a.ulo1 = c->w.ulo1;
-  a.uhi0 = c->w.uhi0;
-  a.uhi1 = c->w.uhi1;
+  a.spec = make_spec(c, sigma_v, sigma_k, seed, round);
   ACMPC_HIP(c, acmpc::launch_sample(layout, a, s));
   return ACMPC_OK;
 }
@@ -499,6 +520,25 @@ int acmpc_sample_device(acmpc_ctx* c, const float* d_centre, int32_t centre_stri
   if (rc != ACMPC_OK) return rc;
   return sample(c, d_centre, centre_stride, d_u_ref, P, N, n, layout, index_offset, sigma_v, sigma_kappa, seed, round,
                 d_U, static_cast<hipStream_t>(stream));
+}
+
+int acmpc_finalize_sampled_device(acmpc_ctx* c, const int64_t* d_keys, const float* d_x0, const float* d_centre,
+                                  int32_t centre_stride, const float* d_u_ref, int32_t P, int32_t N, int32_t n,
+                                  double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round, float* d_records,
+                                  void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (d_x0 == nullptr || d_centre == nullptr || d_records == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (centre_stride < 2 * n) return fail(c, ACMPC_EINVAL, "centre_stride must be at least 2 n");
+  int rc = check_shape(c, P, N, n, ACMPC_LAYOUT_STEP_MAJOR);
+  if (rc != ACMPC_OK) return rc;
+  if (!c->device_ready) return fail(c, ACMPC_ESTATE, "acmpc_rollout_device must run first");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = upload_segments(c, n, s);
+  if (rc != ACMPC_OK) return rc;
+  Regenerate regen{d_centre, centre_stride, d_u_ref, make_spec(c, sigma_v, sigma_kappa, seed, round)};
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, ACMPC_LAYOUT_STEP_MAJOR);
+  return finalize(c, d_keys, nullptr, d_x0, nullptr, P, N, n, ACMPC_LAYOUT_STEP_MAJOR, 0, d_records,
+                  shape.blocks_per_problem, s, &regen);
 }
 
 int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const float* u_ref, int32_t P, int32_t N,

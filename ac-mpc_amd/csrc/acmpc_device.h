@@ -230,6 +230,43 @@ __device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float&
   z1 = r * sn;
 }
 
+constexpr int kKnots = 8;  // raised-cosine knots along the horizon (== kSampleKnots)
+
+// Everything that defines candidate `gidx` of problem `p` in round `round` besides its centre.
+struct SampleSpec {
+  const float* segments;  // [n][2]: left knot (as float), weight of the left knot
+  uint32_t seed_lo, seed_hi, round;
+  float sigma_v, sigma_k;
+  float ulo0, ulo1, uhi0, uhi1;
+};
+
+// the 8 x 2 standard normals of one candidate
+__device__ __forceinline__ void draw_normals(const SampleSpec& sp, uint32_t gidx, uint32_t p, float (&z)[kKnots][2]) {
+  const uint32_t key[2] = {sp.seed_lo, sp.seed_hi};
+#pragma unroll
+  for (int q = 0; q < kKnots / 2; ++q) {
+    const uint32_t ctr[4] = {gidx, p, sp.round, static_cast<uint32_t>(q)};
+    uint32_t r[4];
+    philox4x32_10(ctr, key, r);
+    box_muller(uniform_open(r[0]), uniform_open(r[1]), z[2 * q][0], z[2 * q][1]);
+    box_muller(uniform_open(r[2]), uniform_open(r[3]), z[2 * q + 1][0], z[2 * q + 1][1]);
+  }
+}
+
+__device__ __forceinline__ float candidate_amplitude(uint32_t gidx) {
+  return (gidx == 0u) ? 0.0f : static_cast<float>((gidx & 7u) + 1u) * 0.125f;
+}
+
+// control (v, kappa) of one candidate at one step from the normals of the two knots that bracket it
+__device__ __forceinline__ void blend_control(const SampleSpec& sp, float amp, float w0, float cv, float ck, float z0v,
+                                              float z0k, float z1v, float z1k, float& v, float& k) {
+  const float w1 = 1.0f - w0;
+  v = cv + (sp.sigma_v * amp) * (w0 * z0v + w1 * z1v);
+  k = ck + (sp.sigma_k * amp) * (w0 * z0k + w1 * z1k);
+  v = fminf(fmaxf(v, sp.ulo0), sp.uhi0);
+  k = fminf(fmaxf(k, sp.ulo1), sp.uhi1);
+}
+
 // ---- (cost, index) keys ---------------------------------------------------------------------------------
 // key = (ordered_int32(cost) << 32) | uint32(index): signed 64-bit order == (cost, index) lexicographic order,
 // so min() is np.argmin's "first minimum".  Non-finite costs rank as +inf.

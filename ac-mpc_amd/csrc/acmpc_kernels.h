@@ -28,6 +28,13 @@ struct FinalizeArgs {
   const int64_t* keys_in;       // [P] global keys (after an all-reduce) or nullptr
   int64_t* keys_out;            // [P] or nullptr
   float* records;               // [P][record_floats] or nullptr
+  // regenerate == true: the winner's controls are re-drawn from its global index (counter-based sampler) instead
+  // of being loaded from U, so EVERY rank can write the full record after one all-reduce(MIN) of the keys
+  bool regenerate;
+  const float* centre;
+  const float* u_ref;
+  int centre_stride;
+  SampleSpec spec;
   int blocks_per_problem;
   int P, N, n;
   int64_t index_offset;
@@ -46,19 +53,16 @@ struct SoftminArgs {
   float lambda;
 };
 
-constexpr int kSampleKnots = 8;  // raised-cosine knots along the horizon
+constexpr int kSampleKnots = kKnots;
 
 struct SampleArgs {
   const float* centre;     // [P] x centre_stride floats, first 2n of each = (v, kappa) per step
   const float* u_ref;      // [P][n][2] or nullptr: becomes candidate 1
-  const float* segments;   // [n][2]: knot index (as float) and weight of that knot, the next knot gets 1 - weight
   float* U;                // out, layout per `layout`
   int centre_stride;
   int P, N, n;
   int64_t index_offset;    // global index of local candidate 0 (the counter of the generator)
-  uint32_t seed_lo, seed_hi, round;
-  float sigma_v, sigma_k;  // spread of this round
-  float ulo0, ulo1, uhi0, uhi1;
+  SampleSpec spec;
 };
 
 struct LaunchShape {

@@ -194,6 +194,65 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   }
 }
 
+// ---- candidate sampling ------------------------------------------------------------------------------------
+// U_c = clip(centre + a_c * sigma * (smooth noise)), one lane per candidate.  The noise is a raised-cosine blend of
+// kSampleKnots x 2 standard normals per candidate (smooth along the horizon), a_c cycles through 8 amplitude
+// levels, candidate 0 is the centre itself (so a round can never lose the incumbent) and candidate 1 the reference
+// controls.  Philox counters are (global candidate, problem, round, draw): reproducible on any rank.
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
+  const int p = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.N) return;
+  const int n = a.n;
+  const SampleSpec sp = a.spec;
+  const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
+  float z[kKnots][2];
+  draw_normals(sp, gidx, static_cast<uint32_t>(p), z);
+  const bool use_ref = (gidx == 1u) && (a.u_ref != nullptr);
+  const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
+  const float* __restrict__ centre =
+      use_ref ? a.u_ref + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
+  int i = 0;
+#pragma unroll
+  for (int knot = 0; knot < kKnots - 1; ++knot) {
+    // steps whose left knot is `knot` (segments[] is wave-uniform: scalar loads)
+    while (i < n && static_cast<int>(sp.segments[2 * i]) == knot) {
+      float v, k;
+      blend_control(sp, amp, sp.segments[2 * i + 1], centre[2 * i], centre[2 * i + 1], z[knot][0], z[knot][1],
+                    z[knot + 1][0], z[knot + 1][1], v, k);
+      if constexpr (LAYOUT == 1) {
+        float* row = a.U + (static_cast<size_t>(p) * n + i) * 2 * static_cast<size_t>(a.N) + c;
+        row[0] = v;
+        row[a.N] = k;
+      } else {
+        f32x2 vk;
+        vk[0] = v;
+        vk[1] = k;
+        *reinterpret_cast<f32x2*>(a.U + ((static_cast<size_t>(p) * a.N + c) * n + i) * 2) = vk;
+      }
+      ++i;
+    }
+  }
+}
+
+// The same candidate's control at ONE step, for the finalize kernel's lane-per-step regeneration: identical
+// arithmetic (blend_control on the same operands), the bracketing knots picked by a select chain.
+__device__ __forceinline__ void regenerate_control(const SampleSpec& sp, const float (&z)[kKnots][2], float amp,
+                                                   const float* centre, int i, float& v, float& k) {
+  const int k0 = static_cast<int>(sp.segments[2 * i]);
+  float z0v = z[0][0], z0k = z[0][1], z1v = z[1][0], z1k = z[1][1];
+#pragma unroll
+  for (int knot = 1; knot < kKnots - 1; ++knot) {
+    const bool hit = (k0 == knot);
+    z0v = hit ? z[knot][0] : z0v;
+    z0k = hit ? z[knot][1] : z0k;
+    z1v = hit ? z[knot + 1][0] : z1v;
+    z1k = hit ? z[knot + 1][1] : z1k;
+  }
+  blend_control(sp, amp, sp.segments[2 * i + 1], centre[2 * i], centre[2 * i + 1], z0v, z0k, z1v, z1k, v, k);
+}
+
 // One wave per problem.  The winner is re-rolled by the whole wave in lock-step: lane l fetches step l's controls
 // and table row (one round of parallel loads), each step's inputs are then broadcast with v_readlane (SGPRs), so
 // the sequential chain touches no memory at all; every lane carries the same state and the record image is
@@ -226,7 +285,7 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   const int rec_floats = 4 + 2 * n + 3 * (n + 1);
   float* __restrict__ rec = a.records + static_cast<size_t>(p) * rec_floats;
   const int64_t local = static_cast<int64_t>(static_cast<uint32_t>(key & 0xffffffffLL)) - a.index_offset;
-  const bool owner = local >= 0 && local < a.N;  // wave-uniform
+  const bool owner = a.regenerate || (local >= 0 && local < a.N);  // wave-uniform
   if (!owner) {
     for (int e = lane; e < rec_floats; e += kWave) rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
     return;
@@ -239,6 +298,27 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   const int c = static_cast<int>(local);
   float* su = s_rec + 4;
   float* sx = s_rec + 4 + 2 * n;
+  // where the winner's controls come from: the control matrix, or - regenerate - its global index alone
+  const uint32_t gidx = static_cast<uint32_t>(key & 0xffffffffLL);
+  float z[kKnots][2] = {};
+  float amp = 0.0f;
+  const float* centre = nullptr;
+  if (a.regenerate) {
+    draw_normals(a.spec, gidx, static_cast<uint32_t>(p), z);
+    const bool use_ref = (gidx == 1u) && (a.u_ref != nullptr);
+    amp = use_ref ? 0.0f : candidate_amplitude(gidx);
+    centre = use_ref ? a.u_ref + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
+  }
+  auto winner_control = [&](int step, float& v, float& k) {
+    if (a.regenerate) {
+      regenerate_control(a.spec, z, amp, centre, step, v, k);
+    } else {
+      float vv[1], kk[1];
+      load_controls<LAYOUT, 1>(a.U, p, a.N, n, step, c, vv, kk);
+      v = vv[0];
+      k = kk[0];
+    }
+  };
 
   if constexpr (MODE == 0) {
     // Re-roll split by dependence: only the 9-operation state recurrence is sequential (run by the whole wave in
@@ -252,7 +332,7 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
       float v[1] = {0.0f}, k[1] = {0.0f};
       float row[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       if (valid) {
-        load_controls<LAYOUT, 1>(a.U, p, a.N, n, mine, c, v, k);
+        winner_control(mine, v[0], k[0]);
 #pragma unroll
         for (int q = 0; q < 9; ++q) row[q] = coef[mine * kCoefS + q];
         su[2 * mine] = v[0];
@@ -331,7 +411,7 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
       const int mine = base + lane;
       float v[1] = {0.0f}, k[1] = {0.0f};
       if (mine < n) {
-        load_controls<LAYOUT, 1>(a.U, p, a.N, n, mine, c, v, k);
+        winner_control(mine, v[0], k[0]);
         su[2 * mine] = v[0];
         su[2 * mine + 1] = k[0];
       }
@@ -382,63 +462,6 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   }
   __syncthreads();
   for (int e = lane; e < rec_floats; e += kWave) rec[e] = s_rec[e];
-}
-
-// ---- candidate sampling ------------------------------------------------------------------------------------
-// U_c = clip(centre + a_c * sigma * (smooth noise)), one lane per candidate.  The noise is a raised-cosine blend of
-// kSampleKnots x 2 standard normals per candidate (smooth along the horizon), a_c cycles through 8 amplitude
-// levels, candidate 0 is the centre itself (so a round can never lose the incumbent) and candidate 1 the reference
-// controls.  Philox counters are (global candidate, problem, round, draw): reproducible on any rank.
-template <int LAYOUT>
-__global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
-  const int p = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.N) return;
-  const int n = a.n;
-  const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
-  float z[kSampleKnots][2];
-  const uint32_t key[2] = {a.seed_lo, a.seed_hi};
-#pragma unroll
-  for (int q = 0; q < kSampleKnots / 2; ++q) {
-    const uint32_t ctr[4] = {gidx, static_cast<uint32_t>(p), a.round, static_cast<uint32_t>(q)};
-    uint32_t r[4];
-    philox4x32_10(ctr, key, r);
-    box_muller(uniform_open(r[0]), uniform_open(r[1]), z[2 * q][0], z[2 * q][1]);
-    box_muller(uniform_open(r[2]), uniform_open(r[3]), z[2 * q + 1][0], z[2 * q + 1][1]);
-  }
-  float amp = static_cast<float>((gidx & 7u) + 1u) * 0.125f;
-  if (gidx == 0u) amp = 0.0f;
-  const bool use_ref = (gidx == 1u) && (a.u_ref != nullptr);
-  const float sv = a.sigma_v * amp, sk = a.sigma_k * amp;
-  const float* __restrict__ centre = a.centre + static_cast<size_t>(p) * a.centre_stride;
-  const float* __restrict__ ref = use_ref ? a.u_ref + static_cast<size_t>(p) * n * 2 : centre;
-  int i = 0;
-#pragma unroll
-  for (int knot = 0; knot < kSampleKnots; ++knot) {
-    const float z0v = z[knot][0], z0k = z[knot][1];
-    const float z1v = z[knot + 1 < kSampleKnots ? knot + 1 : knot][0];
-    const float z1k = z[knot + 1 < kSampleKnots ? knot + 1 : knot][1];
-    // steps whose left knot is `knot` (segments[] is wave-uniform: scalar loads)
-    while (i < n && static_cast<int>(a.segments[2 * i]) == knot) {
-      const float w0 = a.segments[2 * i + 1];
-      const float w1 = 1.0f - w0;
-      float v = ref[2 * i] + (use_ref ? 0.0f : sv * (w0 * z0v + w1 * z1v));
-      float k = ref[2 * i + 1] + (use_ref ? 0.0f : sk * (w0 * z0k + w1 * z1k));
-      v = fminf(fmaxf(v, a.ulo0), a.uhi0);
-      k = fminf(fmaxf(k, a.ulo1), a.uhi1);
-      if constexpr (LAYOUT == 1) {
-        float* row = a.U + (static_cast<size_t>(p) * n + i) * 2 * static_cast<size_t>(a.N) + c;
-        row[0] = v;
-        row[a.N] = k;
-      } else {
-        f32x2 vk;
-        vk[0] = v;
-        vk[1] = k;
-        *reinterpret_cast<f32x2*>(a.U + ((static_cast<size_t>(p) * a.N + c) * n + i) * 2) = vk;
-      }
-      ++i;
-    }
-  }
 }
 
 // ---- softmin-weighted mean -------------------------------------------------------------------------------

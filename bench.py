@@ -54,6 +54,9 @@ def parse_args():
     return ap.parse_args()
 
 
+SAMPLE_SIGMA = (2.0, 0.01)   # sigma = (2.0 m/s, 0.01 1/m)
+
+
 def make_controls(batch, P, N, n, layout, device, seed):
     """u_ref + sigma * N(0,1), clipped to the input box, candidate 0 = u_ref, generated on
     the device with a seeded generator so no 400 MB host buffer is needed."""
@@ -259,15 +262,31 @@ def main():
         engines.append(engine)
     batch.coef_host = [engines[0].coefficients(p) for p in range(min(8, P))]
     x0 = torch.tensor(batch.x0 if mode == 0 else batch.pose0, device=device)
-    # every rank draws its own candidates (different seed); global index = rank * N + local index
-    controls = [make_controls(batch, P, N, n, args.layout, device, seed=1000 * b + rank) for b in range(args.buffers)]
+    # Synthetic control matrices, produced on the device by the library's counter-based sampler: candidate
+    # (rank * N + c) of pose p in buffer b = clip(u_ref + amplitude * sigma * smooth noise), candidate 0 = u_ref.
+    # Counter-based means any rank can re-draw any candidate from its global index, which is what lets the
+    # multi-GPU step get by with ONE all-reduce(MIN) of the packed (cost, index) keys.
+    u_ref = torch.tensor(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=torch.float32,
+                         device=device).contiguous()
+    seeds = [1000 + b for b in range(args.buffers)]
+    shape = (P, n, 2, N) if args.layout == 1 else (P, N, n, 2)
+    controls = []
+    for b in range(args.buffers):
+        U = torch.empty(shape, dtype=torch.float32, device=device)
+        engines[0].sample_device(u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, args.layout, rank * N,
+                                 SAMPLE_SIGMA, seeds[b], 0, U.data_ptr(), stream)
+        controls.append(U)
+    torch.cuda.synchronize()
     if not args.pipeline:
         class _Serial:  # rollout and argmin/record back to back on the launch stream
             def __init__(self):
                 self.slot = ShardedRollout(engines[0], P, N, n, args.layout, index_offset=rank * N, device=device)
+                if args.layout == 1:
+                    self.slot.use_sampler(u_ref, u_ref, SAMPLE_SIGMA, seeds[0], 0)
 
-            def step(self, x0_, U_):
-                self.slot.step(x0_, U_, stream)
+            def step(self, x0_, U_, seed=None):
+                self.slot.rollout(x0_, U_, stream)
+                self.slot.select(x0_, U_, stream, seed=seed)
                 return self.slot
 
             def drain(self):
@@ -283,8 +302,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_step(i):
+        b = i % args.buffers
+        if args.pipeline:
+            return pipe.step(x0, controls[b])
+        return pipe.step(x0, controls[b], seed=seeds[b])
+
     for i in range(args.warmup):
-        pipe.step(x0, controls[i % args.buffers])
+        run_step(i)
     pipe.drain()
     barrier()
     # HIP event pairs attached to every rollout dispatch of the timed region (hipExtLaunchKernel through
@@ -295,7 +320,7 @@ def main():
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
-        last = pipe.step(x0, controls[i % args.buffers])
+        last = run_step(i)
     host_enqueue = time.perf_counter() - t0   # (diagnostic) time the host needed to enqueue all steps
     pipe.drain()
     barrier()
@@ -334,7 +359,7 @@ def main():
                             % (args.track, N, H, P, min(P, 256), args.mode),
                 "candidates_per_solve_per_gpu": N, "solves_per_step": P, "horizon": H, "mode": args.mode,
                 "layout": "U[P][n][2][N]" if args.layout == 1 else "U[P][N][n][2]",
-                "parallelism": "candidate-sharded x%d" % world,
+                "parallelism": "candidate-sharded x%d, one all-reduce(MIN) of %d packed keys per step" % (world, P),
                 "pipeline": "argmin/record of batch i overlaps rollout of batch i+1" if args.pipeline else "none (stream order)",
             },
             "roofline": {

@@ -170,6 +170,16 @@ int acmpc_sample_device(acmpc_ctx* ctx, const float* d_centre, int32_t centre_st
                         int32_t P, int32_t N, int32_t n, int32_t layout, int64_t index_offset, double sigma_v,
                         double sigma_kappa, uint64_t seed, uint32_t round, float* d_U, void* stream);
 
+/* Finalize for sampled candidates: the winner's controls are re-drawn from the global index in its key (same
+ * arithmetic as acmpc_sample_device, bit-identical), so after ONE all-reduce(MIN) of `d_keys` every rank writes
+ * the complete winner record itself - no second collective, no owner.  `d_keys` may be NULL on a single GPU
+ * (the handle's partial keys of the preceding rollout are reduced instead).  n_feasible in the record is this
+ * rank's count.  Arguments after `d_x0` must be those the candidates were sampled with. */
+int acmpc_finalize_sampled_device(acmpc_ctx* ctx, const int64_t* d_keys, const float* d_x0, const float* d_centre,
+                                  int32_t centre_stride, const float* d_u_ref, int32_t P, int32_t N, int32_t n,
+                                  double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round,
+                                  float* d_records, void* stream);
+
 /* Replaces: ControlSolver.solve (control.py:15-24) end to end on the device - `rounds` rounds of
  * sample -> rollout + cost -> argmin, each round sampling round the previous winner with the spread shrunk by
  * `shrink`, one host round trip in total (x0, centre, u_ref up; the final records down).  Host pointers:

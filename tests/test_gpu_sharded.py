@@ -241,3 +241,52 @@ def test_profile_hooks_and_pipelined_rollout():
         got.append(slot.records.clone())
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_regenerated_finalize_equals_finalize_from_the_matrix(mode):
+    """Single-collective design: for sampled candidates, finalize that re-draws the winner from its index gives
+    the same record as finalize that reads the control matrix - on the full batch and on two shards of it, where
+    BOTH shards must produce the complete record without owning the winner."""
+    import torch
+    from acmpc_amd import Engine, _capi
+    P, H, total = 3, 50, 3000
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 4, seed=700 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    tables = np.stack([p["table"] for p in problems])
+    u_ref = torch.tensor(np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1)
+                                   for p in problems]).astype(np.float32), device=dev)
+    centre = (u_ref + torch.tensor([-0.7, 0.001], device=dev)).contiguous()
+    x0 = torch.tensor(np.stack([p["x0"] if mode == 0 else p["pose0"] for p in problems]), device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    R = _capi.record_floats(n)
+    sigma, seed, rnd = (3.0, 0.01), 99, 1
+
+    def run(offset, count):
+        eng = Engine(**engine_kwargs(problems[0], mode, P, count, n))
+        eng.set_paths(tables)
+        U = torch.empty(P, n, 2, count, device=dev)
+        eng.sample_device(centre.data_ptr(), 2 * n, u_ref.data_ptr(), P, count, n, 1, offset, sigma, seed, rnd, U.data_ptr(), s)
+        keys = torch.empty(P, dtype=torch.int64, device=dev)
+        eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, count, n, 1, offset, 0, keys.data_ptr(), s)
+        return eng, U, keys
+
+    eng, U, keys = run(0, total)
+    from_matrix = torch.empty(P, R, device=dev)
+    eng.finalize_device(keys.data_ptr(), x0.data_ptr(), U.data_ptr(), P, total, n, 1, 0, from_matrix.data_ptr(), s)
+    regenerated = torch.empty(P, R, device=dev)
+    eng.finalize_sampled_device(keys.data_ptr(), x0.data_ptr(), centre.data_ptr(), 2 * n, u_ref.data_ptr(), P, total, n,
+                                sigma, seed, rnd, regenerated.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(from_matrix, regenerated)
+    shards = [run(0, 1800), run(1800, 1200)]
+    gkeys = torch.minimum(shards[0][2], shards[1][2])
+    assert torch.equal(gkeys, keys)
+    for eng_s, _, _ in shards:
+        rec = torch.empty(P, R, device=dev)
+        eng_s.finalize_sampled_device(gkeys.data_ptr(), x0.data_ptr(), centre.data_ptr(), 2 * n, u_ref.data_ptr(), P,
+                                      eng_s.params.max_candidates, n, sigma, seed, rnd, rec.data_ptr(), s)
+        torch.cuda.synchronize()
+        rec[:, _capi.REC_NFEASIBLE] = from_matrix[:, _capi.REC_NFEASIBLE]  # feasible counts are per shard
+        assert torch.equal(rec, from_matrix)

@@ -102,3 +102,77 @@ def test_shard_range_partitions_exactly():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == total
             for (o1, c1), (o2, _) in zip(spans, spans[1:]):
                 assert o1 + c1 == o2
+
+
+def _worker_sampled(rank, world, port, total, out_dir):
+    for p in (os.path.join(ROOT, "ac-mpc_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import acmpc_oracle as orc
+    from acmpc_amd import _capi
+    from acmpc_amd.sharding import global_select_sampled, shard_range
+    from test_support import make_problem
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, H = 2, 20
+    n = H - 1
+    R = _capi.record_floats(n)
+    sigma, seed, rnd = (2.0, 0.01), 7, 3
+    problems = [make_problem(orc, "spa", H, 4, seed=60 + p) for p in range(P)]
+    offset, count = shard_range(total, rank, world)
+
+    def candidates(p, first, number):
+        prob = problems[p]
+        u_ref = np.stack([prob["table"][orc.ROW_V], prob["table"][orc.ROW_KAPPA]], axis=1)
+        return orc.sample_candidates(u_ref, u_ref, number, first, p, rnd, seed, sigma, prob["u_lo"],
+                                     prob["u_hi"]).astype(np.float32)
+
+    def evaluate(p, U):
+        prob, cfg = problems[p], problems[p]["cfg"]
+        coef = orc.coefficients_spatial(prob["table"], prob["limits"].margin)
+        return orc.rollout_spatial(prob["x0"], coef, U, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], prob["u_lo"],
+                                   prob["u_hi"], 1e6, dtype=np.float32, return_states=True)
+
+    keys = []
+    for p in range(P):
+        cost, _, _ = evaluate(p, candidates(p, offset, count))   # this rank's slice, generated from indices alone
+        j = orc.pick_best(cost)[0]
+        keys.append(_capi.pack_key(cost[j], offset + j))
+    keys = torch.tensor(keys, dtype=torch.int64)
+
+    def regenerate(global_keys):
+        rec = torch.zeros(P, R)
+        for p in range(P):
+            idx = _capi.key_index(int(global_keys[p]))
+            U = candidates(p, idx, 1)                             # any rank can rebuild the winner
+            cost, viol, X = evaluate(p, U)
+            rec[p, _capi.REC_COST], rec[p, _capi.REC_VIOLATION] = float(cost[0]), float(viol[0])
+            rec[p, _capi.REC_OWNER] = 1.0
+            rec[p, _capi.REC_HEADER:_capi.REC_HEADER + 2 * n] = torch.from_numpy(U[0].ravel())
+            rec[p, _capi.REC_HEADER + 2 * n:] = torch.from_numpy(X[0].ravel())
+        return rec
+
+    gkeys, records = global_select_sampled(keys, regenerate)
+    np.save(os.path.join(out_dir, "skeys_%d.npy" % rank), gkeys.numpy())
+    np.save(os.path.join(out_dir, "srecords_%d.npy" % rank), records.numpy())
+    if rank == 0:   # single-process answer over all candidates, for the parent to compare with
+        full = []
+        for p in range(P):
+            cost, _, _ = evaluate(p, candidates(p, 0, total))
+            full.append(orc.pick_best(cost)[0])
+        np.save(os.path.join(out_dir, "sfull.npy"), np.array(full))
+    dist.destroy_process_group()
+
+
+def test_single_collective_protocol_for_counter_based_candidates(tmp_path):
+    """Two gloo ranks, ONE all-reduce(MIN): both ranks end with identical complete records and the global argmin."""
+    from acmpc_amd import _capi
+    world, total = 2, 301
+    mp.spawn(_worker_sampled, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    keys = [np.load(tmp_path / ("skeys_%d.npy" % r)) for r in range(world)]
+    recs = [np.load(tmp_path / ("srecords_%d.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(keys[0], keys[1])
+    np.testing.assert_array_equal(recs[0], recs[1])
+    full = np.load(tmp_path / "sfull.npy")
+    assert [_capi.key_index(int(k)) for k in keys[0]] == list(full)
+    assert (recs[0][:, _capi.REC_OWNER] == 1.0).all()
