@@ -86,6 +86,8 @@ SIGNATURES = {
     "acmpc_optimize": (C.c_int, [_CTX, _F32P, _F32P, _F32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F64P,
                                  C.c_double, C.c_uint64, _F32P]),
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "acmpc_speed_profile_qp": (C.c_int, [_F64P, _F64P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                         C.c_double, C.c_double, _F64P, _F64P, C.c_int32, _I32P]),
     "acmpc_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "acmpc_profile_collect": (C.c_int, [_CTX, _F32P, C.c_int32, _I32P]),
     "acmpc_pack_key": (C.c_int64, [C.c_float, C.c_uint32]),
@@ -287,6 +289,26 @@ class Engine:
                        d_weight_sum: int = 0, stream: int = 0):
         self._check(self._lib.acmpc_softmin_device(self._ctx, d_costs, d_keys, d_U, P, N, n, layout, d_mean,
                                                    d_weight_sum or None, stream or None))
+
+
+def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: float, v_min: float, max_iter: int = 4000,
+                     eps_abs: float = 1e-3, eps_rel: float = 1e-3, warm=None):
+    """Native tridiagonal ADMM for the speed-profile QP; returns (v, y, status, iterations)."""
+    v_hi = np.ascontiguousarray(v_hi, dtype=np.float64)
+    ds = np.ascontiguousarray(ds, dtype=np.float64)
+    n = v_hi.shape[0]
+    v = np.zeros(n)
+    y = np.zeros(2 * n - 1)
+    if warm is not None:
+        v[:], y[:] = warm
+    iters = C.c_int32(0)
+    rc = load_library().acmpc_speed_profile_qp(v_hi.ctypes.data_as(_F64P), ds.ctypes.data_as(_F64P), n, float(a_min),
+                                               float(a_max), float(v_min), int(max_iter), float(eps_abs), float(eps_rel),
+                                               v.ctypes.data_as(_F64P), y.ctypes.data_as(_F64P),
+                                               1 if warm is not None else 0, C.byref(iters))
+    if rc < 0:
+        raise EngineError(rc, "acmpc_speed_profile_qp: bad arguments")
+    return v, y, ("solved" if rc == 0 else "maximum iterations reached"), iters.value
 
 
 def philox4x32(counter, key) -> np.ndarray:

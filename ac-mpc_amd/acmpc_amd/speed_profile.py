@@ -5,8 +5,9 @@ The problem is the reference's:  min 1/2 |v|^2 - v_hi'v  subject to
     a_min <= (v[i+1] - v[i]) / (2 ds[i]) <= a_max        (speed_profile.py:47-51)
     v_min <= v <= v_hi                                    (speed_profile.py:45)
 with v_hi the curvature-limited ceiling sqrt(ay_max / |kappa|) clipped to [v_min, v_max] plus 2 m/s, and the
-last entry forced to the end velocity (speed_profile.py:26-43).  It is solved on the host by `qp.solve_qp`
-instead of the `osqp` package.  `constraints` is held by reference: the control process rewrites its "v_max"
+last entry forced to the end velocity (speed_profile.py:26-43).  It is solved on the host by the library's native
+tridiagonal ADMM (`acmpc_speed_profile_qp`, O(n) per iteration - also for the 10^4-waypoint lap profile) instead of
+the `osqp` package.  `constraints` is held by reference: the control process rewrites its "v_max"
 every tick (controller.py:241-243) and the next solve must see it.
 """
 from __future__ import annotations
@@ -16,7 +17,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from . import qp
+from . import _capi
 from .reference_path import ReferencePath
 
 
@@ -55,13 +56,15 @@ class SpeedProfileSolver:
         return dict(P_diag=np.ones(n), q=-ceiling, A=A, l=lower, u=upper, v_hi=ceiling)
 
     def solve(self, reference_path: ReferencePath, end_velocity: Optional[float] = None) -> SimpleNamespace:
-        prob = self.problem(reference_path, end_velocity)
-        warm = self._warm if self._warm is not None and self._warm[0].shape == prob["q"].shape else (None, None)
-        result = qp.solve_qp(prob["P_diag"], prob["q"], prob["A"], prob["l"], prob["u"],
-                             max_iter=self._max_iterations, x0=warm[0], y0=warm[1])
-        if result.info.status == qp.SOLVED:
-            self._warm = (result.x, result.y)
-        return result
+        """Result shaped like osqp's: `.x`, `.y`, `.info.status` ("solved" on success), `.info.iter`."""
+        c = self._constraints
+        ceiling = self.velocity_ceiling(reference_path, end_velocity)
+        warm = self._warm if self._warm is not None and self._warm[0].shape == ceiling.shape else None
+        x, y, status, iters = _capi.speed_profile_qp(ceiling, reference_path.distances, c["a_min"], c["a_max"],
+                                                     c["v_min"], max_iter=self._max_iterations, warm=warm)
+        if status == "solved":
+            self._warm = (x, y)
+        return SimpleNamespace(x=x, y=y, info=SimpleNamespace(status=status, iter=iters))
 
 
 class LocalisedSpeedProfileSolver(SpeedProfileSolver):

@@ -190,6 +190,16 @@ int acmpc_optimize(acmpc_ctx* ctx, const float* x0, const float* centre, const f
 /* The generator itself, on the host (same code as the kernels): lets tests pin the integer stream. */
 void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 
+/* Replaces: the osqp calls of SpeedProfileSolver (src/acmpc/control/solvers/speed_profile.py:61-86).  Solves
+ *     min 1/2 |v|^2 - v_hi'v   s.t.  a_min <= (v[i+1] - v[i]) / (2 ds[i]) <= a_max,  v_min <= v <= v_hi
+ * on the host with the OSQP splitting specialised to the problem's tridiagonal structure: O(n) per iteration, so the
+ * whole-lap profile (n ~ 1e4, spatial_mpc.py:60-87) is as cheap per iteration as the horizon's.  `v` [n] and `y`
+ * [2n - 1] hold the primal/dual iterate: read when warm_start != 0, always written.  Returns 0 = solved (OSQP's
+ * stopping test at eps_abs / eps_rel), 1 = maximum iterations reached, ACMPC_EINVAL on bad arguments.  No GPU work. */
+int acmpc_speed_profile_qp(const double* v_hi, const double* ds, int32_t n, double a_min, double a_max, double v_min,
+                           int32_t max_iter, double eps_abs, double eps_rel, double* v, double* y, int32_t warm_start,
+                           int32_t* iterations);
+
 /* Measurement hooks.  After acmpc_profile_enable(ctx, K) the next K rollout launches of this handle carry a HIP
  * event pair attached to the dispatch itself (hipExtLaunchKernel: the kernel's own begin/end timestamps on the
  * stream it is launched on, no marker packets between launches); acmpc_profile_collect waits for them, writes the

@@ -60,37 +60,66 @@ def test_speed_profile_problem_matches_reference_inputs(golden, golden_cases):
         path = ReferencePath.from_table(golden[key + "/table_no_v"])
         for cls, tag in ((SpeedProfileSolver, "sp0_"), (LocalisedSpeedProfileSolver, "sp1_")):
             solver = cls({"control_horizon": len(path), "max_iterations": 4000, "constraints": cons})
-            prob = solver.problem(path, cons["end_velocity"])
+            prob = solver.problem(path, cons["end_velocity"])   # dense statement of what the native solver solves
             for name in ("q", "A", "l", "u"):
                 np.testing.assert_allclose(prob[name], golden[key + "/" + tag + name], rtol=1e-14, atol=0)
 
 
-@pytest.mark.parametrize("key", ["monza_H50_chicane_90", "monza_H50_hairpin_10", "spa_H50_chicane_70"])
+@pytest.mark.parametrize("key", ["monza_H50_chicane_90", "monza_H50_hairpin_10", "spa_H50_chicane_70",
+                                 "nordschleife_H80_chicane_70"])
 def test_speed_profile_solution_satisfies_kkt(golden, key):
-    """QP solutions are parity-unpinned (osqp absent), so optimality is certified solver-independently: primal
-    feasibility, dual signs and stationarity at a tight tolerance."""
-    from acmpc_amd import qp
+    """QP solutions are parity-unpinned (osqp absent), so optimality of the native solver is certified
+    solver-independently: primal feasibility, dual signs and stationarity at a tight tolerance - on the QP data
+    the REFERENCE assembled (golden A, l, u, q)."""
+    from acmpc_amd import _capi
     from acmpc_amd.reference_path import ReferencePath
     from acmpc_amd.speed_profile import SpeedProfileSolver
     cons = RACING[key.split("_")[0]]["speed_profile_constraints"]
     path = ReferencePath.from_table(golden[key + "/table_no_v"])
     solver = SpeedProfileSolver({"control_horizon": len(path), "max_iterations": 4000, "constraints": cons})
-    prob = solver.problem(path, cons["end_velocity"])
-    res = qp.solve_qp(prob["P_diag"], prob["q"], prob["A"], prob["l"], prob["u"], max_iter=100000, eps_abs=1e-9,
-                      eps_rel=1e-9)
-    assert res.info.status == "solved"
-    Ax = prob["A"] @ res.x
-    assert (Ax >= prob["l"] - 1e-6).all() and (Ax <= prob["u"] + 1e-6).all()
-    np.testing.assert_allclose(prob["P_diag"] * res.x + prob["q"] + prob["A"].T @ res.y, 0, atol=1e-6)
-    assert (res.y[Ax < prob["u"] - 1e-5] <= 1e-6).all()  # y > 0 only on active upper bounds
-    assert (res.y[Ax > prob["l"] + 1e-5] >= -1e-6).all()  # y < 0 only on active lower bounds
-    # and the default-tolerance solve the controller uses reports "solved" within OSQP's own criterion
-    assert solver.solve(path, cons["end_velocity"]).info.status == "solved"
-    # the oracle's independent restatement of the same published algorithm agrees
-    ref = orc.osqp_restated(prob["P_diag"], prob["q"], prob["A"], prob["l"], prob["u"], max_iter=200000, eps_abs=1e-9,
-                            eps_rel=1e-9, check_every=50)
+    A, l, u, q = (golden[key + "/sp0_" + k] for k in ("A", "l", "u", "q"))
+    ceiling = solver.velocity_ceiling(path, cons["end_velocity"])
+    np.testing.assert_allclose(ceiling, golden[key + "/sp0_v_hi"], rtol=1e-14)
+    x, y, status, iters = _capi.speed_profile_qp(ceiling, path.distances, cons["a_min"], cons["a_max"], cons["v_min"],
+                                                 max_iter=200000, eps_abs=1e-9, eps_rel=1e-9)
+    assert status == "solved"
+    Ax = A @ x
+    assert (Ax >= l - 1e-6).all() and (Ax <= u + 1e-6).all()
+    np.testing.assert_allclose(x + q + A.T @ y, 0, atol=1e-6)       # P = I
+    assert (y[Ax < u - 1e-5] <= 1e-6).all()   # y > 0 only on active upper bounds
+    assert (y[Ax > l + 1e-5] >= -1e-6).all()  # y < 0 only on active lower bounds
+    # the default-tolerance solve the controller uses reports "solved" within OSQP's own criterion, warm-starts
+    first = solver.solve(path, cons["end_velocity"])
+    second = solver.solve(path, cons["end_velocity"])
+    assert first.info.status == "solved" and second.info.status == "solved" and second.info.iter <= first.info.iter
+    assert np.abs(first.x - x).max() < 3.0    # 1e-3 relative tolerance on ~86 m/s
+    # the oracle's independent dense restatement of the same published algorithm agrees
+    ref = orc.osqp_restated(np.ones(len(path)), q, A, l, u, max_iter=200000, eps_abs=1e-9, eps_rel=1e-9, check_every=50)
     if ref.info.status == "solved":
-        np.testing.assert_allclose(res.x, ref.x, atol=1e-4)
+        np.testing.assert_allclose(x, ref.x, atol=1e-4)
+
+
+def test_whole_lap_speed_profile_is_linear_time():
+    """compute_map_speed_profile (spatial_mpc.py:60-87) on a 10^4-waypoint lap: the tridiagonal solver handles it
+    (a dense solver would need an 800 MB matrix) and the result is feasible."""
+    import time
+    from acmpc_amd import workloads
+    from acmpc_amd.mpc import build_mpc
+    mpc = build_mpc(RACING["monza"], PlaceholderVehicle())
+    track = workloads.synthetic_track("monza")
+    centre = track["centre"]
+    coords = np.concatenate([centre, np.full((len(centre), 1), 9.5)], axis=1)
+    path = mpc.construct_waypoints(coords)
+    assert len(path) > 11000
+    t0 = time.time()
+    out = mpc.compute_map_speed_profile(path, ay_max=7.0, a_min=-0.15)     # configs/monza.yaml:83-84
+    elapsed = time.time() - t0
+    v = out.velocities
+    acc = np.diff(v) / (2 * path.distances[:-1])
+    tol = 1e-3 + 1e-3 * v.max()   # "solved" means within OSQP's eps_abs + eps_rel * |Ax| of feasibility
+    assert v.min() >= 8.0 - tol and v.max() <= 84.0 + 2.0 + tol
+    assert acc.min() >= -0.15 - tol and acc.max() <= 1.0 + tol
+    assert elapsed < 60.0
 
 
 def test_command_selection_against_reference(golden):
