@@ -141,7 +141,7 @@ int check_shape(acmpc_ctx* c, int P, int N, int n, int layout) {
 
 int rollout(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int n, int layout, int64_t offset,
             float* d_costs, hipStream_t s, acmpc::LaunchShape* shape_out) {
-  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout);
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout, c->prm.mode, n);
   acmpc::RolloutArgs a{};
   a.U = d_U;
   a.x0 = d_x0;
@@ -448,7 +448,7 @@ int acmpc_finalize_device(acmpc_ctx* c, const int64_t* d_keys, const float* d_x0
   int rc = check_shape(c, P, N, n, layout);
   if (rc != ACMPC_OK) return rc;
   if (!c->device_ready) return fail(c, ACMPC_ESTATE, "acmpc_rollout_device must run first");
-  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout);
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout, c->prm.mode, n);
   return finalize(c, d_keys, nullptr, d_x0, d_U, P, N, n, layout, index_offset, d_records, shape.blocks_per_problem,
                   static_cast<hipStream_t>(stream));
 }
@@ -536,7 +536,7 @@ int acmpc_finalize_sampled_device(acmpc_ctx* c, const int64_t* d_keys, const flo
   rc = upload_segments(c, n, s);
   if (rc != ACMPC_OK) return rc;
   Regenerate regen{d_centre, centre_stride, d_u_ref, make_spec(c, sigma_v, sigma_kappa, seed, round)};
-  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, ACMPC_LAYOUT_STEP_MAJOR);
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, ACMPC_LAYOUT_STEP_MAJOR, c->prm.mode, n);
   return finalize(c, d_keys, nullptr, d_x0, nullptr, P, N, n, ACMPC_LAYOUT_STEP_MAJOR, 0, d_records,
                   shape.blocks_per_problem, s, &regen);
 }

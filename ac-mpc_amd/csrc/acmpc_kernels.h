@@ -69,11 +69,13 @@ struct LaunchShape {
   int block;              // threads per workgroup
   int cpt;                // candidates per thread
   int blocks_per_problem;
+  bool tile;              // candidate-major LDS-tile kernel
 };
 
 // Picks workgroup size / candidates per thread for (P, N, layout); pure function, also used to size workspaces.
-LaunchShape choose_shape(int P, int N, int layout);
+LaunchShape choose_shape(int P, int N, int layout, int mode, int n);
 int max_blocks_per_problem(int N);
+size_t tile_lds_bytes(int mode, int n);
 
 // `start`/`stop` (both or neither) are attached to the dispatch itself (hipExtLaunchKernel): the kernel's own begin
 // and end timestamps, with no marker packets added to the stream.

@@ -194,6 +194,87 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   }
 }
 
+// Candidate-major control matrix U[P][N][n][2] (what NumPy host code holds): a wave's 64 candidates are 64
+// consecutive rows = ONE contiguous span of 64 * 8n bytes.  The wave copies that span into LDS with 16-byte loads
+// (every HBM line fetched exactly once, fully coalesced) and then walks the steps reading its own row with
+// ds_read_b64: the row pitch is 2n dwords, which for odd n (every horizon the reference uses) lands the 32 lanes
+// of a read group on 32 distinct bank pairs - conflict-free without padding.  One wave per workgroup, so the LDS
+// budget (8n * 64 bytes = 25 KB at H = 50) sets the occupancy: 6 waves per CU, each with its whole tile in flight.
+// Measured 3.2 TB/s at H = 50 (a chunked, software-pipelined variant with 16 waves per CU and 8-byte row-wise loads
+// measured 2.9 TB/s, plain per-lane strided loads 3.0 TB/s): the step-major layout is the fast path.
+template <int MODE>
+__global__ void __launch_bounds__(kWave) rollout_tile_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_tile[];  // [64][2n] then (mode T) the waypoint table
+  const int p = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int c0 = blockIdx.x * kWave;
+  const int rows = min(kWave, a.N - c0);
+  const int n = a.n;
+  const int row_floats = 2 * n;
+  const Weights w = a.w;
+  constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+  float* s_wp = s_tile + ((kWave * row_floats + 3) & ~3);
+
+  const size_t first = (static_cast<size_t>(p) * a.N + c0) * row_floats;  // float index of the span
+  const float* __restrict__ src = a.U + first;
+  const int total = rows * row_floats;
+  if ((first & 3) == 0) {
+    const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* dst4 = reinterpret_cast<f32x4*>(s_tile);
+    const int quads = total >> 2;
+#pragma unroll 8
+    for (int q = lane; q < quads; q += kWave) dst4[q] = __builtin_nontemporal_load(src4 + q);
+    for (int e = (quads << 2) + lane; e < total; e += kWave) s_tile[e] = src[e];
+  } else {  // span starts on an 8-byte boundary only (odd p * N): 8-byte copies
+    const f32x2* __restrict__ src2 = reinterpret_cast<const f32x2*>(src);
+    f32x2* dst2 = reinterpret_cast<f32x2*>(s_tile);
+#pragma unroll 8
+    for (int q = lane; q < (total >> 1); q += kWave) dst2[q] = __builtin_nontemporal_load(src2 + q);
+  }
+  if constexpr (MODE == 1) {
+    for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
+  }
+  __syncthreads();
+
+  const bool active = lane < rows;
+  float cost = __builtin_inff();
+  bool feas = false;
+  if (active) {
+    const f32x2* row = reinterpret_cast<const f32x2*>(s_tile + lane * row_floats);
+    if constexpr (MODE == 0) {
+      StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+#pragma unroll 7
+      for (int i = 0; i < n; ++i) {
+        const f32x2 vk = row[i];
+        step_spatial(st, coef + i * kCoefS, vk[0], vk[1], w);
+      }
+      cost = finish_spatial(st, w);
+      feas = st.V == 0.0f;
+    } else {
+      StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+      int nearest = 0;
+      for (int i = 0; i < n; ++i) {
+        const f32x2 vk = row[i];
+        nearest = step_temporal(st, s_wp, n, vk[0], vk[1], w, nearest);
+      }
+      cost = finish_temporal(st, n, w);
+      feas = st.V == 0.0f;
+    }
+    if (a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c0 + lane] = cost;
+  }
+  int64_t key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c0 + lane)) : kKeyMax;
+  int nfeas = (active && feas) ? 1 : 0;
+  key = wave_min_key(key);
+  nfeas = wave_sum_int(nfeas);
+  if (lane == 0) {
+    const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;
+    a.partial_keys[slot] = key;
+    a.partial_feas[slot] = nfeas;
+  }
+}
+
 // ---- candidate sampling ------------------------------------------------------------------------------------
 // U_c = clip(centre + a_c * sigma * (smooth noise)), one lane per candidate.  The noise is a raised-cosine blend of
 // kSampleKnots x 2 standard normals per candidate (smooth along the horizon), a_c cycles through 8 amplitude
@@ -612,9 +693,26 @@ hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, h
   return hipGetLastError();
 }
 
+template <int MODE>
+hipError_t launch_rollout_tile(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
+                               hipEvent_t e1) {
+  const dim3 grid(shape.blocks_per_problem, args.P);
+  const size_t lds = tile_lds_bytes(MODE, args.n);
+  if (e0 != nullptr && e1 != nullptr) {
+    hipExtLaunchKernelGGL((rollout_tile_kernel<MODE>), grid, dim3(kWave), static_cast<std::uint32_t>(lds), s, e0, e1,
+                          0, args);
+  } else {
+    hipLaunchKernelGGL((rollout_tile_kernel<MODE>), grid, dim3(kWave), lds, s, args);
+  }
+  return hipGetLastError();
+}
+
 template <int MODE, int LAYOUT>
 hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                              hipEvent_t e1) {
+  if constexpr (LAYOUT == 0) {
+    if (shape.tile) return launch_rollout_tile<MODE>(shape, args, s, e0, e1);
+  }
   if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 64>(shape, args, s, e0, e1);
   if (shape.block == 256 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 256>(shape, args, s, e0, e1);
   if constexpr (LAYOUT == 1) {
@@ -628,11 +726,25 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
 
 int max_blocks_per_problem(int N) { return (N + kWave - 1) / kWave; }
 
-LaunchShape choose_shape(int P, int N, int layout) {
+size_t tile_lds_bytes(int mode, int n) {
+  const size_t tile = (static_cast<size_t>(kWave) * 2 * n + 3) & ~static_cast<size_t>(3);
+  return (tile + (mode == 1 ? static_cast<size_t>(n) * kCoefT : 0)) * sizeof(float);
+}
+
+LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
   // Fill 256 CUs first (small batches: 64-thread workgroups, one candidate per lane), then widen the
   // per-lane work so that each wave load moves 16 B per lane (large step-major batches).
   LaunchShape s;
+  s.tile = false;
   const long long total = static_cast<long long>(P) * N;
+  if (layout == 0 && tile_lds_bytes(mode, n) <= 64 * 1024 && std::getenv("ACMPC_NO_TILE") == nullptr) {
+    // candidate-major: one wave per workgroup stages its 64 rows in LDS (rollout_tile_kernel)
+    s.tile = true;
+    s.block = kWave;
+    s.cpt = 1;
+    s.blocks_per_problem = (N + kWave - 1) / kWave;
+    return s;
+  }
   // tuning override for experiments: ACMPC_SHAPE="<block>,<cpt>"
   int fb = 0, fc = 0;
   if (const char* env = std::getenv("ACMPC_SHAPE")) {
