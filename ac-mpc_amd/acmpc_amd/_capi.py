@@ -52,6 +52,21 @@ class Params(C.Structure):
     ]
 
 
+class PfParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("max_particles", C.c_int32),
+        ("max_observation_points", C.c_int32),
+        ("score_mean", C.c_double),
+        ("score_sigma", C.c_double),
+        ("threshold_rotation", C.c_double),
+        ("threshold_offset", C.c_double),
+        ("threshold_error", C.c_double),
+        ("wheelbase", C.c_double),
+    ]
+
+
 _F32P = C.POINTER(C.c_float)
 _F64P = C.POINTER(C.c_double)
 _I32P = C.POINTER(C.c_int32)
@@ -88,6 +103,15 @@ SIGNATURES = {
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "acmpc_speed_profile_qp": (C.c_int, [_F64P, _F64P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
                                          C.c_double, C.c_double, _F64P, _F64P, C.c_int32, _I32P]),
+    "acmpc_pf_create": (C.c_int, [C.POINTER(PfParams), _F64P, C.c_int32, _F64P, C.c_int32, _F64P, C.c_int32,
+                                  C.POINTER(_CTX)]),
+    "acmpc_pf_destroy": (None, [_CTX]),
+    "acmpc_pf_last_error": (C.c_char_p, [_CTX]),
+    "acmpc_pf_score_scale": (C.c_double, [_CTX]),
+    "acmpc_pf_score": (C.c_int, [_CTX, _F32P, C.c_int32, _F32P, C.c_int32, _F32P, C.c_int32, _I32P, _F64P, _F64P, _F64P,
+                                 _F64P, C.POINTER(C.c_uint8)]),
+    "acmpc_pf_advance": (C.c_int, [_CTX, _F32P, _F32P, _F32P, C.c_int32, C.c_double]),
+    "acmpc_pf_estimate": (C.c_int, [_CTX, _F32P, _F32P, C.c_int32, _F64P, _F64P, _F64P]),
     "acmpc_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "acmpc_profile_collect": (C.c_int, [_CTX, _F32P, C.c_int32, _I32P]),
     "acmpc_pack_key": (C.c_int64, [C.c_float, C.c_uint32]),

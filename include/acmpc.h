@@ -212,6 +212,49 @@ int64_t acmpc_pack_key(float cost, uint32_t index);
 float acmpc_key_cost(int64_t key);
 uint32_t acmpc_key_index(int64_t key);
 
+/* ---- particle-filter localiser: scoring on the GPU -------------------------------------
+ * Replaces the data-parallel part of LocalisationProcess._update_particles (src/acmpc/localisation/localiser.py:
+ * 255-410): three nearest-point queries per particle against the centre / left / right map polylines (what the
+ * reference's scipy KD-trees answer), the heading offset, the observed track limits placed in every particle's
+ * frame against the map limits ahead of it, the Gaussian score and the validity mask (localiser.py:453-462).
+ * Resampling (sequential, random) stays with the caller.  Same conventions as above; no device work at create. */
+typedef struct acmpc_pf acmpc_pf;
+
+typedef struct acmpc_pf_params {
+  uint32_t struct_size;
+  int32_t device;                   /* HIP device ordinal, -1 = current                                      */
+  int32_t max_particles;            /* localisation.n_particles (configs/monza.yaml:47)                       */
+  int32_t max_observation_points;   /* left + right observed limit points after downsampling                 */
+  double score_mean, score_sigma;   /* localisation.score_distribution (monza.yaml:61-63)                     */
+  double threshold_rotation;        /* [rad]  localisation.thresholds.rotation * pi / 180 (localiser.py:616)  */
+  double threshold_offset;          /* [m]    localisation.thresholds.offset                                  */
+  double threshold_error;           /* [m]    localisation.thresholds.track_limit                             */
+  double wheelbase;                 /* for acmpc_pf_advance (localiser.py:83, 94)                             */
+} acmpc_pf_params;
+
+/* centre / left / right: map polylines [m][2] float64 (utils/load.py:9-35 order x, y); copied. */
+int acmpc_pf_create(const acmpc_pf_params* params, const double* centre, int32_t m_centre, const double* left,
+                    int32_t m_left, const double* right, int32_t m_right, acmpc_pf** out);
+void acmpc_pf_destroy(acmpc_pf* handle);
+const char* acmpc_pf_last_error(const acmpc_pf* handle);
+double acmpc_pf_score_scale(const acmpc_pf* handle); /* max pdf over linspace(-10, 10, 100), localiser.py:655-661 */
+
+/* states [P][3] float32 (x, y, yaw); obs_left [k_left][2], obs_right [k_right][2] float32 in the vehicle frame
+ * (x right, y forward), already downsampled and cut at y < 50 (localiser.py:246-253,336-337).  Outputs per particle:
+ * track_indices [P][3] (centre, left, right), minimum_offset, heading_offset, observation_error, score (float64 as
+ * in the reference), valid (0/1).  Blocking; host pointers. */
+int acmpc_pf_score(acmpc_pf* handle, const float* states, int32_t P, const float* obs_left, int32_t k_left,
+                   const float* obs_right, int32_t k_right, int32_t* track_indices, double* minimum_offset,
+                   double* heading_offset, double* observation_error, double* score, uint8_t* valid);
+
+/* states += (v cos phi, v sin phi, v tan(delta) / L) * dt with per-particle delta, v (localiser.py:66-95). */
+int acmpc_pf_advance(acmpc_pf* handle, float* states, const float* delta, const float* velocity, int32_t P, double dt);
+
+/* Score-weighted mean state with the NaN -> uniform fallback, and the largest distance / yaw difference of any
+ * particle to it - the two numbers the convergence flag compares with its limits (localiser.py:561-579). */
+int acmpc_pf_estimate(acmpc_pf* handle, const float* states, const float* scores, int32_t P, double estimate[3],
+                      double* max_distance, double* max_angle);
+
 /* Library identification: "acmpc-hip <version> gfx950". */
 const char* acmpc_version(void);
 

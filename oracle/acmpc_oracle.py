@@ -666,3 +666,67 @@ def sample_candidates(centre, u_ref, n_candidates, index_offset, problem, round_
     lo = np.asarray(u_lo, dtype=np.float32).astype(np.float64)
     hi = np.asarray(u_hi, dtype=np.float32).astype(np.float64)
     return np.clip(U, lo, hi)
+
+
+# ---------------------------------------------------------------------------
+# Particle-filter scoring of the localiser - restates localisation/localiser.py
+# ---------------------------------------------------------------------------
+def pf_downsample_observation(observation: np.ndarray, average_map_spacing: float) -> np.ndarray:
+    """Thin an observed track limit to the map's point spacing (localiser.py:246-253)."""
+    spacing = np.mean(np.linalg.norm(observation[1:] - observation[:-1], axis=1))
+    n_points = len(observation) * (spacing / average_map_spacing)
+    keep = np.zeros(len(observation), dtype=np.bool_)
+    keep[np.linspace(0, len(observation) - 1, int(n_points), dtype=np.uint16)] = True
+    return observation[keep]
+
+
+def pf_score_scale(mean: float, sigma: float) -> float:
+    """Normaliser of the score: max of the pdf over linspace(-10, 10, 100) (localiser.py:655-661)."""
+    x = (np.linspace(-10, 10, 100) - mean) / sigma
+    return float(np.max(np.exp(-x**2 / 2.0) / np.sqrt(2.0 * np.pi) / sigma))
+
+
+def pf_score_particles(states: np.ndarray, centre: np.ndarray, left: np.ndarray, right: np.ndarray,
+                       obs_left: np.ndarray, obs_right: np.ndarray, mean: float, sigma: float,
+                       thresholds: Dict) -> Dict:
+    """_update_particles + _get_valid_particle_mask (localiser.py:255-410,453-462) for P particles.
+
+    states [P,3] float32 (x, y, yaw); centre/left/right map polylines [M,2] float64; obs_* [K,2] float32 track-limit
+    points in the vehicle frame (x right, y forward), already downsampled.  Returns the reference's particle dict.
+    """
+    # 3 nearest-neighbour queries (:282-289)
+    offsets, i_centre = nearest_waypoint(states[:, :2].astype(np.float64), centre)
+    _, i_left = nearest_waypoint(states[:, :2].astype(np.float64), left)
+    _, i_right = nearest_waypoint(states[:, :2].astype(np.float64), right)
+    track_indices = np.stack([i_centre, i_left, i_right], axis=1)
+    heading = heading_offset(centre, i_centre, states[:, 2])            # (:291-318)
+    # observation into every particle's frame (:330-353): only points nearer than 50 m ahead count
+    obs_left = obs_left[obs_left[:, 1] < 50]
+    obs_right = obs_right[obs_right[:, 1] < 50]
+    obs = np.concatenate([obs_left, obs_right])                          # [K,2]
+    angle = -states[:, 2] + np.pi / 2
+    cos_a, sin_a = np.cos(angle), np.sin(angle)
+    # rotation applied is the TRANSPOSE of [[cos, -sin], [sin, cos]] (:355-364)
+    x = cos_a[:, None] * obs[None, :, 0] + sin_a[:, None] * obs[None, :, 1]
+    y = -sin_a[:, None] * obs[None, :, 0] + cos_a[:, None] * obs[None, :, 1]
+    placed = np.stack([x, y], axis=2) + states[:, None, :2]              # [P,K,2]
+
+    def limits(closest, count, track):                                   # (:391-400)
+        idx = np.linspace(closest, closest + count, count, dtype=np.uint16)
+        return track[np.mod(idx, len(track)).T]
+
+    expected = np.concatenate([limits(i_left, len(obs_left), left), limits(i_right, len(obs_right), right)], axis=1)
+    error = np.mean(np.linalg.norm(placed - expected, axis=2), axis=1)   # (:402-410)
+    z = (error - mean) / sigma
+    score = np.exp(-z**2 / 2.0) / np.sqrt(2.0 * np.pi) / sigma / pf_score_scale(mean, sigma)
+    valid = ((heading < thresholds["rotation"]) & (offsets < thresholds["offset"]) & (error < thresholds["track_limit"]))
+    return dict(track_indices=track_indices, centreline_idx=i_centre, minimum_offset=offsets, heading_offset=heading,
+                observation_error=error, score=score, valid=valid)
+
+
+def pf_convergence(scores: np.ndarray, states: np.ndarray, max_distance: float, max_angle: float):
+    """Weighted-mean estimate and the convergence flag (localiser.py:561-579)."""
+    est = estimate_location(scores, states)
+    dist = np.linalg.norm(states[:, :2] - est[:2], axis=1)
+    ang = np.abs(states[:, 2] - est[2])
+    return est, bool(np.max(dist) < max_distance and np.max(ang) < max_angle)

@@ -263,6 +263,71 @@ def main():
         out["downsample/H%d" % H] = ControlProcess._reference_path.fget(fake_cp)
     out["downsample/centreline"] = cl
 
+    # ---- G12: particle scoring of the localiser (localiser.py:234-410,453-462) on a synthetic map ----------------
+    import multiprocessing as mp
+    from acmpc.perception.shared_memory import SharedPoints
+
+    M = 3000
+    s = np.linspace(0, 2 * np.pi, M + 1)[:-1]
+    centre = np.stack([220 * np.cos(s) + 30 * np.cos(3 * s + 0.4), 150 * np.sin(s) + 18 * np.sin(2 * s)], axis=1)
+    arc = np.concatenate([[0], np.cumsum(np.linalg.norm(np.diff(np.vstack([centre, centre[:1]]), axis=0), axis=1))])
+    t = np.linspace(0, arc[-1], M + 1)[:-1]
+    closed = np.vstack([centre, centre[:1]])
+    centre = np.stack([np.interp(t, arc, closed[:, 0]), np.interp(t, arc, closed[:, 1])], axis=1)
+    tang = np.roll(centre, -1, axis=0) - np.roll(centre, 1, axis=0)
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True)
+    normal = np.stack([-tang[:, 1], tang[:, 0]], axis=1)
+    left, right = centre + 4.75 * normal, centre - 4.75 * normal
+    n_particles = 300
+    proc = object.__new__(LocalisationProcess)       # the reference's own TestLocalisationProcess trick
+    proc.centre_track, proc.left_track, proc.right_track = KDTree(centre), KDTree(left), KDTree(right)
+    proc._set_average_distance_between_map_points(centre)
+    proc._score_distribution_mean, proc._score_distribution_sigma = 0, 10          # configs/monza.yaml:61-63
+    proc._initialise_score_distribution()
+    proc._threshold_error, proc._threshold_offset = 20.0, 10                        # configs/monza.yaml:56-60
+    proc._threshold_rotation = 90 * np.pi / 180
+    proc._max_n_particles = n_particles
+    proc._is_collecting_localisation_data = False
+    proc.particle_lock = mp.Lock()
+    proc._shared_particle_scores = SharedPoints(n_particles, 0)
+    proc._shared_particle_states = SharedPoints(n_particles, 3)
+    true_idx = 700
+    heading = np.arctan2(tang[true_idx, 1], tang[true_idx, 0])
+    pose = np.array([centre[true_idx, 0], centre[true_idx, 1], heading])
+    seeds = rng.integers(0, M, n_particles)
+    states = np.stack([centre[seeds, 0], centre[seeds, 1], np.arctan2(tang[seeds, 1], tang[seeds, 0])], axis=1)
+    states[:150] = pose + rng.normal(0, [2.0, 2.0, 0.1], (150, 3))                  # a cluster near the truth
+    states[150:] += rng.normal(0, [3.0, 3.0, 0.4], (150, 3))                        # the rest spread round the lap
+    states[-5:, 2] += np.pi                                                         # some facing backwards
+    states[-10:-5, :2] += 14.0                                                      # some far off the track
+    proc.particle_scores = np.ones(n_particles, dtype=np.float32)
+    proc.particle_states = states.astype(np.float32)
+
+    def observe(track, count):
+        pts = track[(true_idx + np.arange(count)) % M] - pose[:2]
+        a = np.pi / 2 - heading
+        rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        return (pts @ rot.T + rng.normal(0, 0.15, (count, 2))).astype(np.float32)
+
+    observation = {"left": observe(left, 230), "right": observe(right, 210)}
+    downsampled = proc._downsample_observations({k: v.copy() for k, v in observation.items()})
+    obs_in = [o.copy() for o in downsampled]
+    particles = proc._update_particles(downsampled)        # mutates the list: y < 50 filter
+    out["pf/centre"], out["pf/left"], out["pf/right"] = centre, left, right
+    out["pf/states"] = proc.particle_states
+    out["pf/obs_left_raw"], out["pf/obs_right_raw"] = observation["left"], observation["right"]
+    out["pf/obs_left_downsampled"], out["pf/obs_right_downsampled"] = obs_in
+    out["pf/obs_left_used"], out["pf/obs_right_used"] = downsampled
+    out["pf/track_indices"] = particles["track_indices"]
+    out["pf/minimum_offset"] = particles["minimum_offset"]
+    out["pf/heading_offset"] = particles["heading_offset"]
+    out["pf/observation_error"] = particles["observation_error"]
+    out["pf/score"] = particles["score"]
+    out["pf/valid_mask"] = proc._get_valid_particle_mask(particles)
+    out["pf/scale"] = np.array(proc._scale)
+    out["pf/average_map_spacing"] = np.array(proc._average_distance_between_map_points)
+    out["pf/published_scores"] = proc.particle_scores      # float32 shared array after _update_particle_scores
+
     path = os.path.join(OUT_DIR, "reference_ingredients.npz")
     np.savez_compressed(path, **out)
     print("wrote %s: %d arrays, %.1f kB" % (path, len(out), os.path.getsize(path) / 1e3))

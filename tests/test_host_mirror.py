@@ -161,3 +161,16 @@ def test_build_mpc_constructs_without_touching_the_gpu():
     assert len(path) == 49 and np.allclose(path.psis, np.pi / 2)
     out = mpc.compute_speed_profile(path, False, end_vel=14.0)
     assert out is path and out.velocities.min() > 7.9 and hasattr(mpc, "speed_profile")
+
+
+def test_particle_scorer_host_side(golden):
+    """ParticleScorer construction does no device work; its host-side downsampling equals the reference's."""
+    from acmpc_amd.particle_filter import ParticleScorer
+    cfg = dict(n_particles=500, score_distribution=dict(mean=0, sigma=10),
+               thresholds=dict(offset=10, rotation=90, minimum_particles=20, track_limit=20.0))
+    scorer = ParticleScorer(cfg, dict(centre=golden["pf/centre"], left=golden["pf/left"], right=golden["pf/right"]))
+    assert abs(scorer.scale - float(golden["pf/scale"])) < 1e-17
+    assert abs(scorer._average_distance_between_map_points - float(golden["pf/average_map_spacing"])) < 1e-15
+    obs = scorer.downsample_observations({"left": golden["pf/obs_left_raw"], "right": golden["pf/obs_right_raw"]})
+    np.testing.assert_array_equal(obs[0], golden["pf/obs_left_downsampled"])
+    np.testing.assert_array_equal(obs[1], golden["pf/obs_right_downsampled"])

@@ -148,3 +148,23 @@ def test_downsample_centreline(golden):
         got = orc.downsample_centreline(golden["downsample/centreline"], H)
         assert got.shape == (H, 3)
         np.testing.assert_array_equal(got, golden["downsample/H%d" % H])
+
+
+def test_particle_scoring(golden):
+    # localiser.py:234-410,453-462 on the synthetic map of gen_golden.py
+    g = golden
+    spacing = float(g["pf/average_map_spacing"])
+    for side in ("left", "right"):
+        np.testing.assert_array_equal(orc.pf_downsample_observation(g["pf/obs_%s_raw" % side], spacing),
+                                      g["pf/obs_%s_downsampled" % side])
+    assert abs(orc.pf_score_scale(0, 10) - float(g["pf/scale"])) < 1e-18
+    out = orc.pf_score_particles(g["pf/states"], g["pf/centre"], g["pf/left"], g["pf/right"],
+                                 g["pf/obs_left_downsampled"], g["pf/obs_right_downsampled"], 0, 10,
+                                 dict(rotation=np.pi / 2, offset=10, track_limit=20.0))
+    np.testing.assert_array_equal(out["track_indices"], g["pf/track_indices"])
+    np.testing.assert_allclose(out["minimum_offset"], g["pf/minimum_offset"], rtol=1e-12)
+    np.testing.assert_allclose(out["heading_offset"], g["pf/heading_offset"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out["observation_error"], g["pf/observation_error"], rtol=1e-6)
+    np.testing.assert_allclose(out["score"], g["pf/score"], rtol=1e-6)
+    np.testing.assert_array_equal(out["valid"], g["pf/valid_mask"])
+    np.testing.assert_allclose(out["score"].astype(np.float32), g["pf/published_scores"], rtol=1e-6)
