@@ -224,6 +224,42 @@ def closed_loop_replay(workloads, track_name="silverstone", poses=2000):
     }
 
 
+def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
+    """The other kernels of the path on the same kind of batch, timed alone with dispatch-attached HIP events:
+    mode T (Cartesian rollout + nearest-waypoint projection; exhaustive and windowed search) and the
+    candidate-major layout.  256 poses x N candidates each (1 M candidates per launch)."""
+    P, n = 256, H - 1
+    batch = workloads.problem_batch(track, P, H, seed=0)
+    u_ref = torch.tensor(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=torch.float32,
+                         device=device).contiguous()
+    stream = torch.cuda.current_stream().cuda_stream
+    costs = torch.empty(P, N, device=device)
+    out = {}
+    cases = [("mode_S_candidate_major", 0, 0, None), ("mode_T_exhaustive_search", 1, 1, None),
+             ("mode_T_window_2_5", 1, 1, (2, 5)), ("mode_S_step_major_1M", 0, 1, None)]
+    for name, mode, layout, window in cases:
+        eng = Engine(**workloads.engine_kwargs(batch, mode, N, device=device.index, nn_window=window))
+        eng.set_paths(batch.tables)
+        eng.sync_tables(stream)
+        x0 = torch.tensor(batch.x0 if mode == 0 else batch.pose0, device=device)
+        U = torch.empty((P, n, 2, N) if layout == 1 else (P, N, n, 2), device=device)
+        eng.sample_device(u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, layout, 0, SAMPLE_SIGMA, 77, 0,
+                          U.data_ptr(), stream)
+        for _ in range(3):
+            eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, layout, 0, costs.data_ptr(), 0, stream)
+        eng.profile_enable(iters)
+        for _ in range(iters):
+            eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, layout, 0, costs.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        ms = float(np.median(eng.profile_collect()))
+        byts = P * N * (8 * n + 4)
+        out[name] = {"kernel_us": ms * 1e3, "candidate_trajectories_per_s": P * N / (ms * 1e-3),
+                     "algorithmic_GBps": byts / (ms * 1e-3) / 1e9, "frac_of_hbm_roofline": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        eng.close()
+        del U
+    return out
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -375,6 +411,7 @@ def main():
         if world == 1 and not args.no_single_solve:
             out["single_solve"] = single_solve(workloads, Engine, args.track, H, N, mode, args.layout, device)
             out["closed_loop_replay"] = closed_loop_replay(workloads)
+            out["secondary_kernels"] = secondary_kernels(workloads, Engine, args.track, H, N, device)
         if world == 1 and not args.no_cpu_baseline:
             gpu_costs = last.costs[:8].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
             out["cpu_baseline"] = cpu_baseline(batch, mode, controls[(args.steps - 1) % args.buffers], args.layout, N,

@@ -144,3 +144,41 @@ def test_mode_t_windowed_nearest_search(layout, window):
         best = orc.pick_best(cost)[0]
         assert out["best_idx"][p] == best and out["violation"][p] == viol[best]
         np.testing.assert_array_equal(out["x"][p], S[best])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("H,N,P", [(100, 300, 2), (3, 130, 1), (66, 129, 3)])
+def test_other_horizons(mode, H, N, P):
+    """The reference's mapping horizon (100, configs/monza.yaml:31), the shortest legal one (n = 2) and one with
+    more than 64 steps and an odd count (n = 65: the finalize kernel's second 64-step chunk holds one step)."""
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, N, seed=900 + 7 * H + p) for p in range(P)]
+    eng = _engine(problems, mode, N, n)
+    x0 = np.stack([p["x0"] if mode == 0 else p["pose0"] for p in problems])
+    U = np.stack([p["U"] for p in problems])
+    for layout in (LAYOUT_CM, LAYOUT_SM):
+        out = eng.solve(x0, _as_layout(U, layout), layout=layout)
+        for p, prob in enumerate(problems):
+            cost, viol, X = _oracle(prob, eng.coefficients(p), mode, states=True)[:3]
+            np.testing.assert_array_equal(out["costs"][p], cost)
+            best = orc.pick_best(cost)[0]
+            assert out["best_idx"][p] == best and out["violation"][p] == viol[best]
+            np.testing.assert_array_equal(out["x"][p], X[best])
+            np.testing.assert_array_equal(out["u"][p], prob["U"][best])
+
+
+def test_every_launch_shape_gives_the_same_bits(monkeypatch):
+    """ACMPC_SHAPE forces the workgroup size / candidates per lane; results must not depend on it."""
+    H, N, P = 50, 2048, 2
+    n = H - 1
+    problems = [make_problem(orc, "spa", H, N, seed=1234 + p) for p in range(P)]
+    x0 = np.stack([p["x0"] for p in problems])
+    U = _as_layout(np.stack([p["U"] for p in problems]), LAYOUT_SM)
+    results = []
+    for shape in ("64,1", "256,1", "256,2", "256,4"):
+        monkeypatch.setenv("ACMPC_SHAPE", shape)
+        eng = _engine(problems, 0, N, n)
+        results.append(eng.solve(x0, U, layout=LAYOUT_SM))
+    for other in results[1:]:
+        np.testing.assert_array_equal(other["costs"], results[0]["costs"])
+        np.testing.assert_array_equal(other["records"], results[0]["records"])
