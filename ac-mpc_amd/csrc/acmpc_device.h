@@ -27,11 +27,41 @@ struct Weights {
   int nn_back, nn_ahead;  // mode T search window round the previous nearest index; nn_ahead < 0 = exhaustive
 };
 
-__device__ __forceinline__ float quad(float w, float a) { return (w * a) * a; }
+// The step functions are written once for F = float (one candidate per lane) and F = f32x2 (two candidates per
+// lane).  With two candidates in an ext_vector the adds/multiplies become v_pk_add_f32 / v_pk_mul_f32 - on gfx950 a
+// wave64 VALU instruction issues every 4 cycles per SIMD whether it carries one or two floats per lane, so packing
+// halves the issue slots of everything that has a packed form.  Per element the operations and their order are
+// identical, so results do not depend on F.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float hinge2(float lo_minus_x, float x_minus_hi) {
+template <typename F>
+struct IndexOf {
+  using type = int;
+};
+template <>
+struct IndexOf<f32x2> {
+  using type = i32x2;
+};
+
+template <typename F>
+__device__ __forceinline__ F splat(float v) {
+  return F(v);
+}
+template <typename F>
+__device__ __forceinline__ F vmax(F a, F b) {
+  return __builtin_elementwise_max(a, b);
+}
+
+template <typename F>
+__device__ __forceinline__ F quad(float w, F a) {
+  return (w * a) * a;
+}
+
+template <typename F>
+__device__ __forceinline__ F hinge2(F lo_minus_x, F x_minus_hi) {
   // at most one side of a (non-degenerate) interval can be violated: one v_max3_f32
-  const float v = fmaxf(fmaxf(lo_minus_x, x_minus_hi), 0.0f);
+  const F v = vmax(vmax(lo_minus_x, x_minus_hi), splat<F>(0.0f));
   return v * v;
 }
 
@@ -39,46 +69,66 @@ __device__ __forceinline__ float hinge2(float lo_minus_x, float x_minus_hi) {
 // One step of x_{i+1} = A_i x_i + B_i (u_i - u_ref_i) + f_i (dynamics.py:65-103, control.py:26-45) with the
 // stage cost 1/2 (x'Qx + du'R du) (control.py:72-79,151-158) and the squared violation of the input box, the
 // corridor of x_{i+1} (control.py:57-60) and t >= t_min (control.py:134).
-struct StateS {
-  float ey, ep, t, J, V;
+template <typename F>
+struct StateS_ {
+  F ey, ep, t, J, V;
 };
+using StateS = StateS_<float>;
 
-__device__ __forceinline__ void step_spatial(StateS& s, const float* __restrict__ c, float v, float k,
-                                             const Weights& w) {
-  const float dv = v - c[5];
-  const float dk = k - c[6];
-  float a = quad(w.q0, s.ey);
+template <typename F>
+__device__ __forceinline__ void step_spatial(StateS_<F>& s, const float* __restrict__ c, F v, F k, const Weights& w) {
+  const F dv = v - c[5];
+  const F dk = k - c[6];
+  F a = quad(w.q0, s.ey);
   a = a + quad(w.q1, s.ep);
   a = a + quad(w.q2, s.t);
-  float r = quad(w.r0, dv);
+  F r = quad(w.r0, dv);
   r = r + quad(w.r1, dk);
   s.J = s.J + 0.5f * (a + r);
-  s.V = s.V + hinge2(w.ulo0 - v, v - w.uhi0);
-  s.V = s.V + hinge2(w.ulo1 - k, k - w.uhi1);
+  s.V = s.V + hinge2<F>(w.ulo0 - v, v - w.uhi0);
+  s.V = s.V + hinge2<F>(w.ulo1 - k, k - w.uhi1);
   const float ds = c[0];
-  const float ey_n = s.ey + ds * s.ep;
-  const float ep_n = (s.ep + c[1] * s.ey) + ds * dk;
-  const float t_n = ((s.t + c[2] * s.ey) + c[3] * dv) + c[4];
+  const F ey_n = s.ey + ds * s.ep;
+  const F ep_n = (s.ep + c[1] * s.ey) + ds * dk;
+  const F t_n = ((s.t + c[2] * s.ey) + c[3] * dv) + c[4];
   s.ey = ey_n;
   s.ep = ep_n;
   s.t = t_n;
-  s.V = s.V + hinge2(c[7] - s.ey, s.ey - c[8]);
-  const float tv = fmaxf(w.tmin - s.t, 0.0f);
+  s.V = s.V + hinge2<F>(c[7] - s.ey, s.ey - c[8]);
+  const F tv = vmax(w.tmin - s.t, splat<F>(0.0f));
   s.V = s.V + tv * tv;
 }
 
-__device__ __forceinline__ float finish_spatial(const StateS& s, const Weights& w) {
-  float a = quad(w.qn0, s.ey);
+template <typename F>
+__device__ __forceinline__ F finish_spatial(const StateS_<F>& s, const Weights& w) {
+  F a = quad(w.qn0, s.ey);
   a = a + quad(w.qn1, s.ep);
   a = a + quad(w.qn2, s.t);
-  const float J = s.J + 0.5f * a;
+  const F J = s.J + 0.5f * a;
   return J + w.wbound * s.V;
 }
 
 // ---- mode T --------------------------------------------------------------------------------------------
 // Cody-Waite reduction by pi/2 and the Cephes single-precision minimax polynomials: the same instruction
 // sequence as oracle sincos_spec().
-__device__ __forceinline__ void sincos_spec(float phi, float& sn, float& cs) {
+template <typename F>
+__device__ __forceinline__ void sincos_spec(F phi, F& sn, F& cs) {
+  using I = typename IndexOf<F>::type;
+  const F k = __builtin_elementwise_rint(phi * 0.6366197723675814f);
+  const F r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
+  const F r2 = r * r;
+  F ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
+  ps = -1.6666654611e-1f + r2 * ps;
+  const F s = r + (r * r2) * ps;
+  F pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
+  pc = 4.166664568298827e-2f + r2 * pc;
+  const F c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
+  const I q = __builtin_convertvector(k, I) & 3;
+  sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+  cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+template <>
+__device__ __forceinline__ void sincos_spec<float>(float phi, float& sn, float& cs) {
   const float k = rintf(phi * 0.6366197723675814f);
   const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
   const float r2 = r * r;
@@ -93,61 +143,84 @@ __device__ __forceinline__ void sincos_spec(float phi, float& sn, float& cs) {
   cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }
 
-__device__ __forceinline__ float wrap_spec(float a) {
-  const float b = a + 3.14159265358979f;
-  const float q = floorf(b * 0.159154943091895f);
+template <typename F>
+__device__ __forceinline__ F wrap_spec(F a) {
+  const F b = a + 3.14159265358979f;
+  const F q = __builtin_elementwise_floor(b * 0.159154943091895f);
   return (b - q * 6.28318530717959f) - 3.14159265358979f;
 }
 
-struct StateT {
-  float X, Y, phi, ey, ep, J, V;
+template <typename F>
+struct StateT_ {
+  F X, Y, phi, ey, ep, J, V;
 };
+using StateT = StateT_<float>;
 
 // explicit Euler on the rear-axle kinematic bicycle (localiser.py:66-95); phi_dot = v * kappa
-__device__ __forceinline__ void temporal_advance(StateT& s, float v, float k, const Weights& w) {
-  float sn, cs;
-  sincos_spec(s.phi, sn, cs);
-  const float Xn = s.X + (v * cs) * w.dt;
-  const float Yn = s.Y + (v * sn) * w.dt;
-  const float phin = s.phi + (v * k) * w.dt;
+template <typename F>
+__device__ __forceinline__ void temporal_advance(StateT_<F>& s, F v, F k, const Weights& w) {
+  F sn, cs;
+  sincos_spec<F>(s.phi, sn, cs);
+  const F Xn = s.X + (v * cs) * w.dt;
+  const F Yn = s.Y + (v * sn) * w.dt;
+  const F phin = s.phi + (v * k) * w.dt;
   s.X = Xn;
   s.Y = Yn;
   s.phi = phin;
 }
 
-__device__ __forceinline__ float dist2(float X, float Y, float wx, float wy) {
-  const float dx = X - wx;
-  const float dy = Y - wy;
+template <typename F>
+__device__ __forceinline__ F dist2(F X, F Y, float wx, float wy) {
+  const F dx = X - wx;
+  const F dy = Y - wy;
   return dx * dx + dy * dy;
 }
 
-// nearest waypoint, first minimum of the squared distance (localiser.py:282-289); one lane scans the table
-__device__ __forceinline__ int temporal_nearest(const StateT& s, const float* wp, int n) {
-  float best = __builtin_inff();
-  int j = 0;
+// nearest waypoint, first minimum of the squared distance (localiser.py:282-289); every lane scans the table
+// (wave-uniform addresses: the LDS read is a broadcast and serves both candidates of a packed lane)
+template <typename F>
+__device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const StateT_<F>& s, const float* wp, int n) {
+  using I = typename IndexOf<F>::type;
+  F best = splat<F>(__builtin_inff());
+  I j = I(0);
   for (int i = 0; i < n; ++i) {
-    const float d = dist2(s.X, s.Y, wp[i * kCoefT + 0], wp[i * kCoefT + 1]);
-    const bool better = d < best;
+    const F d = dist2<F>(s.X, s.Y, wp[i * kCoefT + 0], wp[i * kCoefT + 1]);
+    const auto better = d < best;
     best = better ? d : best;
-    j = better ? i : j;
+    j = better ? I(i) : j;
   }
   return j;
 }
 
-// The same search restricted to [j_prev - back, j_prev + ahead] (clipped to the table): progress along the path is
-// monotone and at most about one waypoint per step, so a short window finds the global minimum on every realistic
-// input at a fraction of the ALU work (tests check equality with the exhaustive scan).  Fixed trip count, lanes
-// whose window is clipped mask the tail.
-__device__ __forceinline__ int temporal_nearest_window(const StateT& s, const float* wp, int n, int j_prev,
-                                                       int back, int ahead) {
-  const int lo = max(j_prev - back, 0);
-  const int hi = min(j_prev + ahead, n - 1);
+// The same search restricted to W = back + ahead + 1 consecutive waypoints starting at
+// lo = clamp(j_prev - back, 0, n - W): progress along the path is monotone and at most about one waypoint per step,
+// so a short window finds the global minimum on every realistic input at a fraction of the ALU work (tests check
+// equality with the exhaustive scan).  `xy` is the compact (x, y) copy of the table: the window is W consecutive
+// 8-byte pairs, read with immediate offsets from one base address.  W = 8 is unrolled at compile time.
+template <int W>
+__device__ __forceinline__ int nearest_in_window(float X, float Y, const float* xy, int lo) {
   float best = __builtin_inff();
   int j = lo;
-  const int trips = back + ahead + 1;
-  for (int m = 0; m < trips; ++m) {
-    const int i = min(lo + m, hi);  // the clipped tail re-reads `hi`: equal distance, never "better"
-    const float d = dist2(s.X, s.Y, wp[i * kCoefT + 0], wp[i * kCoefT + 1]);
+#pragma unroll
+  for (int m = 0; m < W; ++m) {
+    const float d = dist2<float>(X, Y, xy[2 * (lo + m)], xy[2 * (lo + m) + 1]);
+    const bool better = d < best;
+    best = better ? d : best;
+    j = better ? lo + m : j;
+  }
+  return j;
+}
+
+__device__ __forceinline__ int temporal_nearest_window(float X, float Y, const float* xy, int n, int j_prev, int back,
+                                                       int ahead) {
+  const int W = back + ahead + 1;
+  const int lo = max(min(j_prev - back, n - W), 0);
+  if (W == 8 && n >= 8) return nearest_in_window<8>(X, Y, xy, lo);
+  const int hi = min(lo + W, n);
+  float best = __builtin_inff();
+  int j = lo;
+  for (int i = lo; i < hi; ++i) {
+    const float d = dist2<float>(X, Y, xy[2 * i], xy[2 * i + 1]);
     const bool better = d < best;
     best = better ? d : best;
     j = better ? i : j;
@@ -155,38 +228,70 @@ __device__ __forceinline__ int temporal_nearest_window(const StateT& s, const fl
   return j;
 }
 
-// Frenet errors w.r.t. waypoint row g (dynamics.py:23-40), stage cost and bound violations
-__device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v, float k, const Weights& w) {
+// Frenet errors w.r.t. waypoint row(s) g (dynamics.py:23-40), stage cost and bound violations.  g0..g7 hold the
+// row entries x, y, cos psi, sin psi, psi, k_ref, v_ref, w/2 - margin per element.
+template <typename F>
+__device__ __forceinline__ void temporal_cost(StateT_<F>& s, const F (&g)[kCoefT], F v, F k, const Weights& w) {
   s.ey = g[2] * (s.Y - g[1]) - g[3] * (s.X - g[0]);
-  s.ep = wrap_spec(s.phi - g[4]);
-  const float dv = v - g[6];
-  const float dk = k - g[5];
-  float a = quad(w.q0, s.ey);
+  s.ep = wrap_spec<F>(s.phi - g[4]);
+  const F dv = v - g[6];
+  const F dk = k - g[5];
+  F a = quad(w.q0, s.ey);
   a = a + quad(w.q1, s.ep);
-  float r = quad(w.r0, dv);
+  F r = quad(w.r0, dv);
   r = r + quad(w.r1, dk);
   s.J = s.J + 0.5f * (a + r);
-  s.V = s.V + hinge2(w.ulo0 - v, v - w.uhi0);
-  s.V = s.V + hinge2(w.ulo1 - k, k - w.uhi1);
-  s.V = s.V + hinge2((-g[7]) - s.ey, s.ey - g[7]);
+  s.V = s.V + hinge2<F>(w.ulo0 - v, v - w.uhi0);
+  s.V = s.V + hinge2<F>(w.ulo1 - k, k - w.uhi1);
+  s.V = s.V + hinge2<F>((-g[7]) - s.ey, s.ey - g[7]);
 }
 
-// `wp` is the waypoint table (kCoefT floats per waypoint); in the rollout kernel it lives in LDS.
-__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, int n, float v, float k,
+// one-candidate form used by the finalize kernel and the tile kernel
+__device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v, float k, const Weights& w) {
+  const float row[kCoefT] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]};
+  temporal_cost<float>(s, row, v, k, w);
+}
+
+// `wp` is the waypoint table (kCoefT floats per waypoint) and `xy` its compact (x, y) copy; in the rollout kernels
+// both live in LDS.  Returns the nearest index (per element) for the next step's search window.
+__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, const float* xy, int n, float v, float k,
                                              const Weights& w, int j_prev) {
-  temporal_advance(s, v, k, w);
-  const int j = (w.nn_ahead < 0) ? temporal_nearest(s, wp, n)
-                                 : temporal_nearest_window(s, wp, n, j_prev, w.nn_back, w.nn_ahead);
+  temporal_advance<float>(s, v, k, w);
+  const int j = (w.nn_ahead < 0) ? temporal_nearest<float>(s, wp, n)
+                                 : temporal_nearest_window(s.X, s.Y, xy, n, j_prev, w.nn_back, w.nn_ahead);
   temporal_cost(s, wp + j * kCoefT, v, k, w);
   return j;
 }
 
-__device__ __forceinline__ float finish_temporal(const StateT& s, int n, const Weights& w) {
+__device__ __forceinline__ i32x2 step_temporal(StateT_<f32x2>& s, const float* wp, const float* xy, int n, f32x2 v,
+                                               f32x2 k, const Weights& w, i32x2 j_prev) {
+  temporal_advance<f32x2>(s, v, k, w);
+  i32x2 j;
+  if (w.nn_ahead < 0) {
+    j = temporal_nearest<f32x2>(s, wp, n);
+  } else {
+    j[0] = temporal_nearest_window(s.X[0], s.Y[0], xy, n, j_prev[0], w.nn_back, w.nn_ahead);
+    j[1] = temporal_nearest_window(s.X[1], s.Y[1], xy, n, j_prev[1], w.nn_back, w.nn_ahead);
+  }
+  f32x2 g[kCoefT];
+  const float* g0 = wp + j[0] * kCoefT;
+  const float* g1 = wp + j[1] * kCoefT;
+#pragma unroll
+  for (int q = 0; q < kCoefT; ++q) {
+    g[q][0] = g0[q];
+    g[q][1] = g1[q];
+  }
+  temporal_cost<f32x2>(s, g, v, k, w);
+  return j;
+}
+
+template <typename F>
+__device__ __forceinline__ F finish_temporal(const StateT_<F>& s, int n, const Weights& w) {
   const float tN = static_cast<float>(n) * w.dt;
-  float a = quad(w.qn0, s.ey);
+  F a = quad(w.qn0, s.ey);
   a = a + quad(w.qn1, s.ep);
-  a = a + quad(w.qn2, tN);
-  const float J = s.J + 0.5f * a;
+  a = a + splat<F>(quad(w.qn2, tN));
+  const F J = s.J + 0.5f * a;
   return J + w.wbound * s.V;
 }
 

@@ -17,6 +17,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -26,7 +27,6 @@ namespace {
 
 constexpr int kMaxBlock = 256;
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CPT>
@@ -93,8 +93,13 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
 
+  float* s_xy = s_wp + n * kCoefT;  // compact (x, y) pairs for the windowed nearest-waypoint search
   if constexpr (MODE == 1) {
     for (int e = tid; e < n * kCoefT; e += BLOCK) s_wp[e] = coef[e];
+    for (int e = tid; e < n; e += BLOCK) {
+      s_xy[2 * e] = coef[e * kCoefT];
+      s_xy[2 * e + 1] = coef[e * kCoefT + 1];
+    }
     __syncthreads();
   }
 
@@ -107,42 +112,72 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   }
 
   if (active) {
+    // two candidates per packed state (v_pk_* arithmetic) whenever the lane owns at least two
+    constexpr int kPack = (CPT >= 2) ? 2 : 1;
+    constexpr int kGroups = CPT / kPack;
+    using F = typename std::conditional<kPack == 2, f32x2, float>::type;
+    using I = typename IndexOf<F>::type;
+    auto pack = [](const float (&src)[CPT], int g) {
+      if constexpr (kPack == 2) {
+        F out;
+        out[0] = src[2 * g];
+        out[1] = src[2 * g + 1];
+        return out;
+      } else {
+        return src[g];
+      }
+    };
+    auto unpack_to = [](F value, float (&dst)[CPT], int g) {
+      if constexpr (kPack == 2) {
+        dst[2 * g] = value[0];
+        dst[2 * g + 1] = value[1];
+      } else {
+        dst[g] = value;
+      }
+    };
+    float viol[CPT];
     if constexpr (MODE == 0) {
-      StateS st[CPT];
+      StateS_<F> st[kGroups];
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) st[j] = StateS{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+      for (int g = 0; g < kGroups; ++g)
+        st[g] = StateS_<F>{splat<F>(x0[0]), splat<F>(x0[1]), splat<F>(x0[2]), splat<F>(0.0f), splat<F>(0.0f)};
 #pragma unroll 7
       for (int i = 0; i < n; ++i) {
         float v[CPT], k[CPT];
         load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
         const float* __restrict__ c = coef + i * kCoefS;  // wave-uniform -> scalar loads
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) step_spatial(st[j], c, v[j], k[j], w);
+        for (int g = 0; g < kGroups; ++g) step_spatial<F>(st[g], c, pack(v, g), pack(k, g), w);
       }
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) {
-        cost[j] = finish_spatial(st[j], w);
-        feas[j] = st[j].V == 0.0f;
+      for (int g = 0; g < kGroups; ++g) {
+        unpack_to(finish_spatial<F>(st[g], w), cost, g);
+        unpack_to(st[g].V, viol, g);
       }
     } else {
-      StateT st[CPT];
+      StateT_<F> st[kGroups];
+      I nearest[kGroups];
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) st[j] = StateT{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
-      int nearest[CPT];
-#pragma unroll
-      for (int j = 0; j < CPT; ++j) nearest[j] = 0;
+      for (int g = 0; g < kGroups; ++g) {
+        st[g] = StateT_<F>{splat<F>(x0[0]), splat<F>(x0[1]), splat<F>(x0[2]), splat<F>(0.0f), splat<F>(0.0f),
+                           splat<F>(0.0f), splat<F>(0.0f)};
+        nearest[g] = I(0);
+      }
       for (int i = 0; i < n; ++i) {
         float v[CPT], k[CPT];
         load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) nearest[j] = step_temporal(st[j], s_wp, n, v[j], k[j], w, nearest[j]);
+        for (int g = 0; g < kGroups; ++g)
+          nearest[g] = step_temporal(st[g], s_wp, s_xy, n, pack(v, g), pack(k, g), w, nearest[g]);
       }
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) {
-        cost[j] = finish_temporal(st[j], n, w);
-        feas[j] = st[j].V == 0.0f;
+      for (int g = 0; g < kGroups; ++g) {
+        unpack_to(finish_temporal<F>(st[g], n, w), cost, g);
+        unpack_to(st[g].V, viol, g);
       }
     }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) feas[j] = viol[j] == 0.0f;
     if (a.costs != nullptr) {
       using V = typename VecOf<CPT>::type;
       float* out = a.costs + static_cast<size_t>(p) * a.N + c0;
@@ -233,8 +268,13 @@ __global__ void __launch_bounds__(kWave) rollout_tile_kernel(const RolloutArgs a
 #pragma unroll 8
     for (int q = lane; q < (total >> 1); q += kWave) dst2[q] = __builtin_nontemporal_load(src2 + q);
   }
+  float* s_xy = s_wp + n * kCoefT;
   if constexpr (MODE == 1) {
     for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
+    for (int e = lane; e < n; e += kWave) {
+      s_xy[2 * e] = coef[e * kCoefT];
+      s_xy[2 * e + 1] = coef[e * kCoefT + 1];
+    }
   }
   __syncthreads();
 
@@ -257,7 +297,7 @@ __global__ void __launch_bounds__(kWave) rollout_tile_kernel(const RolloutArgs a
       int nearest = 0;
       for (int i = 0; i < n; ++i) {
         const f32x2 vk = row[i];
-        nearest = step_temporal(st, s_wp, n, vk[0], vk[1], w, nearest);
+        nearest = step_temporal(st, s_wp, s_xy, n, vk[0], vk[1], w, nearest);
       }
       cost = finish_temporal(st, n, w);
       feas = st.V == 0.0f;
@@ -503,8 +543,9 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
         // nearest waypoint with the lanes scanning the table side by side; (distance, index) keys keep the
         // first minimum exactly like the one-lane scan of the rollout kernel
         // (a search window, when configured, only masks out the waypoints outside it)
-        const int win_lo = (w.nn_ahead < 0) ? 0 : max(j_prev - w.nn_back, 0);
-        const int win_hi = (w.nn_ahead < 0) ? n - 1 : min(j_prev + w.nn_ahead, n - 1);
+        const int win_w = w.nn_back + w.nn_ahead + 1;
+        const int win_lo = (w.nn_ahead < 0) ? 0 : max(min(j_prev - w.nn_back, n - win_w), 0);
+        const int win_hi = (w.nn_ahead < 0) ? n - 1 : min(win_lo + win_w, n) - 1;
         float best = (lane >= win_lo && lane <= win_hi) ? dist2(st.X, st.Y, my_x, my_y) : __builtin_inff();
         int j = lane;
         for (int m = lane + kWave; m <= win_hi; m += kWave) {
@@ -683,7 +724,7 @@ template <int MODE, int LAYOUT, int CPT, int BLOCK>
 hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                             hipEvent_t e1) {
   const dim3 grid(shape.blocks_per_problem, args.P);
-  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * kCoefT * sizeof(float) : 0);
+  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * (kCoefT + 2) * sizeof(float) : 0);
   if (e0 != nullptr && e1 != nullptr) {
     hipExtLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK>), grid, dim3(BLOCK),
                           static_cast<std::uint32_t>(lds), s, e0, e1, 0, args);
@@ -728,7 +769,7 @@ int max_blocks_per_problem(int N) { return (N + kWave - 1) / kWave; }
 
 size_t tile_lds_bytes(int mode, int n) {
   const size_t tile = (static_cast<size_t>(kWave) * 2 * n + 3) & ~static_cast<size_t>(3);
-  return (tile + (mode == 1 ? static_cast<size_t>(n) * kCoefT : 0)) * sizeof(float);
+  return (tile + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 2) : 0)) * sizeof(float);
 }
 
 LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
@@ -758,11 +799,11 @@ LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
   } else if (total <= 256LL * 64 * 8) {
     s.block = 64;
     s.cpt = 1;
-  } else if (layout == 1 && N % 2 == 0 && total >= 256LL * 2048 * 2) {
-    // >= 8 waves per SIMD on every CU even at two candidates per lane (43 VGPRs); four per lane measured slower
-    // (70 VGPRs, half the waves: 97 us vs 78 us on 256 x 4096 x 49)
+  } else if (layout == 1 && N % 4 == 0 && total >= 256LL * 4096) {
+    // from 1 M candidates up: four candidates per lane as two packed pairs (v_pk_* arithmetic, 16-byte loads).
+    // Same-box A/B on 256 x 4 096 x 49 / 1 024 x 4 096 x 49: one per lane 72 / 290 us, two 85 / 285 us, four 68 / 283 us.
     s.block = 256;
-    s.cpt = 2;
+    s.cpt = 4;
   } else {
     s.block = 256;
     s.cpt = 1;

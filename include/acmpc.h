@@ -73,9 +73,10 @@ typedef struct acmpc_params {
   int32_t max_problems;  /* capacity P                                                                */
   int32_t max_candidates;/* capacity N (per problem)                                                  */
   int32_t max_steps;     /* capacity n                                                                */
-  int32_t nn_back;       /* mode T nearest-waypoint search: indices [j_prev - nn_back, j_prev + nn_ahead]   */
-  int32_t nn_ahead;      /*   round the previous step's nearest index (j_prev = 0 at the start); nn_ahead < 0
-                              = exhaustive scan of all n waypoints (KDTree.query semantics, localiser.py:282-289) */
+  int32_t nn_back;       /* mode T nearest-waypoint search: the W = nn_back + nn_ahead + 1 consecutive waypoints   */
+  int32_t nn_ahead;      /*   from clamp(j_prev - nn_back, 0, n - W), j_prev = the previous step's nearest index (0
+                              at the start); nn_ahead < 0 = exhaustive scan of all n waypoints (KDTree.query
+                              semantics, localiser.py:282-289)                                                    */
   /* real-valued fields are doubles so that Python floats cross the ABI exactly; the device gets float32 */
   double step_cost[3];   /* Q  = diag(step_cost)  on (e_y, e_psi, t)     control.py:126               */
   double r_term[2];      /* R  = diag(r_term)     on (v, kappa)          control.py:127               */

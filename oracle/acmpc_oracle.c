@@ -189,9 +189,12 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       float best = INFINITY;
       int j = 0;
       int lo = 0, hi = n - 1;
-      if (w->nn_ahead >= 0) {
-        lo = j_prev - w->nn_back < 0 ? 0 : j_prev - w->nn_back;
-        hi = j_prev + w->nn_ahead > n - 1 ? n - 1 : j_prev + w->nn_ahead;
+      if (w->nn_ahead >= 0) { /* W consecutive waypoints from clamp(j_prev - back, 0, n - W) */
+        const int width = w->nn_back + w->nn_ahead + 1;
+        lo = j_prev - w->nn_back;
+        if (lo > n - width) lo = n - width;
+        if (lo < 0) lo = 0;
+        hi = lo + width > n ? n - 1 : lo + width - 1;
         j = lo;
       }
       for (int m = lo; m <= hi; ++m) {

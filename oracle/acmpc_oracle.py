@@ -482,9 +482,10 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
     Frenet errors (dynamics.py:23-40), a9 cost weights and bounds.
 
     pose0 = (X, Y, phi), wp[n,8] (coefficients_temporal), U[N,n,2] = (v, kappa).
-    nn_window = (back, ahead): search only waypoints [j_prev - back, j_prev + ahead] (clipped; j_prev = previous
-    step's nearest index, 0 at the start) instead of all n - a build-defined shortcut, equal to the exhaustive
-    search whenever progress along the path is slower than the window (checked in tests).
+    nn_window = (back, ahead): search only the W = back + ahead + 1 consecutive waypoints starting at
+    clamp(j_prev - back, 0, n - W) (j_prev = previous step's nearest index, 0 at the start) instead of all n - a
+    build-defined shortcut, equal to the exhaustive search whenever progress along the path is slower than the
+    window (checked in tests).
     """
     T = dtype
     U = np.asarray(U, dtype=T)
@@ -527,10 +528,11 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
                 j = np.where(better, w, j)
         else:
             back, ahead = nn_window
-            lo = np.maximum(j_prev - back, 0)
-            hi = np.minimum(j_prev + ahead, n - 1)
+            width = back + ahead + 1
+            lo = np.maximum(np.minimum(j_prev - back, n - width), 0)
+            hi = np.minimum(lo + width, n) - 1
             j = lo.copy()
-            for m in range(back + ahead + 1):
+            for m in range(width):
                 w = np.minimum(lo + m, hi)
                 dx = X - wp[w, CT_X]
                 dy = Y - wp[w, CT_Y]

@@ -38,3 +38,13 @@ t0 = time.perf_counter()
 for _ in range(20):
     solver.solve(x0, path)
 print("control solve (%d rounds x %d candidates): %.2f ms" % (solver._rounds, solver._n_candidates, (time.perf_counter() - t0) / 20 * 1e3))
+
+# finer breakdown
+import cProfile
+import pstats
+pr = cProfile.Profile()
+pr.enable()
+for p in paths:
+    mpc.get_control(p)
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
