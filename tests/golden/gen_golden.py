@@ -328,6 +328,15 @@ def main():
     out["pf/average_map_spacing"] = np.array(proc._average_distance_between_map_points)
     out["pf/published_scores"] = proc.particle_scores      # float32 shared array after _update_particle_scores
 
+    # ---- G13: map ingestion helper (utils/load.py:30-35) ------------------------------------------------------------
+    from acmpc.utils import load as ref_load
+    pts = np.cumsum(rng.uniform(0.2, 0.6, (400, 2)), axis=0)
+    pts[50] = pts[49]                       # exact duplicate
+    pts[120] = pts[119] + 5e-5              # near duplicate (below 0.1 mm)
+    pts[200] = pts[199] + np.array([2e-4, 0.0])   # just above the threshold: kept
+    out["map/points"] = pts
+    out["map/deduplicated"] = ref_load.remove_near_duplicate_points(pts)
+
     path = os.path.join(OUT_DIR, "reference_ingredients.npz")
     np.savez_compressed(path, **out)
     print("wrote %s: %d arrays, %.1f kB" % (path, len(out), os.path.getsize(path) / 1e3))

@@ -174,3 +174,24 @@ def test_particle_scorer_host_side(golden):
     obs = scorer.downsample_observations({"left": golden["pf/obs_left_raw"], "right": golden["pf/obs_right_raw"]})
     np.testing.assert_array_equal(obs[0], golden["pf/obs_left_downsampled"])
     np.testing.assert_array_equal(obs[1], golden["pf/obs_right_downsampled"])
+
+
+def test_track_map_ingestion(golden, tmp_path):
+    """utils/load.py:9-35 - file format, renaming and de-duplication; agent.py:137-143 - the speed window."""
+    from acmpc_amd import track_map
+    np.testing.assert_array_equal(track_map.remove_near_duplicate_points(golden["map/points"]), golden["map/deduplicated"])
+    pts = golden["map/points"]
+    raw = {"outside_track": pts + 5.0, "inside_track": pts - 5.0, "centre_track": pts}
+    path = tmp_path / "synthetic_map.npy"
+    np.save(path, raw, allow_pickle=True)                     # the reference's map format: a pickled dict
+    loaded = track_map.load_track_map(str(path))
+    assert set(loaded) == {"left", "right", "centre"}
+    np.testing.assert_array_equal(loaded["centre"], golden["map/deduplicated"])
+    np.testing.assert_array_equal(loaded["left"], golden["map/deduplicated"] + 5.0)
+    lap = track_map.lap_reference_path(loaded["centre"])
+    assert lap.shape == (len(loaded["centre"]), 3) and (lap[:, 2] == 9.5).all()
+    speeds = np.arange(1000, dtype=np.float64)
+    assert track_map.reference_speed_window(speeds, 500) == np.mean(np.arange(475, 575))
+    assert track_map.reference_speed_window(speeds, 10) == np.mean(np.r_[985:1000, 0:85])   # wraps round the lap
+    with pytest.raises(ValueError):
+        track_map.load_track_map("map.csv")
