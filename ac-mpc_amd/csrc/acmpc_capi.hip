@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,6 +42,7 @@ struct acmpc_ctx {
   // sampler: per-step (left knot, weight) table, uploaded when n changes
   float* d_segments = nullptr;
   int segments_n = 0;
+  int knot_begin[acmpc::kKnots + 1] = {};
   float* d_centre = nullptr;  // [P][n][2] staging of acmpc_optimize (first round's centre, then u_ref)
   float* d_uref = nullptr;
 
@@ -53,6 +55,22 @@ struct acmpc_ctx {
   float* d_records = nullptr;
   int64_t* d_keys = nullptr;
   int64_t* h_keys = nullptr;  // pinned
+
+  // acmpc_optimize as a hipGraph: the whole sample -> rollout -> finalize chain of `rounds` rounds plus the
+  // transfers either side of it is captured once per shape and replayed; per-call inputs travel through the pinned
+  // staging block `h_opt` (x0 | centre | u_ref | table | seed) and the records come back into `h_opt_records`.
+  hipGraphExec_t opt_graph = nullptr;
+  struct OptKey {
+    int P = 0, N = 0, n = 0, rounds = 0, has_uref = 0;
+    double sigma_v = 0, sigma_k = 0, shrink = 0;
+    bool operator==(const OptKey& o) const {
+      return P == o.P && N == o.N && n == o.n && rounds == o.rounds && has_uref == o.has_uref &&
+             sigma_v == o.sigma_v && sigma_k == o.sigma_k && shrink == o.shrink;
+    }
+  } opt_key;
+  unsigned char* h_opt = nullptr;   // pinned
+  float* h_opt_records = nullptr;   // pinned
+  uint32_t* d_seed = nullptr;
 
   // optional timing of the rollout dispatches (acmpc_profile_*): event pairs attached to the launches
   std::vector<hipEvent_t> prof_start, prof_stop;
@@ -214,6 +232,12 @@ int upload_segments(acmpc_ctx* c, int n, hipStream_t s) {
     seg[2 * i] = static_cast<float>(k0);
     seg[2 * i + 1] = static_cast<float>(0.5 * (1.0 + std::cos(3.14159265358979323846 * frac)));
   }
+  // first step of every knot's segment (left knots are non-decreasing in the step index)
+  for (int k = 0; k <= acmpc::kSampleKnots; ++k) c->knot_begin[k] = n;
+  for (int i = n - 1; i >= 0; --i) c->knot_begin[static_cast<int>(seg[2 * i])] = i;
+  for (int k = acmpc::kSampleKnots - 1; k >= 0; --k)
+    if (c->knot_begin[k] > c->knot_begin[k + 1]) c->knot_begin[k] = c->knot_begin[k + 1];
+  c->knot_begin[0] = 0;
   ACMPC_HIP(c, hipMemcpyAsync(c->d_segments, seg.data(), seg.size() * sizeof(float), hipMemcpyHostToDevice, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));  // `seg` is a local
   c->segments_n = n;
@@ -225,6 +249,8 @@ acmpc::SampleSpec make_spec(const acmpc_ctx* c, double sigma_v, double sigma_k, 
   sp.segments = c->d_segments;
   sp.seed_lo = static_cast<uint32_t>(seed);
   sp.seed_hi = static_cast<uint32_t>(seed >> 32);
+  sp.seed_ptr = nullptr;
+  for (int k = 0; k <= acmpc::kKnots; ++k) sp.knot_begin[k] = c->knot_begin[k];
   sp.round = round;
   sp.sigma_v = static_cast<float>(sigma_v);
   sp.sigma_k = static_cast<float>(sigma_k);
@@ -237,8 +263,8 @@ acmpc::SampleSpec make_spec(const acmpc_ctx* c, double sigma_v, double sigma_k, 
 
 int sample(acmpc_ctx* c, const float* d_centre, int centre_stride, const float* d_uref, int P, int N, int n,
            int layout, int64_t offset, double sigma_v, double sigma_k, uint64_t seed, uint32_t round, float* d_U,
-           hipStream_t s) {
-  const int rc = upload_segments(c, n, s);
+           hipStream_t s, const uint32_t* d_seed = nullptr) {
+  const int rc = upload_segments(c, n, s);  // no-op once the table for this n is resident
   if (rc != ACMPC_OK) return rc;
   acmpc::SampleArgs a{};
   a.centre = d_centre;
@@ -250,6 +276,7 @@ int sample(acmpc_ctx* c, const float* d_centre, int centre_stride, const float* 
   a.n = n;
   a.index_offset = offset;
   a.spec = make_spec(c, sigma_v, sigma_k, seed, round);
+  a.spec.seed_ptr = d_seed;
   ACMPC_HIP(c, acmpc::launch_sample(layout, a, s));
   return ACMPC_OK;
 }
@@ -349,6 +376,10 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_keys);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
+    if (c->opt_graph != nullptr) (void)hipGraphExecDestroy(c->opt_graph);
+    if (c->h_opt != nullptr) (void)hipHostFree(c->h_opt);
+    if (c->h_opt_records != nullptr) (void)hipHostFree(c->h_opt_records);
+    (void)hipFree(c->d_seed);
     if (c->stream != nullptr) (void)hipStreamDestroy(c->stream);
     for (hipEvent_t e : c->prof_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->prof_stop) (void)hipEventDestroy(e);
@@ -541,6 +572,32 @@ int acmpc_finalize_sampled_device(acmpc_ctx* c, const int64_t* d_keys, const flo
                   shape.blocks_per_problem, s, &regen);
 }
 
+namespace {
+
+// the launch sequence of one optimisation, enqueued on `s` (directly, or while `s` is being captured)
+int enqueue_rounds(acmpc_ctx* c, int P, int N, int n, int rounds, double sigma_v, double sigma_k, double shrink,
+                   bool has_uref, uint64_t seed, const uint32_t* d_seed, hipStream_t s) {
+  const int layout = ACMPC_LAYOUT_STEP_MAJOR;
+  const int rec_floats = acmpc_record_floats(n);
+  double scale = 1.0;
+  for (int r = 0; r < rounds; ++r, scale *= shrink) {
+    // round 0 samples round the caller's centre, later rounds round the incumbent = the u block of the records
+    const float* d_c = (r == 0) ? c->d_centre : c->d_records + ACMPC_REC_HEADER;
+    const int stride = (r == 0) ? 2 * n : rec_floats;
+    int rc = sample(c, d_c, stride, has_uref ? c->d_uref : nullptr, P, N, n, layout, 0, sigma_v * scale, sigma_k * scale,
+                    seed, static_cast<uint32_t>(r), c->d_U, s, d_seed);
+    if (rc != ACMPC_OK) return rc;
+    acmpc::LaunchShape shape;
+    rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, nullptr, s, &shape);
+    if (rc != ACMPC_OK) return rc;
+    rc = finalize(c, nullptr, nullptr, c->d_x0, c->d_U, P, N, n, layout, 0, c->d_records, shape.blocks_per_problem, s);
+    if (rc != ACMPC_OK) return rc;
+  }
+  return ACMPC_OK;
+}
+
+}  // namespace
+
 int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const float* u_ref, int32_t P, int32_t N,
                    int32_t n, int32_t rounds, const double sigma[2], double shrink, uint64_t seed, float* records) {
   if (c == nullptr) return ACMPC_EINVAL;
@@ -555,30 +612,98 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   rc = ensure_staging(c);
   if (rc != ACMPC_OK) return rc;
   hipStream_t s = c->stream;
-  rc = upload_tables(c, s);
-  if (rc != ACMPC_OK) return rc;
+  const size_t x0_bytes = static_cast<size_t>(P) * 3 * sizeof(float);
   const size_t path_bytes = static_cast<size_t>(P) * n * 2 * sizeof(float);
-  const int rec_floats = acmpc_record_floats(n);
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_centre, centre, path_bytes, hipMemcpyHostToDevice, s));
-  if (u_ref != nullptr) ACMPC_HIP(c, hipMemcpyAsync(c->d_uref, u_ref, path_bytes, hipMemcpyHostToDevice, s));
-  double scale = 1.0;
-  for (int r = 0; r < rounds; ++r, scale *= shrink) {
-    // round 0 samples round the caller's centre, later rounds round the incumbent = the u block of the records
-    const float* d_c = (r == 0) ? c->d_centre : c->d_records + ACMPC_REC_HEADER;
-    const int stride = (r == 0) ? 2 * n : rec_floats;
-    rc = sample(c, d_c, stride, u_ref != nullptr ? c->d_uref : nullptr, P, N, n, layout, 0, sigma[0] * scale,
-                sigma[1] * scale, seed, static_cast<uint32_t>(r), c->d_U, s);
+  const size_t table_bytes = static_cast<size_t>(P) * n * c->coef_stride * sizeof(float);
+  const size_t rec_bytes = static_cast<size_t>(P) * acmpc_record_floats(n) * sizeof(float);
+  const bool has_uref = u_ref != nullptr;
+
+  // Eager path: when rollout launches are being timed (event pairs cannot be captured) or on request.
+  if (c->prof_used < c->prof_start.size() || std::getenv("ACMPC_NO_GRAPH") != nullptr) {
+    rc = upload_tables(c, s);
     if (rc != ACMPC_OK) return rc;
-    acmpc::LaunchShape shape;
-    rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, nullptr, s, &shape);
+    ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, x0_bytes, hipMemcpyHostToDevice, s));
+    ACMPC_HIP(c, hipMemcpyAsync(c->d_centre, centre, path_bytes, hipMemcpyHostToDevice, s));
+    if (has_uref) ACMPC_HIP(c, hipMemcpyAsync(c->d_uref, u_ref, path_bytes, hipMemcpyHostToDevice, s));
+    rc = enqueue_rounds(c, P, N, n, rounds, sigma[0], sigma[1], shrink, has_uref, seed, nullptr, s);
     if (rc != ACMPC_OK) return rc;
-    rc = finalize(c, nullptr, nullptr, c->d_x0, c->d_U, P, N, n, layout, 0, c->d_records, shape.blocks_per_problem, s);
-    if (rc != ACMPC_OK) return rc;
+    ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
+    ACMPC_HIP(c, hipStreamSynchronize(s));
+    return ACMPC_OK;
   }
-  ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, static_cast<size_t>(P) * rec_floats * sizeof(float),
-                              hipMemcpyDeviceToHost, s));
+
+  // Graph path.  Pinned staging block layout: x0 | centre | u_ref | table | seed (each 16-byte aligned).
+  auto align16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
+  const size_t off_x0 = 0, off_centre = align16(off_x0 + x0_bytes), off_uref = align16(off_centre + path_bytes),
+               off_table = align16(off_uref + path_bytes), off_seed = align16(off_table + table_bytes);
+  if (c->h_opt == nullptr) {
+    const acmpc_params& p = c->prm;
+    const size_t cap = 64 + 16 * 5 + static_cast<size_t>(p.max_problems) *
+                                         (3 + 4 * static_cast<size_t>(p.max_steps) +
+                                          static_cast<size_t>(p.max_steps) * c->coef_stride) * sizeof(float);
+    ACMPC_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_opt), cap, hipHostMallocDefault));
+    ACMPC_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_opt_records),
+                               static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float),
+                               hipHostMallocDefault));
+    ACMPC_HIP(c, hipMalloc(&c->d_seed, 2 * sizeof(uint32_t)));
+  }
+  acmpc_ctx::OptKey key;
+  key.P = P;
+  key.N = N;
+  key.n = n;
+  key.rounds = rounds;
+  key.has_uref = has_uref ? 1 : 0;
+  key.sigma_v = sigma[0];
+  key.sigma_k = sigma[1];
+  key.shrink = shrink;
+  if (c->opt_graph == nullptr || !(key == c->opt_key)) {
+    if (c->opt_graph != nullptr) {
+      (void)hipGraphExecDestroy(c->opt_graph);
+      c->opt_graph = nullptr;
+    }
+    rc = upload_segments(c, n, s);  // must not happen inside the capture (it synchronises)
+    if (rc != ACMPC_OK) return rc;
+    hipGraph_t graph = nullptr;
+    ACMPC_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipSuccess;
+    auto copy_in = [&](void* dst, size_t off, size_t bytes) {
+      if (e == hipSuccess) e = hipMemcpyAsync(dst, c->h_opt + off, bytes, hipMemcpyHostToDevice, s);
+    };
+    copy_in(c->d_x0, off_x0, x0_bytes);
+    copy_in(c->d_centre, off_centre, path_bytes);
+    if (has_uref) copy_in(c->d_uref, off_uref, path_bytes);
+    copy_in(c->d_coef, off_table, table_bytes);
+    copy_in(c->d_seed, off_seed, 2 * sizeof(uint32_t));
+    int rc_rounds = ACMPC_OK;
+    if (e == hipSuccess)
+      rc_rounds = enqueue_rounds(c, P, N, n, rounds, sigma[0], sigma[1], shrink, has_uref, 0, c->d_seed, s);
+    if (e == hipSuccess && rc_rounds == ACMPC_OK)
+      e = hipMemcpyAsync(c->h_opt_records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s);
+    const hipError_t e_end = hipStreamEndCapture(s, &graph);
+    if (rc_rounds != ACMPC_OK) {
+      if (graph != nullptr) (void)hipGraphDestroy(graph);
+      return rc_rounds;
+    }
+    if (e != hipSuccess) {
+      if (graph != nullptr) (void)hipGraphDestroy(graph);
+      return fail_hip(c, e, "capturing the optimisation graph");
+    }
+    ACMPC_HIP(c, e_end);
+    const hipError_t e_inst = hipGraphInstantiate(&c->opt_graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    ACMPC_HIP(c, e_inst);
+    c->opt_key = key;
+  }
+  std::memcpy(c->h_opt + off_x0, x0, x0_bytes);
+  std::memcpy(c->h_opt + off_centre, centre, path_bytes);
+  if (has_uref) std::memcpy(c->h_opt + off_uref, u_ref, path_bytes);
+  std::memcpy(c->h_opt + off_table, c->h_coef.data(), table_bytes);
+  const uint32_t seed_words[2] = {static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
+  std::memcpy(c->h_opt + off_seed, seed_words, sizeof seed_words);
+  c->tables_dirty = false;  // the graph uploads the table itself
+  ACMPC_HIP(c, hipGraphLaunch(c->opt_graph, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
+  std::memcpy(records, c->h_opt_records, rec_bytes);
   return ACMPC_OK;
 }
 

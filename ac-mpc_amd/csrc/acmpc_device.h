@@ -326,28 +326,34 @@ __device__ __forceinline__ float uniform_open(uint32_t bits) {
   return static_cast<float>(bits >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
 }
 
-// Box-Muller on two uniforms -> two standard normals
+// Box-Muller on two uniforms -> two standard normals, on the hardware transcendental units: v_log_f32 for the
+// radius and v_sin_f32 / v_cos_f32, which take their argument in turns - exactly u2, no 2*pi multiply to round.
+// (Absolute error ~1e-6 on a unit normal: noise for a sampler; the library log/sincos cost 10x the instructions and
+// made this kernel the longest of an optimisation round.)
 __device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float& z1) {
-  const float r = sqrtf(-2.0f * logf(u1));
-  float sn, cs;
-  sincosf(6.28318530717958647692f * u2, &sn, &cs);
-  z0 = r * cs;
-  z1 = r * sn;
+  const float r = __builtin_sqrtf(-2.0f * __logf(u1));
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 constexpr int kKnots = 8;  // raised-cosine knots along the horizon (== kSampleKnots)
+constexpr int kKnotsMax = kKnots;
 
 // Everything that defines candidate `gidx` of problem `p` in round `round` besides its centre.
 struct SampleSpec {
   const float* segments;  // [n][2]: left knot (as float), weight of the left knot
+  int knot_begin[kKnotsMax + 1];  // steps [knot_begin[k], knot_begin[k+1]) have left knot k (kernel argument: SGPRs)
   uint32_t seed_lo, seed_hi, round;
+  const uint32_t* seed_ptr;  // when non-null the key is read from device memory (two words) instead of seed_lo/hi:
+                             // lets a captured hipGraph be replayed with a new seed without touching its nodes
   float sigma_v, sigma_k;
   float ulo0, ulo1, uhi0, uhi1;
 };
 
 // the 8 x 2 standard normals of one candidate
 __device__ __forceinline__ void draw_normals(const SampleSpec& sp, uint32_t gidx, uint32_t p, float (&z)[kKnots][2]) {
-  const uint32_t key[2] = {sp.seed_lo, sp.seed_hi};
+  const uint32_t key[2] = {sp.seed_ptr != nullptr ? sp.seed_ptr[0] : sp.seed_lo,
+                           sp.seed_ptr != nullptr ? sp.seed_ptr[1] : sp.seed_hi};
 #pragma unroll
   for (int q = 0; q < kKnots / 2; ++q) {
     const uint32_t ctr[4] = {gidx, p, sp.round, static_cast<uint32_t>(q)};

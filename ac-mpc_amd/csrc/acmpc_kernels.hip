@@ -324,7 +324,6 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
   const int p = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.N) return;
   const int n = a.n;
   const SampleSpec sp = a.spec;
   const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
@@ -334,14 +333,18 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
   const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
   const float* __restrict__ centre =
       use_ref ? a.u_ref + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
-  int i = 0;
+  // blend weights -> LDS once per workgroup; the knot boundaries are kernel arguments, so neither the loop bounds nor
+  // the weights wait on a dependent scalar load (that dependency used to make this the longest kernel of a round)
+  extern __shared__ __attribute__((aligned(16))) float s_w0[];
+  for (int e = threadIdx.x; e < n; e += 256) s_w0[e] = sp.segments[2 * e + 1];
+  __syncthreads();
+  if (c >= a.N) return;
 #pragma unroll
   for (int knot = 0; knot < kKnots - 1; ++knot) {
-    // steps whose left knot is `knot` (segments[] is wave-uniform: scalar loads)
-    while (i < n && static_cast<int>(sp.segments[2 * i]) == knot) {
+    for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
       float v, k;
-      blend_control(sp, amp, sp.segments[2 * i + 1], centre[2 * i], centre[2 * i + 1], z[knot][0], z[knot][1],
-                    z[knot + 1][0], z[knot + 1][1], v, k);
+      blend_control(sp, amp, s_w0[i], centre[2 * i], centre[2 * i + 1], z[knot][0], z[knot][1], z[knot + 1][0],
+                    z[knot + 1][1], v, k);
       if constexpr (LAYOUT == 1) {
         float* row = a.U + (static_cast<size_t>(p) * n + i) * 2 * static_cast<size_t>(a.N) + c;
         row[0] = v;
@@ -352,7 +355,6 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
         vk[1] = k;
         *reinterpret_cast<f32x2*>(a.U + ((static_cast<size_t>(p) * a.N + c) * n + i) * 2) = vk;
       }
-      ++i;
     }
   }
 }
@@ -844,9 +846,9 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
   const dim3 grid((args.N + 255) / 256, args.P);
   if (layout == 0) {
-    hipLaunchKernelGGL((sample_kernel<0>), grid, dim3(256), 0, s, args);
+    hipLaunchKernelGGL((sample_kernel<0>), grid, dim3(256), args.n * sizeof(float), s, args);
   } else if (layout == 1) {
-    hipLaunchKernelGGL((sample_kernel<1>), grid, dim3(256), 0, s, args);
+    hipLaunchKernelGGL((sample_kernel<1>), grid, dim3(256), args.n * sizeof(float), s, args);
   } else {
     return hipErrorInvalidValue;
   }

@@ -150,7 +150,8 @@ def test_device_sampler_matches_its_restatement(layout):
     lo, hi = problems[0]["u_lo"], problems[0]["u_hi"]
     for p in range(P):
         want = orc.sample_candidates(centre[p], u_ref[p], N, 0, p, rnd, seed, sigma, lo, hi)
-        np.testing.assert_allclose(got[p], want, rtol=3e-6, atol=3e-6)
+        # hardware log/sin/cos in the Box-Muller transform: ~1e-6 on a unit normal, times sigma * amplitude
+        np.testing.assert_allclose(got[p], want, rtol=1e-5, atol=3e-5)
         np.testing.assert_array_equal(got[p, 0], np.clip(centre[p], lo.astype(np.float32), hi.astype(np.float32)))
         np.testing.assert_array_equal(got[p, 1], np.clip(u_ref[p], lo.astype(np.float32), hi.astype(np.float32)))
         assert (got[p] >= lo.astype(np.float32)).all() and (got[p] <= hi.astype(np.float32)).all()
