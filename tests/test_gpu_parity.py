@@ -182,3 +182,54 @@ def test_every_launch_shape_gives_the_same_bits(monkeypatch):
     for other in results[1:]:
         np.testing.assert_array_equal(other["costs"], results[0]["costs"])
         np.testing.assert_array_equal(other["records"], results[0]["records"])
+
+
+@pytest.mark.parametrize("track,H,N,mode", [
+    ("spa", 50, 65536, 0),            # BASELINE config 3 at full size
+    ("nordschleife", 80, 262144, 0),  # BASELINE config 4 at full size (all candidates on one GPU)
+    ("spa", 50, 65536, 1),            # config 3, Cartesian mode with the windowed search
+])
+def test_baseline_configs_at_full_size_against_the_c_oracle(track, H, N, mode):
+    """Every one of the N costs bit-identical to the oracle's C restatement (the NumPy oracle would take minutes at
+    these sizes; C == NumPy is established in tests/test_oracle_c_vs_numpy.py), plus argmin and winner record."""
+    import c_oracle
+    from acmpc_amd import Engine
+    n = H - 1
+    prob = make_problem(orc, track, H, 16, seed=4242)
+    rng = np.random.default_rng(99)
+    u_ref = np.stack([prob["table"][orc.ROW_V], prob["table"][orc.ROW_KAPPA]], axis=1)
+    U = (u_ref[None] + rng.standard_normal((N, n, 2), dtype=np.float32) * np.array([2.0, 0.01], dtype=np.float32)
+         * rng.uniform(0.02, 1.0, (N, 1, 1)).astype(np.float32)).astype(np.float32)
+    np.clip(U, prob["u_lo"].astype(np.float32), prob["u_hi"].astype(np.float32), out=U)
+    window = (2, 5) if mode == 1 else None
+    eng = Engine(**engine_kwargs(prob, mode, 1, N, n, nn_window=window))
+    eng.set_paths(prob["table"])
+    cfg = prob["cfg"]
+    w = c_oracle.make_weights(cfg["step_cost"], cfg["r_term"], cfg["final_cost"], prob["u_lo"], prob["u_hi"], 1.0e6,
+                              nn_window=window)
+    x0 = prob["x0"] if mode == 0 else prob["pose0"]
+    want_cost, want_viol, want_states = c_oracle.rollout(mode, x0, eng.coefficients(0), U, 0, w, return_states=True)
+    best = c_oracle.argmin(want_cost)
+    U_sm = np.ascontiguousarray(U.transpose(1, 2, 0))
+    for layout, data in ((LAYOUT_SM, U_sm), (LAYOUT_CM, U)):
+        out = eng.solve(x0[None], data[None], layout=layout)
+        np.testing.assert_array_equal(out["costs"][0], want_cost)
+        assert out["best_idx"][0] == best and out["cost"][0] == want_cost[best]
+        assert out["n_feasible"][0] == np.count_nonzero(want_viol == 0)
+        np.testing.assert_array_equal(out["x"][0], want_states[best])
+        np.testing.assert_array_equal(out["u"][0], U[best])
+
+
+def test_empty_and_oversized_inputs_are_rejected():
+    from acmpc_amd import Engine, EngineError
+    prob = make_problem(orc, "monza", 20, 8, seed=2)
+    eng = Engine(**engine_kwargs(prob, 0, 1, 8, 19))
+    eng.set_paths(prob["table"])
+    with pytest.raises(EngineError) as e:
+        eng.solve(prob["x0"][None], np.zeros((1, 0, 19, 2), np.float32))   # no candidates
+    assert e.value.code == -1
+    with pytest.raises(EngineError) as e:
+        eng.solve(prob["x0"][None], np.zeros((1, 8, 18, 2), np.float32))   # horizon differs from the tables
+    assert e.value.code == -1
+    with pytest.raises(EngineError):
+        eng.set_paths(np.zeros((1, 7, 1)))                                  # a one-point path has no dynamics
