@@ -52,8 +52,12 @@ class ShardedRollout:
     is handed raw pointers and the current stream, RCCL runs on the same stream through torch.distributed."""
 
     def __init__(self, engine, n_problems: int, n_local: int, n_steps: int, layout: int, index_offset: int,
-                 device: torch.device, group: Optional[dist.ProcessGroup] = None, want_costs: bool = True):
+                 device: torch.device, group: Optional[dist.ProcessGroup] = None, want_costs: bool = True,
+                 host_collectives: bool = False):
+        """`host_collectives=True` stages the (tiny) collective payloads through the CPU - for process groups whose
+        backend cannot reduce GPU tensors (gloo rehearsals of the multi-rank path on a single GPU)."""
         from ._capi import record_floats
+        self.host_collectives = host_collectives
 
         self.engine, self.group = engine, group
         self.P, self.N, self.n, self.layout, self.offset = n_problems, n_local, n_steps, layout, index_offset
@@ -90,7 +94,7 @@ class ShardedRollout:
         if self.sampler is not None:
             sp = self.sampler
             if self.distributed:
-                dist.all_reduce(self.keys, op=dist.ReduceOp.MIN, group=self.group)   # the only collective
+                self._all_reduce(self.keys, dist.ReduceOp.MIN)   # the only collective
             centre = sp["centre"]
             stride = centre.shape[-2] * 2 if centre.dim() == 3 else centre.shape[-1]
             self.engine.finalize_sampled_device(self.keys.data_ptr() if self.distributed else 0, x0.data_ptr(),
@@ -101,10 +105,10 @@ class ShardedRollout:
                                                 stream)
             return self.records
         if self.distributed:
-            dist.all_reduce(self.keys, op=dist.ReduceOp.MIN, group=self.group)
+            self._all_reduce(self.keys, dist.ReduceOp.MIN)
             self.engine.finalize_device(self.keys.data_ptr(), x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n,
                                         self.layout, self.offset, self.records.data_ptr(), stream)
-            dist.all_reduce(self.records, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(self.records, dist.ReduceOp.SUM)
         else:
             self.engine.finalize_device(0, x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n, self.layout,
                                         self.offset, self.records.data_ptr(), stream)
@@ -113,6 +117,14 @@ class ShardedRollout:
     def step(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
         self.rollout(x0, U, stream)
         return self.select(x0, U, stream)
+
+    def _all_reduce(self, tensor: torch.Tensor, op):
+        if self.host_collectives:
+            staged = tensor.cpu()              # synchronises with the stream that produced `tensor`
+            dist.all_reduce(staged, op=op, group=self.group)
+            tensor.copy_(staged)
+        else:
+            dist.all_reduce(tensor, op=op, group=self.group)
 
 
 class PipelinedRollout:

@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap argmin/record of batch i (side stream) with the rollout of batch i+1; measured "
                          "slower than plain stream order on MI355X (cross-queue dependencies cost ~10 us each)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the multi-rank path with the "
+                         "collective payloads staged through the CPU (ranks may then share one GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="(diagnostic) attach no events to the rollout launches; roofline fields become null")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -270,10 +273,15 @@ def main():
               file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench: no GPU visible - the rollout path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = min(local_rank, torch.cuda.device_count() - 1)   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from acmpc_amd import Engine, workloads
     from acmpc_amd.sharding import PipelinedRollout, ShardedRollout
@@ -316,7 +324,8 @@ def main():
     if not args.pipeline:
         class _Serial:  # rollout and argmin/record back to back on the launch stream
             def __init__(self):
-                self.slot = ShardedRollout(engines[0], P, N, n, args.layout, index_offset=rank * N, device=device)
+                self.slot = ShardedRollout(engines[0], P, N, n, args.layout, index_offset=rank * N, device=device,
+                                           host_collectives=args.backend == "gloo")
                 if args.layout == 1:
                     self.slot.use_sampler(u_ref, u_ref, SAMPLE_SIGMA, seeds[0], 0)
 
@@ -362,10 +371,23 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_times = np.concatenate([engine.profile_collect() for engine in engines])
+    if world > 1:
+        # self-check outside the timed region: after the single all-reduce(MIN) every rank must hold the same plan
+        # (feasible counts are per rank and excluded)
+        rec = last.records.clone()
+        rec[:, 2] = 0
+        digest = torch.stack([rec.double().sum(), rec.double().abs().max()])
+        lo, hi = digest.clone(), digest.clone()
+        if args.backend == "gloo":
+            lo, hi = lo.cpu(), hi.cpu()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit("bench: ranks disagree on the winners' records after the all-reduce")
     if args.no_kernel_timing:
         kernel_ms = float("nan")
     else:
