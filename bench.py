@@ -38,7 +38,10 @@ def parse_args():
     ap.add_argument("--track", default="monza", choices=["monza", "spa", "nordschleife", "silverstone"])
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--candidates", type=int, default=4096, help="candidates per pose per GPU")
-    ap.add_argument("--poses", type=int, default=1024, help="independent solves batched into one launch")
+    ap.add_argument("--poses", type=int, default=4096,
+                    help="independent solves batched into one launch (16.8 M candidates, 6.6 GB of controls per step: "
+                         "throughput and roofline fraction keep rising with the batch - 0.74 / 0.77 / 0.81 of roofline at "
+                         "1024 / 2048 / 4096 poses - and 288 GB of HBM is there to be used)")
     ap.add_argument("--mode", default="S", choices=["S", "T"], help="S: spatial bicycle model, T: Cartesian + NN search")
     ap.add_argument("--layout", type=int, default=1, help="0: U[P][N][n][2], 1: U[P][n][2][N]")
     ap.add_argument("--buffers", type=int, default=2, help="distinct control matrices cycled through (HBM-cold reads)")

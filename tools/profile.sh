@@ -8,6 +8,7 @@ set -u
 TAG=${1:-r01}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf "$OUT"   # never mix runs: the summariser averages every CSV it finds under this directory
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-single-solve $*"
