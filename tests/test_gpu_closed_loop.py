@@ -1,0 +1,59 @@
+"""Closed loop: the drop-in controller drives a kinematic bicycle round a stretch of the synthetic Monza circuit.
+Not a parity test (the reference has no closed-loop vectors) - a functional one: the plans the GPU sampler produces
+must keep the car inside the corridor, at sensible speed, without a single infeasible solve."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _local_centreline(centre, pose, points=500, lookahead=150.0, spacing=0.5):
+    """Next `lookahead` metres of centreline seen from `pose` = (x, y, yaw), vehicle frame (x right, y forward)."""
+    d2 = ((centre - pose[:2]) ** 2).sum(axis=1)
+    start = int(np.argmin(d2))
+    count = int(lookahead / spacing) + 1
+    window = centre[(start + np.arange(count)) % len(centre)] - pose[:2]
+    a = np.pi / 2 - pose[2]
+    rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    local = window @ rot.T
+    t = np.linspace(0, count - 1, points)
+    return np.stack([np.interp(t, np.arange(count), local[:, 0]), np.interp(t, np.arange(count), local[:, 1])], axis=1), start
+
+
+def test_controller_keeps_the_car_on_the_track():
+    from acmpc_amd import workloads
+    from acmpc_amd.command_selection import TemporalCommandSelector
+    from acmpc_amd.mpc import build_mpc
+    from types import SimpleNamespace
+
+    cfg = copy.deepcopy(workloads.RACING_CONTROL["monza"])
+    cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])     # controller.py:241-243
+    mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
+    track = workloads.synthetic_track("monza")
+    centre = track["centre"]
+    tangent = centre[1] - centre[0]
+    pose = np.array([centre[0, 0], centre[0, 1], np.arctan2(tangent[1], tangent[0])])
+    pose[:2] += 1.2 * np.array([-np.sin(pose[2]), np.cos(pose[2])])                     # start 1.2 m left of centre
+    speed, dt, wheelbase = 15.0, 0.05, workloads.VEHICLE.wheelbase
+    lateral, speeds, progress = [], [], []
+    for tick in range(400):                                                               # 20 s
+        local, start = _local_centreline(centre, pose)
+        mpc.get_control(workloads.reference_path_from_centreline(local, 50))
+        assert mpc.infeasibility_counter == 0, "infeasible solve at tick %d" % tick
+        holder = SimpleNamespace(control_cumtime=mpc.cum_time.astype(np.float32),
+                                 control_inputs=mpc.projected_control.T.astype(np.float32))
+        v_cmd, delta = TemporalCommandSelector(holder)(float(mpc.cum_time[1]))            # the command one step in
+        speed += np.clip(v_cmd - speed, -6.0 * dt, 4.0 * dt)                              # bounded accel/brake
+        pose = pose + np.array([speed * np.cos(pose[2]), speed * np.sin(pose[2]),
+                                speed * np.tan(delta) / wheelbase]) * dt                  # localiser.py:66-95
+        nearest = centre[int(np.argmin(((centre - pose[:2]) ** 2).sum(axis=1)))]
+        lateral.append(np.linalg.norm(pose[:2] - nearest))
+        speeds.append(speed)
+        progress.append(start)
+    lateral = np.array(lateral)
+    assert lateral.max() < 2.5, "left the 9.5 m road: max lateral error %.2f m" % lateral.max()
+    assert lateral[100:].mean() < 0.8, "does not converge to the centreline: %.2f m" % lateral[100:].mean()
+    assert 8.0 <= min(speeds[50:]) and max(speeds) <= 30.1
+    assert (progress[-1] - progress[0]) % len(centre) > 400                              # > 200 m travelled
