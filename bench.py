@@ -125,7 +125,7 @@ def cpu_baseline(batch, mode, U_dev, layout, N, n, gpu_costs, seconds):
         "cores": cores,
         "kind": "port",
         "sample": "%d poses x %d candidates x horizon %d of the same batch, %d passes, %.1f s; oracle/acmpc_oracle.c "
-                  "(gcc -O3 -mavx2, SIMD across candidates, OpenMP threads), costs checked bit-identical to the GPU's" %
+                  "(gcc -O3 -mavx2, 8-wide SIMD across candidates, OpenMP threads), costs checked bit-identical to the GPU's" %
                   (sample, N, n + 1, repeats, elapsed),
     }
 

@@ -101,6 +101,52 @@ static inline float hinge2v(float lo_minus_x, float x_minus_hi) {
 }
 
 #define VB 64
+/* one block of VB candidates through all steps; a plain function with restrict-qualified pointers and the weights
+ * in locals, so that the compiler can prove the lanes independent (inside the OpenMP-outlined region it cannot) */
+static void spatial_block(const float* restrict x0, const float* restrict coef, const float* restrict U, int64_t N,
+                          int n, const oracle_weights* restrict wp, int64_t c0, int m, float* restrict costs,
+                          float* restrict viol) {
+  const oracle_weights w = *wp;
+  float ey[VB], ep[VB], t[VB], J[VB], V[VB];
+  for (int j = 0; j < VB; ++j) ey[j] = x0[0], ep[j] = x0[1], t[j] = x0[2], J[j] = 0.0f, V[j] = 0.0f;
+  for (int i = 0; i < n; ++i) {
+    const float* restrict k_ = coef + (int64_t)i * CS;
+    const float c_ds = k_[0], c_a21 = k_[1], c_a31 = k_[2], c_b31 = k_[3], c_f3 = k_[4], c_vref = k_[5],
+                c_kref = k_[6], c_lo = k_[7], c_hi = k_[8];
+    const float* restrict vrow = U + ((int64_t)i * 2) * N + c0;
+    const float* restrict krow = vrow + N;
+#pragma omp simd
+    for (int j = 0; j < m; ++j) {
+      const float v = vrow[j], k = krow[j];
+      const float dv = v - c_vref;
+      const float dk = k - c_kref;
+      float a = quad(w.q[0], ey[j]);
+      a = a + quad(w.q[1], ep[j]);
+      a = a + quad(w.q[2], t[j]);
+      float r = quad(w.r[0], dv);
+      r = r + quad(w.r[1], dk);
+      J[j] = J[j] + 0.5f * (a + r);
+      float Vj = V[j] + hinge2v(w.ulo[0] - v, v - w.uhi[0]);
+      Vj = Vj + hinge2v(w.ulo[1] - k, k - w.uhi[1]);
+      const float ey_n = ey[j] + c_ds * ep[j];
+      const float ep_n = (ep[j] + c_a21 * ey[j]) + c_ds * dk;
+      const float t_n = ((t[j] + c_a31 * ey[j]) + c_b31 * dv) + c_f3;
+      ey[j] = ey_n, ep[j] = ep_n, t[j] = t_n;
+      Vj = Vj + hinge2v(c_lo - ey_n, ey_n - c_hi);
+      const float tv = max2(w.tmin - t_n, 0.0f);
+      V[j] = Vj + tv * tv;
+    }
+  }
+  for (int j = 0; j < m; ++j) {
+    float a = quad(w.qn[0], ey[j]);
+    a = a + quad(w.qn[1], ep[j]);
+    a = a + quad(w.qn[2], t[j]);
+    const float Jf = J[j] + 0.5f * a;
+    costs[c0 + j] = Jf + w.wbound * V[j];
+    viol[c0 + j] = V[j];
+  }
+}
+
 void acmpc_oracle_rollout_spatial_blocked(const float* x0, const float* coef, const float* U, int64_t N, int n,
                                           const oracle_weights* w, float* costs, float* viol) {
   const int64_t blocks = (N + VB - 1) / VB;
@@ -108,42 +154,7 @@ void acmpc_oracle_rollout_spatial_blocked(const float* x0, const float* coef, co
   for (int64_t b = 0; b < blocks; ++b) {
     const int64_t c0 = b * VB;
     const int m = (int)((N - c0) < VB ? (N - c0) : VB);
-    float ey[VB], ep[VB], t[VB], J[VB], V[VB];
-    for (int j = 0; j < VB; ++j) ey[j] = x0[0], ep[j] = x0[1], t[j] = x0[2], J[j] = 0.0f, V[j] = 0.0f;
-    for (int i = 0; i < n; ++i) {
-      const float* k_ = coef + (int64_t)i * CS;
-      const float* vrow = U + ((int64_t)i * 2) * N + c0;
-      const float* krow = vrow + N;
-#pragma omp simd
-      for (int j = 0; j < m; ++j) {
-        const float v = vrow[j], k = krow[j];
-        const float dv = v - k_[5];
-        const float dk = k - k_[6];
-        float a = quad(w->q[0], ey[j]);
-        a = a + quad(w->q[1], ep[j]);
-        a = a + quad(w->q[2], t[j]);
-        float r = quad(w->r[0], dv);
-        r = r + quad(w->r[1], dk);
-        J[j] = J[j] + 0.5f * (a + r);
-        float Vj = V[j] + hinge2v(w->ulo[0] - v, v - w->uhi[0]);
-        Vj = Vj + hinge2v(w->ulo[1] - k, k - w->uhi[1]);
-        const float ey_n = ey[j] + k_[0] * ep[j];
-        const float ep_n = (ep[j] + k_[1] * ey[j]) + k_[0] * dk;
-        const float t_n = ((t[j] + k_[2] * ey[j]) + k_[3] * dv) + k_[4];
-        ey[j] = ey_n, ep[j] = ep_n, t[j] = t_n;
-        Vj = Vj + hinge2v(k_[7] - ey_n, ey_n - k_[8]);
-        const float tv = max2(w->tmin - t_n, 0.0f);
-        V[j] = Vj + tv * tv;
-      }
-    }
-    for (int j = 0; j < m; ++j) {
-      float a = quad(w->qn[0], ey[j]);
-      a = a + quad(w->qn[1], ep[j]);
-      a = a + quad(w->qn[2], t[j]);
-      const float Jf = J[j] + 0.5f * a;
-      costs[c0 + j] = Jf + w->wbound * V[j];
-      viol[c0 + j] = V[j];
-    }
+    spatial_block(x0, coef, U, N, n, w, c0, m, costs, viol);
   }
 }
 
