@@ -37,8 +37,12 @@ def test_single_gpu_line_has_the_contract_fields():
 
 
 def test_two_rank_rehearsal_agrees_across_ranks():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
            "--poses", "16", "--steps", "5", "--warmup", "2"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, (proc.stdout + proc.stderr)[-3000:]   # a rank disagreement exits non-zero

@@ -72,8 +72,11 @@ def test_sharded_rollout_class_with_a_one_rank_process_group():
     n = H - 1
     problems = [make_problem(orc, "monza", H, N, seed=120 + p) for p in range(P)]
     dev = torch.device("cuda", 0)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29577")
+    import socket
+    with socket.socket() as sock:          # a free port, so that a stale listener cannot make this flaky
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
