@@ -333,18 +333,25 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
   const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
   const float* __restrict__ centre =
       use_ref ? a.u_ref + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
-  // blend weights -> LDS once per workgroup; the knot boundaries are kernel arguments, so neither the loop bounds nor
-  // the weights wait on a dependent scalar load (that dependency used to make this the longest kernel of a round)
-  extern __shared__ __attribute__((aligned(16))) float s_w0[];
+  // blend weights and the centre sequence -> LDS once per workgroup; the knot boundaries are kernel arguments, so
+  // neither the loop bounds nor the per-step operands wait on a dependent scalar/global load (those dependencies used
+  // to make this the longest kernel of an optimisation round)
+  extern __shared__ __attribute__((aligned(16))) float s_smp[];  // [n] weights, then [n][2] centre
+  float* s_w0 = s_smp;
+  float* s_centre = s_smp + ((n + 3) & ~3);
   for (int e = threadIdx.x; e < n; e += 256) s_w0[e] = sp.segments[2 * e + 1];
+  // candidate 1 of a workgroup that holds it reads u_ref instead; every other lane the centre
+  const float* __restrict__ block_centre = a.centre + static_cast<size_t>(p) * a.centre_stride;
+  for (int e = threadIdx.x; e < 2 * n; e += 256) s_centre[e] = block_centre[e];
   __syncthreads();
   if (c >= a.N) return;
 #pragma unroll
   for (int knot = 0; knot < kKnots - 1; ++knot) {
     for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
       float v, k;
-      blend_control(sp, amp, s_w0[i], centre[2 * i], centre[2 * i + 1], z[knot][0], z[knot][1], z[knot + 1][0],
-                    z[knot + 1][1], v, k);
+      const float cv = use_ref ? centre[2 * i] : s_centre[2 * i];
+      const float ck = use_ref ? centre[2 * i + 1] : s_centre[2 * i + 1];
+      blend_control(sp, amp, s_w0[i], cv, ck, z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1], v, k);
       if constexpr (LAYOUT == 1) {
         float* row = a.U + (static_cast<size_t>(p) * n + i) * 2 * static_cast<size_t>(a.N) + c;
         row[0] = v;
@@ -845,10 +852,11 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
 
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
   const dim3 grid((args.N + 255) / 256, args.P);
+  const size_t sample_lds = (((static_cast<size_t>(args.n) + 3) & ~static_cast<size_t>(3)) + 2 * args.n) * sizeof(float);
   if (layout == 0) {
-    hipLaunchKernelGGL((sample_kernel<0>), grid, dim3(256), args.n * sizeof(float), s, args);
+    hipLaunchKernelGGL((sample_kernel<0>), grid, dim3(256), sample_lds, s, args);
   } else if (layout == 1) {
-    hipLaunchKernelGGL((sample_kernel<1>), grid, dim3(256), args.n * sizeof(float), s, args);
+    hipLaunchKernelGGL((sample_kernel<1>), grid, dim3(256), sample_lds, s, args);
   } else {
     return hipErrorInvalidValue;
   }
