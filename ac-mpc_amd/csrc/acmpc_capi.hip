@@ -574,9 +574,11 @@ int acmpc_finalize_sampled_device(acmpc_ctx* c, const int64_t* d_keys, const flo
 
 namespace {
 
-// the launch sequence of one optimisation, enqueued on `s` (directly, or while `s` is being captured)
+// the launch sequence of one optimisation, enqueued on `s` (directly, or while `s` is being captured): per round ONE
+// fused sample + rollout launch (candidates never touch memory) and the finalize that re-draws the winner from its
+// index; `fused == false` keeps the three-kernel form (sample -> U -> rollout -> finalize), which the tests compare
 int enqueue_rounds(acmpc_ctx* c, int P, int N, int n, int rounds, double sigma_v, double sigma_k, double shrink,
-                   bool has_uref, uint64_t seed, const uint32_t* d_seed, hipStream_t s) {
+                   bool has_uref, uint64_t seed, const uint32_t* d_seed, hipStream_t s, bool fused) {
   const int layout = ACMPC_LAYOUT_STEP_MAJOR;
   const int rec_floats = acmpc_record_floats(n);
   double scale = 1.0;
@@ -584,13 +586,44 @@ int enqueue_rounds(acmpc_ctx* c, int P, int N, int n, int rounds, double sigma_v
     // round 0 samples round the caller's centre, later rounds round the incumbent = the u block of the records
     const float* d_c = (r == 0) ? c->d_centre : c->d_records + ACMPC_REC_HEADER;
     const int stride = (r == 0) ? 2 * n : rec_floats;
-    int rc = sample(c, d_c, stride, has_uref ? c->d_uref : nullptr, P, N, n, layout, 0, sigma_v * scale, sigma_k * scale,
-                    seed, static_cast<uint32_t>(r), c->d_U, s, d_seed);
+    const float* d_ref = has_uref ? c->d_uref : nullptr;
+    if (!fused) {
+      int rc = sample(c, d_c, stride, d_ref, P, N, n, layout, 0, sigma_v * scale, sigma_k * scale, seed,
+                      static_cast<uint32_t>(r), c->d_U, s, d_seed);
+      if (rc != ACMPC_OK) return rc;
+      acmpc::LaunchShape shape;
+      rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, nullptr, s, &shape);
+      if (rc != ACMPC_OK) return rc;
+      rc = finalize(c, nullptr, nullptr, c->d_x0, c->d_U, P, N, n, layout, 0, c->d_records, shape.blocks_per_problem, s);
+      if (rc != ACMPC_OK) return rc;
+      continue;
+    }
+    int rc = upload_segments(c, n, s);
     if (rc != ACMPC_OK) return rc;
-    acmpc::LaunchShape shape;
-    rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, nullptr, s, &shape);
-    if (rc != ACMPC_OK) return rc;
-    rc = finalize(c, nullptr, nullptr, c->d_x0, c->d_U, P, N, n, layout, 0, c->d_records, shape.blocks_per_problem, s);
+    acmpc::RolloutArgs ra{};
+    ra.x0 = c->d_x0;
+    ra.coef = c->d_coef;
+    ra.partial_keys = c->d_partial_keys;
+    ra.partial_feas = c->d_partial_feas;
+    ra.P = P;
+    ra.N = N;
+    ra.n = n;
+    ra.index_offset = 0;
+    ra.w = c->w;
+    acmpc::SampleArgs sa{};
+    sa.centre = d_c;
+    sa.centre_stride = stride;
+    sa.u_ref = d_ref;
+    sa.P = P;
+    sa.N = N;
+    sa.n = n;
+    sa.spec = make_spec(c, sigma_v * scale, sigma_k * scale, seed, static_cast<uint32_t>(r));
+    sa.spec.seed_ptr = d_seed;
+    ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, s));
+    Regenerate regen{d_c, stride, d_ref, sa.spec};
+    // NB: the finalize of round r reads its centre from the records it is about to overwrite; it copies the
+    // controls it needs into registers/LDS before lane 0..63 write the new record, and one wave owns one record
+    rc = finalize(c, nullptr, nullptr, c->d_x0, nullptr, P, N, n, layout, 0, c->d_records, (N + 63) / 64, s, &regen);
     if (rc != ACMPC_OK) return rc;
   }
   return ACMPC_OK;
@@ -625,7 +658,8 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, x0_bytes, hipMemcpyHostToDevice, s));
     ACMPC_HIP(c, hipMemcpyAsync(c->d_centre, centre, path_bytes, hipMemcpyHostToDevice, s));
     if (has_uref) ACMPC_HIP(c, hipMemcpyAsync(c->d_uref, u_ref, path_bytes, hipMemcpyHostToDevice, s));
-    rc = enqueue_rounds(c, P, N, n, rounds, sigma[0], sigma[1], shrink, has_uref, seed, nullptr, s);
+    rc = enqueue_rounds(c, P, N, n, rounds, sigma[0], sigma[1], shrink, has_uref, seed, nullptr, s,
+                        std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr);
     if (rc != ACMPC_OK) return rc;
     ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
     ACMPC_HIP(c, hipStreamSynchronize(s));
@@ -676,7 +710,8 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     copy_in(c->d_seed, off_seed, 2 * sizeof(uint32_t));
     int rc_rounds = ACMPC_OK;
     if (e == hipSuccess)
-      rc_rounds = enqueue_rounds(c, P, N, n, rounds, sigma[0], sigma[1], shrink, has_uref, 0, c->d_seed, s);
+      rc_rounds = enqueue_rounds(c, P, N, n, rounds, sigma[0], sigma[1], shrink, has_uref, 0, c->d_seed, s,
+                                 std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr);
     if (e == hipSuccess && rc_rounds == ACMPC_OK)
       e = hipMemcpyAsync(c->h_opt_records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s);
     const hipError_t e_end = hipStreamEndCapture(s, &graph);

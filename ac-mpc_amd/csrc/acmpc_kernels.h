@@ -83,6 +83,9 @@ hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const 
                           hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s);
+// sample + rollout + cost fused: candidates are drawn inside the rollout kernel and never touch memory (the
+// closed-loop solve, where a round is three ~5 us launches of latency-bound work: one launch fewer per round)
+hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample, hipStream_t s);
 int softmin_chunks(int N);
 hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s);
 

@@ -366,6 +366,85 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
   }
 }
 
+// sample_kernel and rollout_kernel fused for the latency-bound closed-loop solve: one lane = one candidate whose
+// controls are drawn (same Philox counters, same blend_control arithmetic: bit-identical to sample_kernel) and
+// consumed step by step without ever being written to memory.  Output: the per-workgroup partial keys, as usual;
+// the winner's controls are re-drawn by finalize_kernel in regenerate mode.
+template <int MODE>
+__global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArgs a, const SampleArgs smp) {
+  extern __shared__ __attribute__((aligned(16))) float s_fused[];  // [n] weights | [n][2] centre | mode T tables
+  const int p = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x * kWave + lane;
+  const int n = a.n;
+  const Weights w = a.w;
+  const SampleSpec sp = smp.spec;
+  constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+  float* s_w0 = s_fused;
+  float* s_centre = s_fused + ((n + 3) & ~3);
+  float* s_wp = s_centre + 2 * n;
+  float* s_xy = s_wp + n * kCoefT;
+  const float* __restrict__ block_centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
+  for (int e = lane; e < n; e += kWave) s_w0[e] = sp.segments[2 * e + 1];
+  for (int e = lane; e < 2 * n; e += kWave) s_centre[e] = block_centre[e];
+  if constexpr (MODE == 1) {
+    for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
+    for (int e = lane; e < n; e += kWave) {
+      s_xy[2 * e] = coef[e * kCoefT];
+      s_xy[2 * e + 1] = coef[e * kCoefT + 1];
+    }
+  }
+  __syncthreads();
+
+  const bool active = c < a.N;
+  float cost = __builtin_inff();
+  bool feas = false;
+  if (active) {
+    const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
+    float z[kKnots][2];
+    draw_normals(sp, gidx, static_cast<uint32_t>(p), z);
+    const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
+    const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
+    const float* __restrict__ ref = smp.u_ref + static_cast<size_t>(p) * n * 2;
+    StateS ss{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+    StateT ts{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+    int nearest = 0;
+#pragma unroll
+    for (int knot = 0; knot < kKnots - 1; ++knot) {
+      for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
+        float v, k;
+        const float cv = use_ref ? ref[2 * i] : s_centre[2 * i];
+        const float ck = use_ref ? ref[2 * i + 1] : s_centre[2 * i + 1];
+        blend_control(sp, amp, s_w0[i], cv, ck, z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1], v, k);
+        if constexpr (MODE == 0) {
+          step_spatial<float>(ss, coef + i * kCoefS, v, k, w);
+        } else {
+          nearest = step_temporal(ts, s_wp, s_xy, n, v, k, w, nearest);
+        }
+      }
+    }
+    if constexpr (MODE == 0) {
+      cost = finish_spatial<float>(ss, w);
+      feas = ss.V == 0.0f;
+    } else {
+      cost = finish_temporal<float>(ts, n, w);
+      feas = ts.V == 0.0f;
+    }
+    if (a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c] = cost;
+  }
+  int64_t key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
+  int nfeas = (active && feas) ? 1 : 0;
+  key = wave_min_key(key);
+  nfeas = wave_sum_int(nfeas);
+  if (lane == 0) {
+    const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;
+    a.partial_keys[slot] = key;
+    a.partial_feas[slot] = nfeas;
+  }
+}
+
 // The same candidate's control at ONE step, for the finalize kernel's lane-per-step regeneration: identical
 // arithmetic (blend_control on the same operands), the bracketing knots picked by a select chain.
 __device__ __forceinline__ void regenerate_control(const SampleSpec& sp, const float (&z)[kKnots][2], float amp,
@@ -857,6 +936,21 @@ hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
     hipLaunchKernelGGL((sample_kernel<0>), grid, dim3(256), sample_lds, s, args);
   } else if (layout == 1) {
     hipLaunchKernelGGL((sample_kernel<1>), grid, dim3(256), sample_lds, s, args);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample, hipStream_t s) {
+  const int n = rollout.n;
+  const dim3 grid((rollout.N + kWave - 1) / kWave, rollout.P);
+  const size_t lds = (((static_cast<size_t>(n) + 3) & ~static_cast<size_t>(3)) + 2 * n +
+                      (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 2) : 0)) * sizeof(float);
+  if (mode == 0) {
+    hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample);
   } else {
     return hipErrorInvalidValue;
   }
