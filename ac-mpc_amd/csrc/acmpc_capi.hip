@@ -69,6 +69,8 @@ struct acmpc_ctx {
     }
   } opt_key;
   unsigned char* h_opt = nullptr;   // pinned
+  unsigned char* d_opt = nullptr;   // device mirror of h_opt: ONE H2D copy per solve
+  size_t opt_capacity = 0;
   float* h_opt_records = nullptr;   // pinned
   uint32_t* d_seed = nullptr;
 
@@ -192,7 +194,7 @@ struct Regenerate {
 
 int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const float* d_x0, const float* d_U, int P,
              int N, int n, int layout, int64_t offset, float* d_records, int blocks_per_problem, hipStream_t s,
-             const Regenerate* regen = nullptr) {
+             const Regenerate* regen = nullptr, const float* d_coef_override = nullptr) {
   acmpc::FinalizeArgs a{};
   if (regen != nullptr) {
     a.regenerate = true;
@@ -203,7 +205,7 @@ int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const 
   }
   a.U = d_U;
   a.x0 = d_x0;
-  a.coef = c->d_coef;
+  a.coef = d_coef_override != nullptr ? d_coef_override : c->d_coef;
   a.partial_keys = c->d_partial_keys;
   a.partial_feas = c->d_partial_feas;
   a.keys_in = d_keys_in;
@@ -380,6 +382,7 @@ void acmpc_destroy(acmpc_ctx* c) {
     if (c->h_opt != nullptr) (void)hipHostFree(c->h_opt);
     if (c->h_opt_records != nullptr) (void)hipHostFree(c->h_opt_records);
     (void)hipFree(c->d_seed);
+    (void)hipFree(c->d_opt);
     if (c->stream != nullptr) (void)hipStreamDestroy(c->stream);
     for (hipEvent_t e : c->prof_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->prof_stop) (void)hipEventDestroy(e);
@@ -577,32 +580,40 @@ namespace {
 // the launch sequence of one optimisation, enqueued on `s` (directly, or while `s` is being captured): per round ONE
 // fused sample + rollout launch (candidates never touch memory) and the finalize that re-draws the winner from its
 // index; `fused == false` keeps the three-kernel form (sample -> U -> rollout -> finalize), which the tests compare
-int enqueue_rounds(acmpc_ctx* c, int P, int N, int n, int rounds, double sigma_v, double sigma_k, double shrink,
-                   bool has_uref, uint64_t seed, const uint32_t* d_seed, hipStream_t s, bool fused) {
+struct OptInputs {
+  const float* x0;
+  const float* centre;
+  const float* uref;  // or nullptr
+  const float* coef;
+};
+
+int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int rounds, double sigma_v, double sigma_k,
+                   double shrink, uint64_t seed, const uint32_t* d_seed, hipStream_t s, bool fused) {
+  const bool has_uref = in.uref != nullptr;
   const int layout = ACMPC_LAYOUT_STEP_MAJOR;
   const int rec_floats = acmpc_record_floats(n);
   double scale = 1.0;
   for (int r = 0; r < rounds; ++r, scale *= shrink) {
     // round 0 samples round the caller's centre, later rounds round the incumbent = the u block of the records
-    const float* d_c = (r == 0) ? c->d_centre : c->d_records + ACMPC_REC_HEADER;
+    const float* d_c = (r == 0) ? in.centre : c->d_records + ACMPC_REC_HEADER;
     const int stride = (r == 0) ? 2 * n : rec_floats;
-    const float* d_ref = has_uref ? c->d_uref : nullptr;
-    if (!fused) {
+    const float* d_ref = has_uref ? in.uref : nullptr;
+    if (!fused) {  // (only with the handle's own buffers: in.coef == c->d_coef)
       int rc = sample(c, d_c, stride, d_ref, P, N, n, layout, 0, sigma_v * scale, sigma_k * scale, seed,
                       static_cast<uint32_t>(r), c->d_U, s, d_seed);
       if (rc != ACMPC_OK) return rc;
       acmpc::LaunchShape shape;
-      rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, nullptr, s, &shape);
+      rc = rollout(c, in.x0, c->d_U, P, N, n, layout, 0, nullptr, s, &shape);
       if (rc != ACMPC_OK) return rc;
-      rc = finalize(c, nullptr, nullptr, c->d_x0, c->d_U, P, N, n, layout, 0, c->d_records, shape.blocks_per_problem, s);
+      rc = finalize(c, nullptr, nullptr, in.x0, c->d_U, P, N, n, layout, 0, c->d_records, shape.blocks_per_problem, s);
       if (rc != ACMPC_OK) return rc;
       continue;
     }
     int rc = upload_segments(c, n, s);
     if (rc != ACMPC_OK) return rc;
     acmpc::RolloutArgs ra{};
-    ra.x0 = c->d_x0;
-    ra.coef = c->d_coef;
+    ra.x0 = in.x0;
+    ra.coef = in.coef;
     ra.partial_keys = c->d_partial_keys;
     ra.partial_feas = c->d_partial_feas;
     ra.P = P;
@@ -623,7 +634,8 @@ int enqueue_rounds(acmpc_ctx* c, int P, int N, int n, int rounds, double sigma_v
     Regenerate regen{d_c, stride, d_ref, sa.spec};
     // NB: the finalize of round r reads its centre from the records it is about to overwrite; it copies the
     // controls it needs into registers/LDS before lane 0..63 write the new record, and one wave owns one record
-    rc = finalize(c, nullptr, nullptr, c->d_x0, nullptr, P, N, n, layout, 0, c->d_records, (N + 63) / 64, s, &regen);
+    rc = finalize(c, nullptr, nullptr, in.x0, nullptr, P, N, n, layout, 0, c->d_records, (N + 63) / 64, s, &regen,
+                  in.coef);
     if (rc != ACMPC_OK) return rc;
   }
   return ACMPC_OK;
@@ -658,7 +670,8 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, x0_bytes, hipMemcpyHostToDevice, s));
     ACMPC_HIP(c, hipMemcpyAsync(c->d_centre, centre, path_bytes, hipMemcpyHostToDevice, s));
     if (has_uref) ACMPC_HIP(c, hipMemcpyAsync(c->d_uref, u_ref, path_bytes, hipMemcpyHostToDevice, s));
-    rc = enqueue_rounds(c, P, N, n, rounds, sigma[0], sigma[1], shrink, has_uref, seed, nullptr, s,
+    const OptInputs in{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef};
+    rc = enqueue_rounds(c, in, P, N, n, rounds, sigma[0], sigma[1], shrink, seed, nullptr, s,
                         std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr);
     if (rc != ACMPC_OK) return rc;
     ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
@@ -676,6 +689,8 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
                                          (3 + 4 * static_cast<size_t>(p.max_steps) +
                                           static_cast<size_t>(p.max_steps) * c->coef_stride) * sizeof(float);
     ACMPC_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_opt), cap, hipHostMallocDefault));
+    ACMPC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_opt), cap));
+    c->opt_capacity = cap;
     ACMPC_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_opt_records),
                                static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float),
                                hipHostMallocDefault));
@@ -699,19 +714,27 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     if (rc != ACMPC_OK) return rc;
     hipGraph_t graph = nullptr;
     ACMPC_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipError_t e = hipSuccess;
-    auto copy_in = [&](void* dst, size_t off, size_t bytes) {
-      if (e == hipSuccess) e = hipMemcpyAsync(dst, c->h_opt + off, bytes, hipMemcpyHostToDevice, s);
-    };
-    copy_in(c->d_x0, off_x0, x0_bytes);
-    copy_in(c->d_centre, off_centre, path_bytes);
-    if (has_uref) copy_in(c->d_uref, off_uref, path_bytes);
-    copy_in(c->d_coef, off_table, table_bytes);
-    copy_in(c->d_seed, off_seed, 2 * sizeof(uint32_t));
+    // ONE host-to-device copy brings x0, centre, u_ref, the table and the seed; the kernels read them in place
+    const size_t in_bytes = off_seed + 2 * sizeof(uint32_t);
+    hipError_t e = hipMemcpyAsync(c->d_opt, c->h_opt, in_bytes, hipMemcpyHostToDevice, s);
+    const bool fused = std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr;
+    OptInputs in{reinterpret_cast<const float*>(c->d_opt + off_x0), reinterpret_cast<const float*>(c->d_opt + off_centre),
+                 has_uref ? reinterpret_cast<const float*>(c->d_opt + off_uref) : nullptr,
+                 reinterpret_cast<const float*>(c->d_opt + off_table)};
+    if (!fused) {  // the three-kernel form runs on the handle's own buffers: copy the block's parts there
+      auto spread = [&](void* dst, size_t off, size_t bytes) {
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, c->d_opt + off, bytes, hipMemcpyDeviceToDevice, s);
+      };
+      spread(c->d_x0, off_x0, x0_bytes);
+      spread(c->d_centre, off_centre, path_bytes);
+      if (has_uref) spread(c->d_uref, off_uref, path_bytes);
+      spread(c->d_coef, off_table, table_bytes);
+      in = OptInputs{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef};
+    }
     int rc_rounds = ACMPC_OK;
     if (e == hipSuccess)
-      rc_rounds = enqueue_rounds(c, P, N, n, rounds, sigma[0], sigma[1], shrink, has_uref, 0, c->d_seed, s,
-                                 std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr);
+      rc_rounds = enqueue_rounds(c, in, P, N, n, rounds, sigma[0], sigma[1], shrink, 0,
+                                 reinterpret_cast<const uint32_t*>(c->d_opt + off_seed), s, fused);
     if (e == hipSuccess && rc_rounds == ACMPC_OK)
       e = hipMemcpyAsync(c->h_opt_records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s);
     const hipError_t e_end = hipStreamEndCapture(s, &graph);
@@ -735,7 +758,6 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   std::memcpy(c->h_opt + off_table, c->h_coef.data(), table_bytes);
   const uint32_t seed_words[2] = {static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
   std::memcpy(c->h_opt + off_seed, seed_words, sizeof seed_words);
-  c->tables_dirty = false;  // the graph uploads the table itself
   ACMPC_HIP(c, hipGraphLaunch(c->opt_graph, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
   std::memcpy(records, c->h_opt_records, rec_bytes);
