@@ -96,20 +96,22 @@ def cpu_baseline(batch, mode, U_dev, layout, N, n, gpu_costs, seconds):
     # the one-GPU box gives this job 16 host cores; never more threads than cores we may run on
     cores = min(16, len(os.sched_getaffinity(0)))
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    sample = min(8, U_dev.shape[0])
+    sample = min(32, U_dev.shape[0])   # 131 072 candidates per pass: enough blocks to keep 16 threads busy
     U = U_dev[:sample].cpu().numpy()
     cfg = batch.cfg
     w = c_oracle.make_weights(cfg["step_cost"], cfg["r_term"], cfg["final_cost"], batch.u_lo, batch.u_hi, 1.0e6)
     x0 = batch.x0 if mode == 0 else batch.pose0
 
+    coef_host = np.stack(batch.coef_host[:sample])
+
     def one_pass(check):
+        if mode == 0 and layout == 1:   # all sampled poses in one call: threads over (pose, 64-candidate block)
+            costs, _ = c_oracle.rollout_spatial_batch(x0[:sample], coef_host, U, w)
+        else:
+            costs = np.stack([c_oracle.rollout(mode, x0[p], batch.coef_host[p], U[p], layout, w)[0] for p in range(sample)])
         for p in range(sample):
-            if mode == 0 and layout == 1:
-                cost, _ = c_oracle.rollout_spatial_blocked(x0[p], batch.coef_host[p], U[p], w)
-            else:
-                cost, _ = c_oracle.rollout(mode, x0[p], batch.coef_host[p], U[p], layout, w)
-            c_oracle.argmin(cost)
-            if check and not np.array_equal(cost, gpu_costs[p]):
+            c_oracle.argmin(costs[p])
+            if check and not np.array_equal(costs[p], gpu_costs[p]):
                 raise SystemExit("bench: GPU costs differ from the oracle on pose %d" % p)
 
     one_pass(check=True)
@@ -307,7 +309,7 @@ def main():
         engine.set_paths(batch.tables)
         engine.sync_tables(stream)
         engines.append(engine)
-    batch.coef_host = [engines[0].coefficients(p) for p in range(min(8, P))]
+    batch.coef_host = [engines[0].coefficients(p) for p in range(min(32, P))]
     x0 = torch.tensor(batch.x0 if mode == 0 else batch.pose0, device=device)
     # Synthetic control matrices, produced on the device by the library's counter-based sampler: candidate
     # (rank * N + c) of pose p in buffer b = clip(u_ref + amplitude * sigma * smooth noise), candidate 0 = u_ref.
@@ -438,7 +440,7 @@ def main():
             out["closed_loop_replay"] = closed_loop_replay(workloads)
             out["secondary_kernels"] = secondary_kernels(workloads, Engine, args.track, H, N, device)
         if world == 1 and not args.no_cpu_baseline:
-            gpu_costs = last.costs[:8].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
+            gpu_costs = last.costs[:32].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
             out["cpu_baseline"] = cpu_baseline(batch, mode, controls[(args.steps - 1) % args.buffers], args.layout, N,
                                                n, gpu_costs, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -158,6 +158,21 @@ void acmpc_oracle_rollout_spatial_blocked(const float* x0, const float* coef, co
   }
 }
 
+/* P problems at once (x0 [P][3], coef [P][n][CS], U [P][n][2][N], costs/viol [P][N]): one parallel region over all
+ * (problem, block) pairs, so that the threads stay busy when a single problem is only a few dozen blocks */
+void acmpc_oracle_rollout_spatial_batch(const float* x0, const float* coef, const float* U, int P, int64_t N, int n,
+                                        const oracle_weights* w, float* costs, float* viol) {
+  const int64_t blocks = (N + VB - 1) / VB;
+#pragma omp parallel for schedule(static)
+  for (int64_t job = 0; job < (int64_t)P * blocks; ++job) {
+    const int64_t p = job / blocks, b = job % blocks;
+    const int64_t c0 = b * VB;
+    const int m = (int)((N - c0) < VB ? (N - c0) : VB);
+    spatial_block(x0 + p * 3, coef + p * (int64_t)n * CS, U + p * (int64_t)n * 2 * N, N, n, w, c0, m, costs + p * N,
+                  viol + p * N);
+  }
+}
+
 static inline void sincos_spec(float phi, float* sn, float* cs) {
   const float k = rintf(phi * 0.6366197723675814f);
   const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;

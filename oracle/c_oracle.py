@@ -36,6 +36,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn.argtypes = [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.POINTER(Weights), fp, fp, fp]
         _lib.acmpc_oracle_rollout_spatial_blocked.restype = None
         _lib.acmpc_oracle_rollout_spatial_blocked.argtypes = [fp, fp, fp, C.c_int64, C.c_int, C.POINTER(Weights), fp, fp]
+        _lib.acmpc_oracle_rollout_spatial_batch.restype = None
+        _lib.acmpc_oracle_rollout_spatial_batch.argtypes = [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.POINTER(Weights),
+                                                            fp, fp]
         _lib.acmpc_oracle_argmin.restype = C.c_int64
         _lib.acmpc_oracle_argmin.argtypes = [fp, C.c_int64]
     return _lib
@@ -82,6 +85,21 @@ def rollout_spatial_blocked(x0, coef, U_step_major, weights: Weights):
     viol = np.empty(N, dtype=np.float32)
     lib.acmpc_oracle_rollout_spatial_blocked(x0.ctypes.data_as(fp), coef.ctypes.data_as(fp), U.ctypes.data_as(fp), N, n,
                                              C.byref(weights), costs.ctypes.data_as(fp), viol.ctypes.data_as(fp))
+    return costs, viol
+
+
+def rollout_spatial_batch(x0, coef, U_step_major, weights: Weights):
+    """P problems in one call: x0 [P,3], coef [P,n,12], U [P,n,2,N] -> costs [P,N], viol [P,N]."""
+    lib = load()
+    fp = C.POINTER(C.c_float)
+    x0 = np.ascontiguousarray(x0, dtype=np.float32)
+    coef = np.ascontiguousarray(coef, dtype=np.float32)
+    U = np.ascontiguousarray(U_step_major, dtype=np.float32)
+    P, n, _, N = U.shape
+    costs = np.empty((P, N), dtype=np.float32)
+    viol = np.empty((P, N), dtype=np.float32)
+    lib.acmpc_oracle_rollout_spatial_batch(x0.ctypes.data_as(fp), coef.ctypes.data_as(fp), U.ctypes.data_as(fp), P, N, n,
+                                           C.byref(weights), costs.ctypes.data_as(fp), viol.ctypes.data_as(fp))
     return costs, viol
 
 

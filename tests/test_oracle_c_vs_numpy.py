@@ -30,9 +30,13 @@ def test_c_matches_numpy(track, H, N, mode):
         np.testing.assert_array_equal(states, want[2])
     assert c_oracle.argmin(want[0]) == orc.pick_best(want[0])[0]
     if mode == 0:  # the vectorised form bench.py times as the CPU baseline
-        cost, viol = c_oracle.rollout_spatial_blocked(x0, coef, np.ascontiguousarray(prob["U"].transpose(1, 2, 0)), w)
+        U_sm = np.ascontiguousarray(prob["U"].transpose(1, 2, 0))
+        cost, viol = c_oracle.rollout_spatial_blocked(x0, coef, U_sm, w)
         np.testing.assert_array_equal(cost, want[0])
         np.testing.assert_array_equal(viol, want[1])
+        costs, viols = c_oracle.rollout_spatial_batch(np.stack([x0, x0]), np.stack([coef, coef]), np.stack([U_sm, U_sm]), w)
+        np.testing.assert_array_equal(costs[1], want[0])
+        np.testing.assert_array_equal(viols[0], want[1])
 
 
 def test_argmin_first_minimum_and_nonfinite():
