@@ -43,6 +43,7 @@ def parse_args():
                          "throughput and roofline fraction keep rising with the batch - 0.74 / 0.77 / 0.81 of roofline at "
                          "1024 / 2048 / 4096 poses - and 288 GB of HBM is there to be used)")
     ap.add_argument("--mode", default="S", choices=["S", "T"], help="S: spatial bicycle model, T: Cartesian + NN search")
+    ap.add_argument("--nn-window", default=None, help="mode T: 'back,ahead' search window (default: exhaustive scan)")
     ap.add_argument("--layout", type=int, default=1, help="0: U[P][N][n][2], 1: U[P][n][2][N]")
     ap.add_argument("--buffers", type=int, default=2, help="distinct control matrices cycled through (HBM-cold reads)")
     ap.add_argument("--pipeline", action="store_true",
@@ -305,7 +306,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     engines = []
     for _ in range(2 if args.pipeline else 1):   # one handle per pipeline slot (own partial-key buffers)
-        engine = Engine(**workloads.engine_kwargs(batch, mode, N, device=local_rank))
+        window = tuple(int(v) for v in args.nn_window.split(",")) if args.nn_window else None
+        engine = Engine(**workloads.engine_kwargs(batch, mode, N, device=local_rank, nn_window=window))
         engine.set_paths(batch.tables)
         engine.sync_tables(stream)
         engines.append(engine)
