@@ -176,3 +176,43 @@ class PipelinedRollout:
 
     def drain(self):
         torch.cuda.current_stream().wait_stream(self.side)
+
+
+class ShardedOptimizer:
+    """The closed-loop solve (`acmpc_optimize`'s rounds) with the candidates of every round spread over the ranks:
+    each rank draws and rolls out its own slice of global candidate indices, ONE all-reduce(MIN) of the keys per
+    round picks the global winner, every rank re-draws that winner from its index and uses it as the next round's
+    centre.  All ranks end every round with identical records, so no other exchange is needed."""
+
+    def __init__(self, engine, n_problems: int, n_local: int, n_steps: int, index_offset: int, device: torch.device,
+                 group: Optional[dist.ProcessGroup] = None, host_collectives: bool = False):
+        from ._capi import LAYOUT_STEP_MAJOR, REC_HEADER, record_floats
+
+        self.shard = ShardedRollout(engine, n_problems, n_local, n_steps, LAYOUT_STEP_MAJOR, index_offset, device, group,
+                                    want_costs=False, host_collectives=host_collectives)
+        self.shard.distributed = self.shard.distributed or host_collectives   # keys must be produced for the reduce
+        self.U = torch.empty(n_problems, n_steps, 2, n_local, dtype=torch.float32, device=device)
+        self._rec_header, self._rec_floats = REC_HEADER, record_floats(n_steps)
+
+    def solve(self, x0: torch.Tensor, centre: torch.Tensor, u_ref: Optional[torch.Tensor], rounds: int, sigma,
+              shrink: float = 0.5, seed: int = 0, stream: int = 0) -> torch.Tensor:
+        """x0 [P,3], centre / u_ref [P,n,2] device tensors -> records [P, R] (identical on every rank)."""
+        shard, n = self.shard, self.shard.n
+        scale = 1.0
+        for r in range(rounds):
+            if r == 0:
+                centre_ptr, stride = centre.data_ptr(), 2 * n
+            else:   # the u block of the previous round's records
+                centre_ptr, stride = shard.records.data_ptr() + 4 * self._rec_header, self._rec_floats
+            sig = (sigma[0] * scale, sigma[1] * scale)
+            ref_ptr = u_ref.data_ptr() if u_ref is not None else 0
+            shard.engine.sample_device(centre_ptr, stride, ref_ptr, shard.P, shard.N, n, shard.layout, shard.offset, sig,
+                                       seed, r, self.U.data_ptr(), stream)
+            shard.rollout(x0, self.U, stream)
+            if shard.distributed and dist.is_initialized() and dist.get_world_size(shard.group) > 1:
+                shard._all_reduce(shard.keys, dist.ReduceOp.MIN)
+            shard.engine.finalize_sampled_device(shard.keys.data_ptr() if shard.distributed else 0, x0.data_ptr(),
+                                                 centre_ptr, stride, ref_ptr,
+                                                 shard.P, shard.N, n, sig, seed, r, shard.records.data_ptr(), stream)
+            scale *= shrink
+        return shard.records

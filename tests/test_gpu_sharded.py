@@ -294,3 +294,62 @@ def test_regenerated_finalize_equals_finalize_from_the_matrix(mode):
         torch.cuda.synchronize()
         rec[:, _capi.REC_NFEASIBLE] = from_matrix[:, _capi.REC_NFEASIBLE]  # feasible counts are per shard
         assert torch.equal(rec, from_matrix)
+
+
+def test_sharded_optimizer_two_shards_equal_one():
+    """ShardedOptimizer on one GPU: a single 'rank' holding all 4 096 candidates vs two emulated ranks holding 2 048
+    each whose keys are min-reduced by hand - identical records after every round, hence identical plans; and the
+    single-rank result equals acmpc_optimize."""
+    import torch
+    from acmpc_amd import Engine, _capi
+    from acmpc_amd.sharding import ShardedOptimizer
+    P, H, N, rounds = 2, 50, 4096, 3
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 4, seed=800 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    tables = np.stack([p["table"] for p in problems])
+    u_ref_h = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]).astype(np.float32)
+    x0_h = np.stack([p["x0"] for p in problems])
+    u_ref, x0 = torch.tensor(u_ref_h, device=dev), torch.tensor(x0_h, device=dev)
+    sigma, seed = (3.0, 0.01), 5
+    s = torch.cuda.current_stream().cuda_stream
+
+    def engine(count):
+        e = Engine(**engine_kwargs(problems[0], 0, P, count, n))
+        e.set_paths(tables)
+        return e
+
+    whole = ShardedOptimizer(engine(N), P, N, n, 0, dev)
+    rec_whole = whole.solve(x0, u_ref, u_ref, rounds, sigma, seed=seed, stream=s).clone()
+    want = engine(N).optimize(x0_h, u_ref_h, u_ref_h, N, rounds, sigma, shrink=0.5, seed=seed)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rec_whole.cpu().numpy(), want["records"])
+
+    # two emulated ranks, advanced round by round with the all-reduce(MIN) done by hand
+    halves = [ShardedOptimizer(engine(N // 2), P, N // 2, n, off, dev) for off in (0, N // 2)]
+    for h in halves:
+        h.shard.distributed = True
+    R = _capi.record_floats(n)
+    scale = 1.0
+    for r in range(rounds):
+        sig = (sigma[0] * scale, sigma[1] * scale)
+        for h in halves:
+            sh = h.shard
+            cptr, stride = (u_ref.data_ptr(), 2 * n) if r == 0 else (sh.records.data_ptr() + 4 * _capi.REC_HEADER, R)
+            sh.engine.sample_device(cptr, stride, u_ref.data_ptr(), P, sh.N, n, 1, sh.offset, sig, seed, r, h.U.data_ptr(), s)
+            sh.rollout(x0, h.U, s)
+        gkeys = torch.minimum(halves[0].shard.keys, halves[1].shard.keys)
+        for h in halves:
+            sh = h.shard
+            cptr, stride = (u_ref.data_ptr(), 2 * n) if r == 0 else (sh.records.data_ptr() + 4 * _capi.REC_HEADER, R)
+            sh.engine.finalize_sampled_device(gkeys.data_ptr(), x0.data_ptr(), cptr, stride, u_ref.data_ptr(), P, sh.N,
+                                              n, sig, seed, r, sh.records.data_ptr(), s)
+        torch.cuda.synchronize()
+        a, b = halves[0].shard.records.clone(), halves[1].shard.records.clone()
+        a[:, _capi.REC_NFEASIBLE] = 0
+        b[:, _capi.REC_NFEASIBLE] = 0
+        assert torch.equal(a, b)
+        scale *= 0.5
+    final = halves[0].shard.records.clone()
+    final[:, _capi.REC_NFEASIBLE] = rec_whole[:, _capi.REC_NFEASIBLE]
+    assert torch.equal(final, rec_whole)
