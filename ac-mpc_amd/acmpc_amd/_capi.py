@@ -38,6 +38,8 @@ class Params(C.Structure):
         ("max_steps", C.c_int32),
         ("nn_back", C.c_int32),
         ("nn_ahead", C.c_int32),
+        ("centre_update", C.c_int32),
+        ("reserved", C.c_int32),
         ("step_cost", C.c_double * 3),
         ("r_term", C.c_double * 2),
         ("final_cost", C.c_double * 3),
@@ -166,7 +168,8 @@ class Engine:
 
     def __init__(self, *, mode: int, max_problems: int, max_candidates: int, max_steps: int, step_cost, r_term,
                  final_cost, u_min, u_max, margin: float, wheelbase: float, t_min: float = 0.01, dt: float = 0.05,
-                 w_bound: float = 1.0e6, softmin_lambda: float = 1.0, device: int = -1, nn_window=None):
+                 w_bound: float = 1.0e6, softmin_lambda: float = 1.0, device: int = -1, nn_window=None,
+                 centre_update: str = "argmin"):
         """`nn_window=(back, ahead)` restricts mode T's nearest-waypoint search to that many waypoints round the
         previous step's nearest index; None = exhaustive scan."""
         self._lib = load_library()
@@ -175,6 +178,7 @@ class Engine:
         p.mode, p.device = mode, device
         p.max_problems, p.max_candidates, p.max_steps = max_problems, max_candidates, max_steps
         p.nn_back, p.nn_ahead = (-1, -1) if nn_window is None else (int(nn_window[0]), int(nn_window[1]))
+        p.centre_update = {"argmin": 0, "softmin": 1}[centre_update]
         p.step_cost[:] = [float(v) for v in step_cost]
         p.r_term[:] = [float(v) for v in r_term]
         p.final_cost[:] = [float(v) for v in final_cost]

@@ -38,6 +38,8 @@ class ControlSolver:
         self._R = np.asarray(config["r_term"], dtype=np.float64)
         self._QN = np.asarray(config["final_cost"], dtype=np.float64)
         self._w_bound = float(config.get("w_bound", 1.0e6))
+        self._centre_update = config.get("sampling_update", "argmin")   # or "softmin" (MPPI-style weighted mean)
+        self._lambda = float(config.get("softmin_lambda", 1.0))
         self._incumbent = None
         self._engine = None  # built on first solve: the input box follows the live velocity limits
 
@@ -57,7 +59,7 @@ class ControlSolver:
                 mode=_capi.MODE_SPATIAL, max_problems=1, max_candidates=self._n_candidates,
                 max_steps=self._n_horizon, step_cost=self._Q, r_term=self._R, final_cost=self._QN, u_min=lo,
                 u_max=hi, margin=self._dynamics_model.margin, wheelbase=self._dynamics_model.length,
-                w_bound=self._w_bound)
+                w_bound=self._w_bound, centre_update=self._centre_update, softmin_lambda=self._lambda)
         return self._engine
 
     def solve(self, spatial_state: np.ndarray, reference_path: ReferencePath) -> SimpleNamespace:

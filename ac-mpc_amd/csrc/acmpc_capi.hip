@@ -333,6 +333,8 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
     return fail(nullptr, ACMPC_EINVAL, "capacities must be positive");
   if (params->nn_ahead >= 0 && (params->nn_back < 0 || params->nn_back + params->nn_ahead + 1 > 64))
     return fail(nullptr, ACMPC_EINVAL, "nearest-waypoint window: need nn_back >= 0 and at most 64 waypoints");
+  if (params->centre_update != 0 && params->centre_update != 1)
+    return fail(nullptr, ACMPC_EINVAL, "centre_update must be 0 (argmin) or 1 (softmin mean)");
   if (params->max_steps > 1024)
     return fail(nullptr, ACMPC_EINVAL, "the waypoint table and the winner record are staged in LDS: max_steps <= 1024");
   acmpc_ctx* c = new (std::nothrow) acmpc_ctx();
@@ -599,14 +601,39 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     const int stride = (r == 0) ? 2 * n : rec_floats;
     const float* d_ref = has_uref ? in.uref : nullptr;
     if (!fused) {  // (only with the handle's own buffers: in.coef == c->d_coef)
-      int rc = sample(c, d_c, stride, d_ref, P, N, n, layout, 0, sigma_v * scale, sigma_k * scale, seed,
-                      static_cast<uint32_t>(r), c->d_U, s, d_seed);
+      const bool softmin = c->prm.centre_update == 1;
+      // softmin rounds: candidate 0 = the weighted mean of the previous round (written into d_centre below),
+      // candidate 1 = the previous round's winner, so the best plan found so far is never lost
+      const bool mean_round = softmin && r > 0;
+      if (mean_round)  // candidate 1 reads its controls at a stride of 2n: stage the winner's u block contiguously
+        ACMPC_HIP(c, hipMemcpy2DAsync(c->d_uref, static_cast<size_t>(2 * n) * sizeof(float),
+                                      c->d_records + ACMPC_REC_HEADER, static_cast<size_t>(rec_floats) * sizeof(float),
+                                      static_cast<size_t>(2 * n) * sizeof(float), P, hipMemcpyDeviceToDevice, s));
+      int rc = sample(c, mean_round ? c->d_centre : d_c, mean_round ? 2 * n : stride, mean_round ? c->d_uref : d_ref, P,
+                      N, n, layout, 0, sigma_v * scale, sigma_k * scale, seed, static_cast<uint32_t>(r), c->d_U, s,
+                      d_seed);
       if (rc != ACMPC_OK) return rc;
       acmpc::LaunchShape shape;
-      rc = rollout(c, in.x0, c->d_U, P, N, n, layout, 0, nullptr, s, &shape);
+      rc = rollout(c, in.x0, c->d_U, P, N, n, layout, 0, softmin ? c->d_costs : nullptr, s, &shape);
       if (rc != ACMPC_OK) return rc;
-      rc = finalize(c, nullptr, nullptr, in.x0, c->d_U, P, N, n, layout, 0, c->d_records, shape.blocks_per_problem, s);
+      rc = finalize(c, nullptr, softmin ? c->d_keys : nullptr, in.x0, c->d_U, P, N, n, layout, 0, c->d_records,
+                    shape.blocks_per_problem, s);
       if (rc != ACMPC_OK) return rc;
+      if (softmin && r + 1 < rounds) {
+        acmpc::SoftminArgs sm{};
+        sm.costs = c->d_costs;
+        sm.keys = c->d_keys;
+        sm.U = c->d_U;
+        sm.partial = c->d_soft_partial;
+        sm.mean = c->d_centre;   // [P][n][2]: the next round's centre
+        sm.weight_sum = nullptr;
+        sm.chunks = acmpc::softmin_chunks(N);
+        sm.P = P;
+        sm.N = N;
+        sm.n = n;
+        sm.lambda = static_cast<float>(c->prm.softmin_lambda);
+        ACMPC_HIP(c, acmpc::launch_softmin(layout, sm, s));
+      }
       continue;
     }
     int rc = upload_segments(c, n, s);
@@ -672,7 +699,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     if (has_uref) ACMPC_HIP(c, hipMemcpyAsync(c->d_uref, u_ref, path_bytes, hipMemcpyHostToDevice, s));
     const OptInputs in{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef};
     rc = enqueue_rounds(c, in, P, N, n, rounds, sigma[0], sigma[1], shrink, seed, nullptr, s,
-                        std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr);
+                        std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr && c->prm.centre_update == 0);
     if (rc != ACMPC_OK) return rc;
     ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
     ACMPC_HIP(c, hipStreamSynchronize(s));
@@ -717,7 +744,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     // ONE host-to-device copy brings x0, centre, u_ref, the table and the seed; the kernels read them in place
     const size_t in_bytes = off_seed + 2 * sizeof(uint32_t);
     hipError_t e = hipMemcpyAsync(c->d_opt, c->h_opt, in_bytes, hipMemcpyHostToDevice, s);
-    const bool fused = std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr;
+    const bool fused = std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr && c->prm.centre_update == 0;
     OptInputs in{reinterpret_cast<const float*>(c->d_opt + off_x0), reinterpret_cast<const float*>(c->d_opt + off_centre),
                  has_uref ? reinterpret_cast<const float*>(c->d_opt + off_uref) : nullptr,
                  reinterpret_cast<const float*>(c->d_opt + off_table)};

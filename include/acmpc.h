@@ -77,6 +77,11 @@ typedef struct acmpc_params {
   int32_t nn_ahead;      /*   from clamp(j_prev - nn_back, 0, n - W), j_prev = the previous step's nearest index (0
                               at the start); nn_ahead < 0 = exhaustive scan of all n waypoints (KDTree.query
                               semantics, localiser.py:282-289)                                                    */
+  int32_t centre_update; /* acmpc_optimize: what the next round samples round - 0 = the round's argmin winner,
+                            1 = the softmin-weighted mean of the round's candidates (weights exp(-(cost - min) /
+                            softmin_lambda), the weighted-reduction form of localiser.py:572-579); in both cases the
+                            best candidate so far stays in the pool, so a round never loses it                  */
+  int32_t reserved;
   /* real-valued fields are doubles so that Python floats cross the ABI exactly; the device gets float32 */
   double step_cost[3];   /* Q  = diag(step_cost)  on (e_y, e_psi, t)     control.py:126               */
   double r_term[2];      /* R  = diag(r_term)     on (v, kappa)          control.py:127               */

@@ -31,8 +31,8 @@ def test_library_exports_every_declared_symbol():
 def test_params_struct_matches_header_layout():
     import ctypes
     from acmpc_amd import _capi
-    # 8 x 4-byte ints then 18 doubles, no padding surprises
-    assert ctypes.sizeof(_capi.Params) == 32 + 18 * 8
+    # 10 x 4-byte ints then 18 doubles, no padding surprises
+    assert ctypes.sizeof(_capi.Params) == 40 + 18 * 8
     assert _capi.record_floats(49) == _capi.load_library().acmpc_record_floats(49) == 4 + 98 + 150
 
 

@@ -46,7 +46,8 @@ def test_get_control_fills_the_reference_attributes(kind):
     assert mpc.infeasibility_counter == 0 and first_cost.shape == (n, 2)
 
 
-def test_sampled_optimum_approaches_the_qp_optimum():
+@pytest.mark.parametrize("update", ["argmin", "softmin"])
+def test_sampled_optimum_approaches_the_qp_optimum(update):
     """Sanity, not parity (QP solutions are unpinned): on the reference's own QP - built by the oracle's
     restatement of control.py and solved by the oracle's ADMM - the sampled plan's objective must come close to
     the QP optimum and never beat it by more than the solver tolerance."""
@@ -54,7 +55,7 @@ def test_sampled_optimum_approaches_the_qp_optimum():
     from acmpc_amd.mpc import build_mpc
     cfg = copy.deepcopy(RACING["monza"])
     cfg["speed_profile_constraints"]["v_max"] = 28.0
-    cfg.update(n_candidates=8192, sampling_rounds=6)
+    cfg.update(n_candidates=8192, sampling_rounds=6, sampling_update=update, softmin_lambda=0.5)
     mpc = build_mpc(cfg, PlaceholderVehicle())
     H, n = 50, 49
     mpc.get_control(_reference_path(H, "curve"), offset=0.2)
@@ -76,6 +77,7 @@ def test_sampled_optimum_approaches_the_qp_optimum():
     j_sampled = orc.qp_objective(qp["P_diag"], qp["q"], z)
     j_qp = orc.qp_objective(qp["P_diag"], qp["q"], ref.x)
     spread = abs(j_qp) + 1.0
+    print("update=%s  J_sampled=%.6g  J_qp=%.6g  gap=%.3g" % (update, j_sampled, j_qp, (j_sampled - j_qp) / spread))
     assert j_sampled >= j_qp - 1e-2 * spread, "a feasible rollout cannot beat the QP optimum"
     assert j_sampled <= j_qp + 0.25 * spread, "sampled plan too far from the QP optimum: %g vs %g" % (j_sampled, j_qp)
 

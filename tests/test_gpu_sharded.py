@@ -1,6 +1,8 @@
 """Sharded entry points on one GPU (needs an MI355X).  The RCCL collectives themselves need >1 GPU; what can be
 proven on one card is everything around them: keys carry global indices, finalize writes the record only on the
 owning shard, and the reduction of per-shard results equals the unsharded solve bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -202,6 +204,56 @@ def test_optimize_equals_the_manual_round_loop():
     np.testing.assert_array_equal(out["records"], rec.cpu().numpy())
     for a, b in zip(costs, costs[1:]):
         assert (b <= a).all()
+
+
+def test_softmin_centre_update_equals_the_manual_round_loop():
+    """centre_update="softmin": each round samples round the softmin-weighted mean of the previous round and keeps
+    the previous winner as candidate 1; equals the loop built from sample/solve/softmin device calls bit for bit, the
+    winner's cost never increases, and the mean itself is checked against the oracle's weighted reduction."""
+    import torch
+    from acmpc_amd import Engine, _capi
+    P, H, N, rounds = 3, 50, 2048, 4
+    n = H - 1
+    problems = [make_problem(orc, "silverstone", H, 4, seed=520 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    eng = Engine(**engine_kwargs(problems[0], 0, P, N, n, centre_update="softmin"))
+    eng.set_paths(np.stack([p["table"] for p in problems]))
+    u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]).astype(np.float32)
+    x0 = np.stack([p["x0"] for p in problems])
+    sigma, seed = (3.0, 0.01), 43
+    out = eng.optimize(x0, u_ref, u_ref, N, rounds, sigma, shrink=0.5, seed=seed)
+    R = _capi.record_floats(n)
+    d_x0, d_ref = torch.tensor(x0, device=dev), torch.tensor(u_ref, device=dev)
+    U = torch.empty(P, n, 2, N, device=dev)
+    rec = torch.empty(P, R, device=dev)
+    keys = torch.empty(P, dtype=torch.int64, device=dev)
+    cost = torch.empty(P, N, device=dev)
+    mean = d_ref.clone()
+    s = torch.cuda.current_stream().cuda_stream
+    best = []
+    for r in range(rounds):
+        ref = d_ref if r == 0 else rec[:, _capi.REC_HEADER:_capi.REC_HEADER + 2 * n].contiguous()
+        eng.sample_device(mean.data_ptr(), 2 * n, ref.data_ptr(), P, N, n, 1, 0, (sigma[0] * 0.5**r, sigma[1] * 0.5**r),
+                          seed, r, U.data_ptr(), s)
+        eng.solve_device(d_x0.data_ptr(), U.data_ptr(), P, N, n, 1, cost.data_ptr(), keys.data_ptr(), rec.data_ptr(), s)
+        eng.softmin_device(cost.data_ptr(), keys.data_ptr(), U.data_ptr(), P, N, n, 1, mean.data_ptr(), 0, s)
+        torch.cuda.synchronize()
+        best.append(rec[:, 0].cpu().numpy().copy())
+        if r == 0:
+            Uh, ch = U.cpu().numpy(), cost.cpu().numpy()
+            for p in range(P):
+                want = orc.softmin_mean(ch[p], np.moveaxis(Uh[p], -1, 0), 0.5)
+                np.testing.assert_allclose(mean[p].cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(out["records"], rec.cpu().numpy())
+    for a, b in zip(best, best[1:]):
+        assert (b <= a).all()
+    # the eager (no graph) form runs the same launches
+    os.environ["ACMPC_NO_GRAPH"] = "1"
+    try:
+        again = eng.optimize(x0, u_ref, u_ref, N, rounds, sigma, shrink=0.5, seed=seed)
+    finally:
+        del os.environ["ACMPC_NO_GRAPH"]
+    np.testing.assert_array_equal(again["records"], out["records"])
 
 
 def test_profile_hooks_and_pipelined_rollout():
