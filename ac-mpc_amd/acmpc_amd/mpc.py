@@ -104,10 +104,15 @@ class SpatialMPC:
         return self.model.s2t(reference_path, spatial_state_prediction)[:-1].T
 
     # -- the entry point ----------------------------------------------------------------------------------
-    def get_control(self, reference_path: np.ndarray, is_localised: bool = False, offset: float = 0.0):
+    def get_control(self, reference_path: np.ndarray, is_localised: bool = False, offset: float = 0.0,
+                    elapsed: float = None):
         """One MPC solve for an H x 3 reference path given in the vehicle frame (car at the origin, heading +y,
-        laterally displaced by `offset`).  Returns None; results are left in attributes."""
+        laterally displaced by `offset`).  Returns None; results are left in attributes.  `elapsed` (optional,
+        not in the reference's signature): seconds since the previous solve - the sampler then starts from the
+        previous plan advanced by that time instead of the plan as it was."""
         n = self.MPC_horizon - 1
+        if elapsed is not None and self.cum_time.shape[0] == n:
+            self._control_solver.shift_warm_start(elapsed, self.cum_time)
         path = self.construct_waypoints(reference_path)
         path = self.compute_speed_profile(path, is_localised,
                                           end_vel=self.speed_profile_constraints["end_velocity"])

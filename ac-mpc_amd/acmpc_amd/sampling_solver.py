@@ -62,6 +62,19 @@ class ControlSolver:
                 w_bound=self._w_bound, centre_update=self._centre_update, softmin_lambda=self._lambda)
         return self._engine
 
+    def shift_warm_start(self, elapsed_time: float, cum_time: np.ndarray) -> None:
+        """Warm start from the previous plan shifted by the time that has passed since it was made:
+        the new step i takes the old plan's controls at `cum_time[i] + elapsed_time`, linearly interpolated between
+        the old steps the way `TemporalCommandInterpolator` blends neighbouring commands
+        (/root/reference/src/acmpc/control/commands.py:41-66); past the old horizon the last command is held."""
+        if self._incumbent is None or elapsed_time <= 0.0:
+            return
+        cum_time = np.asarray(cum_time, dtype=np.float64)
+        if cum_time.shape[0] != self._incumbent.shape[0] or not np.all(np.diff(cum_time) > 0.0):
+            return
+        at = cum_time + float(elapsed_time)
+        self._incumbent = np.stack([np.interp(at, cum_time, self._incumbent[:, k]) for k in range(2)], axis=1)
+
     def solve(self, spatial_state: np.ndarray, reference_path: ReferencePath) -> SimpleNamespace:
         engine = self._ensure_engine()
         n = self._n_horizon

@@ -22,7 +22,8 @@ def _local_centreline(centre, pose, points=500, lookahead=150.0, spacing=0.5):
     return np.stack([np.interp(t, np.arange(count), local[:, 0]), np.interp(t, np.arange(count), local[:, 1])], axis=1), start
 
 
-def test_controller_keeps_the_car_on_the_track():
+@pytest.mark.parametrize("shifted_warm_start", [False, True])
+def test_controller_keeps_the_car_on_the_track(shifted_warm_start):
     from acmpc_amd import workloads
     from acmpc_amd.command_selection import TemporalCommandSelector
     from acmpc_amd.mpc import build_mpc
@@ -40,7 +41,8 @@ def test_controller_keeps_the_car_on_the_track():
     lateral, speeds, progress = [], [], []
     for tick in range(400):                                                               # 20 s
         local, start = _local_centreline(centre, pose)
-        mpc.get_control(workloads.reference_path_from_centreline(local, 50))
+        mpc.get_control(workloads.reference_path_from_centreline(local, 50),
+                        elapsed=dt if shifted_warm_start and tick > 0 else None)
         assert mpc.infeasibility_counter == 0, "infeasible solve at tick %d" % tick
         holder = SimpleNamespace(control_cumtime=mpc.cum_time.astype(np.float32),
                                  control_inputs=mpc.projected_control.T.astype(np.float32))

@@ -195,3 +195,25 @@ def test_track_map_ingestion(golden, tmp_path):
     assert track_map.reference_speed_window(speeds, 10) == np.mean(np.r_[985:1000, 0:85])   # wraps round the lap
     with pytest.raises(ValueError):
         track_map.load_track_map("map.csv")
+
+
+def test_warm_start_shift_follows_the_elapsed_time():
+    """the previous plan advanced by the elapsed time - one whole step shifts by one entry, half a
+    step blends neighbours, the tail holds the last command, and a plan of another horizon is left alone."""
+    from acmpc_amd.sampling_solver import ControlSolver
+    cfg = dict(RACING["monza"], horizon=6)
+    solver = ControlSolver(cfg, SimpleNamespace(min_u=[0, -0.1], max_u=[50, 0.1], margin=1.0, length=2.65))
+    plan = np.array([[10.0, 0.00], [12.0, 0.01], [14.0, 0.02], [16.0, 0.03], [18.0, 0.04]])
+    cum_time = np.array([0.0, 0.1, 0.2, 0.3, 0.4])
+    solver._incumbent = plan.copy()
+    solver.shift_warm_start(0.1, cum_time)
+    np.testing.assert_allclose(solver._incumbent, np.vstack([plan[1:], plan[-1:]]), atol=1e-12)
+    solver._incumbent = plan.copy()
+    solver.shift_warm_start(0.05, cum_time)
+    np.testing.assert_allclose(solver._incumbent[:4], 0.5 * (plan[:4] + plan[1:]), atol=1e-12)
+    np.testing.assert_allclose(solver._incumbent[4], plan[4], atol=1e-12)
+    solver._incumbent = plan.copy()
+    solver.shift_warm_start(0.1, cum_time[:3])   # stale horizon: untouched
+    np.testing.assert_array_equal(solver._incumbent, plan)
+    solver.shift_warm_start(-1.0, cum_time)
+    np.testing.assert_array_equal(solver._incumbent, plan)
