@@ -114,7 +114,8 @@ __device__ __forceinline__ F finish_spatial(const StateS_<F>& s, const Weights& 
 template <typename F>
 __device__ __forceinline__ void sincos_spec(F phi, F& sn, F& cs) {
   using I = typename IndexOf<F>::type;
-  const F k = __builtin_elementwise_rint(phi * 0.6366197723675814f);
+  const F t = phi * 0.6366197723675814f + 12582912.0f;  // 1.5 * 2^23: rint(y) lands in the low mantissa bits
+  const F k = t - 12582912.0f;
   const F r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
   const F r2 = r * r;
   F ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
@@ -123,13 +124,14 @@ __device__ __forceinline__ void sincos_spec(F phi, F& sn, F& cs) {
   F pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
   pc = 4.166664568298827e-2f + r2 * pc;
   const F c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
-  const I q = __builtin_convertvector(k, I) & 3;
+  const I q = __builtin_bit_cast(I, t) & 3;  // no float -> int conversion: defined for every input
   sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
   cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }
 template <>
 __device__ __forceinline__ void sincos_spec<float>(float phi, float& sn, float& cs) {
-  const float k = rintf(phi * 0.6366197723675814f);
+  const float t = phi * 0.6366197723675814f + 12582912.0f;
+  const float k = t - 12582912.0f;
   const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
   const float r2 = r * r;
   float ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
@@ -138,7 +140,7 @@ __device__ __forceinline__ void sincos_spec<float>(float phi, float& sn, float& 
   float pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
   pc = 4.166664568298827e-2f + r2 * pc;
   const float c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
-  const int q = static_cast<int>(k) & 3;
+  const int q = __float_as_int(t) & 3;
   sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
   cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }
@@ -169,8 +171,8 @@ __device__ __forceinline__ void temporal_advance(StateT_<F>& s, F v, F k, const 
   s.phi = phin;
 }
 
-template <typename F>
-__device__ __forceinline__ F dist2(F X, F Y, float wx, float wy) {
+template <typename F, typename G>
+__device__ __forceinline__ F dist2(F X, F Y, G wx, G wy) {
   const F dx = X - wx;
   const F dy = Y - wy;
   return dx * dx + dy * dy;
@@ -195,32 +197,43 @@ __device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const Stat
 // The same search restricted to W = back + ahead + 1 consecutive waypoints starting at
 // lo = clamp(j_prev - back, 0, n - W): progress along the path is monotone and at most about one waypoint per step,
 // so a short window finds the global minimum on every realistic input at a fraction of the ALU work (tests check
-// equality with the exhaustive scan).  `xy` is the compact (x, y) copy of the table: the window is W consecutive
-// 8-byte pairs, read with immediate offsets from one base address.  W = 8 is unrolled at compile time.
+// equality with the exhaustive scan).  `xy` is a planar copy of the table's positions (x_0..x_{n-1}, y_0..y_{n-1}).
+// W = 8 and W = 4 are unrolled: the distances of two neighbouring waypoints are formed by one packed instruction
+// each (v_pk_add/mul_f32: 2.5 instructions per waypoint instead of 5), the minimum by a min chain, and the FIRST
+// index that attains it by an equality scan from the far end - the same answer as the `d < best` scan, one
+// instruction per waypoint cheaper.
 template <int W>
-__device__ __forceinline__ int nearest_in_window(float X, float Y, const float* xy, int lo) {
-  float best = __builtin_inff();
-  int j = lo;
+__device__ __forceinline__ int nearest_in_window(float X, float Y, const float* xs, const float* ys, int lo) {
+  float d[W];
 #pragma unroll
-  for (int m = 0; m < W; ++m) {
-    const float d = dist2<float>(X, Y, xy[2 * (lo + m)], xy[2 * (lo + m) + 1]);
-    const bool better = d < best;
-    best = better ? d : best;
-    j = better ? lo + m : j;
+  for (int m = 0; m < W; m += 2) {
+    const f32x2 wx = {xs[lo + m], xs[lo + m + 1]};
+    const f32x2 wy = {ys[lo + m], ys[lo + m + 1]};
+    const f32x2 dd = dist2<f32x2>(splat<f32x2>(X), splat<f32x2>(Y), wx, wy);
+    d[m] = dd[0];
+    d[m + 1] = dd[1];
   }
-  return j;
+  float best = d[0];
+#pragma unroll
+  for (int m = 1; m < W; ++m) best = __builtin_fminf(best, d[m]);  // NaN distances are skipped, like `d < best`
+  int jm = 0;  // also the answer when nothing compares equal (all NaN), where the `d < best` scan keeps `lo`
+#pragma unroll
+  for (int m = W - 1; m >= 1; --m) jm = (d[m] == best) ? m : jm;
+  jm = (d[0] == best) ? 0 : jm;
+  return lo + jm;
 }
 
 __device__ __forceinline__ int temporal_nearest_window(float X, float Y, const float* xy, int n, int j_prev, int back,
                                                        int ahead) {
   const int W = back + ahead + 1;
   const int lo = max(min(j_prev - back, n - W), 0);
-  if (W == 8 && n >= 8) return nearest_in_window<8>(X, Y, xy, lo);
+  if (W == 8 && n >= 8) return nearest_in_window<8>(X, Y, xy, xy + n, lo);
+  if (W == 4 && n >= 4) return nearest_in_window<4>(X, Y, xy, xy + n, lo);
   const int hi = min(lo + W, n);
   float best = __builtin_inff();
   int j = lo;
   for (int i = lo; i < hi; ++i) {
-    const float d = dist2<float>(X, Y, xy[2 * i], xy[2 * i + 1]);
+    const float d = dist2<float>(X, Y, xy[i], xy[n + i]);
     const bool better = d < best;
     best = better ? d : best;
     j = better ? i : j;
@@ -253,7 +266,7 @@ __device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v
 }
 
 // `wp` is the waypoint table (kCoefT floats per waypoint) and `xy` its compact (x, y) copy; in the rollout kernels
-// both live in LDS.  Returns the nearest index (per element) for the next step's search window.
+// both live in LDS (`xy` planar: all x, then all y).  Returns the nearest index (per element) for the next step's search window.
 __device__ __forceinline__ int step_temporal(StateT& s, const float* wp, const float* xy, int n, float v, float k,
                                              const Weights& w, int j_prev) {
   temporal_advance<float>(s, v, k, w);

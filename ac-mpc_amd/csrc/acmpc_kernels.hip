@@ -93,12 +93,12 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
 
-  float* s_xy = s_wp + n * kCoefT;  // compact (x, y) pairs for the windowed nearest-waypoint search
+  float* s_xy = s_wp + n * kCoefT;  // planar x | y copy for the windowed nearest-waypoint search
   if constexpr (MODE == 1) {
     for (int e = tid; e < n * kCoefT; e += BLOCK) s_wp[e] = coef[e];
     for (int e = tid; e < n; e += BLOCK) {
-      s_xy[2 * e] = coef[e * kCoefT];
-      s_xy[2 * e + 1] = coef[e * kCoefT + 1];
+      s_xy[e] = coef[e * kCoefT];
+      s_xy[n + e] = coef[e * kCoefT + 1];
     }
     __syncthreads();
   }
@@ -272,8 +272,8 @@ __global__ void __launch_bounds__(kWave) rollout_tile_kernel(const RolloutArgs a
   if constexpr (MODE == 1) {
     for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
     for (int e = lane; e < n; e += kWave) {
-      s_xy[2 * e] = coef[e * kCoefT];
-      s_xy[2 * e + 1] = coef[e * kCoefT + 1];
+      s_xy[e] = coef[e * kCoefT];
+      s_xy[n + e] = coef[e * kCoefT + 1];
     }
   }
   __syncthreads();
@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArg
   if constexpr (MODE == 1) {
     for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
     for (int e = lane; e < n; e += kWave) {
-      s_xy[2 * e] = coef[e * kCoefT];
-      s_xy[2 * e + 1] = coef[e * kCoefT + 1];
+      s_xy[e] = coef[e * kCoefT];
+      s_xy[n + e] = coef[e * kCoefT + 1];
     }
   }
   __syncthreads();

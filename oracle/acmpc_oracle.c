@@ -173,8 +173,20 @@ void acmpc_oracle_rollout_spatial_batch(const float* x0, const float* coef, cons
   }
 }
 
+/* rint and quadrant without a float -> int conversion (out-of-range conversions differ between platforms):
+ * t = y + 1.5 * 2^23 carries rint(y) in its low mantissa bits for |y| < 2^22 */
+static inline int32_t float_bits(float f) {
+  union {
+    float f;
+    int32_t i;
+  } b;
+  b.f = f;
+  return b.i;
+}
+
 static inline void sincos_spec(float phi, float* sn, float* cs) {
-  const float k = rintf(phi * 0.6366197723675814f);
+  const float t = phi * 0.6366197723675814f + 12582912.0f;
+  const float k = t - 12582912.0f;
   const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
   const float r2 = r * r;
   float ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
@@ -183,7 +195,7 @@ static inline void sincos_spec(float phi, float* sn, float* cs) {
   float pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
   pc = 4.166664568298827e-2f + r2 * pc;
   const float c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
-  const int q = (int)k & 3;
+  const int q = float_bits(t) & 3;
   *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
   *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }

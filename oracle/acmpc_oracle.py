@@ -381,8 +381,9 @@ def _quad(w, a):
 
 
 def _hinge2(lo_minus_x, x_minus_hi, zero):
-    # distance outside [lo, hi]: at most one side of a non-degenerate interval can be violated
-    v = np.maximum(np.maximum(lo_minus_x, x_minus_hi), zero)
+    # distance outside [lo, hi]: at most one side of a non-degenerate interval can be violated.  IEEE maxNum (a NaN
+    # operand is dropped) - C's fmaxf and the GPU's v_max_f32; np.maximum would propagate the NaN instead
+    v = np.fmax(np.fmax(lo_minus_x, x_minus_hi), zero)
     return v * v
 
 
@@ -425,7 +426,7 @@ def rollout_spatial(x0, coef, U, Q, R, QN, u_lo, u_hi, w_bound, dtype=np.float32
         t_n = ((t + c[CS_A31] * ey) + c[CS_B31] * dv) + c[CS_F3]
         ey, ep, t = ey_n, ep_n, t_n
         V = V + _hinge2(c[CS_EYLO] - ey, ey - c[CS_EYHI], zero)
-        tv = np.maximum(tmin - t, zero)
+        tv = np.fmax(tmin - t, zero)
         V = V + tv * tv
     if return_states:
         X[:, n, 0], X[:, n, 1], X[:, n, 2] = ey, ep, t
@@ -448,11 +449,23 @@ TWO_PI_F = 6.28318530717959
 INV_TWO_PI_F = 0.159154943091895
 
 
+ROUND_MAGIC = 12582912.0  # 1.5 * 2^23: adding it to |y| < 2^22 rounds y to the nearest-even integer in the mantissa
+
+
 def sincos_spec(phi, dtype=np.float32):
     """sin/cos with a fixed instruction sequence (bit-identical on CPU and GPU in float32)."""
     T = dtype
     phi = np.asarray(phi, dtype=T)
-    k = np.rint(phi * T(TWO_OVER_PI))
+    if T is np.float32:
+        # round-to-integer and quadrant WITHOUT a float -> int conversion (whose out-of-range result differs between
+        # x86, NumPy and the GPU): t = y + 1.5 * 2^23 holds rint(y) in its low mantissa bits, k = t - 1.5 * 2^23.
+        # Identical to rint / (int & 3) for |phi| < 6.5e6 rad; beyond that still one fixed bit pattern everywhere.
+        t = phi * T(TWO_OVER_PI) + T(ROUND_MAGIC)
+        q = t.view(np.int32) & 3
+        k = t - T(ROUND_MAGIC)
+    else:  # float64 drift reports only
+        k = np.rint(phi * T(TWO_OVER_PI))
+        q = np.where(np.isfinite(k), k, 0.0).astype(np.int64) & 3
     r = (phi - k * T(PIO2_HI)) - k * T(PIO2_LO)
     r2 = r * r
     ps = T(SIN_C[1]) + r2 * T(SIN_C[2])
@@ -461,7 +474,6 @@ def sincos_spec(phi, dtype=np.float32):
     pc = T(COS_C[1]) + r2 * T(COS_C[2])
     pc = T(COS_C[0]) + r2 * pc
     c = (T(1.0) - T(0.5) * r2) + (r2 * r2) * pc
-    q = k.astype(np.int64) & 3
     sin = np.where(q == 0, s, np.where(q == 1, c, np.where(q == 2, -s, -c)))
     cos = np.where(q == 0, c, np.where(q == 1, -s, np.where(q == 2, -c, s)))
     return sin.astype(T), cos.astype(T)

@@ -122,14 +122,20 @@ def test_capacity_and_state_errors():
 
 
 @pytest.mark.parametrize("layout", [LAYOUT_CM, LAYOUT_SM])
-@pytest.mark.parametrize("window", [(2, 5), (1, 2)])
+@pytest.mark.parametrize("window", [(2, 5), (1, 2), (0, 2)])
 def test_mode_t_windowed_nearest_search(layout, window):
     """Mode T with nn_window: bit-identical to the oracle's windowed spec (also where the window is too short to
-    find the global nearest waypoint - the spec, not the outcome, is what must match)."""
+    find the global nearest waypoint - the spec, not the outcome, is what must match).  Windows of 8 and 4 waypoints
+    take the unrolled packed search, 3 the generic loop; candidates whose state overflows or turns NaN must still
+    pick the same waypoints as the `d < best` scan of the oracle."""
     from acmpc_amd import Engine
     H, N, P = 50, 777, 2
     n = H - 1
     problems = [make_problem(orc, "monza", H, N, seed=300 + p) for p in range(P)]
+    problems[0]["U"][5, 3, 0] = np.nan
+    problems[0]["U"][9, 0, 1] = np.inf
+    problems[0]["U"][11, 10, 0] = 3.0e38     # position overflows to inf two steps later
+    problems[1]["U"][7, 20, 0] = -1.0e30
     eng = Engine(**engine_kwargs(problems[0], 1, P, N, n, nn_window=window))
     eng.set_paths(np.stack([p["table"] for p in problems]))
     x0 = np.stack([p["pose0"] for p in problems])

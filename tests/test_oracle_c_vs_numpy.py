@@ -50,6 +50,11 @@ def test_windowed_nearest_search_c_matches_numpy_and_exhaustive(window):
     """Mode T with the search window: C == NumPy bit for bit; and on these inputs (progress < 1 waypoint per step)
     a (2, 5) window finds the same waypoint as the exhaustive scan at every step of every candidate."""
     prob = make_problem(orc, "monza", 50, 400, seed=11)
+    if window != (2, 5):   # overflowing / NaN states: both restatements must go wrong the same way
+        prob["U"][5, 3, 0] = np.nan
+        prob["U"][9, 0, 1] = np.inf
+        prob["U"][11, 10, 0] = 3.0e38
+        prob["U"][13, 20, 0] = -1.0e30
     cfg = prob["cfg"]
     coef = orc.coefficients_temporal(prob["table"], prob["limits"].margin)
     args = (prob["pose0"], coef, prob["U"], cfg["step_cost"], cfg["r_term"], cfg["final_cost"], prob["u_lo"],
@@ -59,6 +64,7 @@ def test_windowed_nearest_search_c_matches_numpy_and_exhaustive(window):
                               nn_window=window)
     cost, viol, states = c_oracle.rollout(1, prob["pose0"], coef, prob["U"], 0, w, return_states=True)
     np.testing.assert_array_equal(cost, want[0])
+    np.testing.assert_array_equal(viol, want[1])
     np.testing.assert_array_equal(states, want[2])
     if window == (2, 5):
         full = orc.rollout_temporal(*args, dtype=np.float32, return_states=True)
