@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace acmpc {
@@ -223,22 +225,36 @@ __device__ __forceinline__ int nearest_in_window(float X, float Y, const float* 
   return lo + jm;
 }
 
+// How a kernel searches: decided once per launch (the weights are wave-uniform), so the step loop itself is
+// branch-free and the scheduler can interleave the searches of the candidates a lane owns.
+constexpr int kSearchExhaustive = 0;
+constexpr int kSearchGeneric = -1;  // any window width, rolled loop; 8 and 4 name the unrolled widths
+
+__device__ __forceinline__ int search_kind(const Weights& w, int n) {
+  if (w.nn_ahead < 0) return kSearchExhaustive;
+  const int W = w.nn_back + w.nn_ahead + 1;
+  return ((W == 8 || W == 4) && n >= W) ? W : kSearchGeneric;
+}
+
+template <int SEARCH>
 __device__ __forceinline__ int temporal_nearest_window(float X, float Y, const float* xy, int n, int j_prev, int back,
                                                        int ahead) {
-  const int W = back + ahead + 1;
+  const int W = (SEARCH > 0) ? SEARCH : back + ahead + 1;
   const int lo = max(min(j_prev - back, n - W), 0);
-  if (W == 8 && n >= 8) return nearest_in_window<8>(X, Y, xy, xy + n, lo);
-  if (W == 4 && n >= 4) return nearest_in_window<4>(X, Y, xy, xy + n, lo);
-  const int hi = min(lo + W, n);
-  float best = __builtin_inff();
-  int j = lo;
-  for (int i = lo; i < hi; ++i) {
-    const float d = dist2<float>(X, Y, xy[i], xy[n + i]);
-    const bool better = d < best;
-    best = better ? d : best;
-    j = better ? i : j;
+  if constexpr (SEARCH > 0) {
+    return nearest_in_window<SEARCH>(X, Y, xy, xy + n, lo);
+  } else {
+    const int hi = min(lo + W, n);
+    float best = __builtin_inff();
+    int j = lo;
+    for (int i = lo; i < hi; ++i) {
+      const float d = dist2<float>(X, Y, xy[i], xy[n + i]);
+      const bool better = d < best;
+      best = better ? d : best;
+      j = better ? i : j;
+    }
+    return j;
   }
-  return j;
 }
 
 // Frenet errors w.r.t. waypoint row(s) g (dynamics.py:23-40), stage cost and bound violations.  g0..g7 hold the
@@ -265,26 +281,33 @@ __device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v
   temporal_cost<float>(s, row, v, k, w);
 }
 
-// `wp` is the waypoint table (kCoefT floats per waypoint) and `xy` its compact (x, y) copy; in the rollout kernels
-// both live in LDS (`xy` planar: all x, then all y).  Returns the nearest index (per element) for the next step's search window.
-__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, const float* xy, int n, float v, float k,
-                                             const Weights& w, int j_prev) {
+// `wp` is the waypoint table (kCoefT floats per waypoint) and `xy` the planar copy of its positions (all x, then
+// all y); in the rollout kernels both live in LDS.  Returns the nearest index (per element) for the next step's
+// search window.
+template <int SEARCH>
+__device__ __forceinline__ int step_temporal_as(StateT& s, const float* wp, const float* xy, int n, float v, float k,
+                                                const Weights& w, int j_prev) {
   temporal_advance<float>(s, v, k, w);
-  const int j = (w.nn_ahead < 0) ? temporal_nearest<float>(s, wp, n)
-                                 : temporal_nearest_window(s.X, s.Y, xy, n, j_prev, w.nn_back, w.nn_ahead);
+  int j;
+  if constexpr (SEARCH == kSearchExhaustive) {
+    j = temporal_nearest<float>(s, wp, n);
+  } else {
+    j = temporal_nearest_window<SEARCH>(s.X, s.Y, xy, n, j_prev, w.nn_back, w.nn_ahead);
+  }
   temporal_cost(s, wp + j * kCoefT, v, k, w);
   return j;
 }
 
-__device__ __forceinline__ i32x2 step_temporal(StateT_<f32x2>& s, const float* wp, const float* xy, int n, f32x2 v,
-                                               f32x2 k, const Weights& w, i32x2 j_prev) {
+template <int SEARCH>
+__device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float* wp, const float* xy, int n, f32x2 v,
+                                                  f32x2 k, const Weights& w, i32x2 j_prev) {
   temporal_advance<f32x2>(s, v, k, w);
   i32x2 j;
-  if (w.nn_ahead < 0) {
+  if constexpr (SEARCH == kSearchExhaustive) {
     j = temporal_nearest<f32x2>(s, wp, n);
   } else {
-    j[0] = temporal_nearest_window(s.X[0], s.Y[0], xy, n, j_prev[0], w.nn_back, w.nn_ahead);
-    j[1] = temporal_nearest_window(s.X[1], s.Y[1], xy, n, j_prev[1], w.nn_back, w.nn_ahead);
+    j[0] = temporal_nearest_window<SEARCH>(s.X[0], s.Y[0], xy, n, j_prev[0], w.nn_back, w.nn_ahead);
+    j[1] = temporal_nearest_window<SEARCH>(s.X[1], s.Y[1], xy, n, j_prev[1], w.nn_back, w.nn_ahead);
   }
   f32x2 g[kCoefT];
   const float* g0 = wp + j[0] * kCoefT;
@@ -295,6 +318,27 @@ __device__ __forceinline__ i32x2 step_temporal(StateT_<f32x2>& s, const float* w
     g[q][1] = g1[q];
   }
   temporal_cost<f32x2>(s, g, v, k, w);
+  return j;
+}
+
+// run `body(tag)` with tag::value = the launch's search kind (one wave-uniform branch for the whole rollout)
+template <typename Body>
+__device__ __forceinline__ void with_search_kind(const Weights& w, int n, Body&& body) {
+  switch (search_kind(w, n)) {
+    case kSearchExhaustive: body(std::integral_constant<int, kSearchExhaustive>{}); break;
+    case 8: body(std::integral_constant<int, 8>{}); break;
+    case 4: body(std::integral_constant<int, 4>{}); break;
+    default: body(std::integral_constant<int, kSearchGeneric>{}); break;
+  }
+}
+
+// per-step dispatch, for the kernels that roll out one trajectory per wave or tile (finalize, sampled, tile)
+__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, const float* xy, int n, float v, float k,
+                                             const Weights& w, int j_prev) {
+  int j = 0;
+  with_search_kind(w, n, [&](auto kind) {
+    j = step_temporal_as<decltype(kind)::value>(s, wp, xy, n, v, k, w, j_prev);
+  });
   return j;
 }
 

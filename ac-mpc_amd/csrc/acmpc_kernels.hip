@@ -163,13 +163,16 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
                            splat<F>(0.0f), splat<F>(0.0f)};
         nearest[g] = I(0);
       }
-      for (int i = 0; i < n; ++i) {
-        float v[CPT], k[CPT];
-        load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
+      with_search_kind(w, n, [&](auto kind) {
+        for (int i = 0; i < n; ++i) {
+          float v[CPT], k[CPT];
+          load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
 #pragma unroll
-        for (int g = 0; g < kGroups; ++g)
-          nearest[g] = step_temporal(st[g], s_wp, s_xy, n, pack(v, g), pack(k, g), w, nearest[g]);
-      }
+          for (int g = 0; g < kGroups; ++g)
+            nearest[g] = step_temporal_as<decltype(kind)::value>(st[g], s_wp, s_xy, n, pack(v, g), pack(k, g), w,
+                                                                 nearest[g]);
+        }
+      });
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
         unpack_to(finish_temporal<F>(st[g], n, w), cost, g);
