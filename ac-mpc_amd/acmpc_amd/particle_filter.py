@@ -4,8 +4,9 @@ states + downsampled track-limit observations in, the reference's `particles` di
 (`track_indices`, `centreline_idx`, `minimum_offset`, `heading_offset`, `observation_error`, `score`).
 
 The data-parallel work - three nearest-point queries per particle against the map (scipy KD-trees in the
-reference), observation placement, error, score, validity - runs in `csrc/acmpc_pf.hip`; the sequential, random
-resampling (localiser.py:412-545) is left to the caller's NumPy code, exactly as in the reference.
+reference), observation placement, error, score, validity - runs in `csrc/acmpc_pf.hip`.  `ParticleFilter` adds
+the sequential, random part round it (resampling, reset, convergence flag: localiser.py:420-570) in NumPy with
+the reference's draw order, so that a run seeded like the reference reproduces it.
 """
 from __future__ import annotations
 
@@ -116,3 +117,87 @@ class ParticleScorer:
                                                 scores.ctypes.data_as(_capi._F32P), states.shape[0],
                                                 est.ctypes.data_as(_capi._F64P), C.byref(md), C.byref(ma)))
         return est, md.value, ma.value
+
+
+class ParticleFilter:
+    """The filter round the scorer: state arrays + the reference's update cycle
+    (`Localiser.step` -> `_score_particles`: advance, score, resample, convergence flag).
+
+    `rng` is anything with NumPy's `normal` / `choice` (default: the `np.random` module = the global stream the
+    reference draws from).  Live particles are the rows of `states` / `scores` (float32, what the reference keeps
+    in its shared arrays for scores > 0)."""
+
+    def __init__(self, config: Dict, track_map: Dict[str, np.ndarray], wheelbase: float = 2.65, rng=np.random,
+                 **scorer_kwargs):
+        self.scorer = ParticleScorer(config, track_map, wheelbase=wheelbase, **scorer_kwargs)
+        self._centre = np.asarray(track_map["centre"], dtype=np.float64)
+        self._rng = rng
+        self._max_n_particles = int(config["n_particles"])
+        self._n_converged_particles = int(config["n_converged_particles"])
+        self._minimum_particles = int(config["thresholds"]["minimum_particles"])
+        noise = config["sampling_noise"]
+        self._sampling_sigma = (float(noise["x"]), float(noise["y"]), float(noise["yaw"]) * np.pi / 180)
+        control = config["control_noise"]
+        self._control_sigma = (float(control["yaw"]) * np.pi / 180, float(control["velocity"]))
+        criteria = config["convergence_criteria"]
+        self._convergence_distance = float(criteria["maximum_distance"])
+        self._convergence_angle = float(criteria["maximum_angle"])     # compared with radians, as the reference does
+        self.is_converged = False
+        self.was_reset = False
+        self.reset()
+
+    def reset(self):
+        """Spread the particles evenly along the centre line, heading along it (localiser.py:468-485)."""
+        idx = np.linspace(0, len(self._centre) - 3, self._max_n_particles).astype(np.int32)
+        step = self._centre[idx + 1] - self._centre[idx]
+        self.states = np.column_stack([self._centre[idx], np.arctan2(step[:, 1], step[:, 0])]).astype(np.float32)
+        scores = np.ones(self._max_n_particles, dtype=np.float32)
+        self.scores = scores / np.sum(scores)
+        self.is_converged = False
+
+    def step(self, tyre_angle: float, velocity: float, dt: float):
+        """Move every particle with its own noisy control (localiser.py:41-77): yaw noise on the tyre angle,
+        |velocity + noise|; the kinematic step itself runs on the GPU."""
+        n = self.states.shape[0]
+        delta = tyre_angle + self._rng.normal(0, self._control_sigma[0], n)
+        speed = np.abs(velocity + self._rng.normal(0, self._control_sigma[1], n))
+        self.states = self.scorer.advance_particles(self.states, delta, speed, dt)
+
+    def resample(self, particles: Dict):
+        """Drop invalid particles, reset if too few are left, otherwise top up from the valid ones in proportion
+        to their score (localiser.py:420-545)."""
+        valid = particles["valid_mask"]
+        states, scores, score = self.states[valid], self.scores[valid], particles["score"][valid]
+        n_valid = states.shape[0]
+        self.was_reset = n_valid < self._minimum_particles
+        if self.was_reset:
+            self.reset()
+            return
+        desired = self._n_converged_particles if self.is_converged else self._max_n_particles
+        n_new = max(0, desired - n_valid)
+        noise = np.array([self._rng.normal(0, sigma, n_new) for sigma in self._sampling_sigma]).T
+        with np.errstate(all="ignore"):
+            weights = score / np.sum(score)
+        if np.isnan(weights).any():
+            weights = np.ones(n_valid) / n_valid
+        picked = self._rng.choice(n_valid, size=n_new, p=weights)
+        self.states = np.concatenate((states, states[picked] + noise), axis=0).astype(np.float32)
+        self.scores = np.concatenate((scores, scores[picked]), axis=0).astype(np.float32)
+
+    def update(self, observations: Dict[str, np.ndarray]) -> Dict:
+        """One `_score_particles` (localiser.py:234-239): downsample, score on the GPU, publish the scores,
+        resample, refresh the convergence flag.  Returns the `particles` dict of the scoring."""
+        particles = self.scorer.update_particles(self.states, self.scorer.downsample_observations(observations))
+        self.scores = particles["score"].astype(np.float32)                        # _update_particle_scores
+        self.resample(particles)
+        self.update_is_converged_flag()
+        return particles
+
+    def update_is_converged_flag(self):
+        _, max_distance, max_angle = self.scorer.estimate_location(self.scores, self.states)
+        self.is_converged = bool(max_distance < self._convergence_distance and max_angle < self._convergence_angle)
+
+    @property
+    def estimated_location(self) -> np.ndarray:
+        return self.scorer.estimate_location(self.scores, self.states)[0]
+

@@ -744,3 +744,39 @@ def pf_convergence(scores: np.ndarray, states: np.ndarray, max_distance: float, 
     dist = np.linalg.norm(states[:, :2] - est[:2], axis=1)
     ang = np.abs(states[:, 2] - est[2])
     return est, bool(np.max(dist) < max_distance and np.max(ang) < max_angle)
+
+
+def pf_reset(centre: np.ndarray, n_particles: int):
+    """_reset_filter (localiser.py:468-485): particles spread evenly along the centre line, heading along it,
+    uniform scores 1/n (float32, as stored in the shared arrays)."""
+    idx = np.linspace(0, len(centre) - 3, n_particles).astype(np.int32)
+    yaw = np.arctan2(centre[idx + 1, 1] - centre[idx, 1], centre[idx + 1, 0] - centre[idx, 0])
+    states = np.vstack((centre[idx, 0], centre[idx, 1], yaw)).T.astype(np.float32)
+    scores = np.ones(n_particles, dtype=np.float32)
+    scores /= np.sum(scores)
+    return states, scores
+
+
+def pf_resample(states: np.ndarray, scores: np.ndarray, score: np.ndarray, valid: np.ndarray, n_desired: int,
+                minimum_particles: int, noise_sigma, rng=np.random):
+    """_resample_particles (localiser.py:420-545) on the live particles: keep the valid ones in order; with fewer
+    than `minimum_particles` left return None (the caller resets); otherwise top up to `n_desired` with copies of
+    valid particles drawn in proportion to `score` (np.random.choice: inverse CDF on uniform draws) plus Gaussian
+    noise.  Draw order as in the reference: x noise, y noise, yaw noise, then the indices.
+    `states`/`scores` are the float32 published arrays, `score` the float64 scores of this update."""
+    kept_states, kept_scores, kept_score = states[valid], scores[valid], score[valid]
+    n_valid = kept_states.shape[0]
+    if n_valid < minimum_particles:
+        return None
+    n_new = max(0, n_desired - n_valid)
+    noise = np.array([rng.normal(0, noise_sigma[0], n_new), rng.normal(0, noise_sigma[1], n_new),
+                      rng.normal(0, noise_sigma[2], n_new)]).T
+    with np.errstate(all="ignore"):
+        weights = kept_score / np.sum(kept_score)
+    if any(np.isnan(weights)):
+        weights = np.ones(kept_score.shape) / kept_score.shape[0]
+    idx = rng.choice(n_valid, size=n_new, p=weights)
+    new_states = np.concatenate((kept_states, kept_states[idx] + noise), axis=0).astype(np.float32)
+    new_scores = np.concatenate((kept_scores, kept_scores[idx]), axis=0).astype(np.float32)
+    return new_states, new_scores
+

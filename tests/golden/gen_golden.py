@@ -337,6 +337,40 @@ def main():
     out["map/points"] = pts
     out["map/deduplicated"] = ref_load.remove_near_duplicate_points(pts)
 
+    # ---- G14: resampling, reset and convergence flag of the localiser (localiser.py:420-570) -------------------------
+    # continues from the scored particles of G12; the reference draws from NumPy's global stream, seeded here
+    proc._threshold_n_particles = 20                                              # configs/monza.yaml:56-60
+    proc._n_converged_particles = n_particles
+    proc._sampling_noise_x, proc._sampling_noise_y = 1.1, 1.1                       # configs/monza.yaml:49-52
+    proc._sampling_noise_yaw = 3.0 * np.pi / 180
+    proc._convergence_distance, proc._convergence_angle = 50, 90                    # configs/monza.yaml:64-66
+    proc._is_converged = mp.Value("i", False)
+    proc._is_previously_converged = False
+    np.random.seed(20240917)
+    proc._resample_particles(particles)
+    out["pf/resample_seed"] = np.array(20240917)
+    out["pf/resampled_states"] = proc.particle_states
+    out["pf/resampled_scores"] = proc.particle_scores
+    proc._update_is_converged_flag()
+    out["pf/resampled_is_converged"] = np.array(bool(proc.is_converged))
+    # a second round from a tight cluster: converges
+    tight = (pose + rng.normal(0, [1.0, 1.0, 0.05], (n_particles, 3))).astype(np.float32)
+    proc.particle_scores = np.ones(n_particles, dtype=np.float32)
+    proc.particle_states = tight
+    out["pf/tight_states"] = tight
+    particles = proc._update_particles([o.copy() for o in downsampled])
+    out["pf/tight_score"] = particles["score"]
+    np.random.seed(7)
+    proc._resample_particles(particles)
+    proc._update_is_converged_flag()
+    out["pf/tight_resampled_states"], out["pf/tight_resampled_scores"] = proc.particle_states, proc.particle_scores
+    out["pf/tight_is_converged"] = np.array(bool(proc.is_converged))
+    # too few valid particles -> the filter is reset onto the centre line (localiser.py:468-485)
+    proc._threshold_n_particles = n_particles + 1
+    proc._resample_particles({k: v.copy() for k, v in particles.items()})
+    out["pf/reset_states"], out["pf/reset_scores"] = proc.particle_states, proc.particle_scores
+    out["pf/reset_is_converged"] = np.array(bool(proc.is_converged))
+
     path = os.path.join(OUT_DIR, "reference_ingredients.npz")
     np.savez_compressed(path, **out)
     print("wrote %s: %d arrays, %.1f kB" % (path, len(out), os.path.getsize(path) / 1e3))

@@ -82,3 +82,47 @@ def test_capacity_errors(golden):
     with pytest.raises(EngineError) as e:
         scorer.update_particles(golden["pf/states"], [golden["pf/obs_left_downsampled"], golden["pf/obs_right_downsampled"]])
     assert e.value.code == -4
+
+
+def test_filter_cycle_tracks_a_moving_car(golden):
+    """`ParticleFilter` end to end (advance on the GPU with noisy controls, score on the GPU, resample, convergence
+    flag - localiser.py:41-77,234-239): from a cluster round the true pose the weighted-mean estimate must follow a
+    car driving along the centre line.  Functional, not parity: the random part is pinned on the CPU
+    (tests/test_host_mirror.py) and the scoring above."""
+    from acmpc_amd.particle_filter import ParticleFilter
+    g = golden
+    centre, left, right = g["pf/centre"], g["pf/left"], g["pf/right"]
+    M = len(centre)
+    cfg = dict(LOCALISATION, n_particles=300, n_converged_particles=300, sampling_noise=dict(x=1.1, y=1.1, yaw=3.0),
+               control_noise=dict(velocity=0.25, yaw=2.0), convergence_criteria=dict(maximum_distance=50, maximum_angle=90))
+    rng = np.random.default_rng(11)
+    pf = ParticleFilter(cfg, dict(centre=centre, left=left, right=right), wheelbase=2.65, rng=rng)
+    tangent = np.roll(centre, -1, axis=0) - np.roll(centre, 1, axis=0)
+    heading = np.unwrap(np.arctan2(tangent[:, 1], tangent[:, 0]))
+    spacing = float(np.mean(np.linalg.norm(np.diff(centre, axis=0), axis=1)))
+    idx, step, dt = 700, 3, 0.05
+    speed = step * spacing / dt                                             # the truth moves whole map points
+    pose = np.array([centre[idx, 0], centre[idx, 1], heading[idx]])
+    pf.states = (pose + rng.normal(0, [1.0, 1.0, 0.05], (300, 3))).astype(np.float32)
+    pf.scores = np.full(300, 1.0 / 300, dtype=np.float32)
+
+    def observe(track, count, at, yaw):
+        pts = track[(at + np.arange(count)) % M] - centre[at]
+        a = np.pi / 2 - yaw
+        rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        return (pts @ rot.T + rng.normal(0, 0.15, (count, 2))).astype(np.float32)
+
+    errors = []
+    for tick in range(40):
+        yaw_rate = (heading[(idx + step) % M] - heading[idx]) / dt
+        tyre_angle = float(np.arctan(yaw_rate * 2.65 / speed))               # kinematic bicycle, localiser.py:94
+        pf.step(tyre_angle, speed, dt)
+        idx = (idx + step) % M
+        particles = pf.update({"left": observe(left, 230, idx, heading[idx]),
+                               "right": observe(right, 210, idx, heading[idx])})
+        assert particles["score"].shape == (300,) and pf.states.shape == (300, 3) and pf.states.dtype == np.float32
+        assert not pf.was_reset
+        errors.append(np.linalg.norm(pf.estimated_location[:2] - centre[idx]))
+    assert pf.is_converged
+    assert max(errors) < 3.0 and np.mean(errors[20:]) < 2.0, (max(errors), np.mean(errors[20:]))
+

@@ -217,3 +217,37 @@ def test_warm_start_shift_follows_the_elapsed_time():
     np.testing.assert_array_equal(solver._incumbent, plan)
     solver.shift_warm_start(-1.0, cum_time)
     np.testing.assert_array_equal(solver._incumbent, plan)
+
+
+PF_CONFIG = dict(n_particles=300, n_converged_particles=300,                   # configs/monza.yaml:43-66, 300 particles
+                 sampling_noise=dict(x=1.1, y=1.1, yaw=3.0), control_noise=dict(velocity=0.25, yaw=2.0),
+                 thresholds=dict(offset=10, rotation=90, minimum_particles=20, track_limit=20.0),
+                 score_distribution=dict(mean=0, sigma=10),
+                 convergence_criteria=dict(maximum_distance=50, maximum_angle=90))
+
+
+def test_particle_filter_resampling_and_reset_match_the_reference(golden):
+    """`ParticleFilter.resample` / `.reset` (host side, no device work) against the reference's
+    `_resample_particles` / `_reset_filter` run under the same NumPy seed (localiser.py:420-545)."""
+    import copy
+    from acmpc_amd.particle_filter import ParticleFilter
+    g = golden
+    pf = ParticleFilter(PF_CONFIG, dict(centre=g["pf/centre"], left=g["pf/left"], right=g["pf/right"]))
+    np.testing.assert_array_equal(pf.states, g["pf/reset_states"])          # constructed = reset
+    np.testing.assert_array_equal(pf.scores, g["pf/reset_scores"])
+    pf.states, pf.scores = g["pf/states"].copy(), g["pf/published_scores"].copy()
+    np.random.seed(int(g["pf/resample_seed"]))
+    pf.resample({"score": g["pf/score"], "valid_mask": g["pf/valid_mask"]})
+    assert not pf.was_reset
+    np.testing.assert_array_equal(pf.states, g["pf/resampled_states"])
+    np.testing.assert_array_equal(pf.scores, g["pf/resampled_scores"])
+    # own generator instead of the global stream: same law, different numbers, still the valid ones first
+    cfg = copy.deepcopy(PF_CONFIG)
+    cfg["thresholds"]["minimum_particles"] = 301
+    pf2 = ParticleFilter(cfg, dict(centre=g["pf/centre"], left=g["pf/left"], right=g["pf/right"]),
+                         rng=np.random.default_rng(0))
+    pf2.states, pf2.scores = g["pf/states"].copy(), g["pf/published_scores"].copy()
+    pf2.resample({"score": g["pf/score"], "valid_mask": g["pf/valid_mask"]})
+    assert pf2.was_reset and not pf2.is_converged
+    np.testing.assert_array_equal(pf2.states, g["pf/reset_states"])
+

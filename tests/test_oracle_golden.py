@@ -168,3 +168,32 @@ def test_particle_scoring(golden):
     np.testing.assert_allclose(out["score"], g["pf/score"], rtol=1e-6)
     np.testing.assert_array_equal(out["valid"], g["pf/valid_mask"])
     np.testing.assert_allclose(out["score"].astype(np.float32), g["pf/published_scores"], rtol=1e-6)
+
+
+def test_particle_resampling_reset_and_convergence(golden):
+    # localiser.py:420-570, continued from the scored particles above; same global-stream seeds as gen_golden.py
+    g = golden
+    sigma = (1.1, 1.1, 3.0 * np.pi / 180)
+    np.random.seed(int(g["pf/resample_seed"]))
+    states, scores = orc.pf_resample(g["pf/states"], g["pf/published_scores"], g["pf/score"], g["pf/valid_mask"],
+                                     300, 20, sigma)
+    np.testing.assert_array_equal(states, g["pf/resampled_states"])
+    np.testing.assert_array_equal(scores, g["pf/resampled_scores"])
+    assert orc.pf_convergence(scores, states, 50, 90)[1] == bool(g["pf/resampled_is_converged"])
+    # a tight cluster converges
+    tight = orc.pf_score_particles(g["pf/tight_states"], g["pf/centre"], g["pf/left"], g["pf/right"],
+                                   g["pf/obs_left_downsampled"], g["pf/obs_right_downsampled"], 0, 10,
+                                   dict(rotation=np.pi / 2, offset=10, track_limit=20.0))
+    np.testing.assert_allclose(tight["score"], g["pf/tight_score"], rtol=1e-6)
+    np.random.seed(7)
+    states, scores = orc.pf_resample(g["pf/tight_states"], g["pf/tight_score"].astype(np.float32), g["pf/tight_score"],
+                                     tight["valid"], 300, 20, sigma)
+    np.testing.assert_array_equal(states, g["pf/tight_resampled_states"])
+    np.testing.assert_array_equal(scores, g["pf/tight_resampled_scores"])
+    assert orc.pf_convergence(scores, states, 50, 90)[1] == bool(g["pf/tight_is_converged"]) is True
+    # too few valid particles: None = "reset", and the reset itself
+    assert orc.pf_resample(states, scores, g["pf/tight_score"], tight["valid"], 300, 301, sigma) is None
+    states, scores = orc.pf_reset(g["pf/centre"], 300)
+    np.testing.assert_array_equal(states, g["pf/reset_states"])
+    np.testing.assert_array_equal(scores, g["pf/reset_scores"])
+
