@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
 // the winner's controls are re-drawn by finalize_kernel in regenerate mode.
 template <int MODE>
 __global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArgs a, const SampleArgs smp) {
-  extern __shared__ __attribute__((aligned(16))) float s_fused[];  // [n] weights | [n][2] centre | mode T tables
+  extern __shared__ __attribute__((aligned(16))) float s_fused[];  // mode T tables only
   const int p = blockIdx.y;
   const int lane = threadIdx.x;
   const int c = blockIdx.x * kWave + lane;
@@ -385,21 +385,20 @@ __global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArg
   constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
   const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
-  float* s_w0 = s_fused;
-  float* s_centre = s_fused + ((n + 3) & ~3);
-  float* s_wp = s_centre + 2 * n;
+  // centre, reference controls and knot weights sit at wave-uniform addresses: scalar loads, operands in SGPRs
+  const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
+  const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : centre;
+  const float* __restrict__ knot_weight = sp.segments;
+  float* s_wp = s_fused;
   float* s_xy = s_wp + n * kCoefT;
-  const float* __restrict__ block_centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
-  for (int e = lane; e < n; e += kWave) s_w0[e] = sp.segments[2 * e + 1];
-  for (int e = lane; e < 2 * n; e += kWave) s_centre[e] = block_centre[e];
   if constexpr (MODE == 1) {
     for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
     for (int e = lane; e < n; e += kWave) {
       s_xy[e] = coef[e * kCoefT];
       s_xy[n + e] = coef[e * kCoefT + 1];
     }
+    __syncthreads();
   }
-  __syncthreads();
 
   const bool active = c < a.N;
   float cost = __builtin_inff();
@@ -410,17 +409,20 @@ __global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArg
     draw_normals(sp, gidx, static_cast<uint32_t>(p), z);
     const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
-    const float* __restrict__ ref = smp.u_ref + static_cast<size_t>(p) * n * 2;
     StateS ss{x0[0], x0[1], x0[2], 0.0f, 0.0f};
     StateT ts{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
     int nearest = 0;
 #pragma unroll
     for (int knot = 0; knot < kKnots - 1; ++knot) {
+#pragma unroll 4
       for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
         float v, k;
-        const float cv = use_ref ? ref[2 * i] : s_centre[2 * i];
-        const float ck = use_ref ? ref[2 * i + 1] : s_centre[2 * i + 1];
-        blend_control(sp, amp, s_w0[i], cv, ck, z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1], v, k);
+        const float centre_v = centre[2 * i], centre_k = centre[2 * i + 1];  // both loaded (scalar), then selected:
+        const float ref_v = ref[2 * i], ref_k = ref[2 * i + 1];              // a select of ADDRESSES would go flat
+        const float cv = use_ref ? ref_v : centre_v;
+        const float ck = use_ref ? ref_k : centre_k;
+        blend_control(sp, amp, knot_weight[2 * i + 1], cv, ck, z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1],
+                      v, k);
         if constexpr (MODE == 0) {
           step_spatial<float>(ss, coef + i * kCoefS, v, k, w);
         } else {
@@ -948,8 +950,7 @@ hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample, hipStream_t s) {
   const int n = rollout.n;
   const dim3 grid((rollout.N + kWave - 1) / kWave, rollout.P);
-  const size_t lds = (((static_cast<size_t>(n) + 3) & ~static_cast<size_t>(3)) + 2 * n +
-                      (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 2) : 0)) * sizeof(float);
+  const size_t lds = (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 2) : 0) * sizeof(float);
   if (mode == 0) {
     hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample);
   } else if (mode == 1) {
