@@ -100,6 +100,7 @@ SIGNATURES = {
     "acmpc_finalize_sampled_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                                 C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
                                                 C.c_uint32, C.c_void_p, C.c_void_p]),
+    "acmpc_reduce_across_ranks": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "acmpc_optimize": (C.c_int, [_CTX, _F32P, _F32P, _F32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F64P,
                                  C.c_double, C.c_uint64, _F32P]),
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -312,6 +313,10 @@ class Engine:
                         index_offset: int, d_records: int, stream: int = 0):
         self._check(self._lib.acmpc_finalize_device(self._ctx, d_keys or None, d_x0, d_U, P, N, n, layout, index_offset,
                                                     d_records, stream or None))
+
+    def reduce_across_ranks(self, rccl_comm: int, d_keys: int, P: int, stream: int = 0):
+        """In-place all-reduce(MIN) of P packed keys over an `ncclComm_t` the caller owns (RCCL resolved at run time)."""
+        self._check(self._lib.acmpc_reduce_across_ranks(self._ctx, rccl_comm, d_keys, P, stream or None))
 
     def softmin_device(self, d_costs: int, d_keys: int, d_U: int, P: int, N: int, n: int, layout: int, d_mean: int,
                        d_weight_sum: int = 0, stream: int = 0):

@@ -1,6 +1,8 @@
 // C ABI of the rollout-and-cost engine (include/acmpc.h): handle, host-side table preparation, lazy device
 // bring-up, and the launch sequences.  No CPU fallback exists: every compute entry point needs the GPU.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and enums only: RCCL is resolved at run time, not linked
 
 #include <cmath>
 #include <cstdio>
@@ -788,6 +790,54 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   ACMPC_HIP(c, hipGraphLaunch(c->opt_graph, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
   std::memcpy(records, c->h_opt_records, rec_bytes);
+  return ACMPC_OK;
+}
+
+namespace {
+
+using AllReduceFn = ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+using ErrorStringFn = const char* (*)(ncclResult_t);
+
+struct Rccl {
+  AllReduceFn all_reduce = nullptr;
+  ErrorStringFn error_string = nullptr;
+};
+
+// the RCCL that is already in the process owns the caller's communicator; only without one open the system's
+const Rccl& rccl() {
+  static const Rccl api = [] {
+    Rccl r;
+    void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    void* handle = nullptr;
+    if (sym == nullptr) {
+      const char* path = std::getenv("ACMPC_RCCL_LIBRARY");
+      handle = dlopen(path != nullptr ? path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+      if (handle == nullptr && path == nullptr) handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+      if (handle != nullptr) sym = dlsym(handle, "ncclAllReduce");
+    }
+    r.all_reduce = reinterpret_cast<AllReduceFn>(sym);
+    void* err = (handle != nullptr) ? dlsym(handle, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+    r.error_string = reinterpret_cast<ErrorStringFn>(err);
+    return r;
+  }();
+  return api;
+}
+
+}  // namespace
+
+int acmpc_reduce_across_ranks(acmpc_ctx* c, void* rccl_comm, int64_t* d_keys, int32_t P, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (rccl_comm == nullptr || d_keys == nullptr) return fail(c, ACMPC_EINVAL, "null communicator or keys");
+  if (P < 1 || P > c->prm.max_problems) return fail(c, ACMPC_ECAPACITY, "P exceeds the handle's capacity");
+  const Rccl& api = rccl();
+  if (api.all_reduce == nullptr) return fail(c, ACMPC_ESTATE, "no RCCL in the process and librccl.so.1 not loadable");
+  const ncclResult_t rc = api.all_reduce(d_keys, d_keys, static_cast<size_t>(P), ncclInt64, ncclMin,
+                                         static_cast<ncclComm_t>(rccl_comm), static_cast<hipStream_t>(stream));
+  if (rc != ncclSuccess) {
+    std::string msg = "ncclAllReduce: ";
+    msg += (api.error_string != nullptr) ? api.error_string(rc) : "error";
+    return fail(c, ACMPC_EHIP, msg.c_str());
+  }
   return ACMPC_OK;
 }
 

@@ -186,6 +186,14 @@ int acmpc_finalize_sampled_device(acmpc_ctx* ctx, const int64_t* d_keys, const f
                                   double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round,
                                   float* d_records, void* stream);
 
+/* The one collective of the multi-GPU step, for hosts that drive RCCL themselves rather than through
+ * torch.distributed: in-place all-reduce(MIN) of the P packed keys over `rccl_comm` (an `ncclComm_t` the host
+ * created, one rank per GPU), enqueued on `stream`.  Call between acmpc_rollout_device and
+ * acmpc_finalize_sampled_device / acmpc_finalize_device.  RCCL is resolved at the first call: the copy already loaded
+ * in the process if there is one (the one that owns `rccl_comm`), else `librccl.so.1` (or $ACMPC_RCCL_LIBRARY);
+ * the library itself does not link RCCL.  ACMPC_ESTATE when no RCCL can be found, ACMPC_EHIP when RCCL fails. */
+int acmpc_reduce_across_ranks(acmpc_ctx* ctx, void* rccl_comm, int64_t* d_keys, int32_t P, void* stream);
+
 /* Replaces: ControlSolver.solve (control.py:15-24) end to end on the device - `rounds` rounds of
  * sample -> rollout + cost -> argmin, each round sampling round the previous winner with the spread shrunk by
  * `shrink`, one host round trip in total (x0, centre, u_ref up; the final records down).  Host pointers:

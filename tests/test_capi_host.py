@@ -98,6 +98,9 @@ def test_errors_without_device_or_tables():
         eng.set_paths(np.zeros((2, 7, 19)))
     assert e.value.code == -4
     eng.set_paths(prob["table"])
+    with pytest.raises(EngineError) as e:
+        eng.reduce_across_ranks(0, 0, 1)         # no communicator, no keys: rejected before RCCL is looked up
+    assert e.value.code == -1
     if not torch.cuda.is_available():
         with pytest.raises(EngineError) as e:
             eng.solve(prob["x0"][None], prob["U"][None])

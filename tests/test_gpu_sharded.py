@@ -405,3 +405,50 @@ def test_sharded_optimizer_two_shards_equal_one():
     final = halves[0].shard.records.clone()
     final[:, _capi.REC_NFEASIBLE] = rec_whole[:, _capi.REC_NFEASIBLE]
     assert torch.equal(final, rec_whole)
+
+
+def test_reduce_across_ranks_with_a_caller_owned_rccl_communicator():
+    """acmpc_reduce_across_ranks: the C-ABI form of the step's one collective, for hosts that hold an `ncclComm_t`
+    themselves.  One rank is all a single GPU allows: the communicator is created straight on RCCL's C API, the keys
+    of a rollout go through ncclAllReduce(MIN, int64) inside the library and must come back unchanged, and the
+    finalize that follows must equal the plain solve."""
+    import ctypes as C
+    import torch
+    from acmpc_amd import Engine, EngineError
+    P, H, N = 3, 50, 1024
+    n = H - 1
+    problems = [make_problem(orc, "spa", H, N, seed=880 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
+    eng.set_paths(np.stack([p["table"] for p in problems]))
+    x0 = torch.tensor(np.stack([p["x0"] for p in problems]), device=dev)
+    U = torch.tensor(np.ascontiguousarray(np.stack([p["U"] for p in problems]).transpose(0, 2, 3, 1)), device=dev)
+    want = eng.solve(x0.cpu().numpy(), U.cpu().numpy(), layout=1)
+
+    rccl = C.CDLL("librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        keys = torch.empty(P, dtype=torch.int64, device=dev)
+        rec = torch.empty(P, want["records"].shape[1], device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, 0, keys.data_ptr(), s)
+        before = keys.clone()
+        eng.reduce_across_ranks(comm.value, keys.data_ptr(), P, s)
+        eng.finalize_device(keys.data_ptr(), x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, rec.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert torch.equal(keys, before)
+        np.testing.assert_array_equal(rec.cpu().numpy(), want["records"])
+        with pytest.raises(EngineError) as e:
+            eng.reduce_across_ranks(0, keys.data_ptr(), P, s)
+        assert e.value.code == -1
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
