@@ -56,6 +56,7 @@ struct acmpc_ctx {
   float* d_costs = nullptr;
   float* d_records = nullptr;
   int64_t* d_keys = nullptr;
+  int* d_tickets = nullptr;  // [max_problems] last-workgroup counters of the fused finalize; zero between launches
   int64_t* h_keys = nullptr;  // pinned
 
   // acmpc_optimize as a hipGraph: the whole sample -> rollout -> finalize chain of `rounds` rounds plus the
@@ -298,6 +299,9 @@ int ensure_staging(acmpc_ctx* c) {
   ACMPC_HIP(c, hipMalloc(&c->d_records,
                          static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float)));
   ACMPC_HIP(c, hipMalloc(&c->d_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
+  ACMPC_HIP(c, hipMalloc(&c->d_tickets, static_cast<size_t>(p.max_problems) * sizeof(int)));
+  ACMPC_HIP(c, hipMemset(c->d_tickets, 0, static_cast<size_t>(p.max_problems) * sizeof(int)));
+  ACMPC_HIP(c, hipStreamSynchronize(nullptr));  // the handle's own stream does not order against the null stream
   ACMPC_HIP(c, hipHostMalloc(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t), hipHostMallocDefault));
   c->staging_ready = true;
   return ACMPC_OK;
@@ -381,6 +385,7 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_costs);
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_keys);
+    (void)hipFree(c->d_tickets);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
     if (c->opt_graph != nullptr) (void)hipGraphExecDestroy(c->opt_graph);
     if (c->h_opt != nullptr) (void)hipHostFree(c->h_opt);
@@ -591,9 +596,13 @@ struct OptInputs {
   const float* coef;
 };
 
+// `final_records`: where the LAST round's records go when the fused finalize writes them (device memory, or pinned
+// host memory - then the winner lands in the caller's staging buffer without a copy node); nullptr = c->d_records
 int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int rounds, double sigma_v, double sigma_k,
-                   double shrink, uint64_t seed, const uint32_t* d_seed, hipStream_t s, bool fused) {
+                   double shrink, uint64_t seed, const uint32_t* d_seed, hipStream_t s, bool fused,
+                   float* final_records = nullptr) {
   const bool has_uref = in.uref != nullptr;
+  const bool fused_finalize = std::getenv("ACMPC_NO_FUSED_FINALIZE") == nullptr;
   const int layout = ACMPC_LAYOUT_STEP_MAJOR;
   const int rec_floats = acmpc_record_floats(n);
   double scale = 1.0;
@@ -659,13 +668,22 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     sa.n = n;
     sa.spec = make_spec(c, sigma_v * scale, sigma_k * scale, seed, static_cast<uint32_t>(r));
     sa.spec.seed_ptr = d_seed;
-    ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, s));
-    Regenerate regen{d_c, stride, d_ref, sa.spec};
     // NB: the finalize of round r reads its centre from the records it is about to overwrite; it copies the
     // controls it needs into registers/LDS before lane 0..63 write the new record, and one wave owns one record
-    rc = finalize(c, nullptr, nullptr, in.x0, nullptr, P, N, n, layout, 0, c->d_records, (N + 63) / 64, s, &regen,
-                  in.coef);
-    if (rc != ACMPC_OK) return rc;
+    if (fused_finalize) {
+      // one launch per round: the last workgroup of each problem also reduces the partial keys and writes the
+      // record; rounds before the last only need the winner's controls (the next centre), not its re-roll
+      const bool last = r + 1 == rounds;
+      const acmpc::FusedFinalize ff{c->d_tickets, (last && final_records != nullptr) ? final_records : c->d_records,
+                                    !last};
+      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, ff, s));
+    } else {
+      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, acmpc::FusedFinalize{nullptr, nullptr, false}, s));
+      Regenerate regen{d_c, stride, d_ref, sa.spec};
+      rc = finalize(c, nullptr, nullptr, in.x0, nullptr, P, N, n, layout, 0, c->d_records, (N + 63) / 64, s, &regen,
+                    in.coef);
+      if (rc != ACMPC_OK) return rc;
+    }
   }
   return ACMPC_OK;
 }
@@ -761,10 +779,14 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
       in = OptInputs{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef};
     }
     int rc_rounds = ACMPC_OK;
+    // with the fused finalize the last round writes the winners straight into the pinned host buffer (posted
+    // writes over the host link, visible once the stream has drained): no device-to-host copy node
+    const bool direct = fused && std::getenv("ACMPC_NO_FUSED_FINALIZE") == nullptr;
     if (e == hipSuccess)
       rc_rounds = enqueue_rounds(c, in, P, N, n, rounds, sigma[0], sigma[1], shrink, 0,
-                                 reinterpret_cast<const uint32_t*>(c->d_opt + off_seed), s, fused);
-    if (e == hipSuccess && rc_rounds == ACMPC_OK)
+                                 reinterpret_cast<const uint32_t*>(c->d_opt + off_seed), s, fused,
+                                 direct ? c->h_opt_records : nullptr);
+    if (e == hipSuccess && rc_rounds == ACMPC_OK && !direct)
       e = hipMemcpyAsync(c->h_opt_records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s);
     const hipError_t e_end = hipStreamEndCapture(s, &graph);
     if (rc_rounds != ACMPC_OK) {

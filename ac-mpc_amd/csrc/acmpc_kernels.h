@@ -31,6 +31,9 @@ struct FinalizeArgs {
   // regenerate == true: the winner's controls are re-drawn from its global index (counter-based sampler) instead
   // of being loaded from U, so EVERY rank can write the full record after one all-reduce(MIN) of the keys
   bool regenerate;
+  // controls_only == true: write header + u block only (cost taken from the key, violation 0, no re-roll, no x
+  // block) - what the next round of an optimisation needs from the previous one
+  bool controls_only;
   const float* centre;
   const float* u_ref;
   int centre_stride;
@@ -83,9 +86,19 @@ hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const 
                           hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s);
-// sample + rollout + cost fused: candidates are drawn inside the rollout kernel and never touch memory (the
-// closed-loop solve, where a round is three ~5 us launches of latency-bound work: one launch fewer per round)
-hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample, hipStream_t s);
+// Optional tail of the fused launch: the workgroup that finishes a problem LAST (a ticket counter per problem)
+// also runs the finalize for it, in the same launch - argmin over the partial keys, winner re-drawn from its index,
+// record written.  `tickets` [P] must be zero before the launch and is left zero by it.
+struct FusedFinalize {
+  int* tickets;        // nullptr: no fused finalize
+  float* records;      // [P][record_floats]
+  bool controls_only;  // see FinalizeArgs
+};
+
+// sample + rollout + cost (+ finalize) fused: candidates are drawn inside the rollout kernel and never touch memory
+// (the closed-loop solve, where every launch is ~10 us of latency-bound work)
+hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
+                                  const FusedFinalize& fused, hipStream_t s);
 int softmin_chunks(int N);
 hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s);
 

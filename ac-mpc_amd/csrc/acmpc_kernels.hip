@@ -374,8 +374,7 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
 // consumed step by step without ever being written to memory.  Output: the per-workgroup partial keys, as usual;
 // the winner's controls are re-drawn by finalize_kernel in regenerate mode.
 template <int MODE>
-__global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArgs a, const SampleArgs smp) {
-  extern __shared__ __attribute__((aligned(16))) float s_fused[];  // mode T tables only
+__device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const SampleArgs& smp, float* s_fused) {
   const int p = blockIdx.y;
   const int lane = threadIdx.x;
   const int c = blockIdx.x * kWave + lane;
@@ -475,10 +474,21 @@ __device__ __forceinline__ float bcast(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+__device__ __forceinline__ float key_cost(int64_t key) {
+  const int32_t hi = static_cast<int32_t>(key >> 32);
+  union {
+    int32_t i;
+    float f;
+  } b;
+  b.i = (hi >= 0) ? hi : (hi ^ 0x7fffffff);
+  return b.f;
+}
+
+// `s_rec`: LDS for the record image [4 + 2n + 3(n+1)] and, in mode T, the waypoint table behind it.  Called by one
+// whole wave (the only wave of its workgroup).  The partial keys are read with agent-scope atomic loads: when the
+// caller is the last workgroup of a fused rollout (below) they were written by other workgroups of the SAME launch.
 template <int MODE, int LAYOUT>
-__global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float s_rec[];  // [4 + 2n + 3(n+1)] record image
-  const int p = blockIdx.x;
+__device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const int p, float* s_rec) {
   const int lane = threadIdx.x;
   const int n = a.n;
 
@@ -486,8 +496,8 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   int64_t key = kKeyMax;
   for (int b = lane; b < a.blocks_per_problem; b += kWave) {
     const size_t slot = static_cast<size_t>(p) * a.blocks_per_problem + b;
-    nfeas += a.partial_feas[slot];
-    const int64_t kb = a.partial_keys[slot];
+    nfeas += __hip_atomic_load(&a.partial_feas[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t kb = __hip_atomic_load(&a.partial_keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     key = (kb < key) ? kb : key;
   }
   nfeas = wave_sum_int(nfeas);
@@ -533,6 +543,26 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
       k = kk[0];
     }
   };
+
+  if (a.controls_only) {
+    // between the rounds of an optimisation only the winner's controls are needed (the next round's centre):
+    // header = [cost from the key, 0, n_feasible, 1], u block, no re-roll
+    for (int step = lane; step < n; step += kWave) {
+      float v, k;
+      winner_control(step, v, k);
+      su[2 * step] = v;
+      su[2 * step + 1] = k;
+    }
+    if (lane == 0) {
+      s_rec[0] = key_cost(key);
+      s_rec[1] = 0.0f;
+      s_rec[2] = static_cast<float>(nfeas);
+      s_rec[3] = 1.0f;
+    }
+    __syncthreads();
+    for (int e = lane; e < 4 + 2 * n; e += kWave) rec[e] = s_rec[e];
+    return;
+  }
 
   if constexpr (MODE == 0) {
     // Re-roll split by dependence: only the 9-operation state recurrence is sequential (run by the whole wave in
@@ -679,19 +709,53 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   for (int e = lane; e < rec_floats; e += kWave) rec[e] = s_rec[e];
 }
 
+template <int MODE, int LAYOUT>
+__global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_finalize[];
+  finalize_problem<MODE, LAYOUT>(a, blockIdx.x, s_finalize);
+}
+
+// LDS: [rollout part: mode T tables] [finalize part: record image (+ mode T table)]
+template <int MODE>
+__global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArgs a, const SampleArgs smp,
+                                                                const FusedFinalize fused, const int rollout_lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float s_fused[];
+  rollout_sampled_body<MODE>(a, smp, s_fused);
+  if (fused.tickets == nullptr) return;
+  // Last-workgroup-done: publish this workgroup's partials device-wide, take a ticket; whoever draws the last
+  // ticket of its problem knows every other workgroup's partials are visible (each fenced before its increment).
+  const int p = blockIdx.y;
+  __threadfence();
+  int ticket = 0;
+  if (threadIdx.x == 0) ticket = atomicAdd(&fused.tickets[p], 1);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != static_cast<int>(gridDim.x) - 1) return;
+  __threadfence();
+  if (threadIdx.x == 0) fused.tickets[p] = 0;  // the launch leaves the counters as it found them
+  FinalizeArgs f{};
+  f.x0 = a.x0;
+  f.coef = a.coef;
+  f.partial_keys = a.partial_keys;
+  f.partial_feas = a.partial_feas;
+  f.records = fused.records;
+  f.regenerate = true;
+  f.controls_only = fused.controls_only;
+  f.centre = smp.centre;
+  f.u_ref = smp.u_ref;
+  f.centre_stride = smp.centre_stride;
+  f.spec = smp.spec;
+  f.blocks_per_problem = static_cast<int>(gridDim.x);
+  f.P = a.P;
+  f.N = a.N;
+  f.n = a.n;
+  f.index_offset = a.index_offset;
+  f.w = a.w;
+  finalize_problem<MODE, 1>(f, p, s_fused + rollout_lds_floats);
+}
+
 // ---- softmin-weighted mean -------------------------------------------------------------------------------
 constexpr int kSoftChunk = 4096;  // candidates per workgroup
 constexpr int kSoftBlock = 256;
-
-__device__ __forceinline__ float key_cost(int64_t key) {
-  const int32_t hi = static_cast<int32_t>(key >> 32);
-  union {
-    int32_t i;
-    float f;
-  } b;
-  b.i = (hi >= 0) ? hi : (hi ^ 0x7fffffff);
-  return b.f;
-}
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -947,14 +1011,22 @@ hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample, hipStream_t s) {
+hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
+                                  const FusedFinalize& fused, hipStream_t s) {
   const int n = rollout.n;
   const dim3 grid((rollout.N + kWave - 1) / kWave, rollout.P);
-  const size_t lds = (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 2) : 0) * sizeof(float);
+  const size_t rollout_floats = (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + 2) + 3) & ~static_cast<size_t>(3)) : 0;
+  size_t finalize_floats = 0;
+  if (fused.tickets != nullptr) {
+    const size_t rec_floats = static_cast<size_t>(4 + 2 * n + 3 * (n + 1));
+    finalize_floats = ((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? static_cast<size_t>(n) * kCoefT : 0);
+  }
+  const size_t lds = (rollout_floats + finalize_floats) * sizeof(float);
+  const int offset = static_cast<int>(rollout_floats);
   if (mode == 0) {
-    hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample);
+    hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset);
   } else if (mode == 1) {
-    hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample);
+    hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset);
   } else {
     return hipErrorInvalidValue;
   }
