@@ -172,19 +172,21 @@ def test_device_sampler_matches_its_restatement(layout):
     np.testing.assert_array_equal(got_part, got[:, 500:800])
 
 
-def test_optimize_equals_the_manual_round_loop():
-    """acmpc_optimize == sample_device -> solve_device per round with the incumbent fed back, bit for bit; and the
-    winner's cost never increases from round to round."""
+@pytest.mark.parametrize("mode,window", [(0, None), (1, None), (1, (2, 5))])
+def test_optimize_equals_the_manual_round_loop(mode, window):
+    """acmpc_optimize (one fused sample + rollout + finalize launch per round, the last workgroup of a problem
+    writing its record) == sample_device -> solve_device per round with the incumbent fed back, bit for bit; and
+    the winner's cost never increases from round to round."""
     import torch
     from acmpc_amd import Engine, _capi
     P, H, N, rounds = 3, 50, 2048, 4
     n = H - 1
     problems = [make_problem(orc, "silverstone", H, 4, seed=500 + p) for p in range(P)]
     dev = torch.device("cuda", 0)
-    eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
+    eng = Engine(**engine_kwargs(problems[0], mode, P, N, n, nn_window=window))
     eng.set_paths(np.stack([p["table"] for p in problems]))
     u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]).astype(np.float32)
-    x0 = np.stack([p["x0"] for p in problems])
+    x0 = np.stack([p["x0"] if mode == 0 else p["pose0"] for p in problems])
     sigma, seed = (3.0, 0.01), 42
     out = eng.optimize(x0, u_ref, u_ref, N, rounds, sigma, shrink=0.5, seed=seed)
     R = _capi.record_floats(n)
