@@ -245,7 +245,8 @@ def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
     costs = torch.empty(P, N, device=device)
     out = {}
     cases = [("mode_S_candidate_major", 0, 0, None), ("mode_T_exhaustive_search", 1, 1, None),
-             ("mode_T_window_2_5", 1, 1, (2, 5)), ("mode_S_step_major_1M", 0, 1, None)]
+             ("mode_T_window_2_5", 1, 1, (2, 5)), ("mode_T_window_1_2", 1, 1, (1, 2)),
+             ("mode_S_step_major_1M", 0, 1, None)]
     for name, mode, layout, window in cases:
         eng = Engine(**workloads.engine_kwargs(batch, mode, N, device=device.index, nn_window=window))
         eng.set_paths(batch.tables)
