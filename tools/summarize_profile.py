@@ -64,9 +64,10 @@ def main():
         t = json.loads(open(traced).read().strip().splitlines()[-1])
         # the same process, the same launches: HIP events vs rocprofv3's own dispatch timestamps
         summary["hip_events_kernel_ms_under_rocprof"] = t["roofline"]["kernel_ms"]
-        summary["note"] = ("rocprofv3 slows the run (lower clocks under the profiler, MI355X_MICROARCH.md 'DVFS "
-                           "give-back' item 2): compare average_ns with hip_events_kernel_ms_under_rocprof (same "
-                           "process); bench_kernel_ms_hip_events is the un-profiled run")
+        summary["note"] = ("compare average_ns with hip_events_kernel_ms_under_rocprof (the same process, the same "
+                           "launches); bench_kernel_ms_hip_events is a separate, un-profiled run on the same box - "
+                           "the two runs differ by a few per cent either way (clocks, MI355X_MICROARCH.md 'DVFS "
+                           "give-back')")
     json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
     json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
