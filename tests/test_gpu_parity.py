@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import acmpc_oracle as orc
-from test_support import engine_kwargs, make_problem
+from test_support import engine_kwargs, full_size_controls, make_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -202,11 +202,7 @@ def test_baseline_configs_at_full_size_against_the_c_oracle(track, H, N, mode):
     from acmpc_amd import Engine
     n = H - 1
     prob = make_problem(orc, track, H, 16, seed=4242)
-    rng = np.random.default_rng(99)
-    u_ref = np.stack([prob["table"][orc.ROW_V], prob["table"][orc.ROW_KAPPA]], axis=1)
-    U = (u_ref[None] + rng.standard_normal((N, n, 2), dtype=np.float32) * np.array([2.0, 0.01], dtype=np.float32)
-         * rng.uniform(0.02, 1.0, (N, 1, 1)).astype(np.float32)).astype(np.float32)
-    np.clip(U, prob["u_lo"].astype(np.float32), prob["u_hi"].astype(np.float32), out=U)
+    U = full_size_controls(orc, prob, N, n)
     window = (2, 5) if mode == 1 else None
     eng = Engine(**engine_kwargs(prob, mode, 1, N, n, nn_window=window))
     eng.set_paths(prob["table"])

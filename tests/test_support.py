@@ -85,3 +85,16 @@ def engine_kwargs(problem, mode: int, P: int, N: int, n: int, **extra):
               margin=lim.margin, wheelbase=lim.length, t_min=0.01, dt=0.05, w_bound=1.0e6, softmin_lambda=0.5)
     kw.update(extra)
     return kw
+
+
+def full_size_controls(orc, prob, N: int, n: int, seed: int = 99) -> np.ndarray:
+    """U [N, n, 2] float32 for the full-size BASELINE shapes: seeded noise round the reference controls with a
+    per-candidate spread, clipped to the input box, candidate 0 = the reference controls."""
+    rng = np.random.default_rng(seed)
+    u_ref = np.stack([prob["table"][orc.ROW_V], prob["table"][orc.ROW_KAPPA]], axis=1)
+    U = (u_ref[None] + rng.standard_normal((N, n, 2), dtype=np.float32) * np.array([2.0, 0.01], dtype=np.float32)
+         * rng.uniform(0.02, 1.0, (N, 1, 1)).astype(np.float32)).astype(np.float32)
+    np.clip(U, prob["u_lo"].astype(np.float32), prob["u_hi"].astype(np.float32), out=U)
+    U[0] = u_ref
+    return U
+
