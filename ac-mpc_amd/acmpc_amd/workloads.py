@@ -161,3 +161,33 @@ def sample_candidates(batch: SimpleNamespace, n_candidates: int, seed: int, sigm
     U[:, 0] = np.clip(u_ref, batch.u_lo, batch.u_hi)
     U = U.astype(np.float32)
     return U if layout == 0 else np.ascontiguousarray(U.transpose(0, 2, 3, 1))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The four synthetic path families the reference's own MPC script drives the controller with
+# (/root/reference/src/acmpc/control/utils.py:11-32, used by tests/test_spatial_mpc.py:45-75): H x 3 paths in the
+# vehicle frame, turned by `angle` about the origin (clockwise positive, as there).
+# ---------------------------------------------------------------------------------------------------------
+def _turned(x: np.ndarray, y: np.ndarray, angle: float, width: float) -> np.ndarray:
+    c, s = np.cos(angle), np.sin(angle)
+    return np.column_stack([c * x + s * y, c * y - s * x, np.full(x.shape[0], float(width))])
+
+
+def family_path(kind: str, parameter: float, horizon: int, angle: float = 0.0, width: float = 100.0,
+                chicane_width: float = 40.0) -> np.ndarray:
+    """`kind`: "hairpin" (three quarters of a circle of radius `parameter` to the left), "chicane" (a logistic
+    side-step of `chicane_width` centred `parameter` metres ahead), "curve" (a parabola with coefficient `parameter`
+    leaving along +x) or "straight" (`parameter` metres ahead)."""
+    if kind == "hairpin":
+        phi = np.linspace(0.0, 1.5 * np.pi, horizon)
+        return _turned(parameter * np.cos(phi) - parameter, parameter * np.sin(phi), angle, width)
+    if kind == "chicane":
+        ahead = np.linspace(0.0, 100.0, horizon)
+        return _turned(chicane_width / (1.0 + np.exp(-0.1 * (ahead - parameter))), ahead, angle, width)
+    if kind == "curve":
+        along = np.linspace(0.0, 100.0, horizon)
+        return _turned(along, parameter * along**2, angle, width)
+    if kind == "straight":
+        return _turned(np.zeros(horizon), np.linspace(0.0, parameter, horizon), angle, width)
+    raise ValueError("unknown path family %r" % kind)
+

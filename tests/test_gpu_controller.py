@@ -99,3 +99,57 @@ def test_infeasible_problem_keeps_previous_controls():
     np.testing.assert_array_equal(mpc.projected_control, plan)
     mpc.get_control(narrow)
     assert mpc.infeasibility_counter == 2
+
+
+REFERENCE_SCRIPT_CONFIG = {                      # tests/test_spatial_mpc.py:16-31 of the reference, verbatim values
+    "horizon": 100, "unlocalised_max_speed": 28,
+    "speed_profile_constraints": {"v_min": 12.0, "v_max": 84.0, "a_min": -1.0, "a_max": 1.0, "ay_max": 5.5,
+                                  "ki_min": 0.005, "end_velocity": 14.0},
+    "step_cost": [2.0e-3, 5.0e-2, 0.0], "r_term": [1.0e-2, 10.0], "final_cost": [1.0, 0.0, 0.1],
+}
+
+
+@pytest.mark.parametrize("kind,parameters,angle", [
+    ("hairpin", np.linspace(10, 100, 7), -np.pi / 6),        # tests/test_spatial_mpc.py:45-75: 7 experiments each
+    ("chicane", np.linspace(40, 100, 7), 0.1),
+    ("curve", np.linspace(-0.02, 0.02, 7), 0.1),
+    ("straight", np.linspace(40, 200, 7), 0.1),
+])
+def test_the_reference_script_scenarios(kind, parameters, angle):
+    """The reference's own MPC exercise (a plotting script without assertions): one controller, horizon 100, road
+    width 100 m, `get_control(path, offset=0.0)` over four path families x seven parameters.  Here with the checks
+    the plots were eyeballed for: every solve succeeds, the plan respects the input box and the time bound, the
+    predicted positions follow the path, and the published plan is exactly an oracle rollout."""
+    import copy
+    from acmpc_amd import workloads
+    from acmpc_amd.mpc import build_mpc
+    cfg = copy.deepcopy(REFERENCE_SCRIPT_CONFIG)
+    mpc = build_mpc(cfg, PlaceholderVehicle())
+    H = cfg["horizon"]
+    n = H - 1
+    for parameter in parameters:
+        path_in = workloads.family_path(kind, float(parameter), H, angle=angle, width=100.0)
+        mpc.get_control(path_in, offset=0.0)
+        assert mpc.infeasibility_counter == 0, "%s(%g) infeasible" % (kind, parameter)
+        v, delta = mpc.projected_control
+        assert v.shape == (n,) and np.all(v >= 12.0 - 0.1 - 1e-4) and np.all(v <= 84.0 + 0.1 + 1e-4)
+        assert np.all(np.abs(delta) <= mpc.delta_max + 1e-6)
+        # predicted time: 0 at the car, positive afterwards (the linearised time row is not monotone by itself, and
+        # the QP's t >= 0.01 bound (control.py:134) is met to the solver tolerance, as with OSQP's eps)
+        assert mpc.cum_time[0] == 0.0 and np.all(mpc.cum_time[1:] > 0.0)
+        assert mpc.speed_profile.shape == (n,) and np.all(mpc.speed_profile >= 12.0 - 1e-6)
+        # the prediction starts at the car (the origin, up to the along-track part that t2s drops: dynamics.py:23-40)
+        # and stays inside the (100 m wide) road
+        path = mpc.reference_path
+        assert np.linalg.norm(mpc.current_prediction[0]) < 0.5
+        gap = np.linalg.norm(mpc.current_prediction - path.table[:2].T, axis=1)
+        assert gap.max() < 50.0 - mpc.model.margin
+        # the published plan is one of the rollouts: the oracle re-rolls it to the same predicted times
+        coef = orc.coefficients_spatial(path.table, mpc.model.margin)
+        u = np.stack([v, np.tan(delta) / mpc.model.length], axis=1)
+        lo, hi = orc.input_box(mpc.model)
+        x0 = mpc.model.t2s(path.get_state(0), np.array([0.0, 0.0, np.pi / 2]))
+        _, viol, X = orc.rollout_spatial(x0.astype(np.float32), coef, u[None], cfg["step_cost"], cfg["r_term"],
+                                         cfg["final_cost"], lo, hi, 1e6, dtype=np.float64, return_states=True)
+        np.testing.assert_allclose(X[0, :n, 2], mpc.cum_time, rtol=1e-4, atol=1e-5)
+

@@ -251,3 +251,23 @@ def test_particle_filter_resampling_and_reset_match_the_reference(golden):
     assert pf2.was_reset and not pf2.is_converged
     np.testing.assert_array_equal(pf2.states, g["pf/reset_states"])
 
+
+def test_path_families_equal_the_reference_generators(golden, golden_cases):
+    """workloads.family_path == control/utils.py:11-32 with the parameters of tests/test_spatial_mpc.py:45-75
+    (the golden `coords` were produced by the reference's generators)."""
+    from acmpc_amd import workloads
+    exact = {"hairpin": np.linspace(10, 100, 7), "chicane": np.linspace(40, 100, 7),
+             "curve": np.linspace(-0.02, 0.02, 7), "straight": np.linspace(40, 200, 7)}
+    checked = 0
+    for case in golden_cases:
+        track, horizon, kind, printed = case.split("_")          # the name carries the parameter to 6 digits
+        parameter = exact[kind][np.argmin(np.abs(exact[kind] - float(printed)))]
+        H = int(horizon[1:])
+        angle = -np.pi / 6 if kind == "hairpin" else 0.1
+        got = workloads.family_path(kind, parameter, H, angle=angle)
+        np.testing.assert_allclose(got[:, :2], golden[case + "/coords"][:, :2], rtol=0, atol=1e-12)
+        checked += 1
+    assert checked >= 28
+    with pytest.raises(ValueError):
+        workloads.family_path("oval", 1.0, 50)
+
