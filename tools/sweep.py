@@ -21,6 +21,8 @@ def run(spec, iters=30):
     parts = spec.split(",")
     window = (int(parts[5]), int(parts[6])) if len(parts) > 5 else None
     mode_s, layout, P, N, H = parts[:5]
+    if mode_s not in ("S", "T"):
+        raise SystemExit("spec %r: mode must be S or T" % spec)
     mode, layout, P, N, H = (0 if mode_s == "S" else 1), int(layout), int(P), int(N), int(H)
     n = H - 1
     device = torch.device("cuda", 0)
@@ -49,7 +51,7 @@ def run(spec, iters=30):
     ms = np.array([a.elapsed_time(b) for a, b in ev])
     byts = P * N * (8 * n + 4)
     print("%-22s kernel median %.1f us  min %.1f us  -> %.2f TB/s algorithmic (%.1f%% of 8 TB/s), %.3g traj/s"
-          % (spec, np.median(ms) * 1e3, ms.min() * 1e3, byts / np.median(ms) / 1e9, byts / np.median(ms) / 1e9 / 80,
+          % (spec, np.median(ms) * 1e3, ms.min() * 1e3, byts / np.median(ms) / 1e9, byts / np.median(ms) / 1e9 / 8 * 100,
              P * N / np.median(ms) * 1e3), flush=True)
     eng.close()
 
