@@ -172,14 +172,19 @@ def test_device_sampler_matches_its_restatement(layout):
     np.testing.assert_array_equal(got_part, got[:, 500:800])
 
 
-@pytest.mark.parametrize("mode,window", [(0, None), (1, None), (1, (2, 5))])
-def test_optimize_equals_the_manual_round_loop(mode, window):
+@pytest.mark.parametrize("mode,window,P,H,N,rounds", [
+    (0, None, 3, 50, 2048, 4), (1, None, 3, 50, 2048, 4), (1, (2, 5), 3, 50, 2048, 4),
+    (0, None, 2, 3, 65, 2),        # shortest horizon, a ragged last wave
+    (0, None, 1, 100, 4096, 3),    # the mapping horizon: two 64-step chunks in the finalize
+    (0, None, 5, 20, 1, 2),        # a single candidate: one workgroup per problem draws the first and last ticket
+    (1, (1, 2), 2, 66, 130, 1),    # one round only: the full record straight from the fused launch
+])
+def test_optimize_equals_the_manual_round_loop(mode, window, P, H, N, rounds):
     """acmpc_optimize (one fused sample + rollout + finalize launch per round, the last workgroup of a problem
     writing its record) == sample_device -> solve_device per round with the incumbent fed back, bit for bit; and
     the winner's cost never increases from round to round."""
     import torch
     from acmpc_amd import Engine, _capi
-    P, H, N, rounds = 3, 50, 2048, 4
     n = H - 1
     problems = [make_problem(orc, "silverstone", H, 4, seed=500 + p) for p in range(P)]
     dev = torch.device("cuda", 0)
