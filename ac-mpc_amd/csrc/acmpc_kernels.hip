@@ -75,6 +75,19 @@ __device__ __forceinline__ void load_controls(const float* __restrict__ U, int p
   }
 }
 
+// Warms the scalar cache: one s_load per 64-byte line of [base, base + bytes), results discarded.  In the
+// latency-bound kernels every step's table row is otherwise a first-touch miss that the lone wave of a SIMD has to
+// sit out; issued up front, the misses overlap the Philox draws instead.  All loads write the same SGPR (`sink`),
+// which the caller keeps reserved until scalar_touch_wait() - the compiler does not know these loads are in flight.
+__device__ __forceinline__ uint32_t scalar_touch(const void* base, int bytes, uint32_t sink) {
+  for (int off = 0; off < bytes; off += 64)
+    asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(base), "s"(off) : "memory");
+  return sink;
+}
+__device__ __forceinline__ void scalar_touch_wait(uint32_t& sink) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink) : : "memory");
+}
+
 template <int MODE, int LAYOUT, int CPT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -399,13 +412,20 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     __syncthreads();
   }
 
+  uint32_t sink = 0;
+  if constexpr (MODE == 0) sink = scalar_touch(coef, n * kStride * static_cast<int>(sizeof(float)), sink);
+  sink = scalar_touch(centre, 2 * n * static_cast<int>(sizeof(float)), sink);
+  sink = scalar_touch(ref, 2 * n * static_cast<int>(sizeof(float)), sink);
+  sink = scalar_touch(knot_weight, 2 * n * static_cast<int>(sizeof(float)), sink);
+
   const bool active = c < a.N;
   float cost = __builtin_inff();
   bool feas = false;
+  float z[kKnots][2] = {};
+  const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
+  if (active) draw_normals(sp, gidx, static_cast<uint32_t>(p), z);
+  scalar_touch_wait(sink);
   if (active) {
-    const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
-    float z[kKnots][2];
-    draw_normals(sp, gidx, static_cast<uint32_t>(p), z);
     const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     StateS ss{x0[0], x0[1], x0[2], 0.0f, 0.0f};
