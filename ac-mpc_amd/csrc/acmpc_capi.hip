@@ -596,13 +596,17 @@ struct OptInputs {
   const float* coef;
 };
 
+bool use_fused_finalize(const acmpc_ctx* c, int n) {
+  return std::getenv("ACMPC_NO_FUSED_FINALIZE") == nullptr && acmpc::fused_finalize_fits(c->prm.mode, n);
+}
+
 // `final_records`: where the LAST round's records go when the fused finalize writes them (device memory, or pinned
 // host memory - then the winner lands in the caller's staging buffer without a copy node); nullptr = c->d_records
 int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int rounds, double sigma_v, double sigma_k,
                    double shrink, uint64_t seed, const uint32_t* d_seed, hipStream_t s, bool fused,
                    float* final_records = nullptr) {
   const bool has_uref = in.uref != nullptr;
-  const bool fused_finalize = std::getenv("ACMPC_NO_FUSED_FINALIZE") == nullptr;
+  const bool fused_finalize = use_fused_finalize(c, n);
   const int layout = ACMPC_LAYOUT_STEP_MAJOR;
   const int rec_floats = acmpc_record_floats(n);
   double scale = 1.0;
@@ -781,7 +785,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     int rc_rounds = ACMPC_OK;
     // with the fused finalize the last round writes the winners straight into the pinned host buffer (posted
     // writes over the host link, visible once the stream has drained): no device-to-host copy node
-    const bool direct = fused && std::getenv("ACMPC_NO_FUSED_FINALIZE") == nullptr;
+    const bool direct = fused && use_fused_finalize(c, n);
     if (e == hipSuccess)
       rc_rounds = enqueue_rounds(c, in, P, N, n, rounds, sigma[0], sigma[1], shrink, 0,
                                  reinterpret_cast<const uint32_t*>(c->d_opt + off_seed), s, fused,

@@ -99,6 +99,8 @@ struct FusedFinalize {
 // (the closed-loop solve, where every launch is ~10 us of latency-bound work)
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
                                   const FusedFinalize& fused, hipStream_t s);
+// whether rollout + fused finalize fit one workgroup's 64 KB of LDS (mode T at the longest horizons does not)
+bool fused_finalize_fits(int mode, int n);
 int softmin_chunks(int N);
 hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s);
 

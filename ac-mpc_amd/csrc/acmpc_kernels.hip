@@ -1031,17 +1031,28 @@ hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
   return hipGetLastError();
 }
 
+namespace {
+size_t sampled_rollout_floats(int mode, int n) {
+  return (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + 2) + 3) & ~static_cast<size_t>(3)) : 0;
+}
+size_t sampled_finalize_floats(int mode, int n) {
+  const size_t rec_floats = static_cast<size_t>(4 + 2 * n + 3 * (n + 1));
+  return ((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? static_cast<size_t>(n) * kCoefT : 0);
+}
+}  // namespace
+
+bool fused_finalize_fits(int mode, int n) {
+  return (sampled_rollout_floats(mode, n) + sampled_finalize_floats(mode, n)) * sizeof(float) <= 64 * 1024;
+}
+
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
                                   const FusedFinalize& fused, hipStream_t s) {
   const int n = rollout.n;
   const dim3 grid((rollout.N + kWave - 1) / kWave, rollout.P);
-  const size_t rollout_floats = (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + 2) + 3) & ~static_cast<size_t>(3)) : 0;
-  size_t finalize_floats = 0;
-  if (fused.tickets != nullptr) {
-    const size_t rec_floats = static_cast<size_t>(4 + 2 * n + 3 * (n + 1));
-    finalize_floats = ((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? static_cast<size_t>(n) * kCoefT : 0);
-  }
+  const size_t rollout_floats = sampled_rollout_floats(mode, n);
+  const size_t finalize_floats = (fused.tickets != nullptr) ? sampled_finalize_floats(mode, n) : 0;
   const size_t lds = (rollout_floats + finalize_floats) * sizeof(float);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;  // callers check fused_finalize_fits() first
   const int offset = static_cast<int>(rollout_floats);
   if (mode == 0) {
     hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset);

@@ -173,6 +173,34 @@ def test_other_horizons(mode, H, N, P):
             np.testing.assert_array_equal(out["u"][p], prob["U"][best])
 
 
+@pytest.mark.parametrize("mode,window", [(0, None), (1, None), (1, (2, 5))])
+def test_maximum_horizon(mode, window):
+    """n = 1024 control steps, the largest the handle accepts (the finalize's record image and, in mode T, the
+    waypoint table still fit the 64 KB of LDS a workgroup may have): costs, argmin and the winner's 1025 states."""
+    from acmpc_amd import Engine, EngineError
+    H, N = 1025, 130
+    n = H - 1
+    prob = make_problem(orc, "monza", H, N, seed=77)
+    eng = Engine(**engine_kwargs(prob, mode, 1, N, n, nn_window=window))
+    eng.set_paths(prob["table"])
+    x0 = prob["x0"] if mode == 0 else prob["pose0"]
+    cfg = prob["cfg"]
+    args = (prob["U"], cfg["step_cost"], cfg["r_term"], cfg["final_cost"], prob["u_lo"], prob["u_hi"], 1.0e6)
+    if mode == 0:
+        cost, viol, X = orc.rollout_spatial(x0, eng.coefficients(0), *args, dtype=np.float32, return_states=True)
+    else:
+        cost, viol, X, _ = orc.rollout_temporal(x0, eng.coefficients(0), *args, 0.05, dtype=np.float32,
+                                                return_states=True, nn_window=window)
+    for layout in (LAYOUT_CM, LAYOUT_SM):
+        out = eng.solve(x0[None], _as_layout(prob["U"][None], layout), layout=layout)
+        np.testing.assert_array_equal(out["costs"][0], cost)
+        best = orc.pick_best(cost)[0]
+        assert out["best_idx"][0] == best and out["violation"][0] == viol[best]
+        np.testing.assert_array_equal(out["x"][0], X[best])
+    with pytest.raises(EngineError):
+        Engine(**engine_kwargs(prob, mode, 1, N, n + 1))
+
+
 def test_every_launch_shape_gives_the_same_bits(monkeypatch):
     """ACMPC_SHAPE forces the workgroup size / candidates per lane; results must not depend on it."""
     H, N, P = 50, 2048, 2

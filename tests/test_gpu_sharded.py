@@ -178,6 +178,9 @@ def test_device_sampler_matches_its_restatement(layout):
     (0, None, 1, 100, 4096, 3),    # the mapping horizon: two 64-step chunks in the finalize
     (0, None, 5, 20, 1, 2),        # a single candidate: one workgroup per problem draws the first and last ticket
     (1, (1, 2), 2, 66, 130, 1),    # one round only: the full record straight from the fused launch
+    (0, None, 1, 1025, 256, 2),    # the longest horizon the handle accepts
+    (1, (2, 5), 1, 1025, 256, 2),  # ... where mode T's tables + record image exceed one workgroup's LDS: the
+                                   # finalize runs as its own launch again
 ])
 def test_optimize_equals_the_manual_round_loop(mode, window, P, H, N, rounds):
     """acmpc_optimize (one fused sample + rollout + finalize launch per round, the last workgroup of a problem
