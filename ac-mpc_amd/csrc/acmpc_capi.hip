@@ -343,6 +343,8 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
     return fail(nullptr, ACMPC_EINVAL, "centre_update must be 0 (argmin) or 1 (softmin mean)");
   if (params->max_steps > 1024)
     return fail(nullptr, ACMPC_EINVAL, "the waypoint table and the winner record are staged in LDS: max_steps <= 1024");
+  if (params->max_problems > 65535)
+    return fail(nullptr, ACMPC_EINVAL, "problems map to the grid's y dimension: max_problems <= 65535");
   acmpc_ctx* c = new (std::nothrow) acmpc_ctx();
   if (c == nullptr) return fail(nullptr, ACMPC_EINVAL, "out of host memory");
   c->prm = *params;

@@ -70,9 +70,9 @@ typedef struct acmpc_params {
   uint32_t struct_size;  /* sizeof(acmpc_params), for ABI checking                                   */
   int32_t mode;          /* ACMPC_MODE_*                                                              */
   int32_t device;        /* HIP device ordinal                                                        */
-  int32_t max_problems;  /* capacity P                                                                */
+  int32_t max_problems;  /* capacity P (<= 65535)                                                     */
   int32_t max_candidates;/* capacity N (per problem)                                                  */
-  int32_t max_steps;     /* capacity n                                                                */
+  int32_t max_steps;     /* capacity n (<= 1024)                                                      */
   int32_t nn_back;       /* mode T nearest-waypoint search: the W = nn_back + nn_ahead + 1 consecutive waypoints   */
   int32_t nn_ahead;      /*   from clamp(j_prev - nn_back, 0, n - W), j_prev = the previous step's nearest index (0
                               at the start); nn_ahead < 0 = exhaustive scan of all n waypoints (KDTree.query

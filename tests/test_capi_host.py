@@ -90,6 +90,8 @@ def test_errors_without_device_or_tables():
         Engine(**engine_kwargs(prob, 7, 1, 8, 19))  # unknown mode
     with pytest.raises(EngineError):
         Engine(**engine_kwargs(prob, 0, 1, 8, 5000))  # max_steps beyond the LDS staging limit
+    with pytest.raises(EngineError):
+        Engine(**engine_kwargs(prob, 0, 70000, 8, 19))  # more problems than the grid's y dimension holds
     eng = Engine(**engine_kwargs(prob, 0, 1, 8, 19))
     with pytest.raises(EngineError) as e:
         eng.coefficients(0)
