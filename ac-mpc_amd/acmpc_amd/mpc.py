@@ -137,6 +137,17 @@ class SpatialMPC:
         self.infeasibility_counter = 0
 
 
+def published_plan(mpc: SpatialMPC):
+    """What the control process publishes after a solve (controller.py:102-108,274-280): `control_inputs` [n, 2]
+    = projected_control.T, `control_cumtime` [n], `predicted_locations` [n, 2], each float32 as the shared arrays
+    store them (perception/shared_memory.py:98-103).  The returned object is what `TemporalCommandSelector` /
+    `TemporalCommandInterpolator` take as their controller."""
+    from types import SimpleNamespace
+    return SimpleNamespace(control_inputs=np.ascontiguousarray(mpc.projected_control.T, dtype=np.float32),
+                           control_cumtime=np.ascontiguousarray(mpc.cum_time, dtype=np.float32),
+                           predicted_locations=np.ascontiguousarray(mpc.current_prediction, dtype=np.float32))
+
+
 def build_mpc(control_config: Dict, vehicle_data) -> SpatialMPC:
     """Same factory as controller.py:19-29."""
     limits = control_config["speed_profile_constraints"]

@@ -26,8 +26,7 @@ def _local_centreline(centre, pose, points=500, lookahead=150.0, spacing=0.5):
 def test_controller_keeps_the_car_on_the_track(shifted_warm_start):
     from acmpc_amd import workloads
     from acmpc_amd.command_selection import TemporalCommandSelector
-    from acmpc_amd.mpc import build_mpc
-    from types import SimpleNamespace
+    from acmpc_amd.mpc import build_mpc, published_plan
 
     cfg = copy.deepcopy(workloads.RACING_CONTROL["monza"])
     cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])     # controller.py:241-243
@@ -44,9 +43,9 @@ def test_controller_keeps_the_car_on_the_track(shifted_warm_start):
         mpc.get_control(workloads.reference_path_from_centreline(local, 50),
                         elapsed=dt if shifted_warm_start and tick > 0 else None)
         assert mpc.infeasibility_counter == 0, "infeasible solve at tick %d" % tick
-        holder = SimpleNamespace(control_cumtime=mpc.cum_time.astype(np.float32),
-                                 control_inputs=mpc.projected_control.T.astype(np.float32))
-        v_cmd, delta = TemporalCommandSelector(holder)(float(mpc.cum_time[1]))            # the command one step in
+        plan = published_plan(mpc)                                                         # controller.py:274-280
+        assert plan.control_inputs.shape == (49, 2) and plan.predicted_locations.shape == (49, 2)
+        v_cmd, delta = TemporalCommandSelector(plan)(float(mpc.cum_time[1]))            # the command one step in
         speed += np.clip(v_cmd - speed, -6.0 * dt, 4.0 * dt)                              # bounded accel/brake
         pose = pose + np.array([speed * np.cos(pose[2]), speed * np.sin(pose[2]),
                                 speed * np.tan(delta) / wheelbase]) * dt                  # localiser.py:66-95

@@ -21,10 +21,9 @@ LOCALISATION = dict(n_particles=300, n_converged_particles=300,                 
 
 
 def test_localised_racing_on_the_synthetic_circuit():
-    from types import SimpleNamespace
     from acmpc_amd import track_map, workloads
     from acmpc_amd.command_selection import TemporalCommandSelector
-    from acmpc_amd.mpc import build_mpc
+    from acmpc_amd.mpc import build_mpc, published_plan
     from acmpc_amd.particle_filter import ParticleFilter
 
     cfg = copy.deepcopy(workloads.RACING_CONTROL["monza"])
@@ -82,9 +81,9 @@ def test_localised_racing_on_the_synthetic_circuit():
         line = np.stack([np.interp(t, np.arange(301), local[:, 0]), np.interp(t, np.arange(301), local[:, 1])], axis=1)
         mpc.get_control(workloads.reference_path_from_centreline(line, 50), is_localised)
         assert mpc.infeasibility_counter == 0, "infeasible solve at tick %d" % tick
-        holder = SimpleNamespace(control_cumtime=mpc.cum_time.astype(np.float32),
-                                 control_inputs=mpc.projected_control.T.astype(np.float32))
-        v_cmd, delta = TemporalCommandSelector(holder)(float(mpc.cum_time[1]))
+        plan = published_plan(mpc)                                                         # controller.py:274-280
+        assert plan.control_inputs.shape == (49, 2) and plan.predicted_locations.shape == (49, 2)
+        v_cmd, delta = TemporalCommandSelector(plan)(float(mpc.cum_time[1]))
         delta = float(delta)
         speed += float(np.clip(v_cmd - speed, -10.0 * dt, 6.0 * dt))
         pose = pose + np.array([speed * np.cos(pose[2]), speed * np.sin(pose[2]),
