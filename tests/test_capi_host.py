@@ -127,3 +127,26 @@ def test_philox_known_answers_and_oracle_agreement():
     got = orc.philox4x32_10(ctr, key)
     for i in range(50):
         np.testing.assert_array_equal(_capi.philox4x32(ctr[i], key[i]), got[i])
+
+
+def test_key_minimum_is_the_oracles_argmin_on_arbitrary_bit_patterns():
+    """Property (hypothesis): for ANY float32 bit patterns - NaNs of either sign, infinities, denormals, signed
+    zeros - the index inside the smallest packed key is the oracle's pick_best (np.argmin's first minimum with
+    non-finite costs ranked last) and the C restatement's argmin."""
+    import c_oracle
+    from hypothesis import given, settings, strategies as st
+    from acmpc_amd import _capi
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(st.integers(min_value=0, max_value=2**32 - 1), min_size=1, max_size=40))
+    def check(bits):
+        costs = np.array(bits, dtype=np.uint32).view(np.float32)
+        keys = [_capi.pack_key(float(c), j) for j, c in enumerate(costs)]
+        best = _capi.key_index(min(keys))
+        # signed zeros: the key ranks -0.0 just below +0.0, np.argmin treats them as equal -> compare on values
+        want = orc.pick_best(costs)[0]
+        assert best == want or (costs[best] == 0 and costs[want] == 0)
+        assert c_oracle.argmin(costs) == want or (costs[best] == 0 and costs[want] == 0)
+
+    check()
+
