@@ -21,6 +21,11 @@ from . import _capi
 from .reference_path import ReferencePath
 
 SOLVED = "solved"
+# Defaults from tools/sweep_solver_settings.py (600 warm-started solves along the synthetic Silverstone circuit, the
+# car up to 1 m off the centre line): 16 384 x 3 gives a lower plan cost than 4 096 x 4 in less time - one problem
+# of 4 096 candidates leaves three quarters of the chip's CUs idle, so candidates are nearly free, rounds are not.
+DEFAULT_CANDIDATES = 16384
+DEFAULT_ROUNDS = 3
 INFEASIBLE = "primal infeasible"
 
 
@@ -29,8 +34,8 @@ class ControlSolver:
         self._dynamics_model = model
         self._n_horizon = config["horizon"] - 1
         self._max_iterations = config.get("max_iterations", 4000)
-        self._n_candidates = int(config.get("n_candidates", 4096))
-        self._rounds = int(config.get("sampling_rounds", 4))
+        self._n_candidates = int(config.get("n_candidates", DEFAULT_CANDIDATES))
+        self._rounds = int(config.get("sampling_rounds", DEFAULT_ROUNDS))
         self._sigma = np.asarray(config.get("sampling_sigma", (3.0, 0.01)), dtype=np.float64)
         self._seed = int(config.get("sampling_seed", 0))
         self._solves = 0

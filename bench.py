@@ -204,7 +204,8 @@ def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300
 def closed_loop_replay(workloads, track_name="silverstone", poses=2000):
     """BASELINE.json configs[4]: the drop-in controller (`build_mpc(...).get_control`) against consecutive poses
     along the synthetic Silverstone circuit - one full MPC solve per pose (waypoints, host speed-profile QP,
-    4 rounds x 4 096 candidates sampled, rolled out and reduced on the GPU) - wall-clock p50/p99 per solve."""
+    the solver's default rounds x candidates sampled, rolled out and reduced on the GPU) - wall-clock p50/p99 per
+    solve."""
     import copy
     from acmpc_amd.mpc import build_mpc
 
