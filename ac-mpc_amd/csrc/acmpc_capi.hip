@@ -586,6 +586,7 @@ int acmpc_finalize_sampled_device(acmpc_ctx* c, const int64_t* d_keys, const flo
                   shape.blocks_per_problem, s, &regen);
 }
 
+extern "C++" {
 namespace {
 
 // the launch sequence of one optimisation, enqueued on `s` (directly, or while `s` is being captured): per round ONE
@@ -695,6 +696,7 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
 }
 
 }  // namespace
+}  // extern "C++"
 
 int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const float* u_ref, int32_t P, int32_t N,
                    int32_t n, int32_t rounds, const double sigma[2], double shrink, uint64_t seed, float* records) {
@@ -821,6 +823,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   return ACMPC_OK;
 }
 
+extern "C++" {
 namespace {
 
 using AllReduceFn = ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
@@ -852,6 +855,7 @@ const Rccl& rccl() {
 }
 
 }  // namespace
+}  // extern "C++"
 
 int acmpc_reduce_across_ranks(acmpc_ctx* c, void* rccl_comm, int64_t* d_keys, int32_t P, void* stream) {
   if (c == nullptr) return ACMPC_EINVAL;

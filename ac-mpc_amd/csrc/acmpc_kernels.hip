@@ -25,8 +25,6 @@ namespace acmpc {
 
 namespace {
 
-constexpr int kMaxBlock = 256;
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CPT>
