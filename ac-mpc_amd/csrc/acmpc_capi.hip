@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -57,6 +59,9 @@ struct acmpc_ctx {
   float* d_records = nullptr;
   int64_t* d_keys = nullptr;
   int* d_tickets = nullptr;  // [max_problems] last-workgroup counters of the fused finalize; zero between launches
+  // mode T with exhaustive search: thresholds of the verified window search (acmpc_device.h: nearest_verified)
+  std::vector<float> h_nn_thr;  // [P][n][kVerifiedWindow], empty when not applicable
+  float* d_nn_thr = nullptr;
   int64_t* h_keys = nullptr;  // pinned
 
   // acmpc_optimize as a hipGraph: the whole sample -> rollout -> finalize chain of `rounds` rounds plus the
@@ -108,6 +113,46 @@ int fail_hip(const acmpc_ctx* ctx, hipError_t e, const char* what) {
     if (e_ != hipSuccess) return fail_hip((ctx), e_, #call);   \
   } while (0)
 
+// Thresholds of the verified nearest-waypoint search (acmpc_device.h: nearest_verified), from the float32 waypoint
+// positions the kernels use: thr[p][j][o] = (R / (2 (1 + 1e-3)))^2 with R the distance from waypoint j to the
+// nearest waypoint outside the kVerifiedWindow-wide window that starts at j - o (+inf when nothing lies outside; -1 = "always
+// scan" for window positions that cannot occur).  O(n^2) per path through prefix / suffix minima, hence the cap.
+constexpr int kMaxVerifiedSteps = 256;
+
+void verified_thresholds(const float* coef, int P, int n, std::vector<float>* out) {
+  constexpr int W = acmpc::kVerifiedWindow;
+  out->assign(static_cast<size_t>(P) * n * W, -1.0f);
+  std::vector<double> left(static_cast<size_t>(n) + 1), right(static_cast<size_t>(n) + 1);
+  const double inf = std::numeric_limits<double>::infinity();
+  for (int p = 0; p < P; ++p) {
+    const float* t = coef + static_cast<size_t>(p) * n * acmpc::kCoefT;
+    float* thr = out->data() + static_cast<size_t>(p) * n * W;
+    for (int j = 0; j < n; ++j) {
+      const double xj = t[j * acmpc::kCoefT], yj = t[j * acmpc::kCoefT + 1];
+      // left[a] = min distance to waypoints m < a; right[b] = min distance to waypoints m >= b
+      left[0] = inf;
+      for (int m = 0; m < n; ++m) {
+        const double dx = t[m * acmpc::kCoefT] - xj, dy = t[m * acmpc::kCoefT + 1] - yj;
+        left[m + 1] = std::min(left[m], std::sqrt(dx * dx + dy * dy));
+      }
+      right[n] = inf;
+      for (int m = n - 1; m >= 0; --m) {
+        const double dx = t[m * acmpc::kCoefT] - xj, dy = t[m * acmpc::kCoefT + 1] - yj;
+        right[m] = std::min(right[m + 1], std::sqrt(dx * dx + dy * dy));
+      }
+      for (int o = 0; o < W; ++o) {
+        const int lo = j - o;
+        if (lo < 0 || lo + W > n) continue;
+        const double R = std::min(left[lo], right[lo + W]);
+        const double half = R / (2.0 * (1.0 + 1.0e-3));
+        // rounded towards zero: the test `d2 < thr` must never be more permissive than the real-number one
+        thr[j * W + o] = std::isinf(R) ? std::numeric_limits<float>::infinity()
+                                       : std::nextafter(static_cast<float>(half * half), 0.0f);
+      }
+    }
+  }
+}
+
 int ensure_device(acmpc_ctx* c) {
   if (c->device_ready) return ACMPC_OK;
   int count = 0;
@@ -128,6 +173,9 @@ int ensure_device(acmpc_ctx* c) {
   ACMPC_HIP(c, hipMalloc(&c->d_partial_feas, partials * sizeof(int)));
   ACMPC_HIP(c, hipMalloc(&c->d_soft_partial, c->soft_partial_doubles * sizeof(double)));
   ACMPC_HIP(c, hipMalloc(&c->d_segments, static_cast<size_t>(p.max_steps) * 2 * sizeof(float)));
+  if (p.mode == ACMPC_MODE_TEMPORAL && p.nn_ahead < 0)
+    ACMPC_HIP(c, hipMalloc(&c->d_nn_thr, static_cast<size_t>(p.max_problems) * std::min(p.max_steps, kMaxVerifiedSteps) *
+                                             acmpc::kVerifiedWindow * sizeof(float)));
   c->device_ready = true;
   return ACMPC_OK;
 }
@@ -138,6 +186,9 @@ int upload_tables(acmpc_ctx* c, hipStream_t s) {
   const size_t bytes = static_cast<size_t>(c->P_set) * c->n_set * c->coef_stride * sizeof(float);
   // pageable source: hipMemcpyAsync stages it before returning, so h_coef may change afterwards
   ACMPC_HIP(c, hipMemcpyAsync(c->d_coef, c->h_coef.data(), bytes, hipMemcpyHostToDevice, s));
+  if (!c->h_nn_thr.empty() && c->d_nn_thr != nullptr)
+    ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_thr, c->h_nn_thr.data(), c->h_nn_thr.size() * sizeof(float),
+                                hipMemcpyHostToDevice, s));
   c->tables_dirty = false;
   return ACMPC_OK;
 }
@@ -169,6 +220,7 @@ int rollout(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int
   a.U = d_U;
   a.x0 = d_x0;
   a.coef = c->d_coef;
+  a.nn_thr = (!c->h_nn_thr.empty() && std::getenv("ACMPC_NO_VERIFIED_SEARCH") == nullptr) ? c->d_nn_thr : nullptr;
   a.costs = d_costs;
   a.partial_keys = c->d_partial_keys;
   a.partial_feas = c->d_partial_feas;
@@ -388,6 +440,7 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_keys);
     (void)hipFree(c->d_tickets);
+    (void)hipFree(c->d_nn_thr);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
     if (c->opt_graph != nullptr) (void)hipGraphExecDestroy(c->opt_graph);
     if (c->h_opt != nullptr) (void)hipHostFree(c->h_opt);
@@ -439,6 +492,9 @@ int acmpc_set_paths(acmpc_ctx* c, const double* tables, int32_t P, int32_t n) {
       }
     }
   }
+  c->h_nn_thr.clear();
+  if (c->prm.mode == ACMPC_MODE_TEMPORAL && c->prm.nn_ahead < 0 && n >= acmpc::kVerifiedWindow && n <= kMaxVerifiedSteps)
+    verified_thresholds(c->h_coef.data(), P, n, &c->h_nn_thr);
   c->P_set = P;
   c->n_set = n;
   c->tables_dirty = true;

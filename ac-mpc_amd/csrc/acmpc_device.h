@@ -205,7 +205,8 @@ __device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const Stat
 // index that attains it by an equality scan from the far end - the same answer as the `d < best` scan, one
 // instruction per waypoint cheaper.
 template <int W>
-__device__ __forceinline__ int nearest_in_window(float X, float Y, const float* xs, const float* ys, int lo) {
+__device__ __forceinline__ int nearest_in_window(float X, float Y, const float* xs, const float* ys, int lo,
+                                                 float* best_out = nullptr) {
   float d[W];
 #pragma unroll
   for (int m = 0; m < W; m += 2) {
@@ -222,16 +223,94 @@ __device__ __forceinline__ int nearest_in_window(float X, float Y, const float* 
 #pragma unroll
   for (int m = W - 1; m >= 1; --m) jm = (d[m] == best) ? m : jm;
   jm = (d[0] == best) ? 0 : jm;
+  if (best_out != nullptr) *best_out = best;
   return lo + jm;
+}
+
+// one-lane exhaustive scan on plain coordinates (the fallback of the verified search below)
+__device__ __forceinline__ int nearest_scan(float X, float Y, const float* wp, int n) {
+  float best = __builtin_inff();
+  int j = 0;
+  for (int i = 0; i < n; ++i) {
+    const float d = dist2<float>(X, Y, wp[i * kCoefT + 0], wp[i * kCoefT + 1]);
+    const bool better = d < best;
+    best = better ? d : best;
+    j = better ? i : j;
+  }
+  return j;
+}
+
+// EXHAUSTIVE semantics at windowed cost.  The 16 waypoints from lo = clamp(j_prev - 7, 0, n - 16) are searched as
+// above; the host has tabulated, for every waypoint j and every window position o = j - lo, the threshold
+//     thr[j][o] = (R / (2 (1 + 1e-3)))^2,   R = distance from waypoint j to the nearest waypoint OUTSIDE that window.
+// If the window's minimum d2 is below thr, every outside waypoint m is farther: |p - w_m| >= R - |p - w_j| >
+// (1 + 1.9e-3) |p - w_j| by the triangle inequality - a margin a thousand times the rounding error of the float32
+// distances - so the window's first minimum IS the global first minimum and the scan of all n waypoints is
+// skipped.  Otherwise (a candidate far off the path, a non-finite position) all waypoints are scanned - by the whole
+// wave, see nearest_cooperative_fix().  Either way the index is exactly the exhaustive one, bit for bit.
+constexpr int kVerifiedWindow = 16;  // measured on the bench workload: a wave (256 candidates) has to fall back to the
+constexpr int kVerifiedBack = 7;     // full scan in 44 % of its steps with 8 waypoints from j_prev - 2, in 1.5 % with these
+
+// The window part: index of the window's first minimum and whether the threshold test certifies it as global.
+__device__ __forceinline__ int nearest_verified_window(float X, float Y, const float* xy, const float* thr, int n,
+                                                       int j_prev, bool& certified) {
+  const int lo = max(min(j_prev - kVerifiedBack, n - kVerifiedWindow), 0);
+  float best;
+  const int j = nearest_in_window<kVerifiedWindow>(X, Y, xy, xy + n, lo, &best);
+  certified = best < thr[j * kVerifiedWindow + (j - lo)];
+  return j;
+}
+
+// The fallback, wave-cooperative: for every lane whose window result is not certified (a handful per wave and
+// step), ALL 64 lanes scan the waypoint table side by side for that lane's position and reduce to the first
+// minimum - ~40 instructions per uncertified candidate instead of one lane walking all n waypoints while the other
+// 63 wait.  Must be reached by every lane of the wave (the rollout kernel runs its tail lanes on a valid dummy
+// candidate for this reason).  Same answer as nearest_scan(): NaN distances never win, ties go to the lower index,
+// nothing finite found -> 0.
+__device__ __forceinline__ int nearest_cooperative_fix(float X, float Y, bool certified, int j, const float* xy, int n) {
+  unsigned long long pending = __ballot(!certified);
+  const int lane = static_cast<int>(__lane_id());
+  while (pending != 0ull) {
+    const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(pending)) - 1);
+    pending &= pending - 1ull;
+    const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(X), src));
+    const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Y), src));
+    float best = __builtin_inff();
+    int jj = (lane < n) ? lane : 0x7fffffff;
+    for (int m = lane; m < n; m += kWave) {
+      const float d = dist2<float>(px, py, xy[m], xy[n + m]);
+      const bool better = d < best;
+      best = better ? d : best;
+      jj = better ? m : jj;
+    }
+#pragma unroll
+    for (int mask = 32; mask >= 1; mask >>= 1) {
+      const float ob = __shfl_xor(best, mask, kWave);
+      const int oj = __shfl_xor(jj, mask, kWave);
+      const bool take = (ob < best) || (ob == best && oj < jj);
+      best = take ? ob : best;
+      jj = take ? oj : jj;
+    }
+    const int found = __builtin_amdgcn_readfirstlane(jj);
+    j = (lane == src) ? found : j;
+  }
+  return j;
+}
+
+__device__ __forceinline__ int nearest_verified(float X, float Y, const float* xy, const float* thr, int n, int j_prev) {
+  bool certified;
+  const int j = nearest_verified_window(X, Y, xy, thr, n, j_prev, certified);
+  return nearest_cooperative_fix(X, Y, certified, j, xy, n);
 }
 
 // How a kernel searches: decided once per launch (the weights are wave-uniform), so the step loop itself is
 // branch-free and the scheduler can interleave the searches of the candidates a lane owns.
 constexpr int kSearchExhaustive = 0;
-constexpr int kSearchGeneric = -1;  // any window width, rolled loop; 8 and 4 name the unrolled widths
+constexpr int kSearchGeneric = -1;   // any window width, rolled loop; 8 and 4 name the unrolled widths
+constexpr int kSearchVerified = -2;  // exhaustive semantics through nearest_verified() (needs the threshold table)
 
-__device__ __forceinline__ int search_kind(const Weights& w, int n) {
-  if (w.nn_ahead < 0) return kSearchExhaustive;
+__device__ __forceinline__ int search_kind(const Weights& w, int n, bool has_thresholds = false) {
+  if (w.nn_ahead < 0) return (has_thresholds && n >= kVerifiedWindow) ? kSearchVerified : kSearchExhaustive;
   const int W = w.nn_back + w.nn_ahead + 1;
   return ((W == 8 || W == 4) && n >= W) ? W : kSearchGeneric;
 }
@@ -281,16 +360,62 @@ __device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v
   temporal_cost<float>(s, row, v, k, w);
 }
 
+// gather the table row(s) of the nearest waypoint(s) and account the step
+__device__ __forceinline__ void temporal_settle(StateT& s, const float* wp, int j, float v, float k, const Weights& w) {
+  temporal_cost(s, wp + j * kCoefT, v, k, w);
+}
+__device__ __forceinline__ void temporal_settle(StateT_<f32x2>& s, const float* wp, i32x2 j, f32x2 v, f32x2 k,
+                                                const Weights& w) {
+  f32x2 g[kCoefT];
+  const float* g0 = wp + j[0] * kCoefT;
+  const float* g1 = wp + j[1] * kCoefT;
+#pragma unroll
+  for (int q = 0; q < kCoefT; ++q) {
+    g[q][0] = g0[q];
+    g[q][1] = g1[q];
+  }
+  temporal_cost<f32x2>(s, g, v, k, w);
+}
+
+// The verified search in two phases, so that a kernel can run the window phase of ALL the candidates a lane owns
+// before the (rare, wave-wide) fallback phase and keep the window searches free of control flow.
+__device__ __forceinline__ int verified_window(const StateT& s, const float* xy, const float* thr, int n, int j_prev,
+                                               int& uncertified) {
+  bool ok;
+  const int j = nearest_verified_window(s.X, s.Y, xy, thr, n, j_prev, ok);
+  uncertified = ok ? 0 : 1;
+  return j;
+}
+__device__ __forceinline__ i32x2 verified_window(const StateT_<f32x2>& s, const float* xy, const float* thr, int n,
+                                                 i32x2 j_prev, int& uncertified) {
+  bool ok0, ok1;
+  i32x2 j;
+  j[0] = nearest_verified_window(s.X[0], s.Y[0], xy, thr, n, j_prev[0], ok0);
+  j[1] = nearest_verified_window(s.X[1], s.Y[1], xy, thr, n, j_prev[1], ok1);
+  uncertified = (ok0 ? 0 : 1) | (ok1 ? 0 : 2);
+  return j;
+}
+__device__ __forceinline__ int verified_fix(const StateT& s, const float* xy, int n, int j, int uncertified) {
+  return nearest_cooperative_fix(s.X, s.Y, uncertified == 0, j, xy, n);
+}
+__device__ __forceinline__ i32x2 verified_fix(const StateT_<f32x2>& s, const float* xy, int n, i32x2 j, int uncertified) {
+  j[0] = nearest_cooperative_fix(s.X[0], s.Y[0], (uncertified & 1) == 0, j[0], xy, n);
+  j[1] = nearest_cooperative_fix(s.X[1], s.Y[1], (uncertified & 2) == 0, j[1], xy, n);
+  return j;
+}
+
 // `wp` is the waypoint table (kCoefT floats per waypoint) and `xy` the planar copy of its positions (all x, then
 // all y); in the rollout kernels both live in LDS.  Returns the nearest index (per element) for the next step's
 // search window.
 template <int SEARCH>
 __device__ __forceinline__ int step_temporal_as(StateT& s, const float* wp, const float* xy, int n, float v, float k,
-                                                const Weights& w, int j_prev) {
+                                                const Weights& w, int j_prev, const float* thr = nullptr) {
   temporal_advance<float>(s, v, k, w);
   int j;
   if constexpr (SEARCH == kSearchExhaustive) {
     j = temporal_nearest<float>(s, wp, n);
+  } else if constexpr (SEARCH == kSearchVerified) {
+    j = nearest_verified(s.X, s.Y, xy, thr, n, j_prev);
   } else {
     j = temporal_nearest_window<SEARCH>(s.X, s.Y, xy, n, j_prev, w.nn_back, w.nn_ahead);
   }
@@ -300,11 +425,14 @@ __device__ __forceinline__ int step_temporal_as(StateT& s, const float* wp, cons
 
 template <int SEARCH>
 __device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float* wp, const float* xy, int n, f32x2 v,
-                                                  f32x2 k, const Weights& w, i32x2 j_prev) {
+                                                  f32x2 k, const Weights& w, i32x2 j_prev, const float* thr = nullptr) {
   temporal_advance<f32x2>(s, v, k, w);
   i32x2 j;
   if constexpr (SEARCH == kSearchExhaustive) {
     j = temporal_nearest<f32x2>(s, wp, n);
+  } else if constexpr (SEARCH == kSearchVerified) {
+    j[0] = nearest_verified(s.X[0], s.Y[0], xy, thr, n, j_prev[0]);
+    j[1] = nearest_verified(s.X[1], s.Y[1], xy, thr, n, j_prev[1]);
   } else {
     j[0] = temporal_nearest_window<SEARCH>(s.X[0], s.Y[0], xy, n, j_prev[0], w.nn_back, w.nn_ahead);
     j[1] = temporal_nearest_window<SEARCH>(s.X[1], s.Y[1], xy, n, j_prev[1], w.nn_back, w.nn_ahead);
@@ -323,9 +451,10 @@ __device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float
 
 // run `body(tag)` with tag::value = the launch's search kind (one wave-uniform branch for the whole rollout)
 template <typename Body>
-__device__ __forceinline__ void with_search_kind(const Weights& w, int n, Body&& body) {
-  switch (search_kind(w, n)) {
+__device__ __forceinline__ void with_search_kind(const Weights& w, int n, Body&& body, bool has_thresholds = false) {
+  switch (search_kind(w, n, has_thresholds)) {
     case kSearchExhaustive: body(std::integral_constant<int, kSearchExhaustive>{}); break;
+    case kSearchVerified: body(std::integral_constant<int, kSearchVerified>{}); break;
     case 8: body(std::integral_constant<int, 8>{}); break;
     case 4: body(std::integral_constant<int, 4>{}); break;
     default: body(std::integral_constant<int, kSearchGeneric>{}); break;

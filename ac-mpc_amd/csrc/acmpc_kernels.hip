@@ -105,11 +105,16 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   const float* __restrict__ x0 = a.x0 + p * 3;
 
   float* s_xy = s_wp + n * kCoefT;  // planar x | y copy for the windowed nearest-waypoint search
+  float* s_thr = s_xy + 2 * n;      // thresholds of the verified search (exhaustive semantics), when given
   if constexpr (MODE == 1) {
     for (int e = tid; e < n * kCoefT; e += BLOCK) s_wp[e] = coef[e];
     for (int e = tid; e < n; e += BLOCK) {
       s_xy[e] = coef[e * kCoefT];
       s_xy[n + e] = coef[e * kCoefT + 1];
+    }
+    if (a.nn_thr != nullptr) {
+      const float* __restrict__ thr = a.nn_thr + static_cast<size_t>(p) * n * kVerifiedWindow;
+      for (int e = tid; e < n * kVerifiedWindow; e += BLOCK) s_thr[e] = thr[e];
     }
     __syncthreads();
   }
@@ -122,7 +127,11 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
     feas[j] = false;
   }
 
-  if (active) {
+  // Mode T's verified nearest-waypoint search has a wave-cooperative fallback that every lane must reach, so there
+  // the tail lanes of the last workgroup roll a valid dummy (the problem's last candidates) instead of idling.
+  const bool run = active || (MODE == 1 && a.nn_thr != nullptr);
+  const int c_run = active ? c0 : max(a.N - CPT, 0);
+  if (run) {
     // two candidates per packed state (v_pk_* arithmetic) whenever the lane owns at least two
     constexpr int kPack = (CPT >= 2) ? 2 : 1;
     constexpr int kGroups = CPT / kPack;
@@ -155,7 +164,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
 #pragma unroll 7
       for (int i = 0; i < n; ++i) {
         float v[CPT], k[CPT];
-        load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
+        load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c_run, v, k);
         const float* __restrict__ c = coef + i * kCoefS;  // wave-uniform -> scalar loads
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) step_spatial<F>(st[g], c, pack(v, g), pack(k, g), w);
@@ -177,13 +186,33 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
       with_search_kind(w, n, [&](auto kind) {
         for (int i = 0; i < n; ++i) {
           float v[CPT], k[CPT];
-          load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c0, v, k);
+          load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c_run, v, k);
+          if constexpr (decltype(kind)::value == kSearchVerified) {
+            // phases across the lane's candidates: advance + window search of all (straight-line code), then the
+            // wave-wide fallback for whatever was not certified, then rows and costs
+            int uncertified[kGroups];
 #pragma unroll
-          for (int g = 0; g < kGroups; ++g)
-            nearest[g] = step_temporal_as<decltype(kind)::value>(st[g], s_wp, s_xy, n, pack(v, g), pack(k, g), w,
-                                                                 nearest[g]);
+            for (int g = 0; g < kGroups; ++g) {
+              temporal_advance<F>(st[g], pack(v, g), pack(k, g), w);
+              nearest[g] = verified_window(st[g], s_xy, s_thr, n, nearest[g], uncertified[g]);
+            }
+            int any = 0;
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) any |= uncertified[g];
+            if (__ballot(any != 0) != 0ull) {
+#pragma unroll
+              for (int g = 0; g < kGroups; ++g) nearest[g] = verified_fix(st[g], s_xy, n, nearest[g], uncertified[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) temporal_settle(st[g], s_wp, nearest[g], pack(v, g), pack(k, g), w);
+          } else {
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g)
+              nearest[g] = step_temporal_as<decltype(kind)::value>(st[g], s_wp, s_xy, n, pack(v, g), pack(k, g), w,
+                                                                   nearest[g], s_thr);
+          }
         }
-      });
+      }, a.nn_thr != nullptr);
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
         unpack_to(finish_temporal<F>(st[g], n, w), cost, g);
@@ -192,7 +221,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < CPT; ++j) feas[j] = viol[j] == 0.0f;
-    if (a.costs != nullptr) {
+    if (a.costs != nullptr && active) {
       using V = typename VecOf<CPT>::type;
       float* out = a.costs + static_cast<size_t>(p) * a.N + c0;
       if constexpr (CPT == 1) {
@@ -899,7 +928,9 @@ template <int MODE, int LAYOUT, int CPT, int BLOCK>
 hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                             hipEvent_t e1) {
   const dim3 grid(shape.blocks_per_problem, args.P);
-  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * (kCoefT + 2) * sizeof(float) : 0);
+  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * (kCoefT + 2 + (args.nn_thr != nullptr ? kVerifiedWindow : 0)) *
+                                           sizeof(float)
+                                     : 0);
   if (e0 != nullptr && e1 != nullptr) {
     hipExtLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK>), grid, dim3(BLOCK),
                           static_cast<std::uint32_t>(lds), s, e0, e1, 0, args);

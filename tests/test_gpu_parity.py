@@ -201,6 +201,52 @@ def test_maximum_horizon(mode, window):
         Engine(**engine_kwargs(prob, mode, 1, N, n + 1))
 
 
+@pytest.mark.parametrize("layout", [LAYOUT_CM, LAYOUT_SM])
+def test_verified_window_search_is_the_exhaustive_search(layout, monkeypatch):
+    """Mode T with the exhaustive specification runs as a verified window search (acmpc_device.h: nearest_verified).
+    On a path that folds back on itself - waypoints far apart in index are close in space, so the certification
+    thresholds are small and many candidates need the wave-wide fallback - with candidates that wander off their
+    stretch, costs must still equal the oracle's scan over ALL waypoints bit for bit, and the plain-scan
+    kernel's (ACMPC_NO_VERIFIED_SEARCH)."""
+    from acmpc_amd import Engine
+    H, N, P = 50, 1111, 2
+    n = H - 1
+    problems = []
+    for p, gap in enumerate((6.0, 9.0)):
+        prob = make_problem(orc, "monza", H, N, seed=640 + p, sigma=(6.0, 0.05))
+        # out along +y for 69 m, a tight turn, and back `gap` metres to the right: a candidate that drifts right is
+        # nearer to the return leg - forty waypoints further on - than to the stretch it is driving along
+        up = [(0.0, 3.0 * i) for i in range(24)]
+        turn = [(gap / 2 + gap / 2 * np.cos(a), 69.0 + gap / 2 * np.sin(a)) for a in np.radians([135.0, 90.0, 45.0])]
+        down = [(gap, 69.0 - 3.0 * i) for i in range(23)]
+        xy = np.array(up + turn + down)
+        table = orc.construct_waypoints(np.column_stack([xy, np.full(H, 9.5)]))
+        table[orc.ROW_V] = prob["table"][orc.ROW_V]
+        prob["table"] = table
+        problems.append(prob)
+    results = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("ACMPC_NO_VERIFIED_SEARCH", "1")
+        eng = Engine(**engine_kwargs(problems[0], 1, P, N, n))
+        eng.set_paths(np.stack([p["table"] for p in problems]))
+        x0 = np.stack([p["pose0"] for p in problems])
+        U = np.stack([p["U"] for p in problems])
+        results.append((eng.solve(x0, _as_layout(U, layout), layout=layout), [eng.coefficients(p) for p in range(P)]))
+    (out, coefs), (out_plain, _) = results
+    np.testing.assert_array_equal(out["costs"], out_plain["costs"])
+    np.testing.assert_array_equal(out["records"], out_plain["records"])
+    for p, prob in enumerate(problems):
+        cfg = prob["cfg"]
+        cost, viol, S, J = orc.rollout_temporal(prob["pose0"], coefs[p], prob["U"], cfg["step_cost"], cfg["r_term"],
+                                                cfg["final_cost"], prob["u_lo"], prob["u_hi"], 1.0e6, 0.05,
+                                                dtype=np.float32, return_states=True)
+        np.testing.assert_array_equal(out["costs"][p], cost)
+        assert out["best_idx"][p] == orc.pick_best(cost)[0]
+        # the input really is the hard case: some rollouts jump between far-apart stretches of the path
+        assert np.abs(np.diff(J, axis=1)).max() > 8
+
+
 def test_every_launch_shape_gives_the_same_bits(monkeypatch):
     """ACMPC_SHAPE forces the workgroup size / candidates per lane; results must not depend on it."""
     H, N, P = 50, 2048, 2
