@@ -60,3 +60,45 @@ def test_random_shapes_against_the_c_oracle():
                 np.testing.assert_array_equal(out["x"][p], states[best], err_msg=label)
                 np.testing.assert_array_equal(out["u"][p], prob["U"][best], err_msg=label)
         eng.close()
+
+
+def test_random_optimise_shapes_against_the_manual_round_loop():
+    """acmpc_optimize (fused sample + rollout + finalize launches, hipGraph) == the loop of sample_device and
+    solve_device calls, for random modes, windows, horizons, candidate counts, problem counts and round counts."""
+    import torch
+    from acmpc_amd import Engine, _capi
+    cases = max(20, int(os.environ.get("ACMPC_FUZZ_CASES", "40")))
+    rng = np.random.default_rng(777)
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    for index in range(cases):
+        mode = int(rng.integers(0, 2))
+        window = [None, (2, 5), (1, 2), (0, 2)][int(rng.integers(0, 4))] if mode == 1 else None
+        H = int(rng.choice([3, 9, 20, 50, 66, 100]))
+        N = int(rng.choice([1, 63, 64, 65, 500, 2048, 16384]))
+        P = int(rng.integers(1, 4))
+        rounds = int(rng.integers(1, 5))
+        n = H - 1
+        label = "case %d: mode %d window %s H %d N %d P %d rounds %d" % (index, mode, window, H, N, P, rounds)
+        problems = [make_problem(orc, "silverstone", H, 4, seed=12000 + 10 * index + p) for p in range(P)]
+        eng = Engine(**engine_kwargs(problems[0], mode, P, N, n, nn_window=window))
+        eng.set_paths(np.stack([p["table"] for p in problems]))
+        u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1)
+                          for p in problems]).astype(np.float32)
+        x0 = np.stack([p["x0"] if mode == 0 else p["pose0"] for p in problems])
+        sigma, seed = (3.0, 0.01), 100 + index
+        out = eng.optimize(x0, u_ref, u_ref, N, rounds, sigma, shrink=0.5, seed=seed)
+        R = _capi.record_floats(n)
+        d_x0, d_ref = torch.tensor(x0, device=dev), torch.tensor(u_ref, device=dev)
+        U = torch.empty(P, n, 2, N, device=dev)
+        rec = torch.empty(P, R, device=dev)
+        keys = torch.empty(P, dtype=torch.int64, device=dev)
+        for r in range(rounds):
+            centre_ptr, stride = (d_ref.data_ptr(), 2 * n) if r == 0 else (rec.data_ptr() + 4 * _capi.REC_HEADER, R)
+            eng.sample_device(centre_ptr, stride, d_ref.data_ptr(), P, N, n, 1, 0, (sigma[0] * 0.5**r, sigma[1] * 0.5**r),
+                              seed, r, U.data_ptr(), s)
+            eng.solve_device(d_x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, keys.data_ptr(), rec.data_ptr(), s)
+            torch.cuda.synchronize()
+        np.testing.assert_array_equal(out["records"], rec.cpu().numpy(), err_msg=label)
+        eng.close()
+
