@@ -8,7 +8,8 @@ against the QP's own box rows (`csrc/acmpc_device.h`), and the cheapest one wins
 A few refinement rounds (sample around the incumbent, shrink the spread) take the sampled optimum close to the QP
 optimum.  Candidates are generated on the device too (Philox counters, smooth perturbations - `acmpc_optimize`), so
 one solve is a single host round trip.  The rounds, the candidate count and the spread are build parameters read
-from optional config keys (`n_candidates`, `sampling_rounds`, `sampling_sigma`, `sampling_seed`, `w_bound`).
+from optional config keys (`n_candidates`, `sampling_rounds`, `sampling_sigma`, `sampling_cold_rounds`,
+`sampling_cold_sigma`, `sampling_seed`, `w_bound`, `sampling_update`, `softmin_lambda`).
 """
 from __future__ import annotations
 
@@ -22,10 +23,19 @@ from .reference_path import ReferencePath
 
 SOLVED = "solved"
 # Defaults from tools/sweep_solver_settings.py (600 warm-started solves along the synthetic Silverstone circuit, the
-# car up to 1 m off the centre line): 16 384 x 3 gives a lower plan cost than 4 096 x 4 in less time - one problem
-# of 4 096 candidates leaves three quarters of the chip's CUs idle, so candidates are nearly free, rounds are not.
+# car up to 1 m off the centre line; plan cost relative to the best setting per pose).  One problem of a few
+# thousand candidates leaves most of the chip idle, so candidates are nearly free and rounds are not; and the
+# spread has to fit the path: a curvature offset k bends the plan by ~k L^2 / 2 over the L = 150 m the horizon
+# covers, so 1e-3 1/m already sweeps the whole corridor.  16 384 x 2 rounds at (0.5 m/s, 1e-3 1/m): +0.15 % in 155 us;
+# the first settings of this build, 4 096 x 4 at (3 m/s, 1e-2 1/m): +0.5 % in 187 us.
 DEFAULT_CANDIDATES = 16384
-DEFAULT_ROUNDS = 3
+DEFAULT_ROUNDS = 2
+DEFAULT_SIGMA = (0.5, 1.0e-3)
+# A solve without a usable previous plan (the first one, or the one after an infeasible result) explores instead:
+# more rounds from a wide spread - the first settings of this build, which find a feasible plan from a cold start on
+# every scenario of the reference's own MPC script (tests/test_gpu_controller.py).
+COLD_ROUNDS = 4
+COLD_SIGMA = (3.0, 1.0e-2)
 INFEASIBLE = "primal infeasible"
 
 
@@ -36,7 +46,11 @@ class ControlSolver:
         self._max_iterations = config.get("max_iterations", 4000)
         self._n_candidates = int(config.get("n_candidates", DEFAULT_CANDIDATES))
         self._rounds = int(config.get("sampling_rounds", DEFAULT_ROUNDS))
-        self._sigma = np.asarray(config.get("sampling_sigma", (3.0, 0.01)), dtype=np.float64)
+        self._sigma = np.asarray(config.get("sampling_sigma", DEFAULT_SIGMA), dtype=np.float64)
+        self._cold_rounds = int(config.get("sampling_cold_rounds", max(COLD_ROUNDS, self._rounds)))
+        self._cold_sigma = np.asarray(config.get("sampling_cold_sigma", np.maximum(COLD_SIGMA, self._sigma)),
+                                      dtype=np.float64)
+        self._explore = True
         self._seed = int(config.get("sampling_seed", 0))
         self._solves = 0
         self._Q = np.asarray(config["step_cost"], dtype=np.float64)
@@ -87,19 +101,28 @@ class ControlSolver:
         lo, hi = self._box
         u_ref = np.clip(np.stack([reference_path.velocities, reference_path.kappas], axis=1), lo, hi)
         warm = self._incumbent is not None and self._incumbent.shape == u_ref.shape
-        centre = self._incumbent if warm else u_ref
-        self._solves += 1
-        # sample -> rollout + cost -> argmin, `rounds` times, entirely on the device (acmpc_optimize)
-        best = engine.optimize(np.asarray(spatial_state, dtype=np.float32)[None], centre[None], u_ref[None],
-                               self._n_candidates, self._rounds, self._sigma, shrink=0.5,
-                               seed=self._seed + self._solves)
-        u_star = best["u"][0].astype(np.float64)
-        x_star = best["x"][0].astype(np.float64)
-        self._incumbent = u_star
-        # accept a residual bound violation the way the reference's solver does: within eps_abs + eps_rel * |z|
-        tolerance = 1e-3 + 1e-3 * max(np.abs(x_star).max(), np.abs(u_star).max())
-        violation = float(best["violation"][0])
-        status = SOLVED if violation <= n * tolerance**2 else INFEASIBLE
+        explore = self._explore or not warm
+        x0 = np.asarray(spatial_state, dtype=np.float32)[None]
+        total_rounds = 0
+        while True:
+            centre = self._incumbent if warm else u_ref
+            rounds, sigma = (self._cold_rounds, self._cold_sigma) if explore else (self._rounds, self._sigma)
+            self._solves += 1
+            total_rounds += rounds
+            # sample -> rollout + cost -> argmin, `rounds` times, entirely on the device (acmpc_optimize)
+            best = engine.optimize(x0, centre[None], u_ref[None], self._n_candidates, rounds, sigma, shrink=0.5,
+                                   seed=self._seed + self._solves)
+            u_star = best["u"][0].astype(np.float64)
+            x_star = best["x"][0].astype(np.float64)
+            self._incumbent, warm = u_star, True
+            # accept a residual bound violation the way the reference's solver does: within eps_abs + eps_rel * |z|
+            tolerance = 1e-3 + 1e-3 * max(np.abs(x_star).max(), np.abs(u_star).max())
+            violation = float(best["violation"][0])
+            status = SOLVED if violation <= n * tolerance**2 else INFEASIBLE
+            if status == SOLVED or explore:
+                break
+            explore = True    # the refining schedule failed (the path jumped under the old plan): explore once, now
+        self._explore = status != SOLVED      # refine from a good plan, explore again after a bad one
         info = SimpleNamespace(status=status, obj_val=float(best["cost"][0]), violation=violation,
-                               n_feasible=int(best["n_feasible"][0]), iter=self._rounds)
+                               n_feasible=int(best["n_feasible"][0]), iter=total_rounds)
         return SimpleNamespace(x=np.concatenate([x_star.ravel(), u_star.ravel()]), info=info)

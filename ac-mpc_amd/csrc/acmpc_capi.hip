@@ -67,7 +67,6 @@ struct acmpc_ctx {
   // acmpc_optimize as a hipGraph: the whole sample -> rollout -> finalize chain of `rounds` rounds plus the
   // transfers either side of it is captured once per shape and replayed; per-call inputs travel through the pinned
   // staging block `h_opt` (x0 | centre | u_ref | table | seed) and the records come back into `h_opt_records`.
-  hipGraphExec_t opt_graph = nullptr;
   struct OptKey {
     int P = 0, N = 0, n = 0, rounds = 0, has_uref = 0;
     double sigma_v = 0, sigma_k = 0, shrink = 0;
@@ -75,7 +74,14 @@ struct acmpc_ctx {
       return P == o.P && N == o.N && n == o.n && rounds == o.rounds && has_uref == o.has_uref &&
              sigma_v == o.sigma_v && sigma_k == o.sigma_k && shrink == o.shrink;
     }
-  } opt_key;
+  };
+  // a few captured shapes side by side (a controller alternates between its exploring and its refining schedule);
+  // the least recently used slot is re-captured when a new shape arrives
+  static constexpr int kOptGraphs = 4;
+  hipGraphExec_t opt_graph[kOptGraphs] = {nullptr, nullptr, nullptr, nullptr};
+  OptKey opt_key[kOptGraphs];
+  uint64_t opt_used[kOptGraphs] = {0, 0, 0, 0};
+  uint64_t opt_clock = 0;
   unsigned char* h_opt = nullptr;   // pinned
   unsigned char* d_opt = nullptr;   // device mirror of h_opt: ONE H2D copy per solve
   size_t opt_capacity = 0;
@@ -442,7 +448,8 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_tickets);
     (void)hipFree(c->d_nn_thr);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
-    if (c->opt_graph != nullptr) (void)hipGraphExecDestroy(c->opt_graph);
+    for (hipGraphExec_t g : c->opt_graph)
+      if (g != nullptr) (void)hipGraphExecDestroy(g);
     if (c->h_opt != nullptr) (void)hipHostFree(c->h_opt);
     if (c->h_opt_records != nullptr) (void)hipHostFree(c->h_opt_records);
     (void)hipFree(c->d_seed);
@@ -816,10 +823,16 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   key.sigma_v = sigma[0];
   key.sigma_k = sigma[1];
   key.shrink = shrink;
-  if (c->opt_graph == nullptr || !(key == c->opt_key)) {
-    if (c->opt_graph != nullptr) {
-      (void)hipGraphExecDestroy(c->opt_graph);
-      c->opt_graph = nullptr;
+  int slot = -1;
+  for (int g = 0; g < acmpc_ctx::kOptGraphs; ++g)
+    if (c->opt_graph[g] != nullptr && key == c->opt_key[g]) slot = g;
+  if (slot < 0) {
+    slot = 0;
+    for (int g = 1; g < acmpc_ctx::kOptGraphs; ++g)
+      if (c->opt_used[g] < c->opt_used[slot]) slot = g;
+    if (c->opt_graph[slot] != nullptr) {
+      (void)hipGraphExecDestroy(c->opt_graph[slot]);
+      c->opt_graph[slot] = nullptr;
     }
     rc = upload_segments(c, n, s);  // must not happen inside the capture (it synchronises)
     if (rc != ACMPC_OK) return rc;
@@ -862,18 +875,20 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
       return fail_hip(c, e, "capturing the optimisation graph");
     }
     ACMPC_HIP(c, e_end);
-    const hipError_t e_inst = hipGraphInstantiate(&c->opt_graph, graph, nullptr, nullptr, 0);
+    const hipError_t e_inst = hipGraphInstantiate(&c->opt_graph[slot], graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
+    if (e_inst != hipSuccess) c->opt_graph[slot] = nullptr;
     ACMPC_HIP(c, e_inst);
-    c->opt_key = key;
+    c->opt_key[slot] = key;
   }
+  c->opt_used[slot] = ++c->opt_clock;
   std::memcpy(c->h_opt + off_x0, x0, x0_bytes);
   std::memcpy(c->h_opt + off_centre, centre, path_bytes);
   if (has_uref) std::memcpy(c->h_opt + off_uref, u_ref, path_bytes);
   std::memcpy(c->h_opt + off_table, c->h_coef.data(), table_bytes);
   const uint32_t seed_words[2] = {static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
   std::memcpy(c->h_opt + off_seed, seed_words, sizeof seed_words);
-  ACMPC_HIP(c, hipGraphLaunch(c->opt_graph, s));
+  ACMPC_HIP(c, hipGraphLaunch(c->opt_graph[slot], s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
   std::memcpy(records, c->h_opt_records, rec_bytes);
   return ACMPC_OK;

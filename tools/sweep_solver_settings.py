@@ -14,8 +14,11 @@ sys.path.insert(0, os.path.join(ROOT, "ac-mpc_amd"))
 from acmpc_amd import workloads  # noqa: E402
 from acmpc_amd.mpc import build_mpc  # noqa: E402
 
-SETTINGS = [(4096, 4), (4096, 3), (4096, 2), (8192, 3), (8192, 2), (16384, 3), (16384, 2), (32768, 2), (65536, 4)]
-
+# (candidates per round, rounds, sigma of v [m/s], sigma of kappa [1/m] in round 0 - halved every round)
+SETTINGS = [(16384, 3, 3.0, 0.01), (16384, 3, 1.0, 0.001), (16384, 2, 1.0, 0.001), (16384, 2, 0.5, 0.001),
+            (16384, 2, 2.0, 0.001), (16384, 2, 1.0, 0.002), (16384, 2, 1.0, 0.0005), (16384, 2, 0.5, 0.0005),
+            (32768, 2, 1.0, 0.001), (16384, 3, 0.5, 0.0005), (16384, 3, 1.0, 0.002), (8192, 2, 1.0, 0.001),
+            (65536, 4, 1.0, 0.001)]
 
 def main(poses=600):
     track = workloads.synthetic_track("silverstone")
@@ -30,7 +33,7 @@ def main(poses=600):
     costs, walls = {}, {}
     for setting in SETTINGS:
         cfg = copy.deepcopy(base)
-        cfg.update(n_candidates=setting[0], sampling_rounds=setting[1])
+        cfg.update(n_candidates=setting[0], sampling_rounds=setting[1], sampling_sigma=(setting[2], setting[3]))
         mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
         solver = mpc._control_solver
         seen = []
@@ -50,11 +53,13 @@ def main(poses=600):
         costs[setting], walls[setting] = np.array(seen), wall
         assert mpc.infeasibility_counter == 0
     best = np.min(np.stack([costs[s] for s in SETTINGS]), axis=0)
-    print("%9s %6s %10s %10s %14s %14s" % ("N", "rounds", "p50 us", "p99 us", "mean excess", "max excess"))
+    print("%9s %6s %8s %8s %10s %10s %14s %14s" % ("N", "rounds", "sigma_v", "sigma_k", "p50 us", "p99 us", "mean excess",
+                                                     "max excess"))
     for s in SETTINGS:
         excess = (costs[s] - best) / (np.abs(best) + 1.0)
-        print("%9d %6d %10.1f %10.1f %14.3g %14.3g" % (s[0], s[1], np.percentile(walls[s][20:], 50) * 1e6,
-                                                      np.percentile(walls[s][20:], 99) * 1e6, excess[20:].mean(), excess[20:].max()))
+        print("%9d %6d %8g %8g %10.1f %10.1f %14.3g %14.3g" % (s[0], s[1], s[2], s[3], np.percentile(walls[s][20:], 50) * 1e6,
+                                                              np.percentile(walls[s][20:], 99) * 1e6, excess[20:].mean(),
+                                                              excess[20:].max()))
 
 
 if __name__ == "__main__":
