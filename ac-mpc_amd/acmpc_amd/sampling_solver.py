@@ -50,6 +50,7 @@ class ControlSolver:
         self._cold_rounds = int(config.get("sampling_cold_rounds", max(COLD_ROUNDS, self._rounds)))
         self._cold_sigma = np.asarray(config.get("sampling_cold_sigma", np.maximum(COLD_SIGMA, self._sigma)),
                                       dtype=np.float64)
+        self._shrink = float(config.get("sampling_shrink", 0.5))     # spread of round r = sigma * shrink**r
         self._explore = True
         self._seed = int(config.get("sampling_seed", 0))
         self._solves = 0
@@ -110,7 +111,7 @@ class ControlSolver:
             self._solves += 1
             total_rounds += rounds
             # sample -> rollout + cost -> argmin, `rounds` times, entirely on the device (acmpc_optimize)
-            best = engine.optimize(x0, centre[None], u_ref[None], self._n_candidates, rounds, sigma, shrink=0.5,
+            best = engine.optimize(x0, centre[None], u_ref[None], self._n_candidates, rounds, sigma, shrink=self._shrink,
                                    seed=self._seed + self._solves)
             u_star = best["u"][0].astype(np.float64)
             x_star = best["x"][0].astype(np.float64)

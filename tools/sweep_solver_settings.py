@@ -14,11 +14,13 @@ sys.path.insert(0, os.path.join(ROOT, "ac-mpc_amd"))
 from acmpc_amd import workloads  # noqa: E402
 from acmpc_amd.mpc import build_mpc  # noqa: E402
 
-# (candidates per round, rounds, sigma of v [m/s], sigma of kappa [1/m] in round 0 - halved every round)
-SETTINGS = [(16384, 3, 3.0, 0.01), (16384, 3, 1.0, 0.001), (16384, 2, 1.0, 0.001), (16384, 2, 0.5, 0.001),
-            (16384, 2, 2.0, 0.001), (16384, 2, 1.0, 0.002), (16384, 2, 1.0, 0.0005), (16384, 2, 0.5, 0.0005),
-            (32768, 2, 1.0, 0.001), (16384, 3, 0.5, 0.0005), (16384, 3, 1.0, 0.002), (8192, 2, 1.0, 0.001),
-            (65536, 4, 1.0, 0.001)]
+# (candidates per round, rounds, sigma of v [m/s], sigma of kappa [1/m] in round 0, shrink per round)
+SETTINGS = [(4096, 4, 3.0, 0.01, 0.5),       # the first settings of this build
+            (16384, 3, 3.0, 0.01, 0.5),      # more candidates, fewer rounds, same spread
+            (16384, 3, 0.5, 0.001, 0.5), (16384, 2, 0.5, 0.001, 0.5),   # a spread that fits the corridor (2 rounds = default)
+            (16384, 2, 0.5, 0.001, 0.25), (16384, 2, 1.0, 0.002, 0.5), (16384, 2, 0.5, 0.0005, 0.5),
+            (16384, 1, 0.5, 0.001, 0.5), (32768, 2, 0.5, 0.001, 0.5),
+            (65536, 4, 1.0, 0.001, 0.5)]     # the yardstick
 
 def main(poses=600):
     track = workloads.synthetic_track("silverstone")
@@ -33,7 +35,8 @@ def main(poses=600):
     costs, walls = {}, {}
     for setting in SETTINGS:
         cfg = copy.deepcopy(base)
-        cfg.update(n_candidates=setting[0], sampling_rounds=setting[1], sampling_sigma=(setting[2], setting[3]))
+        cfg.update(n_candidates=setting[0], sampling_rounds=setting[1], sampling_sigma=(setting[2], setting[3]),
+                   sampling_shrink=setting[4])
         mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
         solver = mpc._control_solver
         seen = []
@@ -53,11 +56,11 @@ def main(poses=600):
         costs[setting], walls[setting] = np.array(seen), wall
         assert mpc.infeasibility_counter == 0
     best = np.min(np.stack([costs[s] for s in SETTINGS]), axis=0)
-    print("%9s %6s %8s %8s %10s %10s %14s %14s" % ("N", "rounds", "sigma_v", "sigma_k", "p50 us", "p99 us", "mean excess",
-                                                     "max excess"))
+    print("%9s %6s %8s %8s %7s %10s %10s %14s %14s" % ("N", "rounds", "sigma_v", "sigma_k", "shrink", "p50 us", "p99 us",
+                                                         "mean excess", "max excess"))
     for s in SETTINGS:
         excess = (costs[s] - best) / (np.abs(best) + 1.0)
-        print("%9d %6d %8g %8g %10.1f %10.1f %14.3g %14.3g" % (s[0], s[1], s[2], s[3], np.percentile(walls[s][20:], 50) * 1e6,
+        print("%9d %6d %8g %8g %7g %10.1f %10.1f %14.3g %14.3g" % (s[0], s[1], s[2], s[3], s[4], np.percentile(walls[s][20:], 50) * 1e6,
                                                               np.percentile(walls[s][20:], 99) * 1e6, excess[20:].mean(),
                                                               excess[20:].max()))
 
