@@ -21,7 +21,15 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    # gpurun MERGES a call's files into gpurun_out/ and never deletes: after several profile runs the directory holds
+    # one set of CSVs per run (the process id is in the file name).  Only the newest of each kind is this run's.
+    def newest(pattern):
+        found = glob.glob(os.path.join(src, pattern), recursive=True)
+        if not found:
+            raise SystemExit("no %s under %s - run tools/profile.sh %s on the GPU box first" % (pattern, src, tag))
+        return max(found, key=os.path.getmtime)
+
+    stats = newest(os.path.join("trace", "**", "*_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     rows.sort(key=lambda r: (0 if "acmpc" in r["Name"] else 1, -float(r["TotalDurationNs"])))
     with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
@@ -30,7 +38,8 @@ def main():
         w.writerows(rows)
     dom = [r for r in rows if needle in r["Name"]][0]
     counters = collections.defaultdict(list)
-    for path in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+    for pass_dir in sorted(d for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)):
+        path = newest(os.path.join(os.path.basename(pass_dir), "**", "*_counter_collection.csv"))
         for r in csv.DictReader(open(path)):
             if r["Kernel_Name"] == dom["Name"]:
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
