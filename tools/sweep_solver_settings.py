@@ -20,6 +20,8 @@ SETTINGS = [(4096, 4, 3.0, 0.01, 0.5),       # the first settings of this build
             (16384, 3, 0.5, 0.001, 0.5), (16384, 2, 0.5, 0.001, 0.5),   # a spread that fits the corridor (2 rounds = default)
             (16384, 2, 0.5, 0.001, 0.25), (16384, 2, 1.0, 0.002, 0.5), (16384, 2, 0.5, 0.0005, 0.5),
             (16384, 1, 0.5, 0.001, 0.5), (32768, 2, 0.5, 0.001, 0.5),
+            (16384, 2, 0.5, 0.001, 0.5, "softmin", 0.01), (16384, 2, 0.5, 0.001, 0.5, "softmin", 0.1),
+            (16384, 3, 0.5, 0.001, 0.5, "softmin", 0.03),
             (65536, 4, 1.0, 0.001, 0.5)]     # the yardstick
 
 def main(poses=600):
@@ -37,6 +39,8 @@ def main(poses=600):
         cfg = copy.deepcopy(base)
         cfg.update(n_candidates=setting[0], sampling_rounds=setting[1], sampling_sigma=(setting[2], setting[3]),
                    sampling_shrink=setting[4])
+        if len(setting) > 5:
+            cfg.update(sampling_update=setting[5], softmin_lambda=setting[6])
         mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
         solver = mpc._control_solver
         seen = []
@@ -60,9 +64,9 @@ def main(poses=600):
                                                          "mean excess", "max excess"))
     for s in SETTINGS:
         excess = (costs[s] - best) / (np.abs(best) + 1.0)
-        print("%9d %6d %8g %8g %7g %10.1f %10.1f %14.3g %14.3g" % (s[0], s[1], s[2], s[3], s[4], np.percentile(walls[s][20:], 50) * 1e6,
-                                                              np.percentile(walls[s][20:], 99) * 1e6, excess[20:].mean(),
-                                                              excess[20:].max()))
+        print("%9d %6d %8g %8g %7g %10.1f %10.1f %14.3g %14.3g  %s" % (
+            s[0], s[1], s[2], s[3], s[4], np.percentile(walls[s][20:], 50) * 1e6, np.percentile(walls[s][20:], 99) * 1e6,
+            excess[20:].mean(), excess[20:].max(), "argmin" if len(s) < 6 else "%s lambda=%g" % (s[5], s[6])))
 
 
 if __name__ == "__main__":
