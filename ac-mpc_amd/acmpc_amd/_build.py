@@ -9,7 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libacmpc_hip.so")
-SOURCES = ("acmpc_kernels.hip", "acmpc_capi.hip", "acmpc_pf.hip", "acmpc_speed_profile.cpp")
+SOURCES = ("acmpc_kernels.hip", "acmpc_capi.hip", "acmpc_pf.hip", "acmpc_speed_profile.cpp", "acmpc_host_path.cpp")
 HEADERS = ("acmpc_kernels.h", "acmpc_device.h", os.path.join("..", "..", "include", "acmpc.h"))
 
 # -ffp-contract=off: the kernels' float32 arithmetic is specified without fused multiply-add

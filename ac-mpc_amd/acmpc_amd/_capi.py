@@ -81,7 +81,7 @@ SIGNATURES = {
     "acmpc_create": (C.c_int, [C.POINTER(Params), C.POINTER(_CTX)]),
     "acmpc_destroy": (None, [_CTX]),
     "acmpc_last_error": (C.c_char_p, [_CTX]),
-    "acmpc_set_paths": (C.c_int, [_CTX, _F64P, C.c_int32, C.c_int32]),
+    "acmpc_set_paths": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
     "acmpc_get_coefficients": (C.c_int, [_CTX, C.c_int32, _F32P, C.c_int32]),
     "acmpc_record_floats": (C.c_int32, [C.c_int32]),
     "acmpc_solve": (C.c_int, [_CTX, _F32P, _F32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F32P, _I32P, _F32P]),
@@ -101,11 +101,17 @@ SIGNATURES = {
                                                 C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
                                                 C.c_uint32, C.c_void_p, C.c_void_p]),
     "acmpc_reduce_across_ranks": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    "acmpc_optimize": (C.c_int, [_CTX, _F32P, _F32P, _F32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F64P,
-                                 C.c_double, C.c_uint64, _F32P]),
+    # the closed-loop entry points take their buffers as plain addresses (arr.ctypes.data): half the marshalling cost
+    # of typed pointers, which at these sizes is most of the call
+    "acmpc_optimize": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_double, C.c_uint64, C.c_void_p]),
+    "acmpc_waypoint_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
+    "acmpc_velocity_ceiling": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                         C.c_int32, C.c_double, C.c_void_p]),
+    "acmpc_unpack_decision": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_double] + [C.c_void_p] * 6),
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
-    "acmpc_speed_profile_qp": (C.c_int, [_F64P, _F64P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
-                                         C.c_double, C.c_double, _F64P, _F64P, C.c_int32, _I32P]),
+    "acmpc_speed_profile_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, _I32P]),
     "acmpc_pf_create": (C.c_int, [C.POINTER(PfParams), _F64P, C.c_int32, _F64P, C.c_int32, _F64P, C.c_int32,
                                   C.POINTER(_CTX)]),
     "acmpc_pf_destroy": (None, [_CTX]),
@@ -220,7 +226,7 @@ class Engine:
             t = t[None]
         if t.ndim != 3 or t.shape[1] != 7:
             raise ValueError("tables must be [P, 7, n]")
-        self._check(self._lib.acmpc_set_paths(self._ctx, t.ctypes.data_as(_F64P), t.shape[0], t.shape[2]))
+        self._check(self._lib.acmpc_set_paths(self._ctx, t.ctypes.data, t.shape[0], t.shape[2]))
         self.P, self.n = t.shape[0], t.shape[2]
 
     def coefficients(self, problem: int = 0) -> np.ndarray:
@@ -278,10 +284,11 @@ class Engine:
         ref = None
         if u_ref is not None:
             ref = np.ascontiguousarray(u_ref, dtype=np.float32).reshape(P, n, 2)
-        sig = (C.c_double * 2)(float(sigma[0]), float(sigma[1]))
+        sig = np.array([sigma[0], sigma[1]], dtype=np.float64)
         rec = np.empty((P, record_floats(n)), dtype=np.float32)
-        self._check(self._lib.acmpc_optimize(self._ctx, _f32(x0), _f32(centre), _f32(ref) if ref is not None else None,
-                                             P, n_candidates, n, rounds, sig, float(shrink), seed, _f32(rec)))
+        self._check(self._lib.acmpc_optimize(self._ctx, x0.ctypes.data, centre.ctypes.data,
+                                             ref.ctypes.data if ref is not None else None, P, n_candidates, n, rounds,
+                                             sig.ctypes.data, float(shrink), seed, rec.ctypes.data))
         out = split_record(rec, n)
         out["records"] = rec
         return out
@@ -324,6 +331,50 @@ class Engine:
                                                    d_weight_sum or None, stream or None))
 
 
+def waypoint_table(coords: np.ndarray, eps: float = 1e-12) -> np.ndarray:
+    """H x 3 (x, y, width) -> 7 x n ReferencePath table (native; spatial_mpc.py:125-154)."""
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    if coords.ndim != 2 or coords.shape[1] != 3:
+        raise ValueError("waypoint coordinates must be H x 3")
+    table = np.empty((7, coords.shape[0] - 1))
+    if load_library().acmpc_waypoint_table(coords.ctypes.data, coords.shape[0], eps, table.ctypes.data) != OK:
+        raise EngineError(EINVAL, "acmpc_waypoint_table: need at least 3 points")
+    return table
+
+
+def velocity_ceiling(kappa: np.ndarray, ay_max: float, ki_min: float, v_min: float, v_max: float, localised: bool,
+                     end_velocity) -> np.ndarray:
+    kappa = np.ascontiguousarray(kappa, dtype=np.float64)
+    out = np.empty(kappa.shape[0])
+    rc = load_library().acmpc_velocity_ceiling(kappa.ctypes.data, kappa.shape[0], float(ay_max), float(ki_min),
+                                               float(v_min), float(v_max), 1 if localised else 0,
+                                               0 if end_velocity is None else 1,
+                                               0.0 if end_velocity is None else float(end_velocity), out.ctypes.data)
+    if rc != OK:
+        raise EngineError(rc, "acmpc_velocity_ceiling: bad arguments")
+    return out
+
+
+_unpack_buffers = {}   # n -> (arrays, their addresses): persistent outputs, copied out per call
+
+
+def unpack_decision(z: np.ndarray, n: int, table: np.ndarray, wheelbase: float):
+    """dec.x -> (projected_control [2,n], prediction [n,2], cum_time [n], times, accelerations, steer_rates [n-1])."""
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    if z.shape[0] != 5 * n + 3 or table.shape != (7, n):
+        raise ValueError("decision vector / table do not match n = %d" % n)
+    cached = _unpack_buffers.get(n)
+    if cached is None:
+        arrays = (np.empty((2, n)), np.empty((n, 2)), np.empty(n), np.empty(n - 1), np.empty(n - 1), np.empty(n - 1))
+        cached = _unpack_buffers[n] = (arrays, tuple(a.ctypes.data for a in arrays))
+    arrays, addresses = cached
+    rc = load_library().acmpc_unpack_decision(z.ctypes.data, n, table.ctypes.data, float(wheelbase), *addresses)
+    if rc != OK:
+        raise EngineError(rc, "acmpc_unpack_decision: bad arguments")
+    return tuple(a.copy() for a in arrays)
+
+
 def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: float, v_min: float, max_iter: int = 4000,
                      eps_abs: float = 1e-3, eps_rel: float = 1e-3, warm=None):
     """Native tridiagonal ADMM for the speed-profile QP; returns (v, y, status, iterations)."""
@@ -335,10 +386,10 @@ def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: floa
     if warm is not None:
         v[:], y[:] = warm
     iters = C.c_int32(0)
-    rc = load_library().acmpc_speed_profile_qp(v_hi.ctypes.data_as(_F64P), ds.ctypes.data_as(_F64P), n, float(a_min),
-                                               float(a_max), float(v_min), int(max_iter), float(eps_abs), float(eps_rel),
-                                               v.ctypes.data_as(_F64P), y.ctypes.data_as(_F64P),
-                                               1 if warm is not None else 0, C.byref(iters))
+    rc = load_library().acmpc_speed_profile_qp(v_hi.ctypes.data, ds.ctypes.data, n, float(a_min), float(a_max),
+                                               float(v_min), int(max_iter), float(eps_abs), float(eps_rel),
+                                               v.ctypes.data, y.ctypes.data, 1 if warm is not None else 0,
+                                               C.byref(iters))
     if rc < 0:
         raise EngineError(rc, "acmpc_speed_profile_qp: bad arguments")
     return v, y, ("solved" if rc == 0 else "maximum iterations reached"), iters.value

@@ -15,6 +15,7 @@ from typing import Dict
 
 import numpy as np
 
+from . import _capi
 from .bicycle_model import SpatialBicycleModel, wrap_angle
 from .reference_path import ReferencePath
 from .sampling_solver import SOLVED, ControlSolver
@@ -27,7 +28,14 @@ MAX_SOLVER_ITERATIONS = 4000
 
 
 def waypoint_table(waypoint_coordinates: np.ndarray, eps: float = 1e-12) -> np.ndarray:
-    """H x 3 `[x, y, width]` -> 7 x n table with n = H - 1 (what spatial_mpc.py:125-154 computes).
+    """H x 3 `[x, y, width]` -> 7 x n table with n = H - 1 (what spatial_mpc.py:125-154 computes), by the library's
+    host routine (`acmpc_waypoint_table`: the same operations as `waypoint_table_numpy` below without ten NumPy
+    dispatches on 50-element arrays)."""
+    return _capi.waypoint_table(waypoint_coordinates, eps)
+
+
+def waypoint_table_numpy(waypoint_coordinates: np.ndarray, eps: float = 1e-12) -> np.ndarray:
+    """The NumPy statement of `waypoint_table` (tests hold the two to 1e-12 and both to the reference's vectors).
 
     Heading and spacing come from the segment to the next point, the width is the next point's, curvature is
     the wrapped heading change against the previous segment over the spacing.  The previous segment of point 0
@@ -125,15 +133,9 @@ class SpatialMPC:
             self.infeasibility_counter += 1
             return
 
-        controls = np.array(dec.x[-n * self.nu:]).reshape(n, self.nu)
-        self.projected_control = np.array([controls[:, 0], np.arctan(controls[:, 1] * self.model.length)])
-        states = np.reshape(dec.x[: n * self.nx], (n, self.nx))
-        self.current_prediction = self.update_prediction(states, path)
+        (self.projected_control, self.current_prediction, self.cum_time, self.times, self.accelerations,
+         self.steer_rates) = _capi.unpack_decision(dec.x, n, path.table, self.model.length)
         self.reference_path = path
-        self.cum_time = states[:, 2]
-        self.times = np.diff(states[:, 2])
-        self.accelerations = np.diff(states[:, 0]) / self.times
-        self.steer_rates = np.diff(states[:, 1]) / self.times
         self.infeasibility_counter = 0
 
 

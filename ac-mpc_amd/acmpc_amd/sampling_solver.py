@@ -65,20 +65,20 @@ class ControlSolver:
 
     # QP input box, widened by 0.1 m/s like the reference (control.py:130-139)
     def _input_box(self):
-        lo = np.array([self._dynamics_model.min_u[0] - 0.1, self._dynamics_model.min_u[1]])
-        hi = np.array([self._dynamics_model.max_u[0] + 0.1, self._dynamics_model.max_u[1]])
-        return lo, hi
+        model = self._dynamics_model
+        return (float(model.min_u[0]) - 0.1, float(model.min_u[1]), float(model.max_u[0]) + 0.1, float(model.max_u[1]))
 
     def _ensure_engine(self):
-        lo, hi = self._input_box()
-        if self._engine is None or not (np.array_equal(lo, self._box[0]) and np.array_equal(hi, self._box[1])):
+        box = self._input_box()
+        if self._engine is None or box != self._box_key:
             if self._engine is not None:
                 self._engine.close()
-            self._box = (lo, hi)
+            self._box_key = box
+            self._box = (np.array(box[:2]), np.array(box[2:]))
             self._engine = _capi.Engine(
                 mode=_capi.MODE_SPATIAL, max_problems=1, max_candidates=self._n_candidates,
-                max_steps=self._n_horizon, step_cost=self._Q, r_term=self._R, final_cost=self._QN, u_min=lo,
-                u_max=hi, margin=self._dynamics_model.margin, wheelbase=self._dynamics_model.length,
+                max_steps=self._n_horizon, step_cost=self._Q, r_term=self._R, final_cost=self._QN, u_min=self._box[0],
+                u_max=self._box[1], margin=self._dynamics_model.margin, wheelbase=self._dynamics_model.length,
                 w_bound=self._w_bound, centre_update=self._centre_update, softmin_lambda=self._lambda)
         return self._engine
 
@@ -100,7 +100,9 @@ class ControlSolver:
         n = self._n_horizon
         engine.set_paths(reference_path.table)
         lo, hi = self._box
-        u_ref = np.clip(np.stack([reference_path.velocities, reference_path.kappas], axis=1), lo, hi)
+        u_ref = np.empty((n, 2))
+        np.clip(reference_path.velocities, lo[0], hi[0], out=u_ref[:, 0])
+        np.clip(reference_path.kappas, lo[1], hi[1], out=u_ref[:, 1])
         warm = self._incumbent is not None and self._incumbent.shape == u_ref.shape
         explore = self._explore or not warm
         x0 = np.asarray(spatial_state, dtype=np.float32)[None]

@@ -30,7 +30,15 @@ class SpeedProfileSolver:
         self._warm = None
 
     # -- the QP's data ------------------------------------------------------------------------------------
+    _localised = False
+
     def velocity_ceiling(self, reference_path: ReferencePath, end_velocity: Optional[float]) -> np.ndarray:
+        c = self._constraints
+        return _capi.velocity_ceiling(reference_path.kappas, c["ay_max"], c["ki_min"], c["v_min"], c["v_max"],
+                                      self._localised, end_velocity)
+
+    def velocity_ceiling_numpy(self, reference_path: ReferencePath, end_velocity: Optional[float]) -> np.ndarray:
+        """The NumPy statement of `velocity_ceiling` (speed_profile.py:26-43), kept for the tests."""
         c = self._constraints
         curvature = np.abs(reference_path.kappas)
         ceiling = np.sqrt(c["ay_max"] / (curvature + self._eps))
@@ -70,5 +78,7 @@ class SpeedProfileSolver:
 class LocalisedSpeedProfileSolver(SpeedProfileSolver):
     """Once localised the ceiling is the map-derived reference speed itself (speed_profile.py:131-150)."""
 
-    def velocity_ceiling(self, reference_path: ReferencePath, end_velocity: Optional[float]) -> np.ndarray:
+    _localised = True
+
+    def velocity_ceiling_numpy(self, reference_path: ReferencePath, end_velocity: Optional[float]) -> np.ndarray:
         return np.full(self._n_horizon, float(self._constraints["v_max"]))

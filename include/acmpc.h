@@ -201,6 +201,22 @@ int acmpc_reduce_across_ranks(acmpc_ctx* ctx, void* rccl_comm, int64_t* d_keys, 
 int acmpc_optimize(acmpc_ctx* ctx, const float* x0, const float* centre, const float* u_ref, int32_t P, int32_t N,
                    int32_t n, int32_t rounds, const double sigma[2], double shrink, uint64_t seed, float* records);
 
+/* Host-side float64 helpers round one solve (csrc/acmpc_host_path.cpp; no GPU work, no handle).
+ * Replaces: SpatialMPC.construct_waypoints (spatial_mpc.py:125-154).  coords [H][3] = (x, y, width) ->
+ * table [7][n], n = H - 1, rows [x, y, psi, kappa, ds, width, v = 0]. */
+int acmpc_waypoint_table(const double* coords, int32_t H, double eps, double* table);
+/* Replaces: the v_max vector of SpeedProfileSolver / LocalisedSpeedProfileSolver (speed_profile.py:26-43,131-150):
+ * max(v_min, min(sqrt(ay_max / (|kappa| + 1e-12)), v_max)) + 2 with v_max where |kappa| < ki_min, last entry =
+ * end_velocity when given; `localised` != 0: v_max everywhere. */
+int acmpc_velocity_ceiling(const double* kappa, int32_t n, double ay_max, double ki_min, double v_min, double v_max,
+                           int32_t localised, int32_t has_end_velocity, double end_velocity, double* ceiling);
+/* Replaces: the tail of SpatialMPC.get_control (spatial_mpc.py:156-168,195-211).  z = dec.x ([x_0..x_n ; u_0..u_{n-1}],
+ * 5n + 3 doubles), table [7][n] -> projected_control [2][n] = (v, atan(kappa L)), prediction [n][2] (s2t),
+ * cum_time [n], times / accelerations / steer_rates [n - 1]. */
+int acmpc_unpack_decision(const double* z, int32_t n, const double* table, double wheelbase, double* projected_control,
+                          double* prediction, double* cum_time, double* times, double* accelerations,
+                          double* steer_rates);
+
 /* The generator itself, on the host (same code as the kernels): lets tests pin the integer stream. */
 void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 

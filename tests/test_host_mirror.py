@@ -271,3 +271,45 @@ def test_path_families_equal_the_reference_generators(golden, golden_cases):
     with pytest.raises(ValueError):
         workloads.family_path("oval", 1.0, 50)
 
+
+def test_native_host_helpers_equal_their_numpy_statements(golden, golden_cases):
+    """acmpc_waypoint_table / acmpc_velocity_ceiling / acmpc_unpack_decision (csrc/acmpc_host_path.cpp) against the
+    NumPy statements they replaced, on the reference's path families; the NumPy forms are themselves pinned to the
+    reference's golden vectors by the tests above."""
+    from acmpc_amd import _capi
+    from acmpc_amd.bicycle_model import SpatialBicycleModel
+    from acmpc_amd.mpc import waypoint_table, waypoint_table_numpy
+    from acmpc_amd.reference_path import ReferencePath
+    from acmpc_amd.speed_profile import LocalisedSpeedProfileSolver, SpeedProfileSolver
+    rng = np.random.default_rng(3)
+    model = SpatialBicycleModel(PlaceholderVehicle(), {"min": 8.0, "max": 84.0})
+    for case in golden_cases:
+        coords = golden[case + "/coords"]
+        table = waypoint_table(coords)
+        np.testing.assert_allclose(table, waypoint_table_numpy(coords), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(table[:6], golden[case + "/table_no_v"][:6], rtol=0, atol=1e-12)
+        n = table.shape[1]
+        path = ReferencePath.from_table(golden[case + "/table"].copy())
+        cons = dict(RACING["monza"]["speed_profile_constraints"])
+        for cls in (SpeedProfileSolver, LocalisedSpeedProfileSolver):
+            solver = cls({"control_horizon": n, "max_iterations": 4000, "constraints": cons})
+            for end_velocity in (None, 14.0):
+                np.testing.assert_array_equal(solver.velocity_ceiling(path, end_velocity),
+                                              solver.velocity_ceiling_numpy(path, end_velocity))
+        # the tail of get_control, on a random decision vector
+        z = rng.normal(0, 1.0, 5 * n + 3)
+        z[2:3 * (n + 1):3] = np.cumsum(rng.uniform(0.02, 0.08, n + 1))      # times increase
+        pc, pred, cum, times, acc, rates = _capi.unpack_decision(z, n, path.table, model.length)
+        controls = z[-2 * n:].reshape(n, 2)
+        states = z[:3 * n].reshape(n, 3)
+        np.testing.assert_allclose(pc, np.array([controls[:, 0], np.arctan(controls[:, 1] * model.length)]), atol=1e-15)
+        np.testing.assert_allclose(pred, model.s2t(path, states)[:-1].T, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(cum, states[:, 2])
+        np.testing.assert_allclose(times, np.diff(states[:, 2]), rtol=0, atol=1e-15)
+        np.testing.assert_allclose(acc, np.diff(states[:, 0]) / np.diff(states[:, 2]), rtol=1e-13)
+        np.testing.assert_allclose(rates, np.diff(states[:, 1]) / np.diff(states[:, 2]), rtol=1e-13)
+    with pytest.raises(Exception):
+        _capi.waypoint_table(np.zeros((2, 3)))
+    with pytest.raises(ValueError):
+        _capi.unpack_decision(np.zeros(10), 49, np.zeros((7, 49)), 2.65)
+
