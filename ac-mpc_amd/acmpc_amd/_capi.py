@@ -117,10 +117,10 @@ SIGNATURES = {
     "acmpc_pf_destroy": (None, [_CTX]),
     "acmpc_pf_last_error": (C.c_char_p, [_CTX]),
     "acmpc_pf_score_scale": (C.c_double, [_CTX]),
-    "acmpc_pf_score": (C.c_int, [_CTX, _F32P, C.c_int32, _F32P, C.c_int32, _F32P, C.c_int32, _I32P, _F64P, _F64P, _F64P,
-                                 _F64P, C.POINTER(C.c_uint8)]),
-    "acmpc_pf_advance": (C.c_int, [_CTX, _F32P, _F32P, _F32P, C.c_int32, C.c_double]),
-    "acmpc_pf_estimate": (C.c_int, [_CTX, _F32P, _F32P, C.c_int32, _F64P, _F64P, _F64P]),
+    "acmpc_pf_score": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] +
+                       [C.c_void_p] * 6),
+    "acmpc_pf_advance": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double]),
+    "acmpc_pf_estimate": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, _F64P, _F64P]),
     "acmpc_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "acmpc_profile_collect": (C.c_int, [_CTX, _F32P, C.c_int32, _I32P]),
     "acmpc_pack_key": (C.c_int64, [C.c_float, C.c_uint32]),

@@ -87,12 +87,10 @@ class ParticleScorer:
         idx = np.empty((P, 3), dtype=np.int32)
         offset, heading, error, score = (np.empty(P) for _ in range(4))
         valid = np.empty(P, dtype=np.uint8)
-        f32, f64 = _capi._F32P, _capi._F64P
         self._check(self._lib.acmpc_pf_score(
-            self._handle, states.ctypes.data_as(f32), P, left.ctypes.data_as(f32), left.shape[0],
-            right.ctypes.data_as(f32), right.shape[0], idx.ctypes.data_as(_capi._I32P), offset.ctypes.data_as(f64),
-            heading.ctypes.data_as(f64), error.ctypes.data_as(f64), score.ctypes.data_as(f64),
-            valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+            self._handle, states.ctypes.data, P, left.ctypes.data, left.shape[0], right.ctypes.data, right.shape[0],
+            idx.ctypes.data, offset.ctypes.data, heading.ctypes.data, error.ctypes.data, score.ctypes.data,
+            valid.ctypes.data))
         return {"states": states, "track_indices": idx.astype(np.int64), "centreline_idx": idx[:, 0].astype(np.int64),
                 "minimum_offset": offset, "heading_offset": heading, "observation_error": error, "score": score,
                 "valid_mask": valid.astype(bool)}
@@ -102,9 +100,8 @@ class ParticleScorer:
         out = np.ascontiguousarray(states, dtype=np.float32).copy()
         delta = np.ascontiguousarray(delta, dtype=np.float32)
         velocity = np.ascontiguousarray(velocity, dtype=np.float32)
-        f32 = _capi._F32P
-        self._check(self._lib.acmpc_pf_advance(self._handle, out.ctypes.data_as(f32), delta.ctypes.data_as(f32),
-                                               velocity.ctypes.data_as(f32), out.shape[0], float(dt)))
+        self._check(self._lib.acmpc_pf_advance(self._handle, out.ctypes.data, delta.ctypes.data, velocity.ctypes.data,
+                                               out.shape[0], float(dt)))
         return out
 
     def estimate_location(self, scores: np.ndarray, states: np.ndarray):
@@ -113,9 +110,8 @@ class ParticleScorer:
         scores = np.ascontiguousarray(scores, dtype=np.float32)
         est = np.empty(3)
         md, ma = C.c_double(0), C.c_double(0)
-        self._check(self._lib.acmpc_pf_estimate(self._handle, states.ctypes.data_as(_capi._F32P),
-                                                scores.ctypes.data_as(_capi._F32P), states.shape[0],
-                                                est.ctypes.data_as(_capi._F64P), C.byref(md), C.byref(ma)))
+        self._check(self._lib.acmpc_pf_estimate(self._handle, states.ctypes.data, scores.ctypes.data, states.shape[0],
+                                                est.ctypes.data, C.byref(md), C.byref(ma)))
         return est, md.value, ma.value
 
 
