@@ -135,6 +135,33 @@ def library_path() -> str:
     return os.environ.get("ACMPC_HIP_LIBRARY", _build.LIB_PATH)
 
 
+def _share_torchs_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 and look them up by the unversioned file
+    name; this library needs them by SONAME.  Whichever of the two is loaded first decides: torch first - one
+    runtime, shared (the loader matches our SONAME against torch's copy); ours first - the system's runtime is
+    mapped, torch later maps its own beside it, and the second HSA runtime in the process finds no GPU
+    ("No HIP GPUs are available").  So when torch is installed but not imported yet, map torch's copies first; the
+    later `import torch` then resolves to the very same files.  ACMPC_SYSTEM_HIP=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("ACMPC_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return   # an unusable bundle: fall back to the system runtime
+
+
 def load_library() -> C.CDLL:
     """dlopen libacmpc_hip.so and bind every declared symbol.  Raises if the library is absent: build it with
     `python -m acmpc_amd._build` (or `__graft_entry__.build()`)."""
@@ -145,6 +172,7 @@ def load_library() -> C.CDLL:
     if not os.path.exists(path):
         raise EngineError(ENODEVICE, "HIP extension %s is missing - build it with acmpc_amd._build.build_library(); "
                           "there is no CPU fallback" % path)
+    _share_torchs_hip_runtime()
     lib = C.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
