@@ -153,3 +153,41 @@ def test_the_reference_script_scenarios(kind, parameters, angle):
                                          cfg["final_cost"], lo, hi, 1e6, dtype=np.float64, return_states=True)
         np.testing.assert_allclose(X[0, :n, 2], mpc.cum_time, rtol=1e-4, atol=1e-5)
 
+
+def test_two_controllers_in_one_process_do_not_disturb_each_other():
+    """The control process holds a mapping (horizon 100) and a racing (horizon 50) MPC side by side
+    (controller.py:293-297).  Each has its own handle, stream and captured graphs: interleaving their solves must
+    give each exactly the plans it produces alone."""
+    import copy
+    from acmpc_amd import workloads
+    from acmpc_amd.mpc import build_mpc
+
+    def make(horizon):
+        cfg = copy.deepcopy(RACING["monza"])
+        cfg["horizon"] = horizon
+        cfg["speed_profile_constraints"]["v_max"] = 28.0
+        return build_mpc(cfg, PlaceholderVehicle())
+
+    track = workloads.synthetic_track("monza")
+    lines = [workloads.local_centreline(track, 40 * i) for i in range(12)]
+    paths = {H: [workloads.reference_path_from_centreline(line, H) for line in lines] for H in (50, 100)}
+
+    def run(order):
+        controllers = {50: make(50), 100: make(100)}
+        plans = {50: [], 100: []}
+        for H, index in order:
+            mpc = controllers[H]
+            mpc.get_control(paths[H][index], offset=0.2)
+            assert mpc.infeasibility_counter == 0
+            plans[H].append((mpc.projected_control.copy(), mpc.cum_time.copy(), mpc.current_prediction.copy()))
+        return plans
+
+    alone_50 = run([(50, i) for i in range(12)])[50]
+    alone_100 = run([(100, i) for i in range(12)])[100]
+    mixed = run([(H, i) for i in range(12) for H in (50, 100)])
+    for got, want in ((mixed[50], alone_50), (mixed[100], alone_100)):
+        assert len(got) == len(want) == 12
+        for a, b in zip(got, want):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+
