@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Development probe: a long run of SpatialMPC.get_control - latency drift and host/device memory growth."""
+import copy, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ac-mpc_amd"))
+from acmpc_amd import workloads
+from acmpc_amd.mpc import build_mpc
+
+
+def rss_mb():
+    for line in open("/proc/self/status"):
+        if line.startswith("VmRSS"):
+            return int(line.split()[1]) / 1024
+
+
+solves = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"]); cfg["speed_profile_constraints"]["v_max"] = 32.0
+mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
+track = workloads.synthetic_track("silverstone")
+paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % 11000), 50) for i in range(2000)]
+for p in paths[:50]:
+    mpc.get_control(p)
+start_rss = rss_mb()
+block = []
+t_start = time.perf_counter()
+for i in range(solves):
+    t0 = time.perf_counter()
+    mpc.get_control(paths[i % 2000])
+    block.append(time.perf_counter() - t0)
+    if (i + 1) % (solves // 5) == 0:
+        b = np.array(block) * 1e6
+        print("solves %7d: p50 %.1f us p99 %.1f us max %.0f us  rss %.0f MB (+%.1f)  infeasible %d" % (
+            i + 1, np.percentile(b, 50), np.percentile(b, 99), b.max(), rss_mb(), rss_mb() - start_rss,
+            mpc.infeasibility_counter), flush=True)
+        block = []
+print("total %.1f s" % (time.perf_counter() - t_start))
