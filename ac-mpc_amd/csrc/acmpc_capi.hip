@@ -107,6 +107,7 @@ int fail(const acmpc_ctx* ctx, int code, const std::string& msg) {
 }
 
 int fail_hip(const acmpc_ctx* ctx, hipError_t e, const char* what) {
+  (void)hipGetLastError();  // do not leave the error behind for the next launch check (of this or any other library)
   const bool nodev = (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver ||
                       e == hipErrorNotInitialized);
   return fail(ctx, nodev ? ACMPC_ENODEVICE : ACMPC_EHIP,

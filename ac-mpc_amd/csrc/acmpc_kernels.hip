@@ -964,6 +964,10 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
 
 }  // namespace
 
+// hipGetLastError() returns (and clears) the last error of ANY earlier runtime call of the thread - a failed
+// allocation of this or another library minutes ago included.  Launch status is read with it, so clear it first.
+static inline void clear_stale_error() { (void)hipGetLastError(); }
+
 int max_blocks_per_problem(int N) { return (N + kWave - 1) / kWave; }
 
 size_t tile_lds_bytes(int mode, int n) {
@@ -1014,6 +1018,7 @@ LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
 
 hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                           hipEvent_t e0, hipEvent_t e1) {
+  clear_stale_error();
   if (mode == 0 && layout == 0) return launch_rollout_ml<0, 0>(shape, args, s, e0, e1);
   if (mode == 0 && layout == 1) return launch_rollout_ml<0, 1>(shape, args, s, e0, e1);
   if (mode == 1 && layout == 0) return launch_rollout_ml<1, 0>(shape, args, s, e0, e1);
@@ -1022,6 +1027,7 @@ hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const 
 }
 
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s) {
+  clear_stale_error();
   const dim3 grid(args.P), block(kWave);
   // record image, then (mode T) the waypoint table
   const size_t rec_floats = static_cast<size_t>(4 + 2 * args.n + 3 * (args.n + 1));
@@ -1041,6 +1047,7 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
 }
 
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
+  clear_stale_error();
   const dim3 grid((args.N + 255) / 256, args.P);
   const size_t sample_lds = (((static_cast<size_t>(args.n) + 3) & ~static_cast<size_t>(3)) + 2 * args.n) * sizeof(float);
   if (layout == 0) {
@@ -1069,6 +1076,7 @@ bool fused_finalize_fits(int mode, int n) {
 
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
                                   const FusedFinalize& fused, hipStream_t s) {
+  clear_stale_error();
   const int n = rollout.n;
   const dim3 grid((rollout.N + kWave - 1) / kWave, rollout.P);
   const size_t rollout_floats = sampled_rollout_floats(mode, n);
@@ -1089,6 +1097,7 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
 int softmin_chunks(int N) { return (N + kSoftChunk - 1) / kSoftChunk; }
 
 hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s) {
+  clear_stale_error();
   const dim3 grid(args.chunks, args.P);
   if (layout == 0) {
     hipLaunchKernelGGL((softmin_partial_kernel<0>), grid, dim3(kSoftBlock), 0, s, args);

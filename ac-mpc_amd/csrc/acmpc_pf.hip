@@ -378,6 +378,7 @@ int acmpc_pf_score(acmpc_pf* h, const float* states, int32_t P, const float* obs
   a.error = h->d_out + 2 * static_cast<size_t>(P);
   a.score = h->d_out + 3 * static_cast<size_t>(P);
   a.valid = h->d_valid;
+  (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
   hipLaunchKernelGGL(pf_score_kernel, dim3(P), dim3(kBlock), 0, s, a);
   PF_HIP(h, hipGetLastError());
   const size_t pd = static_cast<size_t>(P) * sizeof(double);
@@ -402,6 +403,7 @@ int acmpc_pf_advance(acmpc_pf* h, float* states, const float* delta, const float
   PF_HIP(h, hipMemcpyAsync(h->d_states, states, 3 * pf, hipMemcpyHostToDevice, s));
   PF_HIP(h, hipMemcpyAsync(h->d_aux, delta, pf, hipMemcpyHostToDevice, s));
   PF_HIP(h, hipMemcpyAsync(h->d_aux + P, velocity, pf, hipMemcpyHostToDevice, s));
+  (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
   hipLaunchKernelGGL(pf_advance_kernel, dim3((P + 255) / 256), dim3(256), 0, s, h->d_states, h->d_aux, h->d_aux + P, P,
                      static_cast<float>(h->prm.wheelbase), static_cast<float>(dt));
   PF_HIP(h, hipGetLastError());
@@ -421,6 +423,7 @@ int acmpc_pf_estimate(acmpc_pf* h, const float* states, const float* scores, int
   PF_HIP(h, hipMemcpyAsync(h->d_states, states, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
   PF_HIP(h, hipMemcpyAsync(h->d_aux, scores, static_cast<size_t>(P) * sizeof(float), hipMemcpyHostToDevice, s));
   double* d_res = h->d_out + 4 * static_cast<size_t>(h->prm.max_particles);
+  (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
   hipLaunchKernelGGL(pf_estimate_kernel, dim3(1), dim3(kBlock), 0, s, h->d_states, h->d_aux, P, d_res);
   PF_HIP(h, hipGetLastError());
   double res[5];

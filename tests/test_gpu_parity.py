@@ -309,3 +309,24 @@ def test_empty_and_oversized_inputs_are_rejected():
     assert e.value.code == -1
     with pytest.raises(EngineError):
         eng.set_paths(np.zeros((1, 7, 1)))                                  # a one-point path has no dynamics
+
+
+def test_device_allocation_failure_is_an_error_not_a_crash():
+    """A capacity no GPU can hold: the first device call reports the failed hipMalloc (ACMPC_EHIP, with the HIP
+    message) and the process carries on - a handle of sensible size works afterwards."""
+    import torch
+    from acmpc_amd import Engine, EngineError
+    prob = make_problem(orc, "monza", 20, 64, seed=5)
+    huge = Engine(**engine_kwargs(prob, 0, 65535, 2**31 - 1, 19))      # petabytes of partial keys
+    huge.set_paths(np.stack([prob["table"]] * 2))
+    x0 = torch.zeros(2, 3, device="cuda")
+    U = torch.zeros(2, 19, 2, 64, device="cuda")
+    with pytest.raises(EngineError) as e:
+        huge.rollout_device(x0.data_ptr(), U.data_ptr(), 2, 64, 19, LAYOUT_SM, 0, 0, 0, 0)
+    assert e.value.code == -2 and "memory" in str(e.value).lower()
+    huge.close()
+    eng = _engine([prob], 0, 64, 19)
+    out = eng.solve(prob["x0"][None], prob["U"][None])
+    cost = _oracle(prob, eng.coefficients(0), 0)[0]
+    np.testing.assert_array_equal(out["costs"][0], cost)
+
