@@ -330,3 +330,19 @@ def test_device_allocation_failure_is_an_error_not_a_crash():
     cost = _oracle(prob, eng.coefficients(0), 0)[0]
     np.testing.assert_array_equal(out["costs"][0], cost)
 
+
+def test_bad_device_ordinal_and_closed_handle_are_errors():
+    from acmpc_amd import Engine, EngineError
+    prob = make_problem(orc, "monza", 20, 16, seed=6)
+    eng = Engine(**engine_kwargs(prob, 0, 1, 16, 19, device=99))      # construction does no device work
+    eng.set_paths(prob["table"])
+    with pytest.raises(EngineError) as e:
+        eng.solve(prob["x0"][None], prob["U"][None])
+    assert e.value.code in (-2, -3)
+    eng.close()
+    eng.close()                                                        # idempotent
+    with pytest.raises(EngineError):
+        eng.solve(prob["x0"][None], prob["U"][None])                   # a closed handle is refused, not dereferenced
+    good = _engine([prob], 0, 16, 19)
+    assert good.solve(prob["x0"][None], prob["U"][None])["owner"][0] == 1.0
+
