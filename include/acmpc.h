@@ -10,6 +10,8 @@
  *   - every function returns 0 on success or a negative ACMPC_E* code; no exception crosses the ABI;
  *     `acmpc_last_error()` gives the message of the last failure on that handle;
  *   - a handle is not thread-safe; buffers passed in are only read for the duration of the call;
+ *   - a handle lives on ONE device (`acmpc_params.device`, or the thread's current device when -1): the calling
+ *     thread's current HIP device must be that device on every call (one process per GPU does this once);
  *   - `acmpc_create`, `acmpc_set_paths` and `acmpc_get_coefficients` do no device work: the reference builds
  *     its MPC objects in the parent process and then forks the ControlProcess
  *     (src/acmpc/control/controller.py:94-100,293-297), so the HIP context is created lazily on the first call
