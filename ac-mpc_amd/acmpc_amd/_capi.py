@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import numpy as np
@@ -383,7 +384,8 @@ def velocity_ceiling(kappa: np.ndarray, ay_max: float, ki_min: float, v_min: flo
     return out
 
 
-_unpack_buffers = {}   # n -> (arrays, their addresses): persistent outputs, copied out per call
+_unpack_local = threading.local()   # per thread: n -> (arrays, their addresses), persistent outputs copied out per
+                                     # call (ctypes releases the GIL during the call, so threads must not share them)
 
 
 def unpack_decision(z: np.ndarray, n: int, table: np.ndarray, wheelbase: float):
@@ -392,10 +394,13 @@ def unpack_decision(z: np.ndarray, n: int, table: np.ndarray, wheelbase: float):
     table = np.ascontiguousarray(table, dtype=np.float64)
     if z.shape[0] != 5 * n + 3 or table.shape != (7, n):
         raise ValueError("decision vector / table do not match n = %d" % n)
-    cached = _unpack_buffers.get(n)
+    buffers = getattr(_unpack_local, "buffers", None)
+    if buffers is None:
+        buffers = _unpack_local.buffers = {}
+    cached = buffers.get(n)
     if cached is None:
         arrays = (np.empty((2, n)), np.empty((n, 2)), np.empty(n), np.empty(n - 1), np.empty(n - 1), np.empty(n - 1))
-        cached = _unpack_buffers[n] = (arrays, tuple(a.ctypes.data for a in arrays))
+        cached = buffers[n] = (arrays, tuple(a.ctypes.data for a in arrays))
     arrays, addresses = cached
     rc = load_library().acmpc_unpack_decision(z.ctypes.data, n, table.ctypes.data, float(wheelbase), *addresses)
     if rc != OK:

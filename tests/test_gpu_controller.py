@@ -191,3 +191,38 @@ def test_two_controllers_in_one_process_do_not_disturb_each_other():
             for x, y in zip(a, b):
                 np.testing.assert_array_equal(x, y)
 
+
+
+def test_two_controllers_in_two_threads():
+    """Handles are not thread-safe, but two handles may live in two threads: each thread drives its own controller;
+    the plans equal the single-threaded ones (per-thread output buffers in the host helpers, one stream per handle)."""
+    import copy
+    import threading
+    from acmpc_amd import workloads
+    from acmpc_amd.mpc import build_mpc
+
+    track = workloads.synthetic_track("spa")
+    paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, 30 * i), 50) for i in range(60)]
+
+    def drive(out):
+        cfg = copy.deepcopy(RACING["spa"])
+        cfg["speed_profile_constraints"]["v_max"] = 8.0
+        mpc = build_mpc(cfg, PlaceholderVehicle())
+        for p in paths:
+            mpc.get_control(p, offset=0.1)
+            out.append((mpc.infeasibility_counter, mpc.projected_control.copy(), mpc.current_prediction.copy()))
+
+    reference = []
+    drive(reference)
+    results = [[], []]
+    threads = [threading.Thread(target=drive, args=(r,)) for r in results]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    for r in results:
+        assert len(r) == len(reference)
+        for (bad, pc, pred), (bad0, pc0, pred0) in zip(r, reference):
+            assert bad == bad0 == 0
+            np.testing.assert_array_equal(pc, pc0)
+            np.testing.assert_array_equal(pred, pred0)
