@@ -313,3 +313,29 @@ def test_native_host_helpers_equal_their_numpy_statements(golden, golden_cases):
     with pytest.raises(ValueError):
         _capi.unpack_decision(np.zeros(10), 49, np.zeros((7, 49)), 2.65)
 
+
+
+def test_native_waypoint_table_equals_numpy_on_arbitrary_paths():
+    """Property (hypothesis): for arbitrary finite coordinates - repeated points, reversals, huge and tiny steps -
+    the library's waypoint table equals the NumPy statement: positions, spacings and widths exactly, headings to the
+    last bit or two (libm's atan2 vs NumPy's), curvature accordingly - where the 1e-12-regularised division by a
+    vanishing spacing amplifies that bit, only relative to its own huge magnitude."""
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+    from acmpc_amd.mpc import waypoint_table, waypoint_table_numpy
+
+    finite = st.floats(min_value=-1e4, max_value=1e4, allow_nan=False, allow_infinity=False, width=64)
+
+    @settings(max_examples=200, deadline=None)
+    @given(hnp.arrays(np.float64, st.tuples(st.integers(3, 40), st.just(3)), elements=finite))
+    def check(coords):
+        got, want = waypoint_table(coords), waypoint_table_numpy(coords)
+        assert got.shape == want.shape == (7, coords.shape[0] - 1)
+        for row in (0, 1, 4, 5, 6):
+            np.testing.assert_array_equal(got[row], want[row])
+        # headings: libm's atan2 here, NumPy's own (on some CPUs vectorised, 1 ulp apart) there
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-14, atol=1e-15)
+        np.testing.assert_allclose(got[3], want[3], rtol=1e-9, atol=1e-3 * np.abs(want[3]).max() if np.abs(want[3]).max() > 1e9 else 1e-9)
+        assert got[3, 0] == got[3, 1]
+
+    check()
