@@ -462,3 +462,20 @@ def test_reduce_across_ranks_with_a_caller_owned_rccl_communicator():
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
 
+
+
+def test_sharded_optimizer_two_ranks_equal_the_unsharded_solve():
+    """The multi-GPU closed-loop solve rehearsed with two ranks on the one card (gloo carries the key all-reduce):
+    `tests/sharded_optimizer_ranks.py` under torch.distributed.run; both modes, three rounds."""
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(here, "sharded_optimizer_ranks.py")]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, (proc.stdout + proc.stderr)[-3000:]
+    assert "sharded optimizer ok" in proc.stdout
