@@ -9,12 +9,15 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libacmpc_hip.so")
-SOURCES = ("acmpc_kernels.hip", "acmpc_capi.hip", "acmpc_pf.hip", "acmpc_speed_profile.cpp", "acmpc_host_path.cpp")
-HEADERS = ("acmpc_kernels.h", "acmpc_device.h", os.path.join("..", "..", "include", "acmpc.h"))
+SOURCES = ("acmpc_kernels.hip", "acmpc_kernels_temporal.hip", "acmpc_capi.hip", "acmpc_prologue.hip", "acmpc_pf.hip",
+           "acmpc_speed_profile.cpp", "acmpc_host_path.cpp")
+HEADERS = ("acmpc_kernels.h", "acmpc_device.h", "acmpc_admm.h", "acmpc_prologue.h",
+           os.path.join("..", "..", "include", "acmpc.h"))
 
-# -ffp-contract=off: the kernels' float32 arithmetic is specified without fused multiply-add
-HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-Wall", "-Wextra")
+# -ffp-contract=off: no IMPLICIT fused multiply-add anywhere; the FMAs of mode T's specification are spelt out
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra")
+# per-source extras: the mode-T rollout is faster without the SLP vectoriser's v_pk_* re-packing (measured, see the source)
+EXTRA_FLAGS = {"acmpc_kernels_temporal.hip": ("-fno-slp-vectorize",)}
 
 
 def find_hipcc() -> str:
@@ -28,7 +31,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC_DIR, f) for f in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC_DIR, f) for f in SOURCES + HEADERS]   # (acmpc_kernels_temporal.hip includes acmpc_kernels.hip)
     return any(os.path.getmtime(d) > built for d in deps)
 
 
@@ -37,12 +40,23 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [find_hipcc(), *HIPCC_FLAGS, *[os.path.join(CSRC_DIR, s) for s in SOURCES], "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = find_hipcc()
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+
+    from concurrent.futures import ThreadPoolExecutor
+    objects = [os.path.join(obj_dir, os.path.splitext(src)[0] + ".o") for src in SOURCES]
+    with ThreadPoolExecutor(max_workers=4) as pool:   # one hipcc per source (they carry different flags), then one link
+        list(pool.map(lambda so: run([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(so[0], ()), "-c",
+                                      os.path.join(CSRC_DIR, so[0]), "-o", so[1]]), zip(SOURCES, objects)))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objects, "-o", LIB_PATH])
     return LIB_PATH
 
 

@@ -70,6 +70,35 @@ class PfParams(C.Structure):
     ]
 
 
+class Tick(C.Structure):
+    """acmpc_tick: the per-tick inputs of acmpc_control_tick."""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("horizon", C.c_int32),
+        ("localised", C.c_int32),
+        ("has_end_velocity", C.c_int32),
+        ("n_candidates", C.c_int32),
+        ("rounds", C.c_int32),
+        ("centre_is_reference", C.c_int32),
+        ("qp_max_iter", C.c_int32),
+        ("qp_check_every", C.c_int32),
+        ("reserved", C.c_int32),
+        ("offset", C.c_double),
+        ("v_min", C.c_double),
+        ("v_max", C.c_double),
+        ("a_min", C.c_double),
+        ("a_max", C.c_double),
+        ("ay_max", C.c_double),
+        ("ki_min", C.c_double),
+        ("end_velocity", C.c_double),
+        ("sigma", C.c_double * 2),
+        ("shrink", C.c_double),
+        ("qp_eps_abs", C.c_double),
+        ("qp_eps_rel", C.c_double),
+        ("seed", C.c_uint64),
+    ]
+
+
 _F32P = C.POINTER(C.c_float)
 _F64P = C.POINTER(C.c_double)
 _I32P = C.POINTER(C.c_int32)
@@ -106,13 +135,18 @@ SIGNATURES = {
     # of typed pointers, which at these sizes is most of the call
     "acmpc_optimize": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_double, C.c_uint64, C.c_void_p]),
+    "acmpc_control_tick": (C.c_int, [_CTX, C.POINTER(Tick)] + [C.c_void_p] * 12),
+    "acmpc_tick_read_device_tables": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acmpc_speed_profile_qp_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                                C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p,
+                                                C.c_void_p, C.c_int32, _I32P]),
     "acmpc_waypoint_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "acmpc_velocity_ceiling": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                          C.c_int32, C.c_double, C.c_void_p]),
     "acmpc_unpack_decision": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_double] + [C.c_void_p] * 6),
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "acmpc_speed_profile_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
-                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, _I32P]),
+                                         C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, _I32P]),
     "acmpc_pf_create": (C.c_int, [C.POINTER(PfParams), _F64P, C.c_int32, _F64P, C.c_int32, _F64P, C.c_int32,
                                   C.POINTER(_CTX)]),
     "acmpc_pf_destroy": (None, [_CTX]),
@@ -322,6 +356,53 @@ class Engine:
         out["records"] = rec
         return out
 
+    def control_tick(self, tick: Tick, coords: np.ndarray, centre):
+        """One whole control tick on the device (acmpc_control_tick).  coords [H,3] float64, centre [n,2] float32 or
+        None (with tick.centre_is_reference).  Returns a dict of fresh arrays: table [7,n], record, decision [5n+3],
+        projected_control [2,n], prediction [n,2], cum_time [n], times / accelerations / steer_rates [n-1], info [8]."""
+        n = tick.horizon - 1
+        buf = self._tick_buffers.get(n) if hasattr(self, "_tick_buffers") else None
+        if buf is None:
+            if not hasattr(self, "_tick_buffers"):
+                self._tick_buffers = {}
+            arrays = dict(table=np.empty((7, n)), record=np.empty(record_floats(n), dtype=np.float32),
+                          decision=np.empty(5 * n + 3), projected_control=np.empty((2, n)), prediction=np.empty((n, 2)),
+                          cum_time=np.empty(n), times=np.empty(n - 1), accelerations=np.empty(n - 1),
+                          steer_rates=np.empty(n - 1), info=np.empty(8))
+            buf = self._tick_buffers[n] = (arrays, tuple(a.ctypes.data for a in arrays.values()))
+        arrays, addresses = buf
+        rc = self._lib.acmpc_control_tick(self._ctx, C.byref(tick), coords.ctypes.data,
+                                          centre.ctypes.data if centre is not None else None, *addresses)
+        if rc != OK:
+            self._check(rc)
+        return {k: a.copy() for k, a in arrays.items()}
+
+    def tick_device_tables(self, n: int):
+        """(x0 [3], u_ref [n,2], coef [n,12]) the last tick's prologue left on the device (test hook)."""
+        x0 = np.empty(3, dtype=np.float32)
+        u_ref = np.empty((n, 2), dtype=np.float32)
+        coef = np.empty((n, COEF_STRIDE[MODE_SPATIAL]), dtype=np.float32)
+        self._check(self._lib.acmpc_tick_read_device_tables(self._ctx, x0.ctypes.data, u_ref.ctypes.data, coef.ctypes.data))
+        return x0, u_ref, coef
+
+    def speed_profile_qp_device(self, v_hi, ds, a_min, a_max, v_min, max_iter=4000, eps_abs=1e-3, eps_rel=1e-3,
+                                warm=None, check_every=10):
+        """The prologue's ADMM alone on the GPU (test hook); same return as `speed_profile_qp`."""
+        v_hi = np.ascontiguousarray(v_hi, dtype=np.float64)
+        ds = np.ascontiguousarray(ds, dtype=np.float64)
+        n = v_hi.shape[0]
+        v, y = np.zeros(n), np.zeros(2 * n - 1)
+        if warm is not None:
+            v[:], y[:] = warm
+        iters = C.c_int32(0)
+        rc = self._lib.acmpc_speed_profile_qp_device(self._ctx, v_hi.ctypes.data, ds.ctypes.data, n, float(a_min),
+                                                     float(a_max), float(v_min), int(max_iter), int(check_every),
+                                                     float(eps_abs), float(eps_rel), v.ctypes.data, y.ctypes.data,
+                                                     1 if warm is not None else 0, C.byref(iters))
+        if rc < 0:
+            self._check(rc)
+        return v, y, ("solved" if rc == 0 else "maximum iterations reached"), iters.value
+
     def profile_enable(self, capacity: int):
         """Attach event pairs to the next `capacity` rollout launches (no extra packets on the stream)."""
         self._check(self._lib.acmpc_profile_enable(self._ctx, capacity))
@@ -409,7 +490,7 @@ def unpack_decision(z: np.ndarray, n: int, table: np.ndarray, wheelbase: float):
 
 
 def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: float, v_min: float, max_iter: int = 4000,
-                     eps_abs: float = 1e-3, eps_rel: float = 1e-3, warm=None):
+                     eps_abs: float = 1e-3, eps_rel: float = 1e-3, warm=None, check_every: int = 10):
     """Native tridiagonal ADMM for the speed-profile QP; returns (v, y, status, iterations)."""
     v_hi = np.ascontiguousarray(v_hi, dtype=np.float64)
     ds = np.ascontiguousarray(ds, dtype=np.float64)
@@ -420,7 +501,8 @@ def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: floa
         v[:], y[:] = warm
     iters = C.c_int32(0)
     rc = load_library().acmpc_speed_profile_qp(v_hi.ctypes.data, ds.ctypes.data, n, float(a_min), float(a_max),
-                                               float(v_min), int(max_iter), float(eps_abs), float(eps_rel),
+                                               float(v_min), int(max_iter), int(check_every), float(eps_abs),
+                                               float(eps_rel),
                                                v.ctypes.data, y.ctypes.data, 1 if warm is not None else 0,
                                                C.byref(iters))
     if rc < 0:

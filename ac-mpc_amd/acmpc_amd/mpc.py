@@ -79,6 +79,10 @@ class SpatialMPC:
         }
         self._speed_profile_solver = SpeedProfileSolver(profile_config)
         self._localised_speed_profile_solver = LocalisedSpeedProfileSolver(profile_config)
+        # optional build keys: `device_prologue` (default on: the per-tick prologue runs on the GPU inside the solve's
+        # hipGraph; off = the host statements of the same steps), `speed_profile_check_every`
+        self._device_prologue = bool(config.get("device_prologue", True))
+        self._qp_check_every = int(config.get("speed_profile_check_every", 10))
 
     # -- speed profiles -----------------------------------------------------------------------------------
     def compute_map_speed_profile(self, reference_path: ReferencePath, ay_max: float, a_min: float) -> ReferencePath:
@@ -121,6 +125,8 @@ class SpatialMPC:
         n = self.MPC_horizon - 1
         if elapsed is not None and self.cum_time.shape[0] == n:
             self._control_solver.shift_warm_start(elapsed, self.cum_time)
+        if self._device_prologue and self._control_solver.supports_tick():
+            return self._get_control_tick(reference_path, is_localised, offset)
         path = self.construct_waypoints(reference_path)
         path = self.compute_speed_profile(path, is_localised,
                                           end_vel=self.speed_profile_constraints["end_velocity"])
@@ -135,6 +141,32 @@ class SpatialMPC:
 
         (self.projected_control, self.current_prediction, self.cum_time, self.times, self.accelerations,
          self.steer_rates) = _capi.unpack_decision(dec.x, n, path.table, self.model.length)
+        self.reference_path = path
+        self.infeasibility_counter = 0
+
+
+    def _get_control_tick(self, reference_path: np.ndarray, is_localised: bool, offset: float):
+        """The same solve as one round trip (`acmpc_control_tick`): waypoints, speed profile, Frenet start state and
+        linearisation run on the device as the first node of the solve's hipGraph; this method only keeps the
+        reference's bookkeeping (spatial_mpc.py:98-122,193-217)."""
+        coords = np.ascontiguousarray(reference_path, dtype=np.float64)
+        if coords.shape != (self.MPC_horizon, 3):
+            raise ValueError("reference_path must be %d x 3" % self.MPC_horizon)
+        out, status, _ = self._control_solver.solve_tick(coords, float(offset), self.speed_profile_constraints,
+                                                         is_localised, qp_max_iter=MAX_SOLVER_ITERATIONS,
+                                                         qp_check_every=self._qp_check_every)
+        path = ReferencePath.from_table(out["table"])
+        if out["info"][4] == 0.0:
+            self.speed_profile = path.velocities.copy()
+        else:  # the path keeps the velocities it was built with (spatial_mpc.py:119-122)
+            logger.warning("Infeasible speed profile (maximum iterations reached); keeping previous velocities")
+        if status != SOLVED:
+            logger.warning("Infeasible problem! Failed %d time(s).", self.infeasibility_counter)
+            self.infeasibility_counter += 1
+            return
+        self.projected_control, self.current_prediction, self.cum_time = (out["projected_control"], out["prediction"],
+                                                                          out["cum_time"])
+        self.times, self.accelerations, self.steer_rates = out["times"], out["accelerations"], out["steer_rates"]
         self.reference_path = path
         self.infeasibility_counter = 0
 

@@ -16,6 +16,7 @@
 
 #include "../../include/acmpc.h"
 #include "acmpc_kernels.h"
+#include "acmpc_prologue.h"
 
 namespace {
 
@@ -34,9 +35,11 @@ struct acmpc_ctx {
   std::vector<float> h_coef;
   int P_set = 0, n_set = 0;
   bool tables_dirty = false;
+  bool thr_dirty = false;  // the verified-search thresholds of the current paths are not on the device yet
 
   // device state (created lazily)
   bool device_ready = false;
+  bool touched_device = false;  // a HIP call has been made for this handle (acmpc_destroy must not make the first one)
   float* d_coef = nullptr;
   int64_t* d_partial_keys = nullptr;
   int* d_partial_feas = nullptr;
@@ -82,11 +85,34 @@ struct acmpc_ctx {
   OptKey opt_key[kOptGraphs];
   uint64_t opt_used[kOptGraphs] = {0, 0, 0, 0};
   uint64_t opt_clock = 0;
+  bool opt_ready = false;
   unsigned char* h_opt = nullptr;   // pinned
   unsigned char* d_opt = nullptr;   // device mirror of h_opt: ONE H2D copy per solve
   size_t opt_capacity = 0;
   float* h_opt_records = nullptr;   // pinned
   uint32_t* d_seed = nullptr;
+
+  // acmpc_control_tick: prologue + rounds as one captured graph per (N, n, rounds, spread); per-tick inputs travel
+  // through the pinned block `h_tick` (TickHeader | coords | centre), results come back into `h_tick_out`
+  // (record | table | QP status) by posted writes
+  struct TickKey {
+    int N = 0, n = 0, rounds = 0;
+    double sigma_v = 0, sigma_k = 0, shrink = 0;
+    bool operator==(const TickKey& o) const {
+      return N == o.N && n == o.n && rounds == o.rounds && sigma_v == o.sigma_v && sigma_k == o.sigma_k &&
+             shrink == o.shrink;
+    }
+  };
+  bool tick_ready = false;
+  hipGraphExec_t tick_graph[kOptGraphs] = {nullptr, nullptr, nullptr, nullptr};
+  TickKey tick_key[kOptGraphs];
+  uint64_t tick_used[kOptGraphs] = {0, 0, 0, 0};
+  unsigned char* h_tick = nullptr;      // pinned
+  unsigned char* d_tick = nullptr;
+  unsigned char* h_tick_out = nullptr;  // pinned
+  double* d_warm = nullptr;             // speed-profile iterate of the two solvers, kept between ticks
+  int warm_stride = 0;
+  int tick_last_n = 0;
 
   // optional timing of the rollout dispatches (acmpc_profile_*): event pairs attached to the launches
   std::vector<hipEvent_t> prof_start, prof_stop;
@@ -160,8 +186,23 @@ void verified_thresholds(const float* coef, int P, int n, std::vector<float>* ou
   }
 }
 
+// Allocate only what is not there yet: after a mid-way failure (out of memory) the buffers already obtained stay
+// owned by the handle, a retry on the same handle picks up where the failed call stopped, and acmpc_destroy frees
+// whatever exists.
+template <typename T>
+hipError_t alloc_once(T** slot, size_t bytes) {
+  if (*slot != nullptr) return hipSuccess;
+  return hipMalloc(reinterpret_cast<void**>(slot), bytes);
+}
+template <typename T>
+hipError_t host_alloc_once(T** slot, size_t bytes) {
+  if (*slot != nullptr) return hipSuccess;
+  return hipHostMalloc(reinterpret_cast<void**>(slot), bytes, hipHostMallocDefault);
+}
+
 int ensure_device(acmpc_ctx* c) {
   if (c->device_ready) return ACMPC_OK;
+  c->touched_device = true;
   int count = 0;
   const hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0) {
@@ -175,28 +216,41 @@ int ensure_device(acmpc_ctx* c) {
   const size_t partials = static_cast<size_t>(p.max_problems) * acmpc::max_blocks_per_problem(p.max_candidates);
   c->soft_partial_doubles = static_cast<size_t>(p.max_problems) * acmpc::softmin_chunks(p.max_candidates) *
                             (4 * static_cast<size_t>(p.max_steps) + 1);
-  ACMPC_HIP(c, hipMalloc(&c->d_coef, coef_floats * sizeof(float)));
-  ACMPC_HIP(c, hipMalloc(&c->d_partial_keys, partials * sizeof(int64_t)));
-  ACMPC_HIP(c, hipMalloc(&c->d_partial_feas, partials * sizeof(int)));
-  ACMPC_HIP(c, hipMalloc(&c->d_soft_partial, c->soft_partial_doubles * sizeof(double)));
-  ACMPC_HIP(c, hipMalloc(&c->d_segments, static_cast<size_t>(p.max_steps) * 2 * sizeof(float)));
+  ACMPC_HIP(c, alloc_once(&c->d_coef, coef_floats * sizeof(float)));
+  ACMPC_HIP(c, alloc_once(&c->d_partial_keys, partials * sizeof(int64_t)));
+  ACMPC_HIP(c, alloc_once(&c->d_partial_feas, partials * sizeof(int)));
+  ACMPC_HIP(c, alloc_once(&c->d_soft_partial, c->soft_partial_doubles * sizeof(double)));
+  ACMPC_HIP(c, alloc_once(&c->d_segments, static_cast<size_t>(p.max_steps) * 2 * sizeof(float)));
   if (p.mode == ACMPC_MODE_TEMPORAL && p.nn_ahead < 0)
-    ACMPC_HIP(c, hipMalloc(&c->d_nn_thr, static_cast<size_t>(p.max_problems) * std::min(p.max_steps, kMaxVerifiedSteps) *
-                                             acmpc::kVerifiedWindow * sizeof(float)));
+    ACMPC_HIP(c, alloc_once(&c->d_nn_thr, static_cast<size_t>(p.max_problems) * std::min(p.max_steps, kMaxVerifiedSteps) *
+                                              acmpc::kVerifiedWindow * sizeof(float)));
   c->device_ready = true;
   return ACMPC_OK;
 }
 
 int upload_tables(acmpc_ctx* c, hipStream_t s) {
   if (c->P_set == 0) return fail(c, ACMPC_ESTATE, "acmpc_set_paths has not been called");
-  if (!c->tables_dirty) return ACMPC_OK;
-  const size_t bytes = static_cast<size_t>(c->P_set) * c->n_set * c->coef_stride * sizeof(float);
-  // pageable source: hipMemcpyAsync stages it before returning, so h_coef may change afterwards
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_coef, c->h_coef.data(), bytes, hipMemcpyHostToDevice, s));
-  if (!c->h_nn_thr.empty() && c->d_nn_thr != nullptr)
+  // pageable source: hipMemcpyAsync stages it before returning, so the host vectors may change afterwards
+  if (c->thr_dirty && !c->h_nn_thr.empty() && c->d_nn_thr != nullptr) {
     ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_thr, c->h_nn_thr.data(), c->h_nn_thr.size() * sizeof(float),
                                 hipMemcpyHostToDevice, s));
+    c->thr_dirty = false;
+  }
+  if (!c->tables_dirty) return ACMPC_OK;
+  const size_t bytes = static_cast<size_t>(c->P_set) * c->n_set * c->coef_stride * sizeof(float);
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_coef, c->h_coef.data(), bytes, hipMemcpyHostToDevice, s));
   c->tables_dirty = false;
+  return ACMPC_OK;
+}
+
+// The captured optimisation carries the coefficient table in its staging block but not the thresholds of mode T's
+// verified nearest-waypoint search, which the three-kernel form of a round reads (rollout(): a.nn_thr): bring them
+// up to date on the launch stream before the graph runs.
+int upload_thresholds(acmpc_ctx* c, hipStream_t s) {
+  if (!c->thr_dirty || c->h_nn_thr.empty() || c->d_nn_thr == nullptr) return ACMPC_OK;
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_thr, c->h_nn_thr.data(), c->h_nn_thr.size() * sizeof(float),
+                              hipMemcpyHostToDevice, s));
+  c->thr_dirty = false;
   return ACMPC_OK;
 }
 
@@ -347,21 +401,22 @@ int sample(acmpc_ctx* c, const float* d_centre, int centre_stride, const float* 
 
 int ensure_staging(acmpc_ctx* c) {
   if (c->staging_ready) return ACMPC_OK;
+  c->touched_device = true;
   const acmpc_params& p = c->prm;
   const size_t cand = static_cast<size_t>(p.max_problems) * p.max_candidates;
-  ACMPC_HIP(c, hipMalloc(&c->d_centre, static_cast<size_t>(p.max_problems) * p.max_steps * 2 * sizeof(float)));
-  ACMPC_HIP(c, hipMalloc(&c->d_uref, static_cast<size_t>(p.max_problems) * p.max_steps * 2 * sizeof(float)));
-  ACMPC_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  ACMPC_HIP(c, hipMalloc(&c->d_U, cand * p.max_steps * 2 * sizeof(float)));
-  ACMPC_HIP(c, hipMalloc(&c->d_x0, static_cast<size_t>(p.max_problems) * 3 * sizeof(float)));
-  ACMPC_HIP(c, hipMalloc(&c->d_costs, cand * sizeof(float)));
-  ACMPC_HIP(c, hipMalloc(&c->d_records,
-                         static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float)));
-  ACMPC_HIP(c, hipMalloc(&c->d_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
-  ACMPC_HIP(c, hipMalloc(&c->d_tickets, static_cast<size_t>(p.max_problems) * sizeof(int)));
+  ACMPC_HIP(c, alloc_once(&c->d_centre, static_cast<size_t>(p.max_problems) * p.max_steps * 2 * sizeof(float)));
+  ACMPC_HIP(c, alloc_once(&c->d_uref, static_cast<size_t>(p.max_problems) * p.max_steps * 2 * sizeof(float)));
+  if (c->stream == nullptr) ACMPC_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  ACMPC_HIP(c, alloc_once(&c->d_U, cand * p.max_steps * 2 * sizeof(float)));
+  ACMPC_HIP(c, alloc_once(&c->d_x0, static_cast<size_t>(p.max_problems) * 3 * sizeof(float)));
+  ACMPC_HIP(c, alloc_once(&c->d_costs, cand * sizeof(float)));
+  ACMPC_HIP(c, alloc_once(&c->d_records,
+                          static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float)));
+  ACMPC_HIP(c, alloc_once(&c->d_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
+  ACMPC_HIP(c, alloc_once(&c->d_tickets, static_cast<size_t>(p.max_problems) * sizeof(int)));
   ACMPC_HIP(c, hipMemset(c->d_tickets, 0, static_cast<size_t>(p.max_problems) * sizeof(int)));
   ACMPC_HIP(c, hipStreamSynchronize(nullptr));  // the handle's own stream does not order against the null stream
-  ACMPC_HIP(c, hipHostMalloc(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t), hipHostMallocDefault));
+  ACMPC_HIP(c, host_alloc_once(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
   c->staging_ready = true;
   return ACMPC_OK;
 }
@@ -417,6 +472,13 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
   w.qn0 = static_cast<float>(params->final_cost[0]);
   w.qn1 = static_cast<float>(params->final_cost[1]);
   w.qn2 = static_cast<float>(params->final_cost[2]);
+  w.hq0 = 0.5f * w.q0;
+  w.hq1 = 0.5f * w.q1;
+  w.hr0 = 0.5f * w.r0;
+  w.hr1 = 0.5f * w.r1;
+  w.hqn0 = 0.5f * w.qn0;
+  w.hqn1 = 0.5f * w.qn1;
+  w.hqn2 = 0.5f * w.qn2;
   w.ulo0 = static_cast<float>(params->u_min[0]);
   w.ulo1 = static_cast<float>(params->u_min[1]);
   w.uhi0 = static_cast<float>(params->u_max[0]);
@@ -432,7 +494,7 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
 
 void acmpc_destroy(acmpc_ctx* c) {
   if (c == nullptr) return;
-  if (c->device_ready || c->staging_ready) {
+  if (c->touched_device) {  // also after a failed bring-up: whatever was allocated before the failure is freed
     if (c->prm.device >= 0) (void)hipSetDevice(c->prm.device);
     (void)hipFree(c->d_coef);
     (void)hipFree(c->d_partial_keys);
@@ -451,6 +513,12 @@ void acmpc_destroy(acmpc_ctx* c) {
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
     for (hipGraphExec_t g : c->opt_graph)
       if (g != nullptr) (void)hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : c->tick_graph)
+      if (g != nullptr) (void)hipGraphExecDestroy(g);
+    if (c->h_tick != nullptr) (void)hipHostFree(c->h_tick);
+    if (c->h_tick_out != nullptr) (void)hipHostFree(c->h_tick_out);
+    (void)hipFree(c->d_tick);
+    (void)hipFree(c->d_warm);
     if (c->h_opt != nullptr) (void)hipHostFree(c->h_opt);
     if (c->h_opt_records != nullptr) (void)hipHostFree(c->h_opt_records);
     (void)hipFree(c->d_seed);
@@ -506,6 +574,7 @@ int acmpc_set_paths(acmpc_ctx* c, const double* tables, int32_t P, int32_t n) {
   c->P_set = P;
   c->n_set = n;
   c->tables_dirty = true;
+  c->thr_dirty = !c->h_nn_thr.empty();
   return ACMPC_OK;
 }
 
@@ -554,6 +623,7 @@ int acmpc_finalize_device(acmpc_ctx* c, const int64_t* d_keys, const float* d_x0
                           void* stream) {
   if (c == nullptr) return ACMPC_EINVAL;
   if (d_x0 == nullptr || d_U == nullptr || d_records == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (index_offset < 0 || index_offset + N > 0xffffffffLL) return fail(c, ACMPC_EINVAL, "global index exceeds 32 bits");
   int rc = check_shape(c, P, N, n, layout);
   if (rc != ACMPC_OK) return rc;
   if (!c->device_ready) return fail(c, ACMPC_ESTATE, "acmpc_rollout_device must run first");
@@ -802,18 +872,18 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   auto align16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
   const size_t off_x0 = 0, off_centre = align16(off_x0 + x0_bytes), off_uref = align16(off_centre + path_bytes),
                off_table = align16(off_uref + path_bytes), off_seed = align16(off_table + table_bytes);
-  if (c->h_opt == nullptr) {
+  if (!c->opt_ready) {
     const acmpc_params& p = c->prm;
     const size_t cap = 64 + 16 * 5 + static_cast<size_t>(p.max_problems) *
                                          (3 + 4 * static_cast<size_t>(p.max_steps) +
                                           static_cast<size_t>(p.max_steps) * c->coef_stride) * sizeof(float);
-    ACMPC_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_opt), cap, hipHostMallocDefault));
-    ACMPC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_opt), cap));
+    ACMPC_HIP(c, host_alloc_once(&c->h_opt, cap));
+    ACMPC_HIP(c, alloc_once(&c->d_opt, cap));
     c->opt_capacity = cap;
-    ACMPC_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_opt_records),
-                               static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float),
-                               hipHostMallocDefault));
-    ACMPC_HIP(c, hipMalloc(&c->d_seed, 2 * sizeof(uint32_t)));
+    ACMPC_HIP(c, host_alloc_once(&c->h_opt_records,
+                                 static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float)));
+    ACMPC_HIP(c, alloc_once(&c->d_seed, 2 * sizeof(uint32_t)));
+    c->opt_ready = true;
   }
   acmpc_ctx::OptKey key;
   key.P = P;
@@ -889,10 +959,258 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   std::memcpy(c->h_opt + off_table, c->h_coef.data(), table_bytes);
   const uint32_t seed_words[2] = {static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
   std::memcpy(c->h_opt + off_seed, seed_words, sizeof seed_words);
+  rc = upload_thresholds(c, s);
+  if (rc != ACMPC_OK) return rc;
   ACMPC_HIP(c, hipGraphLaunch(c->opt_graph[slot], s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
   std::memcpy(records, c->h_opt_records, rec_bytes);
   return ACMPC_OK;
+}
+
+
+extern "C++" {
+namespace {
+
+size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+
+// layout of the tick staging block for a horizon of n steps (device and pinned host copies share it)
+struct TickLayout {
+  size_t coords, centre, upload, x0, uref, coef, total;
+  explicit TickLayout(int n) {
+    coords = align16(sizeof(acmpc::TickHeader));
+    centre = align16(coords + static_cast<size_t>(n + 1) * 3 * sizeof(double));
+    upload = align16(centre + static_cast<size_t>(n) * 2 * sizeof(float));
+    x0 = upload;
+    uref = align16(x0 + 4 * sizeof(float));
+    coef = align16(uref + static_cast<size_t>(n) * 2 * sizeof(float));
+    total = align16(coef + static_cast<size_t>(n) * ACMPC_COEF_STRIDE_SPATIAL * sizeof(float));
+  }
+};
+
+// layout of the pinned result block
+struct TickOutLayout {
+  size_t record, table, status, total;
+  explicit TickOutLayout(int n) {
+    record = 0;
+    table = align16(static_cast<size_t>(acmpc_record_floats(n)) * sizeof(float));
+    status = align16(table + static_cast<size_t>(7) * n * sizeof(double));
+    total = status + 16;
+  }
+};
+
+int ensure_tick(acmpc_ctx* c) {
+  if (c->tick_ready) return ACMPC_OK;
+  c->touched_device = true;
+  const int n_cap = std::min(c->prm.max_steps, acmpc::kPrologueMaxSteps);
+  ACMPC_HIP(c, host_alloc_once(&c->h_tick, TickLayout(n_cap).total));
+  ACMPC_HIP(c, alloc_once(&c->d_tick, TickLayout(n_cap).total));
+  ACMPC_HIP(c, host_alloc_once(&c->h_tick_out, TickOutLayout(n_cap).total));
+  c->warm_stride = 2 + 3 * n_cap;
+  const size_t warm_bytes = static_cast<size_t>(2) * c->warm_stride * sizeof(double);
+  ACMPC_HIP(c, alloc_once(&c->d_warm, warm_bytes));
+  ACMPC_HIP(c, hipMemset(c->d_warm, 0, warm_bytes));  // valid flags 0: the first tick of each solver starts cold
+  ACMPC_HIP(c, hipStreamSynchronize(nullptr));
+  c->tick_ready = true;
+  return ACMPC_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, const float* centre, double* table,
+                       float* record, double* decision, double* projected_control, double* prediction,
+                       double* cum_time, double* times, double* accelerations, double* steer_rates, double* info) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (t == nullptr || coords == nullptr || table == nullptr || record == nullptr || decision == nullptr ||
+      projected_control == nullptr || prediction == nullptr || cum_time == nullptr || times == nullptr ||
+      accelerations == nullptr || steer_rates == nullptr || info == nullptr)
+    return fail(c, ACMPC_EINVAL, "null argument");
+  if (t->struct_size != sizeof(acmpc_tick)) return fail(c, ACMPC_EINVAL, "acmpc_tick size mismatch");
+  if (c->prm.mode != ACMPC_MODE_SPATIAL || c->prm.centre_update != 0)
+    return fail(c, ACMPC_ESTATE, "acmpc_control_tick needs a mode S handle with centre_update = 0");
+  const int H = t->horizon, n = H - 1, N = t->n_candidates;
+  if (H < 3 || t->rounds < 1 || N < 1) return fail(c, ACMPC_EINVAL, "need horizon >= 3, rounds >= 1, n_candidates >= 1");
+  if (n > c->prm.max_steps || N > c->prm.max_candidates) return fail(c, ACMPC_ECAPACITY, "horizon or candidates exceed capacity");
+  if (n > acmpc::kPrologueMaxSteps) return fail(c, ACMPC_ESTATE, "the device prologue holds at most 256 steps");
+  if (centre == nullptr && t->centre_is_reference == 0) return fail(c, ACMPC_EINVAL, "null centre");
+  if (!acmpc::fused_finalize_fits(c->prm.mode, n)) return fail(c, ACMPC_ESTATE, "fused finalize does not fit");
+  int rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_staging(c);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_tick(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = c->stream;
+  const TickLayout in(n);
+  const TickOutLayout out(n);
+  const int rec_floats = acmpc_record_floats(n);
+
+  acmpc_ctx::TickKey key;
+  key.N = N;
+  key.n = n;
+  key.rounds = t->rounds;
+  key.sigma_v = t->sigma[0];
+  key.sigma_k = t->sigma[1];
+  key.shrink = t->shrink;
+  int slot = -1;
+  for (int g = 0; g < acmpc_ctx::kOptGraphs; ++g)
+    if (c->tick_graph[g] != nullptr && key == c->tick_key[g]) slot = g;
+  if (slot < 0) {
+    slot = 0;
+    for (int g = 1; g < acmpc_ctx::kOptGraphs; ++g)
+      if (c->tick_used[g] < c->tick_used[slot]) slot = g;
+    if (c->tick_graph[slot] != nullptr) {
+      (void)hipGraphExecDestroy(c->tick_graph[slot]);
+      c->tick_graph[slot] = nullptr;
+    }
+    rc = upload_segments(c, n, s);  // must not happen inside the capture (it synchronises)
+    if (rc != ACMPC_OK) return rc;
+    acmpc::PrologueArgs pa{};
+    pa.header = reinterpret_cast<const acmpc::TickHeader*>(c->d_tick);
+    pa.coords = reinterpret_cast<const double*>(c->d_tick + in.coords);
+    pa.x0 = reinterpret_cast<float*>(c->d_tick + in.x0);
+    pa.u_ref = reinterpret_cast<float*>(c->d_tick + in.uref);
+    pa.coef = reinterpret_cast<float*>(c->d_tick + in.coef);
+    pa.centre = reinterpret_cast<float*>(c->d_tick + in.centre);
+    pa.table_out = reinterpret_cast<double*>(c->h_tick_out + out.table);
+    pa.status = reinterpret_cast<int*>(c->h_tick_out + out.status);
+    pa.warm_state = c->d_warm;
+    pa.warm_stride = c->warm_stride;
+    pa.warm_capacity = (c->warm_stride - 2) / 3;
+    pa.margin = c->prm.margin;
+    pa.u_lo0 = c->prm.u_min[0];
+    pa.u_lo1 = c->prm.u_min[1];
+    pa.u_hi0 = c->prm.u_max[0];
+    pa.u_hi1 = c->prm.u_max[1];
+    hipGraph_t graph = nullptr;
+    ACMPC_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipMemcpyAsync(c->d_tick, c->h_tick, in.upload, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = acmpc::launch_prologue(pa, n, s);
+    int rc_rounds = ACMPC_OK;
+    const bool direct = use_fused_finalize(c, n);
+    if (e == hipSuccess) {
+      const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef};
+      const uint32_t* d_seed = reinterpret_cast<const uint32_t*>(c->d_tick + offsetof(acmpc::TickHeader, seed_lo));
+      rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink, 0, d_seed, s, true,
+                                 direct ? reinterpret_cast<float*>(c->h_tick_out + out.record) : nullptr);
+    }
+    if (e == hipSuccess && rc_rounds == ACMPC_OK && !direct)
+      e = hipMemcpyAsync(c->h_tick_out + out.record, c->d_records, static_cast<size_t>(rec_floats) * sizeof(float),
+                         hipMemcpyDeviceToHost, s);
+    const hipError_t e_end = hipStreamEndCapture(s, &graph);
+    if (rc_rounds != ACMPC_OK) {
+      if (graph != nullptr) (void)hipGraphDestroy(graph);
+      return rc_rounds;
+    }
+    if (e != hipSuccess) {
+      if (graph != nullptr) (void)hipGraphDestroy(graph);
+      return fail_hip(c, e, "capturing the tick graph");
+    }
+    ACMPC_HIP(c, e_end);
+    const hipError_t e_inst = hipGraphInstantiate(&c->tick_graph[slot], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e_inst != hipSuccess) c->tick_graph[slot] = nullptr;
+    ACMPC_HIP(c, e_inst);
+    c->tick_key[slot] = key;
+  }
+  c->tick_used[slot] = ++c->opt_clock;
+
+  acmpc::TickHeader* h = reinterpret_cast<acmpc::TickHeader*>(c->h_tick);
+  h->offset = t->offset;
+  h->v_min = t->v_min;
+  h->v_max = t->v_max;
+  h->a_min = t->a_min;
+  h->a_max = t->a_max;
+  h->ay_max = t->ay_max;
+  h->ki_min = t->ki_min;
+  h->end_velocity = t->end_velocity;
+  h->qp_eps_abs = t->qp_eps_abs;
+  h->qp_eps_rel = t->qp_eps_rel;
+  h->eps = kEps;
+  h->horizon = H;
+  h->localised = t->localised;
+  h->has_end_velocity = t->has_end_velocity;
+  h->centre_is_reference = t->centre_is_reference;
+  h->qp_max_iter = t->qp_max_iter;
+  h->qp_check_every = t->qp_check_every;
+  h->seed_lo = static_cast<uint32_t>(t->seed);
+  h->seed_hi = static_cast<uint32_t>(t->seed >> 32);
+  std::memcpy(c->h_tick + in.coords, coords, static_cast<size_t>(H) * 3 * sizeof(double));
+  if (centre != nullptr) std::memcpy(c->h_tick + in.centre, centre, static_cast<size_t>(n) * 2 * sizeof(float));
+  ACMPC_HIP(c, hipGraphLaunch(c->tick_graph[slot], s));
+  ACMPC_HIP(c, hipStreamSynchronize(s));
+  c->tick_last_n = n;
+
+  const float* rec = reinterpret_cast<const float*>(c->h_tick_out + out.record);
+  std::memcpy(record, rec, static_cast<size_t>(rec_floats) * sizeof(float));
+  std::memcpy(table, c->h_tick_out + out.table, static_cast<size_t>(7) * n * sizeof(double));
+  const int* status = reinterpret_cast<const int*>(c->h_tick_out + out.status);
+  // dec.x = [x_0 .. x_n ; u_0 .. u_{n-1}] (control.py:121-158) from the record's [u ; x] blocks
+  const float* ru = rec + ACMPC_REC_HEADER;
+  const float* rx = ru + 2 * n;
+  double biggest = 0.0;
+  for (int i = 0; i < 3 * (n + 1); ++i) {
+    decision[i] = static_cast<double>(rx[i]);
+    biggest = std::max(biggest, std::fabs(decision[i]));
+  }
+  for (int i = 0; i < 2 * n; ++i) {
+    decision[3 * (n + 1) + i] = static_cast<double>(ru[i]);
+    biggest = std::max(biggest, std::fabs(static_cast<double>(ru[i])));
+  }
+  rc = acmpc_unpack_decision(decision, n, table, c->prm.wheelbase, projected_control, prediction, cum_time, times,
+                             accelerations, steer_rates);
+  if (rc != ACMPC_OK) return fail(c, rc, "acmpc_unpack_decision");
+  info[0] = rec[ACMPC_REC_COST];
+  info[1] = rec[ACMPC_REC_VIOLATION];
+  info[2] = rec[ACMPC_REC_NFEASIBLE];
+  info[3] = biggest;
+  info[4] = status[0];
+  info[5] = status[1];
+  info[6] = 0.0;
+  info[7] = 0.0;
+  return ACMPC_OK;
+}
+
+int acmpc_tick_read_device_tables(acmpc_ctx* c, float* x0, float* u_ref, float* coef) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (x0 == nullptr || u_ref == nullptr || coef == nullptr) return fail(c, ACMPC_EINVAL, "null output");
+  if (!c->tick_ready || c->tick_last_n == 0) return fail(c, ACMPC_ESTATE, "acmpc_control_tick has not run");
+  const int n = c->tick_last_n;
+  const TickLayout in(n);
+  ACMPC_HIP(c, hipMemcpy(x0, c->d_tick + in.x0, 3 * sizeof(float), hipMemcpyDeviceToHost));
+  ACMPC_HIP(c, hipMemcpy(u_ref, c->d_tick + in.uref, static_cast<size_t>(n) * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  ACMPC_HIP(c, hipMemcpy(coef, c->d_tick + in.coef, static_cast<size_t>(n) * ACMPC_COEF_STRIDE_SPATIAL * sizeof(float),
+                         hipMemcpyDeviceToHost));
+  return ACMPC_OK;
+}
+
+int acmpc_speed_profile_qp_device(acmpc_ctx* c, const double* v_hi, const double* ds, int32_t n, double a_min,
+                                  double a_max, double v_min, int32_t max_iter, int32_t check_every, double eps_abs,
+                                  double eps_rel, double* v, double* y, int32_t warm_start, int32_t* iterations) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (v_hi == nullptr || ds == nullptr || v == nullptr || y == nullptr || n < 2) return fail(c, ACMPC_EINVAL, "bad argument");
+  if (n > acmpc::kPrologueMaxSteps) return fail(c, ACMPC_ECAPACITY, "the device solver holds at most 256 points");
+  int rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  double* d = nullptr;  // v_hi | ds | v | y | status
+  const size_t doubles = static_cast<size_t>(5) * n + 2;
+  ACMPC_HIP(c, hipMalloc(reinterpret_cast<void**>(&d), doubles * sizeof(double)));
+  double *d_vhi = d, *d_ds = d + n, *d_v = d + 2 * n, *d_y = d + 3 * n;
+  int* d_out = reinterpret_cast<int*>(d + 5 * n);
+  hipError_t e = hipMemcpy(d_vhi, v_hi, static_cast<size_t>(n) * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_ds, ds, static_cast<size_t>(n) * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_v, v, static_cast<size_t>(n) * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_y, y, static_cast<size_t>(2 * n - 1) * sizeof(double), hipMemcpyHostToDevice);
+  const acmpc::admm::Settings st{a_min, a_max, v_min, max_iter, check_every > 0 ? check_every : 10, eps_abs, eps_rel};
+  if (e == hipSuccess) e = acmpc::launch_admm(d_vhi, d_ds, n, st, d_v, d_y, warm_start, d_out, nullptr);
+  int out[2] = {1, 0};
+  if (e == hipSuccess) e = hipMemcpy(v, d_v, static_cast<size_t>(n) * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(y, d_y, static_cast<size_t>(2 * n - 1) * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof out, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail_hip(c, e, "acmpc_speed_profile_qp_device");
+  if (iterations != nullptr) *iterations = out[1];
+  return out[0];
 }
 
 extern "C++" {

@@ -1,8 +1,10 @@
 // Device-side arithmetic of the rollout-and-cost path, gfx950 only.
 //
-// Every function here is the float32 "spec order" of DESIGN.md: one fixed association, no FMA contraction
-// (the translation unit is built with -ffp-contract=off and the pragma below), no library transcendentals.
-// That is what makes costs bit-identical to oracle/acmpc_oracle.{py,c}.
+// Every function here is the float32 "spec order" of DESIGN.md: one fixed association, no library transcendentals,
+// and no IMPLICIT fused multiply-add (the translation unit is built with -ffp-contract=off and the pragma below).
+// Mode S uses no FMA at all.  Mode T's specification names its FMAs explicitly (fma_() below = IEEE fmaf, one
+// rounding): the oracle restates them with C's fmaf and, in NumPy, with an exact emulation (float64 product +
+// TwoSum + round-to-odd).  That is what makes costs bit-identical to oracle/acmpc_oracle.{py,c}.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,6 +24,8 @@ struct Weights {
   float q0, q1, q2;     // Q   (control.py:126)
   float r0, r1;         // R   (control.py:127)
   float qn0, qn1, qn2;  // QN  (control.py:128)
+  // mode T accumulates J += (w/2 * a) * a term by term: the halved weights 0.5f * w (float32 products, exact)
+  float hq0, hq1, hr0, hr1, hqn0, hqn1, hqn2;
   float ulo0, ulo1, uhi0, uhi1;  // input box incl. the 0.1 m/s slack (control.py:130-139)
   float tmin;           // 0.01 (control.py:134)
   float wbound;
@@ -36,6 +40,9 @@ struct Weights {
 // identical, so results do not depend on F.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ f32x2 abs_(f32x2 a) { return __builtin_elementwise_abs(a); }
 
 template <typename F>
 struct IndexOf {
@@ -59,6 +66,9 @@ template <typename F>
 __device__ __forceinline__ F quad(float w, F a) {
   return (w * a) * a;
 }
+
+// fused multiply-add with ONE rounding (v_fma_f32 / v_fmac_f32 / v_pk_fma_f32): only where the specification says so
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 template <typename F>
 __device__ __forceinline__ F hinge2(F lo_minus_x, F x_minus_hi) {
@@ -111,47 +121,58 @@ __device__ __forceinline__ F finish_spatial(const StateS_<F>& s, const Weights& 
 }
 
 // ---- mode T --------------------------------------------------------------------------------------------
-// Cody-Waite reduction by pi/2 and the Cephes single-precision minimax polynomials: the same instruction
-// sequence as oracle sincos_spec().
+// sin / cos of the heading: Cody-Waite reduction by pi (phi = k pi + r, |r| <= pi/2, two-term pi) and odd / even
+// polynomials on [-pi/2, pi/2] fitted for this build (Lawson-weighted least squares, coefficients rounded to
+// float32; evaluated in float32 with the FMAs below |error| < 1.5e-7), every multiply-add fused: the same operation
+// sequence as oracle sincos_spec().  t = fma(phi, 1/pi, 1.5 * 2^23) holds k = rint(phi / pi) in its low mantissa
+// bits - no float -> int conversion (defined for every input, the same bits on every platform) - and
+//     sin phi = (-1)^k sin r,   cos phi = (-1)^k cos r:
+// a reduction by pi needs no quadrant swap, only the sign bit `bits(t) << 31`, at the price of two more polynomial
+// terms than a reduction by pi/2 (the rollout is bound by instruction issue, and a select costs twice an FMA).
+constexpr float kInvPi = 0.3183098861837907f;
+constexpr float kPiHi = 3.140625f;            // 9 significant bits: k * kPiHi is exact for |k| < 2^15
+constexpr float kPiLo = 9.67653589793e-4f;    // pi - kPiHi
+constexpr float kSinC[4] = {-0.16666656732559204f, 0.008333016186952591f, -0.00019806546333711594f,
+                            2.59990065387683e-06f};
+constexpr float kCosC[5] = {-0.5f, 0.04166664183139801f, -0.0013888402609154582f, 2.4761806344031356e-05f,
+                            -2.607563374112942e-07f};
+
+// |sin|-side and |cos|-side values s = sin r, c = cos r and the sign mask (0 or 0x80000000) of (-1)^k
+template <typename F>
+__device__ __forceinline__ void sincos_reduced(F phi, F& s, F& c, typename IndexOf<F>::type& sign) {
+  using I = typename IndexOf<F>::type;
+  const F t = fma_(phi, splat<F>(kInvPi), splat<F>(12582912.0f));
+  const F k = t - 12582912.0f;
+  F r = fma_(-k, splat<F>(kPiHi), phi);
+  r = fma_(-k, splat<F>(kPiLo), r);
+  const F r2 = r * r;
+  F ps = fma_(r2, splat<F>(kSinC[3]), splat<F>(kSinC[2]));
+  ps = fma_(r2, ps, splat<F>(kSinC[1]));
+  ps = fma_(r2, ps, splat<F>(kSinC[0]));
+  s = fma_(r * r2, ps, r);
+  F pc = fma_(r2, splat<F>(kCosC[4]), splat<F>(kCosC[3]));
+  pc = fma_(r2, pc, splat<F>(kCosC[2]));
+  pc = fma_(r2, pc, splat<F>(kCosC[1]));
+  pc = fma_(r2, pc, splat<F>(kCosC[0]));
+  c = fma_(r2, pc, splat<F>(1.0f));
+  sign = __builtin_bit_cast(I, t) << 31;
+}
+
 template <typename F>
 __device__ __forceinline__ void sincos_spec(F phi, F& sn, F& cs) {
   using I = typename IndexOf<F>::type;
-  const F t = phi * 0.6366197723675814f + 12582912.0f;  // 1.5 * 2^23: rint(y) lands in the low mantissa bits
-  const F k = t - 12582912.0f;
-  const F r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
-  const F r2 = r * r;
-  F ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
-  ps = -1.6666654611e-1f + r2 * ps;
-  const F s = r + (r * r2) * ps;
-  F pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
-  pc = 4.166664568298827e-2f + r2 * pc;
-  const F c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
-  const I q = __builtin_bit_cast(I, t) & 3;  // no float -> int conversion: defined for every input
-  sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
-  cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
-}
-template <>
-__device__ __forceinline__ void sincos_spec<float>(float phi, float& sn, float& cs) {
-  const float t = phi * 0.6366197723675814f + 12582912.0f;
-  const float k = t - 12582912.0f;
-  const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
-  const float r2 = r * r;
-  float ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
-  ps = -1.6666654611e-1f + r2 * ps;
-  const float s = r + (r * r2) * ps;
-  float pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
-  pc = 4.166664568298827e-2f + r2 * pc;
-  const float c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
-  const int q = __float_as_int(t) & 3;
-  sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
-  cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+  F s, c;
+  I sign;
+  sincos_reduced<F>(phi, s, c, sign);
+  sn = __builtin_bit_cast(F, __builtin_bit_cast(I, s) ^ sign);
+  cs = __builtin_bit_cast(F, __builtin_bit_cast(I, c) ^ sign);
 }
 
 template <typename F>
 __device__ __forceinline__ F wrap_spec(F a) {
   const F b = a + 3.14159265358979f;
   const F q = __builtin_elementwise_floor(b * 0.159154943091895f);
-  return (b - q * 6.28318530717959f) - 3.14159265358979f;
+  return fma_(-q, splat<F>(6.28318530717959f), b) - 3.14159265358979f;
 }
 
 template <typename F>
@@ -163,11 +184,16 @@ using StateT = StateT_<float>;
 // explicit Euler on the rear-axle kinematic bicycle (localiser.py:66-95); phi_dot = v * kappa
 template <typename F>
 __device__ __forceinline__ void temporal_advance(StateT_<F>& s, F v, F k, const Weights& w) {
-  F sn, cs;
-  sincos_spec<F>(s.phi, sn, cs);
-  const F Xn = s.X + (v * cs) * w.dt;
-  const F Yn = s.Y + (v * sn) * w.dt;
-  const F phin = s.phi + (v * k) * w.dt;
+  // specification: X += (v cos phi) dt with cos phi = (-1)^k cos r.  The sign is applied to v once instead of to the
+  // sine and the cosine: (-v) c and v (-c) are the same float32 product
+  using I = typename IndexOf<F>::type;
+  F sr, cr;
+  I sign;
+  sincos_reduced<F>(s.phi, sr, cr, sign);
+  const F vs = __builtin_bit_cast(F, __builtin_bit_cast(I, v) ^ sign);
+  const F Xn = fma_(vs * cr, splat<F>(w.dt), s.X);
+  const F Yn = fma_(vs * sr, splat<F>(w.dt), s.Y);
+  const F phin = fma_(v * k, splat<F>(w.dt), s.phi);
   s.X = Xn;
   s.Y = Yn;
   s.phi = phin;
@@ -177,7 +203,7 @@ template <typename F, typename G>
 __device__ __forceinline__ F dist2(F X, F Y, G wx, G wy) {
   const F dx = X - wx;
   const F dy = Y - wy;
-  return dx * dx + dy * dy;
+  return fma_(dy, dy, dx * dx);
 }
 
 // nearest waypoint, first minimum of the squared distance (localiser.py:282-289); every lane scans the table
@@ -219,10 +245,26 @@ __device__ __forceinline__ int nearest_in_window(float X, float Y, const float* 
   float best = d[0];
 #pragma unroll
   for (int m = 1; m < W; ++m) best = __builtin_fminf(best, d[m]);  // NaN distances are skipped, like `d < best`
-  int jm = 0;  // also the answer when nothing compares equal (all NaN), where the `d < best` scan keeps `lo`
+  // FIRST index that attains the minimum (0 when nothing compares equal - all NaN - where the `d < best` scan keeps
+  // `lo`).  The W compare results are lane masks in scalar registers; which window position holds each lane's first
+  // hit is worked out on the scalar unit (prefix ORs, one-hot first hits, one mask per index bit), so the vector unit
+  // sees W compares and log2(W) selects instead of W compares and W selects.
+  static_assert((W & (W - 1)) == 0 && W <= 16, "window widths with an unrolled search");
+  unsigned long long hit[W], before = 0ull, bit[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
-  for (int m = W - 1; m >= 1; --m) jm = (d[m] == best) ? m : jm;
-  jm = (d[0] == best) ? 0 : jm;
+  for (int m = 0; m < W; ++m) hit[m] = __builtin_amdgcn_ballot_w64(d[m] == best);
+#pragma unroll
+  for (int m = 0; m < W; ++m) {
+    const unsigned long long first = hit[m] & ~before;  // lanes whose first hit is position m
+    before |= hit[m];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if ((m >> q) & 1) bit[q] |= first;
+  }
+  int jm = __builtin_amdgcn_inverse_ballot_w64(bit[0]) ? 1 : 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q)
+    if ((1 << q) < W) jm |= __builtin_amdgcn_inverse_ballot_w64(bit[q]) ? (1 << q) : 0;
   if (best_out != nullptr) *best_out = best;
   return lo + jm;
 }
@@ -340,18 +382,21 @@ __device__ __forceinline__ int temporal_nearest_window(float X, float Y, const f
 // row entries x, y, cos psi, sin psi, psi, k_ref, v_ref, w/2 - margin per element.
 template <typename F>
 __device__ __forceinline__ void temporal_cost(StateT_<F>& s, const F (&g)[kCoefT], F v, F k, const Weights& w) {
-  s.ey = g[2] * (s.Y - g[1]) - g[3] * (s.X - g[0]);
+  s.ey = fma_(g[2], s.Y - g[1], -(g[3] * (s.X - g[0])));
   s.ep = wrap_spec<F>(s.phi - g[4]);
   const F dv = v - g[6];
   const F dk = k - g[5];
-  F a = quad(w.q0, s.ey);
-  a = a + quad(w.q1, s.ep);
-  F r = quad(w.r0, dv);
-  r = r + quad(w.r1, dk);
-  s.J = s.J + 0.5f * (a + r);
-  s.V = s.V + hinge2<F>(w.ulo0 - v, v - w.uhi0);
-  s.V = s.V + hinge2<F>(w.ulo1 - k, k - w.uhi1);
-  s.V = s.V + hinge2<F>((-g[7]) - s.ey, s.ey - g[7]);
+  // J += 1/2 (q0 ey^2 + q1 ep^2 + r0 dv^2 + r1 dk^2), one fused term at a time with the halved weights
+  s.J = fma_(w.hq0 * s.ey, s.ey, s.J);
+  s.J = fma_(w.hq1 * s.ep, s.ep, s.J);
+  s.J = fma_(w.hr0 * dv, dv, s.J);
+  s.J = fma_(w.hr1 * dk, dk, s.J);
+  const F hv = vmax(vmax(w.ulo0 - v, v - w.uhi0), splat<F>(0.0f));
+  s.V = fma_(hv, hv, s.V);
+  const F hk = vmax(vmax(w.ulo1 - k, k - w.uhi1), splat<F>(0.0f));
+  s.V = fma_(hk, hk, s.V);
+  const F hc = vmax(abs_(s.ey) - g[7], splat<F>(0.0f));  // outside the corridor |e_y| <= w/2 - margin
+  s.V = fma_(hc, hc, s.V);
 }
 
 // one-candidate form used by the finalize kernel and the tile kernel
@@ -474,11 +519,11 @@ __device__ __forceinline__ int step_temporal(StateT& s, const float* wp, const f
 template <typename F>
 __device__ __forceinline__ F finish_temporal(const StateT_<F>& s, int n, const Weights& w) {
   const float tN = static_cast<float>(n) * w.dt;
-  F a = quad(w.qn0, s.ey);
-  a = a + quad(w.qn1, s.ep);
-  a = a + splat<F>(quad(w.qn2, tN));
-  const F J = s.J + 0.5f * a;
-  return J + w.wbound * s.V;
+  F a = (w.hqn0 * s.ey) * s.ey;
+  a = fma_(w.hqn1 * s.ep, s.ep, a);
+  a = fma_(splat<F>(w.hqn2 * tN), splat<F>(tN), a);
+  const F J = s.J + a;
+  return fma_(splat<F>(w.wbound), s.V, J);
 }
 
 // ---- candidate sampling ------------------------------------------------------------------------------------

@@ -74,6 +74,7 @@ struct LaunchShape {
   int cpt;                // candidates per thread
   int blocks_per_problem;
   bool tile;              // candidate-major LDS-tile kernel
+  int pack;               // mode T, cpt >= 2: candidates per arithmetic state (2 = v_pk_* pairs, 1 = plain float32)
 };
 
 // Picks workgroup size / candidates per thread for (P, N, layout); pure function, also used to size workspaces.
@@ -85,6 +86,9 @@ size_t tile_lds_bytes(int mode, int n);
 // and end timestamps, with no marker packets added to the stream.
 hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                           hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// (defined in acmpc_kernels_temporal.hip, the translation unit built without the SLP vectoriser)
+hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
+                                         hipEvent_t start, hipEvent_t stop);
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s);
 // Optional tail of the fused launch: the workgroup that finishes a problem LAST (a ticket counter per problem)

@@ -86,7 +86,8 @@ __device__ __forceinline__ void scalar_touch_wait(uint32_t& sink) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink) : : "memory");
 }
 
-template <int MODE, int LAYOUT, int CPT, int BLOCK>
+// PACK = candidates per arithmetic state: 2 = pairs in v_pk_* instructions, 1 = plain float32 instructions.
+template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1)>
 __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // carve: [0,32) wave keys | [32,48) wave feasible counts | [64, ...) mode-T waypoint table
@@ -132,8 +133,8 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   const bool run = active || (MODE == 1 && a.nn_thr != nullptr);
   const int c_run = active ? c0 : max(a.N - CPT, 0);
   if (run) {
-    // two candidates per packed state (v_pk_* arithmetic) whenever the lane owns at least two
-    constexpr int kPack = (CPT >= 2) ? 2 : 1;
+    constexpr int kPack = PACK;
+    static_assert(CPT % PACK == 0, "a lane's candidates split evenly into arithmetic states");
     constexpr int kGroups = CPT / kPack;
     using F = typename std::conditional<kPack == 2, f32x2, float>::type;
     using I = typename IndexOf<F>::type;
@@ -917,7 +918,7 @@ __global__ void __launch_bounds__(kSoftBlock) softmin_final_kernel(const Softmin
   if (threadIdx.x == 0 && a.weight_sum != nullptr) a.weight_sum[p] = wsum;
 }
 
-template <int MODE, int LAYOUT, int CPT, int BLOCK>
+template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1)>
 hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                             hipEvent_t e1) {
   const dim3 grid(shape.blocks_per_problem, args.P);
@@ -925,10 +926,10 @@ hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, h
                                            sizeof(float)
                                      : 0);
   if (e0 != nullptr && e1 != nullptr) {
-    hipExtLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK>), grid, dim3(BLOCK),
+    hipExtLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK, PACK>), grid, dim3(BLOCK),
                           static_cast<std::uint32_t>(lds), s, e0, e1, 0, args);
   } else {
-    hipLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK>), grid, dim3(BLOCK), lds, s, args);
+    hipLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK, PACK>), grid, dim3(BLOCK), lds, s, args);
   }
   return hipGetLastError();
 }
@@ -947,9 +948,14 @@ hipError_t launch_rollout_tile(const LaunchShape& shape, const RolloutArgs& args
   return hipGetLastError();
 }
 
+#ifndef ACMPC_TEMPORAL_TU
 template <int MODE, int LAYOUT>
 hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                              hipEvent_t e1) {
+  if constexpr (MODE == 1 && LAYOUT == 1) {
+    // plain float32 arithmetic, one state per candidate: built in its own translation unit (acmpc_kernels_temporal.hip)
+    if (shape.pack == 1) return launch_rollout_temporal_plain(shape, args, s, e0, e1);
+  }
   if constexpr (LAYOUT == 0) {
     if (shape.tile) return launch_rollout_tile<MODE>(shape, args, s, e0, e1);
   }
@@ -961,8 +967,25 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
   }
   return hipErrorInvalidConfiguration;
 }
+#endif  // ACMPC_TEMPORAL_TU
 
 }  // namespace
+
+#ifdef ACMPC_TEMPORAL_TU
+// Mode T on the step-major layout with one arithmetic state per candidate (plain v_*_f32 instructions).  The kernel is
+// bound by instruction issue and by the latency of its two dependent LDS gathers per step, not by HBM: measured on
+// MI355X (1 M candidates per launch) the compiler's SLP re-packing of neighbouring candidates into v_pk_* pairs costs
+// 15 % at the 8-waypoint window (183 -> 155 us), because a packed instruction issues at half the rate of a plain one
+// and the packing adds moves - so this translation unit is compiled with -fno-slp-vectorize (ac-mpc_amd/acmpc_amd/_build.py).
+hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
+                                         hipEvent_t e0, hipEvent_t e1) {
+  if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<1, 1, 1, 64, 1>(shape, args, s, e0, e1);
+  if (shape.block == 256 && shape.cpt == 1) return launch_rollout_t<1, 1, 1, 256, 1>(shape, args, s, e0, e1);
+  if (shape.block == 256 && shape.cpt == 2) return launch_rollout_t<1, 1, 2, 256, 1>(shape, args, s, e0, e1);
+  if (shape.block == 256 && shape.cpt == 4) return launch_rollout_t<1, 1, 4, 256, 1>(shape, args, s, e0, e1);
+  return hipErrorInvalidConfiguration;
+}
+#else
 
 // hipGetLastError() returns (and clears) the last error of ANY earlier runtime call of the thread - a failed
 // allocation of this or another library minutes ago included.  Launch status is read with it, so clear it first.
@@ -980,6 +1003,8 @@ LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
   // per-lane work so that each wave load moves 16 B per lane (large step-major batches).
   LaunchShape s;
   s.tile = false;
+  s.pack = (mode == 1) ? 1 : 2;  // mode T: plain float32 states (see launch_rollout_temporal_plain)
+  if (const char* env = std::getenv("ACMPC_T_PACK")) s.pack = (env[0] == '1') ? 1 : 2;
   const long long total = static_cast<long long>(P) * N;
   if (layout == 0 && tile_lds_bytes(mode, n) <= 64 * 1024 && std::getenv("ACMPC_NO_TILE") == nullptr) {
     // candidate-major: one wave per workgroup stages its 64 rows in LDS (rollout_tile_kernel)
@@ -1002,6 +1027,11 @@ LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
   } else if (total <= 256LL * 64 * 8) {
     s.block = 64;
     s.cpt = 1;
+  } else if (mode == 1 && layout == 1 && N % 2 == 0) {
+    // mode T waits on LDS gathers: two candidates per lane keep twice the waves in flight that four would at the same
+    // batch size (1 M candidates: 155 us against 175 us at the 8-waypoint window)
+    s.block = 256;
+    s.cpt = 2;
   } else if (layout == 1 && N % 4 == 0 && total >= 256LL * 4096) {
     // from 1 M candidates up: four candidates per lane as two packed pairs (v_pk_* arithmetic, 16-byte loads).
     // Same-box A/B on 256 x 4 096 x 49 / 1 024 x 4 096 x 49: one per lane 72 / 290 us, two 85 / 285 us, four 68 / 283 us.
@@ -1111,5 +1141,6 @@ hipError_t launch_softmin(int layout, const SoftminArgs& args, hipStream_t s) {
   hipLaunchKernelGGL(softmin_final_kernel, dim3(args.P), dim3(kSoftBlock), 0, s, args);
   return hipGetLastError();
 }
+#endif  // ACMPC_TEMPORAL_TU
 
 }  // namespace acmpc

@@ -1,0 +1,51 @@
+// Host-callable launcher of the per-tick prologue kernel (definitions in acmpc_prologue.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "acmpc_admm.h"
+
+namespace acmpc {
+
+// Head of the per-tick staging block (host pinned -> device, ONE copy per solve): everything that changes from
+// tick to tick and therefore cannot be a kernel argument of the captured graph.  Followed in the block by the
+// H x 3 reference path (float64) and the centre sequence [n][2] (float32).
+struct TickHeader {
+  double offset;                          // lateral displacement of the car (spatial_mpc.py:187)
+  double v_min, v_max, a_min, a_max, ay_max, ki_min, end_velocity;  // speed_profile_constraints (live dict)
+  double qp_eps_abs, qp_eps_rel;
+  double eps;                             // 1e-12 of construct_waypoints (spatial_mpc.py:34)
+  int32_t horizon;                        // H; n = H - 1
+  int32_t localised;                      // LocalisedSpeedProfileSolver instead of SpeedProfileSolver
+  int32_t has_end_velocity;
+  int32_t centre_is_reference;            // sample round the reference controls (no previous plan)
+  int32_t qp_max_iter, qp_check_every;
+  uint32_t seed_lo, seed_hi;              // Philox key of this solve (read by the rollout kernels through seed_ptr)
+};
+
+struct PrologueArgs {
+  const TickHeader* header;   // device copy of the block's head
+  const double* coords;       // [H][3] (x, y, width), device
+  float* x0;                  // [3]        out: Frenet start state
+  float* u_ref;               // [n][2]     out: reference controls clipped to the input box
+  float* coef;                // [n][12]    out: packed mode-S table
+  float* centre;              // [n][2]     in (uploaded) / out when header->centre_is_reference
+  double* table_out;          // [7][n]     out, pinned host memory
+  int* status;                // [2]        out, pinned host memory: QP status (0 solved), iterations
+  double* warm_state;         // 2 solver slots x warm_stride doubles: [valid, n, v (n), y (2n - 1)]
+  int warm_stride;
+  int warm_capacity;          // largest n a slot can hold
+  double margin;              // vehicle width / 2 (dynamics.py:14)
+  double u_lo0, u_lo1, u_hi0, u_hi1;  // QP input box incl. the 0.1 m/s slack (control.py:130-139)
+};
+
+constexpr int kPrologueMaxSteps = 256;  // LDS budget of the single-workgroup prologue (224 n bytes)
+
+size_t prologue_lds_bytes(int n);
+hipError_t launch_prologue(const PrologueArgs& args, int n, hipStream_t s);
+
+// test hook: the device ADMM alone (device pointers; v / y are read when warm != 0 and always written)
+hipError_t launch_admm(const double* d_v_hi, const double* d_ds, int n, const admm::Settings& s, double* d_v, double* d_y,
+                       int warm, int* d_out, hipStream_t stream);
+
+}  // namespace acmpc

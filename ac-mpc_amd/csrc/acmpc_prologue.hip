@@ -1,0 +1,231 @@
+// Per-tick prologue of the closed-loop solve, on the device: everything
+// SpatialMPC.get_control does between receiving the H x 3 reference path and calling the control solver
+// (src/acmpc/control/spatial_mpc.py:180-191), as ONE single-wavefront kernel that is the first node of the solve's
+// hipGraph:
+//
+//   construct_waypoints   spatial_mpc.py:125-154      H x 3 (x, y, width) -> 7 x n table
+//   velocity ceiling      speed_profile.py:26-43,131-150
+//   speed-profile QP      speed_profile.py:47-59      tridiagonal ADMM (acmpc_admm.h), warm-started from the state this
+//                                                     handle keeps on the device between ticks
+//   t2s                   dynamics.py:23-40           pose (offset, 0, pi/2) -> Frenet start state
+//   linearise + corridor  dynamics.py:65-103, control.py:57-60   -> the packed float32 table the rollout reads
+//   reference controls    control.py:26-33            u_ref = clip((v_ref, kappa), input box)
+//
+// float64 throughout, the same operations in the same order as the host path (acmpc_waypoint_table,
+// acmpc_velocity_ceiling, acmpc_speed_profile_qp, acmpc_set_paths); results are written as float32 straight into the
+// staging block the rollout kernels of the same graph read, and the 7 x n table goes to pinned host memory for the
+// caller's read-after-call attributes.  The device's atan2 / sin / cos may differ from the host libm's in the last
+// float64 bit; everything else (+, -, *, /, sqrt, fmod, comparisons) is IEEE-exact on both sides.
+#include <hip/hip_runtime.h>
+
+#include "acmpc_admm.h"
+#include "acmpc_prologue.h"
+
+#pragma clang fp contract(off)
+
+namespace acmpc {
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// np.mod(a + pi, 2 pi) - pi: floored modulo, result in [-pi, pi)
+__device__ __forceinline__ double wrap_angle(double a) {
+  const double two_pi = 2.0 * kPi;
+  double m = fmod(a + kPi, two_pi);
+  if (m != 0.0 && (m < 0.0)) m += two_pi;
+  return m - kPi;
+}
+
+struct WaveTeam {
+  static constexpr int size = 64;
+  __device__ __forceinline__ int rank() const { return static_cast<int>(threadIdx.x); }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ double max(double v, double*) const {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const double o = __shfl_xor(v, m, 64);
+      v = o > v ? o : v;
+    }
+    return v;
+  }
+};
+
+}  // namespace
+
+__global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  const TickHeader& h = *a.header;
+  const int lane = static_cast<int>(threadIdx.x);
+  const int H = h.horizon;
+  const int n = H - 1;
+  const int m = n - 1;
+  // LDS: table [7][n] | v_hi [n] | psi_seg [n + 1] (heading of every segment incl. the closing one) | v [n] |
+  //      y [2n - 1] | ADMM workspace
+  double* table = s_mem;
+  double *tx = table, *ty = table + n, *tpsi = table + 2 * n, *tkappa = table + 3 * n, *tds = table + 4 * n,
+         *twidth = table + 5 * n, *tv = table + 6 * n;
+  double* v_hi = table + 7 * n;
+  double* seg = v_hi + n;
+  double* qv = seg + (n + 1);
+  double* qy = qv + n;
+  admm::Workspace ws;
+  ws.bind(qy + 2 * n, n);
+  const double* __restrict__ coords = a.coords;
+  const WaveTeam team;
+
+  // ---- construct_waypoints (spatial_mpc.py:125-154) ------------------------------------------------------------
+  // headings of the n forward segments and of the segment that closes the loop from the last point to point 0
+  for (int i = lane; i <= n; i += 64) {
+    const double* here = coords + 3 * ((i == n) ? 0 : i);
+    const double* from = coords + 3 * ((i == n) ? H - 1 : i);
+    const double* to = coords + 3 * ((i == n) ? 0 : i + 1);
+    const double ax = to[0] - from[0], ay = to[1] - from[1];
+    seg[i] = atan2(ay, ax);
+    if (i < n) {
+      tx[i] = here[0];
+      ty[i] = here[1];
+      tds[i] = sqrt(ax * ax + ay * ay);
+      twidth[i] = to[2];
+    }
+  }
+  team.sync();
+  for (int i = lane; i < n; i += 64) {
+    const double psi = seg[i];
+    const double behind = seg[(i == 0) ? n : i - 1];  // atan2 of (here - prev): the forward segment of point i - 1
+    tpsi[i] = psi;
+    tkappa[i] = wrap_angle(psi - behind) / (tds[i] + h.eps) + h.eps;
+  }
+  team.sync();
+  if (lane == 0) tkappa[0] = tkappa[1];
+  team.sync();
+
+  // ---- velocity ceiling (speed_profile.py:26-43, localised: 131-150) ----------------------------------------------
+  for (int i = lane; i < n; i += 64) {
+    double c;
+    if (h.localised != 0) {
+      c = h.v_max;
+    } else {
+      const double curvature = fabs(tkappa[i]);
+      c = sqrt(h.ay_max / (curvature + 1e-12));
+      if (curvature < h.ki_min) c = h.v_max;
+      c = fmin(c, h.v_max);
+      c = fmax(h.v_min, c);
+      c = c + 2.0;
+      if (h.has_end_velocity != 0 && i == n - 1) c = h.end_velocity;
+    }
+    v_hi[i] = c;
+  }
+  // ---- speed-profile QP, warm-started from the previous tick's iterate of the same solver ----------------------------
+  double* state = a.warm_state + static_cast<size_t>(h.localised != 0 ? 1 : 0) * a.warm_stride;
+  // state: [valid, n] [v n] [y 2n - 1]
+  const bool warm = state[0] == 1.0 && state[1] == static_cast<double>(n) && a.warm_capacity >= n;
+  if (warm) {
+    for (int i = lane; i < n; i += 64) qv[i] = state[2 + i];
+    for (int i = lane; i < 2 * n - 1; i += 64) qy[i] = state[2 + n + i];
+  }
+  team.sync();
+  const admm::Settings settings{h.a_min, h.a_max, h.v_min, h.qp_max_iter, h.qp_check_every > 0 ? h.qp_check_every : 10,
+                                h.qp_eps_abs, h.qp_eps_rel};
+  int iterations = 0;
+  const int status = admm::solve(team, ws, v_hi, tds, n, settings, qv, qy, warm ? 1 : 0, &iterations);
+  if (status == 0 && a.warm_capacity >= n) {  // keep the iterate only when solved, as the host solver object does
+    for (int i = lane; i < n; i += 64) state[2 + i] = qv[i];
+    for (int i = lane; i < 2 * n - 1; i += 64) state[2 + n + i] = qy[i];
+    if (lane == 0) {
+      state[0] = 1.0;
+      state[1] = static_cast<double>(n);
+    }
+  }
+  // an unsolved profile leaves the velocities the path was built with: zero (spatial_mpc.py:119-122,140)
+  for (int i = lane; i < n; i += 64) tv[i] = (status == 0) ? qv[i] : 0.0;
+  team.sync();
+
+  // ---- t2s of the pose (offset, 0, pi/2) w.r.t. waypoint 0 (dynamics.py:23-40, spatial_mpc.py:187) -------------------
+  if (lane == 0) {
+    const double wx = tx[0], wy = ty[0], wpsi = tpsi[0];
+    const double lateral = cos(wpsi) * (0.0 - wy) - sin(wpsi) * (h.offset - wx);
+    a.x0[0] = static_cast<float>(lateral);
+    a.x0[1] = static_cast<float>(wrap_angle(kPi / 2.0 - wpsi));
+    a.x0[2] = 0.0f;
+    a.status[0] = status;
+    a.status[1] = iterations;
+  }
+  // ---- linearise + corridor rows + reference controls, rounded once to float32 (as acmpc_set_paths does) --------------
+  for (int i = lane; i < n; i += 64) {
+    const double v = tv[i], ds = tds[i], kappa = tkappa[i], width = twidth[i];
+    const double vds = v * ds + 1e-12;
+    float* out = a.coef + static_cast<size_t>(i) * 12;
+    out[0] = static_cast<float>(ds);
+    out[1] = static_cast<float>(-(kappa * kappa) * ds);
+    out[2] = static_cast<float>(-kappa / vds);
+    out[3] = static_cast<float>(-1.0 / (v * v * ds + 1e-12));
+    out[4] = static_cast<float>(1.0 / vds);
+    out[5] = static_cast<float>(v);
+    out[6] = static_cast<float>(kappa);
+    out[7] = static_cast<float>(-width / 2.0 + a.margin);
+    out[8] = static_cast<float>(width / 2.0 - a.margin);
+    out[9] = 0.0f;
+    out[10] = 0.0f;
+    out[11] = 0.0f;
+    const double uv = fmin(fmax(v, a.u_lo0), a.u_hi0);       // np.clip(velocities, lo, hi)
+    const double uk = fmin(fmax(kappa, a.u_lo1), a.u_hi1);
+    a.u_ref[2 * i] = static_cast<float>(uv);
+    a.u_ref[2 * i + 1] = static_cast<float>(uk);
+    if (h.centre_is_reference != 0) {  // a solve without a previous plan samples round the reference controls
+      a.centre[2 * i] = static_cast<float>(uv);
+      a.centre[2 * i + 1] = static_cast<float>(uk);
+    }
+  }
+  // the 7 x n table for the caller (pinned host memory: posted writes, visible once the stream has drained)
+  for (int e = lane; e < 7 * n; e += 64) a.table_out[e] = table[e];
+  (void)m;
+}
+
+size_t prologue_lds_bytes(int n) {
+  return static_cast<size_t>(7 * n + n + (n + 1) + n + 2 * n + admm::workspace_doubles(n)) * sizeof(double);
+}
+
+hipError_t launch_prologue(const PrologueArgs& args, int n, hipStream_t s) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(prologue_kernel, dim3(1), dim3(64), prologue_lds_bytes(n), s, args);
+  return hipGetLastError();
+}
+
+// ---- test hook: the device ADMM alone on caller-supplied (v_hi, ds) -----------------------------------------------------
+__global__ void __launch_bounds__(64) admm_kernel(const double* v_hi_in, const double* ds_in, int n, admm::Settings s,
+                                                  double* v, double* y, int warm, int* out) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  double* v_hi = s_mem;
+  double* ds = v_hi + n;
+  double* qv = ds + n;
+  double* qy = qv + n;
+  admm::Workspace ws;
+  ws.bind(qy + 2 * n, n);
+  const int lane = static_cast<int>(threadIdx.x);
+  for (int i = lane; i < n; i += 64) {
+    v_hi[i] = v_hi_in[i];
+    ds[i] = ds_in[i];
+    qv[i] = v[i];
+  }
+  for (int i = lane; i < 2 * n - 1; i += 64) qy[i] = y[i];
+  __syncthreads();
+  int iterations = 0;
+  const int status = admm::solve(WaveTeam{}, ws, v_hi, ds, n, s, qv, qy, warm, &iterations);
+  for (int i = lane; i < n; i += 64) v[i] = qv[i];
+  for (int i = lane; i < 2 * n - 1; i += 64) y[i] = qy[i];
+  if (lane == 0) {
+    out[0] = status;
+    out[1] = iterations;
+  }
+}
+
+hipError_t launch_admm(const double* d_v_hi, const double* d_ds, int n, const admm::Settings& s, double* d_v, double* d_y,
+                       int warm, int* d_out, hipStream_t stream) {
+  (void)hipGetLastError();
+  const size_t lds = static_cast<size_t>(5 * n + admm::workspace_doubles(n)) * sizeof(double);
+  hipLaunchKernelGGL(admm_kernel, dim3(1), dim3(64), lds, stream, d_v_hi, d_ds, n, s, d_v, d_y, warm, d_out);
+  return hipGetLastError();
+}
+
+}  // namespace acmpc

@@ -203,6 +203,53 @@ int acmpc_reduce_across_ranks(acmpc_ctx* ctx, void* rccl_comm, int64_t* d_keys, 
 int acmpc_optimize(acmpc_ctx* ctx, const float* x0, const float* centre, const float* u_ref, int32_t P, int32_t N,
                    int32_t n, int32_t rounds, const double sigma[2], double shrink, uint64_t seed, float* records);
 
+/* Replaces: the whole of SpatialMPC.get_control (spatial_mpc.py:170-217) for one tick of the control loop, as ONE host
+ * round trip: the H x 3 reference path, the constraints and the centre sequence go up in one copy; the device runs
+ *   prologue (one wavefront): construct_waypoints (spatial_mpc.py:125-154) -> velocity ceiling + speed-profile QP
+ *     (speed_profile.py:26-59, tridiagonal ADMM warm-started from the state the handle keeps on the device) -> t2s
+ *     (dynamics.py:23-40) -> linearise + corridor rows (dynamics.py:65-103, control.py:57-60) -> reference controls,
+ *   `rounds` rounds of sample -> rollout + cost -> argmin (as acmpc_optimize),
+ * all nodes of one captured hipGraph; the winner's record, the 7 x n table and the QP status come back through pinned
+ * host memory, and the tail of get_control (acmpc_unpack_decision) runs before the call returns.  Mode S handles with
+ * centre_update = 0 and horizon - 1 <= 256 only (ACMPC_ESTATE otherwise: use acmpc_set_paths + acmpc_optimize). */
+typedef struct acmpc_tick {
+  uint32_t struct_size;        /* sizeof(acmpc_tick)                                                            */
+  int32_t horizon;             /* H = rows of `coords`; n = H - 1                                               */
+  int32_t localised;           /* != 0: LocalisedSpeedProfileSolver (ceiling = v_max everywhere, no end velocity) */
+  int32_t has_end_velocity;    /* != 0: last ceiling entry = end_velocity (speed_profile.py:42-43)              */
+  int32_t n_candidates;        /* N per round                                                                   */
+  int32_t rounds;
+  int32_t centre_is_reference; /* != 0: sample round the reference controls (`centre` is ignored, may be NULL)  */
+  int32_t qp_max_iter;         /* speed-profile QP: iteration cap (the reference passes 4000, spatial_mpc.py:17) */
+  int32_t qp_check_every;      /* stopping test every this many iterations (<= 0: 10)                           */
+  int32_t reserved;
+  double offset;               /* lateral displacement of the car: pose (offset, 0, pi/2), spatial_mpc.py:187   */
+  double v_min, v_max, a_min, a_max, ay_max, ki_min, end_velocity; /* speed_profile_constraints, read every tick */
+  double sigma[2];             /* first round's spread of (v, kappa); round r uses sigma * shrink^r             */
+  double shrink;
+  double qp_eps_abs, qp_eps_rel;
+  uint64_t seed;
+} acmpc_tick;
+
+/* coords [H][3] float64 (x, y, width) in the vehicle frame; centre [n][2] float32 (v, kappa) or NULL.
+ * Outputs (all required): table [7][n] float64 (rows x, y, psi, kappa, ds, width, v); record
+ * [acmpc_record_floats(n)]; decision [5n + 3] = dec.x ([x_0..x_n ; u_0..u_{n-1}], control.py:121-158);
+ * projected_control [2][n], prediction [n][2], cum_time [n], times / accelerations / steer_rates [n - 1] as
+ * acmpc_unpack_decision writes them; info [8] = {cost, violation, n_feasible, max |dec.x|, QP status (0 = solved,
+ * 1 = maximum iterations), QP iterations, 0, 0}. */
+int acmpc_control_tick(acmpc_ctx* ctx, const acmpc_tick* tick, const double* coords, const float* centre, double* table,
+                       float* record, double* decision, double* projected_control, double* prediction,
+                       double* cum_time, double* times, double* accelerations, double* steer_rates, double* info);
+
+/* Test hooks of the tick path.  acmpc_tick_read_device_tables copies what the last tick's prologue left on the device
+ * for the rollout - x0 [3], u_ref [n][2], the packed table [n][ACMPC_COEF_STRIDE_SPATIAL] - back to the host.
+ * acmpc_speed_profile_qp_device runs the prologue's ADMM alone on the GPU (host pointers, blocking): same arguments
+ * and, bit for bit, the same results as acmpc_speed_profile_qp. */
+int acmpc_tick_read_device_tables(acmpc_ctx* ctx, float* x0, float* u_ref, float* coef);
+int acmpc_speed_profile_qp_device(acmpc_ctx* ctx, const double* v_hi, const double* ds, int32_t n, double a_min,
+                                  double a_max, double v_min, int32_t max_iter, int32_t check_every, double eps_abs,
+                                  double eps_rel, double* v, double* y, int32_t warm_start, int32_t* iterations);
+
 /* Host-side float64 helpers round one solve (csrc/acmpc_host_path.cpp; no GPU work, no handle).
  * Replaces: SpatialMPC.construct_waypoints (spatial_mpc.py:125-154).  coords [H][3] = (x, y, width) ->
  * table [7][n], n = H - 1, rows [x, y, psi, kappa, ds, width, v = 0]. */
@@ -226,11 +273,13 @@ void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t
  *     min 1/2 |v|^2 - v_hi'v   s.t.  a_min <= (v[i+1] - v[i]) / (2 ds[i]) <= a_max,  v_min <= v <= v_hi
  * on the host with the OSQP splitting specialised to the problem's tridiagonal structure: O(n) per iteration, so the
  * whole-lap profile (n ~ 1e4, spatial_mpc.py:60-87) is as cheap per iteration as the horizon's.  `v` [n] and `y`
- * [2n - 1] hold the primal/dual iterate: read when warm_start != 0, always written.  Returns 0 = solved (OSQP's
- * stopping test at eps_abs / eps_rel), 1 = maximum iterations reached, ACMPC_EINVAL on bad arguments.  No GPU work. */
+ * [2n - 1] hold the primal/dual iterate: read when warm_start != 0, always written.  The stopping test (OSQP's, at
+ * eps_abs / eps_rel) runs every `check_every` iterations (<= 0: 10).  Returns 0 = solved, 1 = maximum iterations
+ * reached, ACMPC_EINVAL on bad arguments.  No GPU work.  The device prologue of acmpc_control_tick runs the same
+ * statement of the algorithm (csrc/acmpc_admm.h) on one wavefront: same float64 operations in the same order. */
 int acmpc_speed_profile_qp(const double* v_hi, const double* ds, int32_t n, double a_min, double a_max, double v_min,
-                           int32_t max_iter, double eps_abs, double eps_rel, double* v, double* y, int32_t warm_start,
-                           int32_t* iterations);
+                           int32_t max_iter, int32_t check_every, double eps_abs, double eps_rel, double* v, double* y,
+                           int32_t warm_start, int32_t* iterations);
 
 /* Measurement hooks.  After acmpc_profile_enable(ctx, K) the next K rollout launches of this handle carry a HIP
  * event pair attached to the dispatch itself (hipExtLaunchKernel: the kernel's own begin/end timestamps on the

@@ -2,7 +2,8 @@
  * acmpc_oracle.c - scalar C restatement of the sampling composition (TEST INFRASTRUCTURE ONLY).
  *
  * Same float32 "spec order" as oracle/acmpc_oracle.py (rollout_spatial / rollout_temporal): one fixed
- * association, no FMA contraction (-ffp-contract=off), no libm transcendentals in the rollouts.  It exists to
+ * association, no implicit FMA contraction (-ffp-contract=off), no libm transcendentals in the rollouts; mode T's
+ * specification names its fused multiply-adds explicitly and they are fmaf() here (IEEE, one rounding).  It exists to
  * (a) cross-check the NumPy oracle bit-for-bit at sizes NumPy finishes slowly, and (b) serve as the CPU baseline
  * ("port") that bench.py times beside the GPU.  Nothing under ac-mpc_amd/ links or loads it.
  *
@@ -184,30 +185,38 @@ static inline int32_t float_bits(float f) {
   return b.i;
 }
 
+/* phi = k pi + r, k = rint(phi / pi) read from the mantissa of t, sin phi = (-1)^k sin r, cos phi = (-1)^k cos r */
 static inline void sincos_spec(float phi, float* sn, float* cs) {
-  const float t = phi * 0.6366197723675814f + 12582912.0f;
+  const float t = fmaf(phi, 0.3183098861837907f, 12582912.0f);
   const float k = t - 12582912.0f;
-  const float r = (phi - k * 1.5703125f) - k * 4.838267948966e-4f;
+  float r = fmaf(-k, 3.140625f, phi);
+  r = fmaf(-k, 9.67653589793e-4f, r);
   const float r2 = r * r;
-  float ps = 8.3321608736e-3f + r2 * -1.9515295891e-4f;
-  ps = -1.6666654611e-1f + r2 * ps;
-  const float s = r + (r * r2) * ps;
-  float pc = -1.388731625493765e-3f + r2 * 2.443315711809948e-5f;
-  pc = 4.166664568298827e-2f + r2 * pc;
-  const float c = (1.0f - 0.5f * r2) + (r2 * r2) * pc;
-  const int q = float_bits(t) & 3;
-  *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
-  *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+  float ps = fmaf(r2, 2.59990065387683e-06f, -0.00019806546333711594f);
+  ps = fmaf(r2, ps, 0.008333016186952591f);
+  ps = fmaf(r2, ps, -0.16666656732559204f);
+  const float s = fmaf(r * r2, ps, r);
+  float pc = fmaf(r2, -2.607563374112942e-07f, 2.4761806344031356e-05f);
+  pc = fmaf(r2, pc, -0.0013888402609154582f);
+  pc = fmaf(r2, pc, 0.04166664183139801f);
+  pc = fmaf(r2, pc, -0.5f);
+  const float c = fmaf(r2, pc, 1.0f);
+  const int odd = float_bits(t) & 1;
+  *sn = odd ? -s : s;
+  *cs = odd ? -c : c;
 }
 
 static inline float wrap_spec(float a) {
   const float b = a + 3.14159265358979f;
   const float q = floorf(b * 0.159154943091895f);
-  return (b - q * 6.28318530717959f) - 3.14159265358979f;
+  return fmaf(-q, 6.28318530717959f, b) - 3.14159265358979f;
 }
 
 void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const float* U, int layout, int64_t N, int n,
                                    const oracle_weights* w, float* costs, float* viol, float* states) {
+  /* the halved weights of the term-by-term accumulation J += (w/2 a) a */
+  const float hq0 = 0.5f * w->q[0], hq1 = 0.5f * w->q[1], hr0 = 0.5f * w->r[0], hr1 = 0.5f * w->r[1];
+  const float hqn0 = 0.5f * w->qn[0], hqn1 = 0.5f * w->qn[1], hqn2 = 0.5f * w->qn[2];
 #pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < N; ++c) {
     float X = pose0[0], Y = pose0[1], phi = pose0[2], ey = 0.0f, ep = 0.0f, J = 0.0f, V = 0.0f;
@@ -220,9 +229,9 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       float v, k, sn, cs;
       fetch(U, layout, N, n, c, i, &v, &k);
       sincos_spec(phi, &sn, &cs);
-      const float Xn = X + (v * cs) * w->dt;
-      const float Yn = Y + (v * sn) * w->dt;
-      const float phin = phi + (v * k) * w->dt;
+      const float Xn = fmaf(v * cs, w->dt, X);
+      const float Yn = fmaf(v * sn, w->dt, Y);
+      const float phin = fmaf(v * k, w->dt, phi);
       X = Xn, Y = Yn, phi = phin;
       float best = INFINITY;
       int j = 0;
@@ -238,7 +247,7 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       for (int m = lo; m <= hi; ++m) {
         const float dx = X - wp[m * CT + 0];
         const float dy = Y - wp[m * CT + 1];
-        const float d = dx * dx + dy * dy;
+        const float d = fmaf(dy, dy, dx * dx);
         if (d < best) {
           best = d;
           j = m;
@@ -246,29 +255,31 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       }
       j_prev = j;
       const float* g = wp + j * CT;
-      ey = g[2] * (Y - g[1]) - g[3] * (X - g[0]);
+      ey = fmaf(g[2], Y - g[1], -(g[3] * (X - g[0])));
       ep = wrap_spec(phi - g[4]);
       const float dv = v - g[6];
       const float dk = k - g[5];
-      float a = quad(w->q[0], ey);
-      a = a + quad(w->q[1], ep);
-      float r = quad(w->r[0], dv);
-      r = r + quad(w->r[1], dk);
-      J = J + 0.5f * (a + r);
-      V = V + hinge2(w->ulo[0] - v, v - w->uhi[0]);
-      V = V + hinge2(w->ulo[1] - k, k - w->uhi[1]);
-      V = V + hinge2((-g[7]) - ey, ey - g[7]);
+      J = fmaf(hq0 * ey, ey, J);
+      J = fmaf(hq1 * ep, ep, J);
+      J = fmaf(hr0 * dv, dv, J);
+      J = fmaf(hr1 * dk, dk, J);
+      const float hv = fmaxf(fmaxf(w->ulo[0] - v, v - w->uhi[0]), 0.0f);
+      V = fmaf(hv, hv, V);
+      const float hk = fmaxf(fmaxf(w->ulo[1] - k, k - w->uhi[1]), 0.0f);
+      V = fmaf(hk, hk, V);
+      const float hc = fmaxf(fabsf(ey) - g[7], 0.0f);
+      V = fmaf(hc, hc, V);
       if (states) {
         float* s = states + (c * (n + 1) + i + 1) * 3;
         s[0] = X, s[1] = Y, s[2] = phi;
       }
     }
     const float tN = (float)n * w->dt;
-    float a = quad(w->qn[0], ey);
-    a = a + quad(w->qn[1], ep);
-    a = a + quad(w->qn[2], tN);
-    J = J + 0.5f * a;
-    costs[c] = J + w->wbound * V;
+    float a = (hqn0 * ey) * ey;
+    a = fmaf(hqn1 * ep, ep, a);
+    a = fmaf(hqn2 * tN, tN, a);
+    J = J + a;
+    costs[c] = fmaf(w->wbound, V, J);
     viol[c] = V;
   }
 }

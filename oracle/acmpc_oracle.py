@@ -22,9 +22,13 @@ Parity status
 
 Numerical specification of the sampling path ("spec order")
 -----------------------------------------------------------
-The float32 variants below fix one operation order with no fused multiply-add
-and no library transcendentals, so that NumPy (here), the C restatement
-(`acmpc_oracle.c`) and the HIP kernels (`-ffp-contract=off`) are bit-identical.
+The float32 variants below fix one operation order with no library
+transcendentals and no implicit fused multiply-add, so that NumPy (here), the C
+restatement (`acmpc_oracle.c`) and the HIP kernels (`-ffp-contract=off`) are
+bit-identical.  Mode S uses no FMA at all.  Mode T's specification names its
+FMAs explicitly (`fma32` below: an exact emulation of IEEE `fmaf` - float64
+product, TwoSum, round-to-odd, one rounding to float32 - which C states as
+`fmaf` and the kernels as `v_fma_f32` / `v_pk_fma_f32`).
 The float64 variants are the same formulas in double precision with libm
 trigonometry: they measure the fp32 drift, they are not the parity target.
 """
@@ -380,6 +384,37 @@ def _quad(w, a):
     return (w * a) * a
 
 
+def fma32(a, b, c):
+    """IEEE-754 fmaf on float32 arrays: round_to_float32(a * b + c) with ONE rounding, bit for bit.
+
+    The product of two float32 values is exact in float64 (48 <= 53 significant bits).  The float64 sum p + c is
+    rounded; TwoSum (Knuth) recovers its rounding error exactly, and when that error is not zero the sum is moved to
+    the neighbouring float64 whose last mantissa bit is odd ("round to odd", Boldo & Melquiond 2008): rounding THAT
+    to float32 equals rounding the exact a * b + c to float32, because float64 carries more than 24 + 2 bits.
+    Infinities and NaNs pass through the float64 operations unchanged."""
+    a64 = np.asarray(a, dtype=np.float32).astype(np.float64)
+    b64 = np.asarray(b, dtype=np.float32).astype(np.float64)
+    c64 = np.asarray(c, dtype=np.float32).astype(np.float64)
+    with np.errstate(all="ignore"):
+        p = a64 * b64
+        raw = p + c64
+        s = np.atleast_1d(raw)
+        bb = s - p
+        err = (p - (s - bb)) + (c64 - bb)
+        inexact = np.isfinite(s) & (err != 0.0) & ((s.view(np.int64) & 1) == 0)
+        odd = np.nextafter(s, np.where(err > 0.0, np.inf, -np.inf))
+        out = np.where(inexact, odd, s).astype(np.float32)
+    return out.reshape(np.shape(raw)) if np.ndim(raw) else np.float32(out[0])
+
+
+def _fma_for(dtype):
+    """The fused multiply-add of the mode-T specification in `dtype`: exact fmaf in float32; in float64 (drift
+    reports only) a plain multiply and add."""
+    if dtype is np.float32:
+        return fma32
+    return lambda a, b, c: a * b + c
+
+
 def _hinge2(lo_minus_x, x_minus_hi, zero):
     # distance outside [lo, hi]: at most one side of a non-degenerate interval can be violated.  IEEE maxNum (a NaN
     # operand is dropped) - C's fmaxf and the GPU's v_max_f32; np.maximum would propagate the NaN instead
@@ -438,12 +473,14 @@ def rollout_spatial(x0, coef, U, Q, R, QN, u_lo, u_hi, w_bound, dtype=np.float32
     return (cost, V, X) if return_states else (cost, V)
 
 
-# --- spec trigonometry (Cody-Waite reduction + Cephes single-precision minimax polynomials) -------
-TWO_OVER_PI = 0.6366197723675814
-PIO2_HI = 1.5703125  # 8 significant bits: k*PIO2_HI is exact for |k| < 2^16
-PIO2_LO = 4.838267948966e-4  # pi/2 - PIO2_HI
-SIN_C = (-1.6666654611e-1, 8.3321608736e-3, -1.9515295891e-4)
-COS_C = (4.166664568298827e-2, -1.388731625493765e-3, 2.443315711809948e-5)
+# --- spec trigonometry (Cody-Waite reduction by pi + odd / even polynomials on [-pi/2, pi/2] fitted for this build) ---
+INV_PI = 0.3183098861837907
+PI_HI = 3.140625  # 9 significant bits: k*PI_HI is exact for |k| < 2^15
+PI_LO = 9.67653589793e-4  # pi - PI_HI
+# sin r = r + r^3 (S0 + S1 r^2 + S2 r^4 + S3 r^6),  cos r = 1 + r^2 (C0 + C1 r^2 + ... + C4 r^8): Lawson-weighted least
+# squares on [-pi/2, pi/2], coefficients rounded to float32; |error| < 1.5e-7 evaluated in float32 with the FMAs below
+SIN_C = (-0.16666656732559204, 0.008333016186952591, -0.00019806546333711594, 2.59990065387683e-06)
+COS_C = (-0.5, 0.04166664183139801, -0.0013888402609154582, 2.4761806344031356e-05, -2.607563374112942e-07)
 PI_F = 3.14159265358979
 TWO_PI_F = 6.28318530717959
 INV_TWO_PI_F = 0.159154943091895
@@ -453,38 +490,45 @@ ROUND_MAGIC = 12582912.0  # 1.5 * 2^23: adding it to |y| < 2^22 rounds y to the 
 
 
 def sincos_spec(phi, dtype=np.float32):
-    """sin/cos with a fixed instruction sequence (bit-identical on CPU and GPU in float32)."""
+    """sin/cos with a fixed instruction sequence (bit-identical on CPU and GPU in float32): phi = k pi + r with
+    k = rint(phi / pi), sin phi = (-1)^k sin r, cos phi = (-1)^k cos r, every multiply-add fused."""
     T = dtype
+    fma = _fma_for(T)
     phi = np.asarray(phi, dtype=T)
     if T is np.float32:
-        # round-to-integer and quadrant WITHOUT a float -> int conversion (whose out-of-range result differs between
-        # x86, NumPy and the GPU): t = y + 1.5 * 2^23 holds rint(y) in its low mantissa bits, k = t - 1.5 * 2^23.
-        # Identical to rint / (int & 3) for |phi| < 6.5e6 rad; beyond that still one fixed bit pattern everywhere.
-        t = phi * T(TWO_OVER_PI) + T(ROUND_MAGIC)
-        q = t.view(np.int32) & 3
-        k = t - T(ROUND_MAGIC)
+        # round-to-integer WITHOUT a float -> int conversion (whose out-of-range result differs between x86, NumPy
+        # and the GPU): t = fma(phi, 1/pi, 1.5 * 2^23) holds rint(y) in its low mantissa bits, k = t - 1.5 * 2^23.
+        # Identical to rint for |phi| < 1.3e7 rad; beyond that still one fixed bit pattern everywhere.
+        t = np.atleast_1d(fma(phi, T(INV_PI), T(ROUND_MAGIC)))
+        odd = ((t.view(np.int32) & 1) != 0).reshape(np.shape(phi))
+        k = t.reshape(np.shape(phi)) - T(ROUND_MAGIC)
     else:  # float64 drift reports only
-        k = np.rint(phi * T(TWO_OVER_PI))
-        q = np.where(np.isfinite(k), k, 0.0).astype(np.int64) & 3
-    r = (phi - k * T(PIO2_HI)) - k * T(PIO2_LO)
+        k = np.rint(phi * T(INV_PI))
+        odd = (np.where(np.isfinite(k), k, 0.0).astype(np.int64) & 1) != 0
+    r = fma(-k, T(PI_HI), phi)
+    r = fma(-k, T(PI_LO), r)
     r2 = r * r
-    ps = T(SIN_C[1]) + r2 * T(SIN_C[2])
-    ps = T(SIN_C[0]) + r2 * ps
-    s = r + (r * r2) * ps
-    pc = T(COS_C[1]) + r2 * T(COS_C[2])
-    pc = T(COS_C[0]) + r2 * pc
-    c = (T(1.0) - T(0.5) * r2) + (r2 * r2) * pc
-    sin = np.where(q == 0, s, np.where(q == 1, c, np.where(q == 2, -s, -c)))
-    cos = np.where(q == 0, c, np.where(q == 1, -s, np.where(q == 2, -c, s)))
+    ps = fma(r2, T(SIN_C[3]), T(SIN_C[2]))
+    ps = fma(r2, ps, T(SIN_C[1]))
+    ps = fma(r2, ps, T(SIN_C[0]))
+    s = fma(r * r2, ps, r)
+    pc = fma(r2, T(COS_C[4]), T(COS_C[3]))
+    pc = fma(r2, pc, T(COS_C[2]))
+    pc = fma(r2, pc, T(COS_C[1]))
+    pc = fma(r2, pc, T(COS_C[0]))
+    c = fma(r2, pc, T(1.0))
+    sin = np.where(odd, -s, s)
+    cos = np.where(odd, -c, c)
     return sin.astype(T), cos.astype(T)
 
 
 def wrap_spec(angle, dtype=np.float32):
-    """(-pi, pi] wrap as a - floor(a/2pi)*2pi - pi with a reciprocal multiply (no division)."""
+    """(-pi, pi] wrap as fma(-floor(b / 2pi), 2pi, b) - pi, b = a + pi, with a reciprocal multiply (no division)."""
     T = dtype
+    fma = _fma_for(T)
     a = angle + T(PI_F)
     q = np.floor(a * T(INV_TWO_PI_F))
-    return (a - q * T(TWO_PI_F)) - T(PI_F)
+    return fma(-q, T(TWO_PI_F), a) - T(PI_F)
 
 
 def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.float32,
@@ -506,6 +550,8 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
     Q, R, QN = (np.asarray(a, dtype=T) for a in (Q, R, QN))
     u_lo, u_hi = np.asarray(u_lo, dtype=T), np.asarray(u_hi, dtype=T)
     half, zero, wb, dtT = T(0.5), T(0.0), T(w_bound), T(dt)
+    fma = _fma_for(T)
+    hQ, hR, hQN = half * Q, half * R, half * QN   # the halved weights (products in `dtype`, exact)
     X = np.full(N, T(pose0[0]), dtype=T)
     Y = np.full(N, T(pose0[1]), dtype=T)
     phi = np.full(N, T(pose0[2]), dtype=T)
@@ -524,9 +570,9 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
             sn, cs = np.sin(phi).astype(T), np.cos(phi).astype(T)
         else:
             sn, cs = sincos_spec(phi, T)
-        Xn = X + (v * cs) * dtT
-        Yn = Y + (v * sn) * dtT
-        phin = phi + (v * k) * dtT
+        Xn = fma(v * cs, dtT, X)
+        Yn = fma(v * sn, dtT, Y)
+        phin = fma(v * k, dtT, phi)
         X, Y, phi = Xn, Yn, phin
         best = np.full(N, np.inf, dtype=T)
         if nn_window is None:
@@ -534,7 +580,7 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
             for w in range(n):
                 dx = X - wp[w, CT_X]
                 dy = Y - wp[w, CT_Y]
-                d = dx * dx + dy * dy
+                d = fma(dy, dy, dx * dx)
                 better = d < best
                 best = np.where(better, d, best)
                 j = np.where(better, w, j)
@@ -548,36 +594,39 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
                 w = np.minimum(lo + m, hi)
                 dx = X - wp[w, CT_X]
                 dy = Y - wp[w, CT_Y]
-                d = dx * dx + dy * dy
+                d = fma(dy, dy, dx * dx)
                 better = d < best
                 best = np.where(better, d, best)
                 j = np.where(better, w, j)
         j_prev = j
         g = wp[j]
-        ey = g[:, CT_COS] * (Y - g[:, CT_Y]) - g[:, CT_SIN] * (X - g[:, CT_X])
+        ey = fma(g[:, CT_COS], Y - g[:, CT_Y], -(g[:, CT_SIN] * (X - g[:, CT_X])))
         if libm_trig:
             ep = wrap_to_pi(phi - g[:, CT_PSI]).astype(T)
         else:
             ep = wrap_spec(phi - g[:, CT_PSI], T)
         dv = v - g[:, CT_VREF]
         dk = k - g[:, CT_KREF]
-        s = _quad(Q[0], ey)
-        s = s + _quad(Q[1], ep)
-        r = _quad(R[0], dv)
-        r = r + _quad(R[1], dk)
-        J = J + half * (s + r)
-        V = V + _hinge2(u_lo[0] - v, v - u_hi[0], zero)
-        V = V + _hinge2(u_lo[1] - k, k - u_hi[1], zero)
-        V = V + _hinge2((-g[:, CT_HALF]) - ey, ey - g[:, CT_HALF], zero)
+        # J += 1/2 (q0 ey^2 + q1 ep^2 + r0 dv^2 + r1 dk^2), one fused term at a time with the halved weights
+        J = fma(hQ[0] * ey, ey, J)
+        J = fma(hQ[1] * ep, ep, J)
+        J = fma(hR[0] * dv, dv, J)
+        J = fma(hR[1] * dk, dk, J)
+        hv = np.fmax(np.fmax(u_lo[0] - v, v - u_hi[0]), zero)   # IEEE maxNum: a NaN operand is dropped
+        V = fma(hv, hv, V)
+        hk = np.fmax(np.fmax(u_lo[1] - k, k - u_hi[1]), zero)
+        V = fma(hk, hk, V)
+        hc = np.fmax(np.abs(ey) - g[:, CT_HALF], zero)           # outside the corridor |e_y| <= w/2 - margin
+        V = fma(hc, hc, V)
         if return_states:
             S[:, i + 1, 0], S[:, i + 1, 1], S[:, i + 1, 2] = X, Y, phi
             J_idx[:, i] = j
     tN = T(n) * dtT
-    s = _quad(QN[0], ey)
-    s = s + _quad(QN[1], ep)
-    s = s + _quad(QN[2], tN)
-    J = J + half * s
-    cost = J + wb * V
+    s = (hQN[0] * ey) * ey
+    s = fma(hQN[1] * ep, ep, s)
+    s = fma(hQN[2] * tN, tN, s)
+    J = J + s
+    cost = fma(wb, V, J)
     return (cost, V, S, J_idx) if return_states else (cost, V)
 
 
