@@ -17,7 +17,9 @@ HEADERS = ("acmpc_kernels.h", "acmpc_device.h", "acmpc_admm.h", "acmpc_prologue.
 # -ffp-contract=off: no IMPLICIT fused multiply-add anywhere; the FMAs of mode T's specification are spelt out
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra")
 # per-source extras: the mode-T rollout is faster without the SLP vectoriser's v_pk_* re-packing (measured, see the source)
-EXTRA_FLAGS = {"acmpc_kernels_temporal.hip": ("-fno-slp-vectorize",)}
+# -mfma on the host-only solver: its three sequential sweeps spell out one fma per step (csrc/acmpc_admm.h), which
+# should be the instruction, not a libm call
+EXTRA_FLAGS = {"acmpc_kernels_temporal.hip": ("-fno-slp-vectorize",), "acmpc_speed_profile.cpp": ("-mfma",)}
 
 
 def find_hipcc() -> str:

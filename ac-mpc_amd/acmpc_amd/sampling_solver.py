@@ -98,7 +98,7 @@ class ControlSolver:
     def supports_tick(self) -> bool:
         """Whether `solve_tick` (the one-round-trip path, prologue on the device) applies: argmin centre update and a
         horizon the single-workgroup prologue holds."""
-        return self._centre_update == "argmin" and self._n_horizon <= 256
+        return self._centre_update == "argmin" and self._n_horizon <= 128
 
     def solve_tick(self, coords: np.ndarray, offset: float, constraints: Dict, is_localised: bool,
                    qp_max_iter: int = 4000, qp_check_every: int = 10):

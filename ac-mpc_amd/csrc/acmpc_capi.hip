@@ -973,15 +973,19 @@ namespace {
 
 size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
-// layout of the tick staging block for a horizon of n steps (device and pinned host copies share it)
+// layout of the tick blocks for a horizon of n steps: the pinned host input block (header | coords | centre) and the
+// device block the prologue fills for the rollout kernels (seed | x0 | centre | u_ref | table)
 struct TickLayout {
-  size_t coords, centre, upload, x0, uref, coef, total;
+  size_t coords, centre_in, host_total;            // pinned host block
+  size_t seed, x0, centre, uref, coef, total;      // device block
   explicit TickLayout(int n) {
     coords = align16(sizeof(acmpc::TickHeader));
-    centre = align16(coords + static_cast<size_t>(n + 1) * 3 * sizeof(double));
-    upload = align16(centre + static_cast<size_t>(n) * 2 * sizeof(float));
-    x0 = upload;
-    uref = align16(x0 + 4 * sizeof(float));
+    centre_in = align16(coords + static_cast<size_t>(n + 1) * 3 * sizeof(double));
+    host_total = align16(centre_in + static_cast<size_t>(n) * 2 * sizeof(float));
+    seed = 0;
+    x0 = 16;
+    centre = 32;
+    uref = align16(centre + static_cast<size_t>(n) * 2 * sizeof(float));
     coef = align16(uref + static_cast<size_t>(n) * 2 * sizeof(float));
     total = align16(coef + static_cast<size_t>(n) * ACMPC_COEF_STRIDE_SPATIAL * sizeof(float));
   }
@@ -1002,7 +1006,7 @@ int ensure_tick(acmpc_ctx* c) {
   if (c->tick_ready) return ACMPC_OK;
   c->touched_device = true;
   const int n_cap = std::min(c->prm.max_steps, acmpc::kPrologueMaxSteps);
-  ACMPC_HIP(c, host_alloc_once(&c->h_tick, TickLayout(n_cap).total));
+  ACMPC_HIP(c, host_alloc_once(&c->h_tick, TickLayout(n_cap).host_total));
   ACMPC_HIP(c, alloc_once(&c->d_tick, TickLayout(n_cap).total));
   ACMPC_HIP(c, host_alloc_once(&c->h_tick_out, TickOutLayout(n_cap).total));
   c->warm_stride = 2 + 3 * n_cap;
@@ -1031,7 +1035,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   const int H = t->horizon, n = H - 1, N = t->n_candidates;
   if (H < 3 || t->rounds < 1 || N < 1) return fail(c, ACMPC_EINVAL, "need horizon >= 3, rounds >= 1, n_candidates >= 1");
   if (n > c->prm.max_steps || N > c->prm.max_candidates) return fail(c, ACMPC_ECAPACITY, "horizon or candidates exceed capacity");
-  if (n > acmpc::kPrologueMaxSteps) return fail(c, ACMPC_ESTATE, "the device prologue holds at most 256 steps");
+  if (n > acmpc::kPrologueMaxSteps) return fail(c, ACMPC_ESTATE, "the device prologue holds at most 128 steps");
   if (centre == nullptr && t->centre_is_reference == 0) return fail(c, ACMPC_EINVAL, "null centre");
   if (!acmpc::fused_finalize_fits(c->prm.mode, n)) return fail(c, ACMPC_ESTATE, "fused finalize does not fit");
   int rc = ensure_device(c);
@@ -1045,75 +1049,88 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   const TickOutLayout out(n);
   const int rec_floats = acmpc_record_floats(n);
 
-  acmpc_ctx::TickKey key;
-  key.N = N;
-  key.n = n;
-  key.rounds = t->rounds;
-  key.sigma_v = t->sigma[0];
-  key.sigma_k = t->sigma[1];
-  key.shrink = t->shrink;
-  int slot = -1;
-  for (int g = 0; g < acmpc_ctx::kOptGraphs; ++g)
-    if (c->tick_graph[g] != nullptr && key == c->tick_key[g]) slot = g;
-  if (slot < 0) {
-    slot = 0;
-    for (int g = 1; g < acmpc_ctx::kOptGraphs; ++g)
-      if (c->tick_used[g] < c->tick_used[slot]) slot = g;
-    if (c->tick_graph[slot] != nullptr) {
-      (void)hipGraphExecDestroy(c->tick_graph[slot]);
-      c->tick_graph[slot] = nullptr;
-    }
-    rc = upload_segments(c, n, s);  // must not happen inside the capture (it synchronises)
-    if (rc != ACMPC_OK) return rc;
-    acmpc::PrologueArgs pa{};
-    pa.header = reinterpret_cast<const acmpc::TickHeader*>(c->d_tick);
-    pa.coords = reinterpret_cast<const double*>(c->d_tick + in.coords);
-    pa.x0 = reinterpret_cast<float*>(c->d_tick + in.x0);
-    pa.u_ref = reinterpret_cast<float*>(c->d_tick + in.uref);
-    pa.coef = reinterpret_cast<float*>(c->d_tick + in.coef);
-    pa.centre = reinterpret_cast<float*>(c->d_tick + in.centre);
-    pa.table_out = reinterpret_cast<double*>(c->h_tick_out + out.table);
-    pa.status = reinterpret_cast<int*>(c->h_tick_out + out.status);
-    pa.warm_state = c->d_warm;
-    pa.warm_stride = c->warm_stride;
-    pa.warm_capacity = (c->warm_stride - 2) / 3;
-    pa.margin = c->prm.margin;
-    pa.u_lo0 = c->prm.u_min[0];
-    pa.u_lo1 = c->prm.u_min[1];
-    pa.u_hi0 = c->prm.u_max[0];
-    pa.u_hi1 = c->prm.u_max[1];
-    hipGraph_t graph = nullptr;
-    ACMPC_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipError_t e = hipMemcpyAsync(c->d_tick, c->h_tick, in.upload, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = acmpc::launch_prologue(pa, n, s);
-    int rc_rounds = ACMPC_OK;
-    const bool direct = use_fused_finalize(c, n);
-    if (e == hipSuccess) {
-      const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef};
-      const uint32_t* d_seed = reinterpret_cast<const uint32_t*>(c->d_tick + offsetof(acmpc::TickHeader, seed_lo));
-      rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink, 0, d_seed, s, true,
-                                 direct ? reinterpret_cast<float*>(c->h_tick_out + out.record) : nullptr);
-    }
-    if (e == hipSuccess && rc_rounds == ACMPC_OK && !direct)
+  acmpc::PrologueArgs pa{};
+  pa.header = reinterpret_cast<const acmpc::TickHeader*>(c->h_tick);   // read in place over the host link
+  pa.coords = reinterpret_cast<const double*>(c->h_tick + in.coords);
+  pa.centre_in = reinterpret_cast<const float*>(c->h_tick + in.centre_in);
+  pa.x0 = reinterpret_cast<float*>(c->d_tick + in.x0);
+  pa.u_ref = reinterpret_cast<float*>(c->d_tick + in.uref);
+  pa.coef = reinterpret_cast<float*>(c->d_tick + in.coef);
+  pa.centre = reinterpret_cast<float*>(c->d_tick + in.centre);
+  pa.seed = reinterpret_cast<uint32_t*>(c->d_tick + in.seed);
+  pa.table_out = reinterpret_cast<double*>(c->h_tick_out + out.table);
+  pa.status = reinterpret_cast<int*>(c->h_tick_out + out.status);
+  pa.warm_state = c->d_warm;
+  pa.warm_stride = c->warm_stride;
+  pa.warm_capacity = (c->warm_stride - 2) / 3;
+  pa.margin = c->prm.margin;
+  pa.u_lo0 = c->prm.u_min[0];
+  pa.u_lo1 = c->prm.u_min[1];
+  pa.u_hi0 = c->prm.u_max[0];
+  pa.u_hi1 = c->prm.u_max[1];
+  const bool direct = use_fused_finalize(c, n);
+  // prologue -> rounds (-> copy of the record when the fused finalize cannot write it to the host itself)
+  auto enqueue = [&](hipStream_t q, int* rc_rounds) -> hipError_t {
+    hipError_t e = acmpc::launch_prologue(pa, n, q);
+    if (e != hipSuccess) return e;
+    const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef};
+    *rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink, 0, pa.seed, q, true,
+                                direct ? reinterpret_cast<float*>(c->h_tick_out + out.record) : nullptr);
+    if (*rc_rounds == ACMPC_OK && !direct)
       e = hipMemcpyAsync(c->h_tick_out + out.record, c->d_records, static_cast<size_t>(rec_floats) * sizeof(float),
-                         hipMemcpyDeviceToHost, s);
-    const hipError_t e_end = hipStreamEndCapture(s, &graph);
-    if (rc_rounds != ACMPC_OK) {
-      if (graph != nullptr) (void)hipGraphDestroy(graph);
-      return rc_rounds;
+                         hipMemcpyDeviceToHost, q);
+    return e;
+  };
+  // Three short kernels behind one another: launched directly they start sooner than a graph replay does (the
+  // replay's fixed cost is ~10 us on this runtime, a launch on an idle stream ~4 us, and the later launches overlap
+  // the prologue's execution).  ACMPC_TICK_GRAPH=1 replays a captured graph instead.
+  static const bool use_graph = std::getenv("ACMPC_TICK_GRAPH") != nullptr;
+  int slot = -1;
+  if (use_graph) {
+    acmpc_ctx::TickKey key;
+    key.N = N;
+    key.n = n;
+    key.rounds = t->rounds;
+    key.sigma_v = t->sigma[0];
+    key.sigma_k = t->sigma[1];
+    key.shrink = t->shrink;
+    for (int g = 0; g < acmpc_ctx::kOptGraphs; ++g)
+      if (c->tick_graph[g] != nullptr && key == c->tick_key[g]) slot = g;
+    if (slot < 0) {
+      slot = 0;
+      for (int g = 1; g < acmpc_ctx::kOptGraphs; ++g)
+        if (c->tick_used[g] < c->tick_used[slot]) slot = g;
+      if (c->tick_graph[slot] != nullptr) {
+        (void)hipGraphExecDestroy(c->tick_graph[slot]);
+        c->tick_graph[slot] = nullptr;
+      }
+      rc = upload_segments(c, n, s);  // must not happen inside the capture (it synchronises)
+      if (rc != ACMPC_OK) return rc;
+      hipGraph_t graph = nullptr;
+      ACMPC_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      int rc_rounds = ACMPC_OK;
+      const hipError_t e = enqueue(s, &rc_rounds);
+      const hipError_t e_end = hipStreamEndCapture(s, &graph);
+      if (rc_rounds != ACMPC_OK) {
+        if (graph != nullptr) (void)hipGraphDestroy(graph);
+        return rc_rounds;
+      }
+      if (e != hipSuccess) {
+        if (graph != nullptr) (void)hipGraphDestroy(graph);
+        return fail_hip(c, e, "capturing the tick graph");
+      }
+      ACMPC_HIP(c, e_end);
+      const hipError_t e_inst = hipGraphInstantiate(&c->tick_graph[slot], graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e_inst != hipSuccess) c->tick_graph[slot] = nullptr;
+      ACMPC_HIP(c, e_inst);
+      c->tick_key[slot] = key;
     }
-    if (e != hipSuccess) {
-      if (graph != nullptr) (void)hipGraphDestroy(graph);
-      return fail_hip(c, e, "capturing the tick graph");
-    }
-    ACMPC_HIP(c, e_end);
-    const hipError_t e_inst = hipGraphInstantiate(&c->tick_graph[slot], graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e_inst != hipSuccess) c->tick_graph[slot] = nullptr;
-    ACMPC_HIP(c, e_inst);
-    c->tick_key[slot] = key;
+    c->tick_used[slot] = ++c->opt_clock;
+  } else {
+    rc = upload_segments(c, n, s);  // (a no-op once the table for this n is resident)
+    if (rc != ACMPC_OK) return rc;
   }
-  c->tick_used[slot] = ++c->opt_clock;
 
   acmpc::TickHeader* h = reinterpret_cast<acmpc::TickHeader*>(c->h_tick);
   h->offset = t->offset;
@@ -1136,8 +1153,15 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   h->seed_lo = static_cast<uint32_t>(t->seed);
   h->seed_hi = static_cast<uint32_t>(t->seed >> 32);
   std::memcpy(c->h_tick + in.coords, coords, static_cast<size_t>(H) * 3 * sizeof(double));
-  if (centre != nullptr) std::memcpy(c->h_tick + in.centre, centre, static_cast<size_t>(n) * 2 * sizeof(float));
-  ACMPC_HIP(c, hipGraphLaunch(c->tick_graph[slot], s));
+  if (centre != nullptr) std::memcpy(c->h_tick + in.centre_in, centre, static_cast<size_t>(n) * 2 * sizeof(float));
+  if (use_graph) {
+    ACMPC_HIP(c, hipGraphLaunch(c->tick_graph[slot], s));
+  } else {
+    int rc_rounds = ACMPC_OK;
+    const hipError_t e = enqueue(s, &rc_rounds);
+    if (rc_rounds != ACMPC_OK) return rc_rounds;
+    ACMPC_HIP(c, e);
+  }
   ACMPC_HIP(c, hipStreamSynchronize(s));
   c->tick_last_n = n;
 
@@ -1189,7 +1213,7 @@ int acmpc_speed_profile_qp_device(acmpc_ctx* c, const double* v_hi, const double
                                   double eps_rel, double* v, double* y, int32_t warm_start, int32_t* iterations) {
   if (c == nullptr) return ACMPC_EINVAL;
   if (v_hi == nullptr || ds == nullptr || v == nullptr || y == nullptr || n < 2) return fail(c, ACMPC_EINVAL, "bad argument");
-  if (n > acmpc::kPrologueMaxSteps) return fail(c, ACMPC_ECAPACITY, "the device solver holds at most 256 points");
+  if (n > acmpc::kPrologueMaxSteps) return fail(c, ACMPC_ECAPACITY, "the device solver holds at most 128 points");
   int rc = ensure_device(c);
   if (rc != ACMPC_OK) return rc;
   double* d = nullptr;  // v_hi | ds | v | y | status

@@ -7,9 +7,10 @@
 
 namespace acmpc {
 
-// Head of the per-tick staging block (host pinned -> device, ONE copy per solve): everything that changes from
-// tick to tick and therefore cannot be a kernel argument of the captured graph.  Followed in the block by the
-// H x 3 reference path (float64) and the centre sequence [n][2] (float32).
+// Head of the per-tick input block in pinned host memory: everything that changes from tick to tick and therefore
+// cannot be a kernel argument of the captured graph.  Followed in the block by the H x 3 reference path (float64) and
+// the centre sequence [n][2] (float32).  The prologue kernel reads the block in place, over the host link (1.7 kB at
+// H = 50: one round of loads) - no copy node in front of it - and leaves on the device what the rollout kernels read.
 struct TickHeader {
   double offset;                          // lateral displacement of the car (spatial_mpc.py:187)
   double v_min, v_max, a_min, a_max, ay_max, ki_min, end_velocity;  // speed_profile_constraints (live dict)
@@ -24,12 +25,14 @@ struct TickHeader {
 };
 
 struct PrologueArgs {
-  const TickHeader* header;   // device copy of the block's head
-  const double* coords;       // [H][3] (x, y, width), device
+  const TickHeader* header;   // pinned host memory
+  const double* coords;       // [H][3] (x, y, width), pinned host memory
+  const float* centre_in;     // [n][2] pinned host memory (ignored when header->centre_is_reference)
   float* x0;                  // [3]        out: Frenet start state
   float* u_ref;               // [n][2]     out: reference controls clipped to the input box
   float* coef;                // [n][12]    out: packed mode-S table
-  float* centre;              // [n][2]     in (uploaded) / out when header->centre_is_reference
+  float* centre;              // [n][2]     out: the sequence round 0 samples round (centre_in or u_ref)
+  uint32_t* seed;             // [2]        out: Philox key of this solve (the rollout kernels' seed_ptr)
   double* table_out;          // [7][n]     out, pinned host memory
   int* status;                // [2]        out, pinned host memory: QP status (0 solved), iterations
   double* warm_state;         // 2 solver slots x warm_stride doubles: [valid, n, v (n), y (2n - 1)]
@@ -39,7 +42,8 @@ struct PrologueArgs {
   double u_lo0, u_lo1, u_hi0, u_hi1;  // QP input box incl. the 0.1 m/s slack (control.py:130-139)
 };
 
-constexpr int kPrologueMaxSteps = 256;  // LDS budget of the single-workgroup prologue (224 n bytes)
+constexpr int kPrologueMaxSteps = admm::kPcrMaxN;  // LDS budget of the single-workgroup prologue (~390 n bytes) and the
+                                                   // size up to which the tridiagonal solve is the parallel one
 
 size_t prologue_lds_bytes(int n);
 hipError_t launch_prologue(const PrologueArgs& args, int n, hipStream_t s);

@@ -55,7 +55,7 @@ struct WaveTeam {
 
 __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
-  const TickHeader& h = *a.header;
+  const TickHeader h = *a.header;  // ONE read of the head over the host link; everything below uses the copy
   const int lane = static_cast<int>(threadIdx.x);
   const int H = h.horizon;
   const int n = H - 1;
@@ -150,6 +150,8 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     a.x0[2] = 0.0f;
     a.status[0] = status;
     a.status[1] = iterations;
+    a.seed[0] = h.seed_lo;
+    a.seed[1] = h.seed_hi;
   }
   // ---- linearise + corridor rows + reference controls, rounded once to float32 (as acmpc_set_paths does) --------------
   for (int i = lane; i < n; i += 64) {
@@ -172,10 +174,9 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     const double uk = fmin(fmax(kappa, a.u_lo1), a.u_hi1);
     a.u_ref[2 * i] = static_cast<float>(uv);
     a.u_ref[2 * i + 1] = static_cast<float>(uk);
-    if (h.centre_is_reference != 0) {  // a solve without a previous plan samples round the reference controls
-      a.centre[2 * i] = static_cast<float>(uv);
-      a.centre[2 * i + 1] = static_cast<float>(uk);
-    }
+    // a solve without a previous plan samples round the reference controls
+    a.centre[2 * i] = (h.centre_is_reference != 0) ? static_cast<float>(uv) : a.centre_in[2 * i];
+    a.centre[2 * i + 1] = (h.centre_is_reference != 0) ? static_cast<float>(uk) : a.centre_in[2 * i + 1];
   }
   // the 7 x n table for the caller (pinned host memory: posted writes, visible once the stream has drained)
   for (int e = lane; e < 7 * n; e += 64) a.table_out[e] = table[e];
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
 }
 
 size_t prologue_lds_bytes(int n) {
-  return static_cast<size_t>(7 * n + n + (n + 1) + n + 2 * n + admm::workspace_doubles(n)) * sizeof(double);
+  return static_cast<size_t>(7 * n + n + (n + 1) + n + 2 * n + admm::workspace_doubles(n)) * sizeof(double);  // < 64 kB
 }
 
 hipError_t launch_prologue(const PrologueArgs& args, int n, hipStream_t s) {

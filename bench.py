@@ -54,11 +54,23 @@ def parse_args():
                          "collective payloads staged through the CPU (ranks may then share one GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="(diagnostic) attach no events to the rollout launches; roofline fields become null")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank evaluates its own --candidates of every pose.  strong: BASELINE.json "
+                         "configs[3] as stated - Nordschleife, 262 144 candidates x horizon 80 in TOTAL, split over the ranks "
+                         "(262 144 / N each), one all-reduce(MIN) of the packed keys per step; latency-bound by design")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-single-solve", action="store_true",
                     help="skip the extra 'single_solve' block (one 4096-candidate problem per launch: latency)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.scaling == "strong":   # configs[3]: the track, horizon and TOTAL candidate count are the configuration
+        args.track, args.horizon, args.layout, args.mode = "nordschleife", 80, 1, "S"
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        args.total_candidates = 262144
+        args.candidates = args.total_candidates // max(world, 1)
+        if args.poses == 4096:     # (not given) one problem per step, as the controller would pose it
+            args.poses = 1
+    return args
 
 
 SAMPLE_SIGMA = (2.0, 0.01)   # sigma = (2.0 m/s, 0.01 1/m)
@@ -133,6 +145,112 @@ def cpu_baseline(batch, mode, U_dev, layout, N, n, gpu_costs, seconds):
     }
 
 
+def numpy_baseline(batch, U_dev, layout, N, n, gpu_costs, seconds=3.0):
+    """SURVEY.md 8(d)'s other CPU figure: the oracle's single-process NumPy restatement (vectorised over candidates,
+    sequential over steps) on ONE pose of the same batch, repeated for ~`seconds`; parity of the pose re-checked."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import acmpc_oracle as orc
+    U = U_dev[0].cpu().numpy()
+    if layout == 1:
+        U = np.ascontiguousarray(U.transpose(2, 0, 1))    # [N, n, 2]
+    cfg = batch.cfg
+    args = (batch.x0[0], batch.coef_host[0], U, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], batch.u_lo, batch.u_hi,
+            1.0e6)
+    cost, _ = orc.rollout_spatial(*args, dtype=np.float32)
+    if not np.array_equal(cost, gpu_costs[0]):
+        raise SystemExit("bench: GPU costs differ from the NumPy oracle")
+    repeats, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.pick_best(orc.rollout_spatial(*args, dtype=np.float32)[0])
+        repeats += 1
+    elapsed = time.perf_counter() - t0
+    return {"value": N * repeats / elapsed, "unit": "candidate-trajectories/s", "cores": 1, "kind": "port",
+            "sample": "1 pose x %d candidates x horizon %d, %d passes, %.1f s; oracle/acmpc_oracle.py rollout_spatial "
+                      "(NumPy float32, one process), costs bit-identical to the GPU's" % (N, n + 1, repeats, elapsed)}
+
+
+def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50):
+    """BASELINE.json configs[4] exactly as SURVEY.md 8(d) defines it: 10 000 consecutive poses along the synthetic
+    Silverstone circuit, one solve each of N = 4 096 candidates through the host-pointer `acmpc_solve` (H2D of the
+    1.6 MB control matrix + rollout + argmin + record + D2H), wall-clock p50 / p99 per solve.  Candidates are
+    u_ref + sigma * N(0, 1) clipped to the input box, candidate 0 = u_ref (one seeded noise matrix, re-centred per pose)."""
+    import copy
+    from acmpc_amd import _capi
+    from acmpc_amd.bicycle_model import SpatialBicycleModel
+    from acmpc_amd.mpc import waypoint_table
+    name, n = "silverstone", H - 1
+    cfg = copy.deepcopy(workloads.RACING_CONTROL[name])
+    cons = dict(cfg["speed_profile_constraints"], v_max=float(cfg["unlocalised_max_speed"]))
+    model = SpatialBicycleModel(workloads.PlaceholderVehicle(), {"min": cons["v_min"], "max": cons["v_max"]})
+    track = workloads.synthetic_track(name)
+    lo = np.array([model.min_u[0] - 0.1, model.min_u[1]], dtype=np.float32)
+    hi = np.array([model.max_u[0] + 0.1, model.max_u[1]], dtype=np.float32)
+    eng = Engine(mode=0, max_problems=1, max_candidates=N, max_steps=n, step_cost=cfg["step_cost"], r_term=cfg["r_term"],
+                 final_cost=cfg["final_cost"], u_min=lo, u_max=hi, margin=model.margin, wheelbase=model.length,
+                 device=device.index)
+    noise = (np.random.default_rng(5).standard_normal((N, n, 2)) * np.array(SAMPLE_SIGMA)).astype(np.float32)
+    noise[0] = 0.0
+    U = np.empty((1, N, n, 2), dtype=np.float32)
+    warm, wall, infeasible = None, np.empty(poses), 0
+    for i in range(poses + 20):
+        coords = workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % len(track["centre"])), H)
+        table = waypoint_table(coords)
+        v_hi = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
+                                      cons["end_velocity"])
+        v, y, status, _ = _capi.speed_profile_qp(v_hi, table[4], cons["a_min"], cons["a_max"], cons["v_min"], warm=warm)
+        if status == "solved":
+            warm, table[6] = (v, y), v
+        eng.set_paths(table)
+        x0 = model.t2s(table[:3, 0], np.array([0.0, 0.0, np.pi / 2])).astype(np.float32)[None]
+        u_ref = np.stack([table[6], table[3]], axis=1).astype(np.float32)
+        np.add(noise, u_ref, out=U[0])
+        np.clip(U[0], lo, hi, out=U[0])
+        t0 = time.perf_counter()
+        out = eng.solve(x0, U, layout=0, want_costs=False)
+        if i >= 20:
+            wall[i - 20] = time.perf_counter() - t0
+            infeasible += int(out["violation"][0] > 0.0)
+    eng.close()
+    return {"workload": "%s (synthetic circuit): %d consecutive poses 1 m apart, one acmpc_solve each (host pointers), %d "
+                        "candidates x horizon %d" % (name, poses, N, H),
+            "solve_us_p50": float(np.percentile(wall, 50) * 1e6), "solve_us_p99": float(np.percentile(wall, 99) * 1e6),
+            "traj_per_s_at_p50": N / float(np.percentile(wall, 50)), "winners_with_a_bound_violation": infeasible,
+            "note": "PCIe-inclusive (1.6 MB of controls up per solve): never `value`"}
+
+
+def particle_filter_block(workloads, iters=20):
+    """the localiser's particle scoring (three nearest-point queries against the ~11.6 k-point map
+    polylines, observation placement, score) through the host-pointer seam, at the reference's size (500 particles,
+    configs/monza.yaml:47) and at 100 000."""
+    from acmpc_amd.particle_filter import ParticleScorer
+    track = workloads.synthetic_track("monza")
+    cfg = dict(n_particles=100000, score_distribution=dict(mean=0, sigma=10),
+               thresholds=dict(offset=10, rotation=90, minimum_particles=20, track_limit=20.0))
+    scorer = ParticleScorer(cfg, track)
+    rng = np.random.default_rng(0)
+    centre = track["centre"]
+    left = np.stack([-4.7 + rng.normal(0, 0.1, 100), np.linspace(0, 49, 100)], axis=1).astype(np.float32)
+    right = np.stack([4.7 + rng.normal(0, 0.1, 100), np.linspace(0, 49, 100)], axis=1).astype(np.float32)
+    out = {"map_points": int(3 * len(centre)), "observation_points": 200}
+    for P in (500, 100000):
+        seeds = rng.integers(0, len(centre), P)
+        states = np.concatenate([centre[seeds] + rng.normal(0, 2.0, (P, 2)), rng.uniform(-3, 3, (P, 1))],
+                                axis=1).astype(np.float32)
+        scorer.update_particles(states, [left, right])
+        t = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            scorer.update_particles(states, [left, right])
+            t.append(time.perf_counter() - t0)
+        us = float(np.median(t) * 1e6)
+        pairs = P * 3 * len(centre)   # particle x map-point distance evaluations (5 float64 flops + a compare each)
+        out["particles_%d" % P] = {"update_us": us, "particles_per_s": P / (us * 1e-6),
+                                   "distance_evaluations_per_s": pairs / (us * 1e-6),
+                                   "fp64_TFLOPs": pairs * 5 / (us * 1e-6) / 1e12}
+    scorer.close()
+    return out
+
+
 def latest_traffic(algorithmic_bytes, kernel_name):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary for this exact workload
     (profiles/*_summary.json, produced by tools/profile.sh + tools/summarize_profile.py: separate --pmc passes,
@@ -150,7 +268,7 @@ def latest_traffic(algorithmic_bytes, kernel_name):
     return best
 
 
-def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300):
+def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300, host_pointer=True):
     """BASELINE.json configs[1] as ONE problem per call (the closed-loop shape): device-resident solve latency
     (rollout + argmin + winner record, HIP events) and the host-pointer acmpc_solve (H2D + kernels + D2H)."""
     n = H - 1
@@ -180,6 +298,15 @@ def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300
         b.record()
     torch.cuda.synchronize()
     dev_us = np.array([a.elapsed_time(b) for a, b in ev]) * 1e3
+    p50 = float(np.percentile(dev_us, 50))
+    if not host_pointer:
+        eng.close()
+        byts = N * (8 * n + 4)
+        return {"workload": "%s: 1 solve x %d candidates x horizon %d per call, device-resident" % (track, N, H),
+                "device_resident_us_p50": p50, "device_resident_us_p99": float(np.percentile(dev_us, 99)),
+                "device_resident_traj_per_s": N / (p50 * 1e-6),
+                "frac_of_hbm_roofline": byts / (p50 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "note": "one problem per launch: rollout + argmin + winner record (two launches), latency-bound"}
     U_host, x0_host = U.cpu().numpy(), x0.cpu().numpy()
     wall = []
     for _ in range(20):
@@ -285,11 +412,23 @@ def main():
         local_rank = min(local_rank, torch.cuda.device_count() - 1)   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    collective = None
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend="gloo")
+        # the process group must really span --gpus ranks, one per device (backend "nccl" is RCCL on ROCm)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+        mine = torch.tensor([local_rank], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        seen = [int(t.item()) for t in seen]
+        if args.backend == "nccl" and len(set(seen)) != world:
+            raise SystemExit("bench: ranks share devices: LOCAL_RANKs %s" % seen)
+        collective = {"backend": "rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)",
+                      "world_size": dist.get_world_size(), "local_ranks": seen}
 
     from acmpc_amd import Engine, workloads
     from acmpc_amd.sharding import PipelinedRollout, ShardedRollout
@@ -384,6 +523,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_times = np.concatenate([engine.profile_collect() for engine in engines])
+    step_latency = None
+    if args.scaling == "strong":
+        # the number a controller feels: one step at a time (rollout of this rank's slice, the all-reduce(MIN) of the
+        # keys, every rank re-drawing the winner), drained before the next one starts; max over ranks per step
+        lat = np.empty(min(args.steps, 200))
+        for i in range(lat.shape[0]):
+            barrier()
+            t1 = time.perf_counter()
+            run_step(i)
+            torch.cuda.synchronize()
+            lat[i] = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor(lat, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            lat = t.cpu().numpy()
+        step_latency = {"p50_us": float(np.percentile(lat, 50) * 1e6), "p99_us": float(np.percentile(lat, 99) * 1e6),
+                        "includes": "rollout of %d candidates per rank + all-reduce(MIN) of %d key(s) over %d rank(s) + "
+                                    "winner record on every rank" % (N, P, world)}
     if world > 1:
         # self-check outside the timed region: after the single all-reduce(MIN) every rank must hold the same plan
         # (feasible counts are per rank and excluded)
@@ -407,6 +564,14 @@ def main():
         algorithmic_bytes = P * N * (8 * n + 4)  # 8n B of controls read + 4 B of cost written
         achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
         total_candidates = P * N * world
+        if args.scaling == "strong":
+            workload = ("%s (synthetic circuit), BASELINE configs[3]: %d candidates x horizon %d in total, %d per GPU over %d "
+                        "GPU(s), %d problem(s) per step; mode S rollout + cost + one all-reduce(MIN) of the packed keys + "
+                        "winner record on every rank" % (args.track, N * world, H, N, world, P))
+        else:
+            workload = ("%s (synthetic circuit): %d candidates x horizon %d per solve per GPU, %d solves (poses) "
+                        "batched per launch (%d distinct poses); mode %s rollout + cost + argmin + winner record"
+                        % (args.track, N, H, P, min(P, 256), args.mode))
         out = {
             "metric": "candidate-trajectories/sec (horizon=%d)" % H,
             "value": total_candidates * args.steps / elapsed,
@@ -416,14 +581,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s (synthetic circuit): %d candidates x horizon %d per solve per GPU, %d solves (poses) "
-                            "batched per launch (%d distinct poses); mode %s rollout + cost + argmin + winner record"
-                            % (args.track, N, H, P, min(P, 256), args.mode),
+                "workload": workload,
                 "candidates_per_solve_per_gpu": N, "solves_per_step": P, "horizon": H, "mode": args.mode,
                 "layout": "U[P][n][2][N]" if args.layout == 1 else "U[P][N][n][2]",
                 "parallelism": "candidate-sharded x%d, one all-reduce(MIN) of %d packed keys per step" % (world, P),
@@ -439,7 +602,11 @@ def main():
         traffic = latest_traffic(algorithmic_bytes, "rollout_kernel<%d, %d" % (mode, args.layout))
         if traffic is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic
-        if world == 1 and not args.no_single_solve:
+        if step_latency is not None:
+            out["step_latency"] = step_latency
+        if collective is not None:
+            out["collective"] = collective
+        if world == 1 and not args.no_single_solve and args.scaling == "weak":
             out["single_solve"] = single_solve(workloads, Engine, args.track, H, N, mode, args.layout, device)
             out["closed_loop_replay"] = closed_loop_replay(workloads)
             # the second half of BASELINE.json's metric ("+ MPC solve p50 latency"): the drop-in get_control
@@ -447,10 +614,19 @@ def main():
                                            "p99": out["closed_loop_replay"]["solve_ms_p99"],
                                            "of": "SpatialMPC.get_control, closed_loop_replay workload"}
             out["secondary_kernels"] = secondary_kernels(workloads, Engine, args.track, H, N, device)
+            # the other BASELINE configurations as ONE problem per call (what DESIGN.md quotes for them)
+            out["config3_single"] = single_solve(workloads, Engine, "spa", 50, 65536, 0, 1, device, host_pointer=False)
+            out["config4_share"] = single_solve(workloads, Engine, "nordschleife", 80, 32768, 0, 1, device,
+                                                host_pointer=False)
+            out["config5_host_pointer"] = config5_host_pointer(workloads, Engine, device)
+            out["particle_filter"] = particle_filter_block(workloads)
         if world == 1 and not args.no_cpu_baseline:
             gpu_costs = last.costs[:32].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
             out["cpu_baseline"] = cpu_baseline(batch, mode, controls[(args.steps - 1) % args.buffers], args.layout, N,
                                                n, gpu_costs, args.cpu_seconds)
+            if mode == 0:
+                out["cpu_baseline"]["numpy"] = numpy_baseline(batch, controls[(args.steps - 1) % args.buffers],
+                                                              args.layout, N, n, gpu_costs)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

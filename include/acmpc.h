@@ -211,7 +211,7 @@ int acmpc_optimize(acmpc_ctx* ctx, const float* x0, const float* centre, const f
  *   `rounds` rounds of sample -> rollout + cost -> argmin (as acmpc_optimize),
  * all nodes of one captured hipGraph; the winner's record, the 7 x n table and the QP status come back through pinned
  * host memory, and the tail of get_control (acmpc_unpack_decision) runs before the call returns.  Mode S handles with
- * centre_update = 0 and horizon - 1 <= 256 only (ACMPC_ESTATE otherwise: use acmpc_set_paths + acmpc_optimize). */
+ * centre_update = 0 and horizon - 1 <= 128 only (ACMPC_ESTATE otherwise: use acmpc_set_paths + acmpc_optimize). */
 typedef struct acmpc_tick {
   uint32_t struct_size;        /* sizeof(acmpc_tick)                                                            */
   int32_t horizon;             /* H = rows of `coords`; n = H - 1                                               */

@@ -34,6 +34,41 @@ def test_single_gpu_line_has_the_contract_fields():
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert out["closed_loop_replay"]["infeasible_solves"] == 0
+    # every number DESIGN.md quotes travels in the driver's line
+    assert cpu["numpy"]["cores"] == 1 and 0 < cpu["numpy"]["value"] < cpu["value"]
+    assert out["config3_single"]["device_resident_us_p50"] > 0 and out["config4_share"]["device_resident_us_p50"] > 0
+    five = out["config5_host_pointer"]
+    assert "10000 consecutive poses" in five["workload"] and 0 < five["solve_us_p50"] <= five["solve_us_p99"]
+    pf = out["particle_filter"]
+    assert pf["particles_500"]["update_us"] > 0 and pf["particles_100000"]["particles_per_s"] > 1e6
+
+
+def test_strong_scaling_mode_is_config_4():
+    """`--scaling strong`: Nordschleife, 262 144 candidates x horizon 80 in total, one problem per step, latency reported."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", "strong", "--steps", "20",
+                           "--warmup", "3", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    out = _last_json(proc.stdout)
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1
+    assert out["config"]["horizon"] == 80 and out["config"]["candidates_per_solve_per_gpu"] == 262144
+    assert "configs[3]" in out["config"]["workload"] and out["step_latency"]["p50_us"] > 0
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == 262144 * (8 * 79 + 4)
+
+
+def test_strong_scaling_two_rank_rehearsal():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--scaling", "strong", "--steps", "10", "--warmup", "2"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, (proc.stdout + proc.stderr)[-3000:]
+    out = _last_json(proc.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["candidates_per_solve_per_gpu"] == 131072
+    assert out["collective"]["world_size"] == 2 and out["step_latency"]["p50_us"] > 0
 
 
 def test_two_rank_rehearsal_agrees_across_ranks():

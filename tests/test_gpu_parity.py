@@ -264,12 +264,15 @@ def test_every_launch_shape_gives_the_same_bits(monkeypatch):
         np.testing.assert_array_equal(other["records"], results[0]["records"])
 
 
-@pytest.mark.parametrize("track,H,N,mode", [
-    ("spa", 50, 65536, 0),            # BASELINE config 3 at full size
-    ("nordschleife", 80, 262144, 0),  # BASELINE config 4 at full size (all candidates on one GPU)
-    ("spa", 50, 65536, 1),            # config 3, Cartesian mode with the windowed search
+@pytest.mark.parametrize("track,H,N,mode,window", [
+    ("spa", 50, 65536, 0, None),            # BASELINE config 3 at full size
+    ("nordschleife", 80, 262144, 0, None),  # BASELINE config 4 at full size (all candidates on one GPU)
+    ("spa", 50, 65536, 1, (2, 5)),          # config 3, Cartesian mode with the windowed search
+    ("spa", 50, 65536, 1, None),            # config 3, mode T's DEFAULT search: exhaustive semantics (verified window
+    ("nordschleife", 80, 262144, 1, None),  #   + wave-cooperative fallback) against the C oracle's scan of all n
+    ("nordschleife", 80, 262144, 1, (2, 5)),
 ])
-def test_baseline_configs_at_full_size_against_the_c_oracle(track, H, N, mode):
+def test_baseline_configs_at_full_size_against_the_c_oracle(track, H, N, mode, window):
     """Every one of the N costs bit-identical to the oracle's C restatement (the NumPy oracle would take minutes at
     these sizes; C == NumPy is established in tests/test_oracle_c_vs_numpy.py), plus argmin and winner record."""
     import c_oracle
@@ -277,7 +280,6 @@ def test_baseline_configs_at_full_size_against_the_c_oracle(track, H, N, mode):
     n = H - 1
     prob = make_problem(orc, track, H, 16, seed=4242)
     U = full_size_controls(orc, prob, N, n)
-    window = (2, 5) if mode == 1 else None
     eng = Engine(**engine_kwargs(prob, mode, 1, N, n, nn_window=window))
     eng.set_paths(prob["table"])
     cfg = prob["cfg"]
