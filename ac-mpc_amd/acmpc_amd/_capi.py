@@ -96,6 +96,11 @@ class Tick(C.Structure):
         ("qp_eps_abs", C.c_double),
         ("qp_eps_rel", C.c_double),
         ("seed", C.c_uint64),
+        ("map_index", C.c_int32),
+        ("centreline_points", C.c_int32),
+        ("pose_x", C.c_double),
+        ("pose_y", C.c_double),
+        ("lateral_offset", C.c_double),
     ]
 
 
@@ -135,7 +140,10 @@ SIGNATURES = {
     # of typed pointers, which at these sizes is most of the call
     "acmpc_optimize": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_double, C.c_uint64, C.c_void_p]),
-    "acmpc_control_tick": (C.c_int, [_CTX, C.POINTER(Tick)] + [C.c_void_p] * 12),
+    "acmpc_control_tick": (C.c_int, [_CTX, C.POINTER(Tick)] + [C.c_void_p] * 13),
+    "acmpc_bind_map": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_double]),
+    "acmpc_map_reference_path": (C.c_int, [_CTX, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                           C.c_void_p, _I32P]),
     "acmpc_tick_read_device_tables": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acmpc_speed_profile_qp_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double,
                                                 C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p,
@@ -357,9 +365,11 @@ class Engine:
         return out
 
     def control_tick(self, tick: Tick, coords: np.ndarray, centre):
-        """One whole control tick on the device (acmpc_control_tick).  coords [H,3] float64, centre [n,2] float32 or
-        None (with tick.centre_is_reference).  Returns a dict of fresh arrays: table [7,n], record, decision [5n+3],
-        projected_control [2,n], prediction [n,2], cum_time [n], times / accelerations / steer_rates [n-1], info [8]."""
+        """One whole control tick on the device (acmpc_control_tick).  coords [H,3] float64 - or None: the path is
+        cut out of the bound map at tick.map_index / the pose - centre [n,2] float32 or None (with
+        tick.centre_is_reference).  Returns a dict of fresh arrays: table [7,n], record, decision [5n+3],
+        projected_control [2,n], prediction [n,2], cum_time [n], times / accelerations / steer_rates [n-1], info [8],
+        coords [H,3] (the path used)."""
         n = tick.horizon - 1
         buf = self._tick_buffers.get(n) if hasattr(self, "_tick_buffers") else None
         if buf is None:
@@ -368,14 +378,29 @@ class Engine:
             arrays = dict(table=np.empty((7, n)), record=np.empty(record_floats(n), dtype=np.float32),
                           decision=np.empty(5 * n + 3), projected_control=np.empty((2, n)), prediction=np.empty((n, 2)),
                           cum_time=np.empty(n), times=np.empty(n - 1), accelerations=np.empty(n - 1),
-                          steer_rates=np.empty(n - 1), info=np.empty(8))
+                          steer_rates=np.empty(n - 1), info=np.empty(8), coords=np.empty((n + 1, 3)))
             buf = self._tick_buffers[n] = (arrays, tuple(a.ctypes.data for a in arrays.values()))
         arrays, addresses = buf
-        rc = self._lib.acmpc_control_tick(self._ctx, C.byref(tick), coords.ctypes.data,
+        rc = self._lib.acmpc_control_tick(self._ctx, C.byref(tick), coords.ctypes.data if coords is not None else None,
                                           centre.ctypes.data if centre is not None else None, *addresses)
         if rc != OK:
             self._check(rc)
         return {k: a.copy() for k, a in arrays.items()}
+
+    def bind_map(self, centre: np.ndarray, spacing: float):
+        """Centre polyline [M,2] float64 of the map the tick may cut its reference path from (acmpc_bind_map)."""
+        centre = np.ascontiguousarray(centre, dtype=np.float64)
+        self._check(self._lib.acmpc_bind_map(self._ctx, centre.ctypes.data, centre.shape[0], float(spacing)))
+
+    def map_reference_path(self, horizon: int, map_index: int = -1, pose=(0.0, 0.0), lateral_offset: float = 0.0,
+                           centreline_points: int = 500):
+        """(coords [H,3], first map index): the window kernel alone (acmpc_map_reference_path)."""
+        coords = np.empty((horizon, 3))
+        first = C.c_int32(0)
+        self._check(self._lib.acmpc_map_reference_path(self._ctx, int(map_index), float(pose[0]), float(pose[1]),
+                                                       float(lateral_offset), horizon, centreline_points,
+                                                       coords.ctypes.data, C.byref(first)))
+        return coords, first.value
 
     def tick_device_tables(self, n: int):
         """(x0 [3], u_ref [n,2], coef [n,12]) the last tick's prologue left on the device (test hook)."""

@@ -76,6 +76,7 @@ class SpatialMPC:
             "control_horizon": self.MPC_horizon - 1,
             "max_iterations": MAX_SOLVER_ITERATIONS,
             "constraints": self.speed_profile_constraints,
+            "check_every": int(config.get("speed_profile_check_every", 5)),
         }
         self._speed_profile_solver = SpeedProfileSolver(profile_config)
         self._localised_speed_profile_solver = LocalisedSpeedProfileSolver(profile_config)
@@ -147,16 +148,37 @@ class SpatialMPC:
         self.infeasibility_counter = 0
 
 
-    def _get_control_tick(self, reference_path: np.ndarray, is_localised: bool, offset: float):
+    # -- reference path straight from the map (not in the reference: there perception publishes the centre line) -----
+    def bind_map(self, track_map: Dict[str, np.ndarray]) -> None:
+        """`track_map`: the dict of utils/load.py:9-35 (`centre` [M, 2], `spacing` in metres).  After this,
+        `get_control_at` cuts the reference path out of the map on the device."""
+        self._control_solver.bind_map(track_map["centre"], float(track_map.get("spacing", 0.5)))
+
+    def get_control_at(self, map_index: int = -1, pose=(0.0, 0.0), lateral_offset: float = 0.0,
+                       is_localised: bool = False, offset: float = 0.0, centreline_points: int = None):
+        """One solve for a pose on the bound map: the 150 m window from `map_index` (or from the map point nearest to
+        `pose`) is moved into the vehicle frame, resampled and downsampled to the H x 3 path on the device
+        (`workloads.local_centreline` + `ControlProcess._reference_path`, controller.py:256-267), and feeds the same
+        prologue and rounds as `get_control`.  The path used is left in `self.reference_coordinates`."""
+        if not (self._device_prologue and self._control_solver.supports_tick()):
+            raise ValueError("get_control_at needs the device prologue (argmin centre update, horizon <= 129)")
+        points = centreline_points or self.MPC_horizon * (500 // self.MPC_horizon)
+        return self._get_control_tick(None, is_localised, offset, map_index=int(map_index), pose=pose,
+                                      lateral_offset=float(lateral_offset), centreline_points=points)
+
+    def _get_control_tick(self, reference_path, is_localised: bool, offset: float, **from_map):
         """The same solve as one round trip (`acmpc_control_tick`): waypoints, speed profile, Frenet start state and
-        linearisation run on the device as the first node of the solve's hipGraph; this method only keeps the
-        reference's bookkeeping (spatial_mpc.py:98-122,193-217)."""
-        coords = np.ascontiguousarray(reference_path, dtype=np.float64)
-        if coords.shape != (self.MPC_horizon, 3):
-            raise ValueError("reference_path must be %d x 3" % self.MPC_horizon)
+        linearisation run on the device in front of the sampling rounds; this method only keeps the reference's
+        bookkeeping (spatial_mpc.py:98-122,193-217)."""
+        coords = None
+        if reference_path is not None:
+            coords = np.ascontiguousarray(reference_path, dtype=np.float64)
+            if coords.shape != (self.MPC_horizon, 3):
+                raise ValueError("reference_path must be %d x 3" % self.MPC_horizon)
         out, status, _ = self._control_solver.solve_tick(coords, float(offset), self.speed_profile_constraints,
                                                          is_localised, qp_max_iter=MAX_SOLVER_ITERATIONS,
-                                                         qp_check_every=self._qp_check_every)
+                                                         qp_check_every=self._qp_check_every, **from_map)
+        self.reference_coordinates = out["coords"]
         path = ReferencePath.from_table(out["table"])
         if out["info"][4] == 0.0:
             self.speed_profile = path.velocities.copy()

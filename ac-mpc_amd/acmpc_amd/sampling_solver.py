@@ -80,6 +80,8 @@ class ControlSolver:
                 max_steps=self._n_horizon, step_cost=self._Q, r_term=self._R, final_cost=self._QN, u_min=self._box[0],
                 u_max=self._box[1], margin=self._dynamics_model.margin, wheelbase=self._dynamics_model.length,
                 w_bound=self._w_bound, centre_update=self._centre_update, softmin_lambda=self._lambda)
+            if getattr(self, "_map", None) is not None:
+                self._engine.bind_map(*self._map)
         return self._engine
 
     def shift_warm_start(self, elapsed_time: float, cum_time: np.ndarray) -> None:
@@ -100,13 +102,21 @@ class ControlSolver:
         horizon the single-workgroup prologue holds."""
         return self._centre_update == "argmin" and self._n_horizon <= 128
 
-    def solve_tick(self, coords: np.ndarray, offset: float, constraints: Dict, is_localised: bool,
-                   qp_max_iter: int = 4000, qp_check_every: int = 10):
+    def bind_map(self, centre: np.ndarray, spacing: float):
+        """Map centre line the tick may cut its reference path from (`solve_tick(None, ..., map_index=...)`)."""
+        self._map = (np.ascontiguousarray(centre, dtype=np.float64), float(spacing))
+        if self._engine is not None:
+            self._engine.bind_map(*self._map)
+
+    def solve_tick(self, coords, offset: float, constraints: Dict, is_localised: bool,
+                   qp_max_iter: int = 4000, qp_check_every: int = 10, map_index: int = -1, pose=(0.0, 0.0),
+                   lateral_offset: float = 0.0, centreline_points: int = 500):
         """One whole tick of `SpatialMPC.get_control` as a single call into the library (`acmpc_control_tick`):
         waypoints, speed profile, Frenet start state, linearisation and the sampling rounds all run on the device
         inside one captured hipGraph.  `coords` is the H x 3 reference path (float64, C-contiguous), `constraints` the
-        live speed-profile dict.  Returns (outputs dict, status string, total rounds); the explore / refine schedule
-        and the acceptance test are those of `solve`."""
+        live speed-profile dict; with `coords=None` the path is cut out of the bound map on the device (window of
+        150 m from `map_index`, or from the map point nearest to `pose`).  Returns (outputs dict, status string, total
+        rounds); the explore / refine schedule and the acceptance test are those of `solve`."""
         engine = self._ensure_engine()
         n = self._n_horizon
         tick = getattr(self, "_tick", None)
@@ -126,6 +136,8 @@ class ControlSolver:
         tick.a_min, tick.a_max = constraints["a_min"], constraints["a_max"]
         tick.ay_max, tick.ki_min = constraints["ay_max"], constraints["ki_min"]
         tick.qp_max_iter, tick.qp_check_every = qp_max_iter, qp_check_every
+        tick.map_index, tick.centreline_points = map_index, centreline_points
+        tick.pose_x, tick.pose_y, tick.lateral_offset = pose[0], pose[1], lateral_offset
         warm = self._incumbent is not None and self._incumbent.shape == (n, 2)
         explore = self._explore or not warm
         total_rounds = 0

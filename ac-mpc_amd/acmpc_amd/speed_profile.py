@@ -26,6 +26,7 @@ class SpeedProfileSolver:
         self._n_horizon = config["control_horizon"]
         self._max_iterations = config["max_iterations"]
         self._constraints = config["constraints"]
+        self._check_every = int(config.get("check_every", 10))   # the stopping test runs every this many iterations
         self._eps = 1e-12
         self._warm = None
 
@@ -69,7 +70,8 @@ class SpeedProfileSolver:
         ceiling = self.velocity_ceiling(reference_path, end_velocity)
         warm = self._warm if self._warm is not None and self._warm[0].shape == ceiling.shape else None
         x, y, status, iters = _capi.speed_profile_qp(ceiling, reference_path.distances, c["a_min"], c["a_max"],
-                                                     c["v_min"], max_iter=self._max_iterations, warm=warm)
+                                                     c["v_min"], max_iter=self._max_iterations, warm=warm,
+                                                     check_every=self._check_every)
         if status == "solved":
             self._warm = (x, y)
         return SimpleNamespace(x=x, y=y, info=SimpleNamespace(status=status, iter=iters))

@@ -96,11 +96,11 @@ struct acmpc_ctx {
   // through the pinned block `h_tick` (TickHeader | coords | centre), results come back into `h_tick_out`
   // (record | table | QP status) by posted writes
   struct TickKey {
-    int N = 0, n = 0, rounds = 0;
+    int N = 0, n = 0, rounds = 0, from_map = 0;
     double sigma_v = 0, sigma_k = 0, shrink = 0;
     bool operator==(const TickKey& o) const {
-      return N == o.N && n == o.n && rounds == o.rounds && sigma_v == o.sigma_v && sigma_k == o.sigma_k &&
-             shrink == o.shrink;
+      return N == o.N && n == o.n && rounds == o.rounds && from_map == o.from_map && sigma_v == o.sigma_v &&
+             sigma_k == o.sigma_k && shrink == o.shrink;
     }
   };
   bool tick_ready = false;
@@ -110,6 +110,11 @@ struct acmpc_ctx {
   unsigned char* h_tick = nullptr;      // pinned
   unsigned char* d_tick = nullptr;
   unsigned char* h_tick_out = nullptr;  // pinned
+  std::vector<double> h_map;            // bound map: centre polyline [M][2]
+  double map_spacing = 0.0;
+  bool map_dirty = false;
+  double* d_map = nullptr;
+  double* d_coords = nullptr;           // [H][3] path the window kernel builds for the prologue
   double* d_warm = nullptr;             // speed-profile iterate of the two solvers, kept between ticks
   int warm_stride = 0;
   int tick_last_n = 0;
@@ -519,6 +524,8 @@ void acmpc_destroy(acmpc_ctx* c) {
     if (c->h_tick_out != nullptr) (void)hipHostFree(c->h_tick_out);
     (void)hipFree(c->d_tick);
     (void)hipFree(c->d_warm);
+    (void)hipFree(c->d_map);
+    (void)hipFree(c->d_coords);
     if (c->h_opt != nullptr) (void)hipHostFree(c->h_opt);
     if (c->h_opt_records != nullptr) (void)hipHostFree(c->h_opt_records);
     (void)hipFree(c->d_seed);
@@ -993,14 +1000,43 @@ struct TickLayout {
 
 // layout of the pinned result block
 struct TickOutLayout {
-  size_t record, table, status, total;
+  size_t record, table, status, coords, total;
   explicit TickOutLayout(int n) {
     record = 0;
     table = align16(static_cast<size_t>(acmpc_record_floats(n)) * sizeof(float));
-    status = align16(table + static_cast<size_t>(7) * n * sizeof(double));
-    total = status + 16;
+    status = align16(table + static_cast<size_t>(7) * n * sizeof(double));   // QP status, iterations, map index
+    coords = status + 16;
+    total = coords + static_cast<size_t>(n + 1) * 3 * sizeof(double);
   }
 };
+
+// the bound map -> device (when bound or re-bound since the last upload)
+int upload_map(acmpc_ctx* c, hipStream_t s) {
+  if (!c->map_dirty) return ACMPC_OK;
+  (void)hipFree(c->d_map);
+  c->d_map = nullptr;
+  ACMPC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_map), c->h_map.size() * sizeof(double)));
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_map, c->h_map.data(), c->h_map.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  ACMPC_HIP(c, hipStreamSynchronize(s));
+  c->map_dirty = false;
+  return ACMPC_OK;
+}
+
+int map_window_args(acmpc_ctx* c, int H, int points, const TickOutLayout& out, acmpc::MapWindowArgs* a) {
+  if (c->h_map.empty()) return fail(c, ACMPC_ESTATE, "no map bound (acmpc_bind_map)");
+  if (points < H || points % H != 0) return fail(c, ACMPC_EINVAL, "centreline_points must be a multiple of the horizon");
+  a->header = reinterpret_cast<const acmpc::TickHeader*>(c->h_tick);
+  a->centre = c->d_map;
+  a->M = static_cast<int>(c->h_map.size() / 2);
+  a->count = static_cast<int>(std::lround(150.0 / c->map_spacing)) + 1;   // BEV look-ahead, perception/tracks.py:14
+  if (a->count < 2 || a->count > a->M) return fail(c, ACMPC_EINVAL, "the map is shorter than the 150 m look-ahead window");
+  a->points = points;
+  a->H = H;
+  a->coords = c->d_coords;
+  a->coords_out = reinterpret_cast<double*>(c->h_tick_out + out.coords);
+  a->index_out = reinterpret_cast<int*>(c->h_tick_out + out.status) + 2;
+  return ACMPC_OK;
+}
 
 int ensure_tick(acmpc_ctx* c) {
   if (c->tick_ready) return ACMPC_OK;
@@ -1009,6 +1045,7 @@ int ensure_tick(acmpc_ctx* c) {
   ACMPC_HIP(c, host_alloc_once(&c->h_tick, TickLayout(n_cap).host_total));
   ACMPC_HIP(c, alloc_once(&c->d_tick, TickLayout(n_cap).total));
   ACMPC_HIP(c, host_alloc_once(&c->h_tick_out, TickOutLayout(n_cap).total));
+  ACMPC_HIP(c, alloc_once(&c->d_coords, static_cast<size_t>(n_cap + 1) * 3 * sizeof(double)));
   c->warm_stride = 2 + 3 * n_cap;
   const size_t warm_bytes = static_cast<size_t>(2) * c->warm_stride * sizeof(double);
   ACMPC_HIP(c, alloc_once(&c->d_warm, warm_bytes));
@@ -1023,9 +1060,10 @@ int ensure_tick(acmpc_ctx* c) {
 
 int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, const float* centre, double* table,
                        float* record, double* decision, double* projected_control, double* prediction,
-                       double* cum_time, double* times, double* accelerations, double* steer_rates, double* info) {
+                       double* cum_time, double* times, double* accelerations, double* steer_rates, double* info,
+                       double* coords_out) {
   if (c == nullptr) return ACMPC_EINVAL;
-  if (t == nullptr || coords == nullptr || table == nullptr || record == nullptr || decision == nullptr ||
+  if (t == nullptr || table == nullptr || record == nullptr || decision == nullptr ||
       projected_control == nullptr || prediction == nullptr || cum_time == nullptr || times == nullptr ||
       accelerations == nullptr || steer_rates == nullptr || info == nullptr)
     return fail(c, ACMPC_EINVAL, "null argument");
@@ -1037,6 +1075,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   if (n > c->prm.max_steps || N > c->prm.max_candidates) return fail(c, ACMPC_ECAPACITY, "horizon or candidates exceed capacity");
   if (n > acmpc::kPrologueMaxSteps) return fail(c, ACMPC_ESTATE, "the device prologue holds at most 128 steps");
   if (centre == nullptr && t->centre_is_reference == 0) return fail(c, ACMPC_EINVAL, "null centre");
+  if (coords == nullptr && c->h_map.empty()) return fail(c, ACMPC_EINVAL, "null coords and no map bound");
   if (!acmpc::fused_finalize_fits(c->prm.mode, n)) return fail(c, ACMPC_ESTATE, "fused finalize does not fit");
   int rc = ensure_device(c);
   if (rc != ACMPC_OK) return rc;
@@ -1048,10 +1087,19 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   const TickLayout in(n);
   const TickOutLayout out(n);
   const int rec_floats = acmpc_record_floats(n);
+  const bool from_map = coords == nullptr;
+  acmpc::MapWindowArgs ma{};
+  if (from_map) {
+    rc = map_window_args(c, H, t->centreline_points, out, &ma);
+    if (rc != ACMPC_OK) return rc;
+    rc = upload_map(c, s);
+    if (rc != ACMPC_OK) return rc;
+    ma.centre = c->d_map;
+  }
 
   acmpc::PrologueArgs pa{};
   pa.header = reinterpret_cast<const acmpc::TickHeader*>(c->h_tick);   // read in place over the host link
-  pa.coords = reinterpret_cast<const double*>(c->h_tick + in.coords);
+  pa.coords = from_map ? c->d_coords : reinterpret_cast<const double*>(c->h_tick + in.coords);
   pa.centre_in = reinterpret_cast<const float*>(c->h_tick + in.centre_in);
   pa.x0 = reinterpret_cast<float*>(c->d_tick + in.x0);
   pa.u_ref = reinterpret_cast<float*>(c->d_tick + in.uref);
@@ -1071,7 +1119,8 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   const bool direct = use_fused_finalize(c, n);
   // prologue -> rounds (-> copy of the record when the fused finalize cannot write it to the host itself)
   auto enqueue = [&](hipStream_t q, int* rc_rounds) -> hipError_t {
-    hipError_t e = acmpc::launch_prologue(pa, n, q);
+    hipError_t e = from_map ? acmpc::launch_map_window(ma, q) : hipSuccess;
+    if (e == hipSuccess) e = acmpc::launch_prologue(pa, n, q);
     if (e != hipSuccess) return e;
     const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef};
     *rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink, 0, pa.seed, q, true,
@@ -1094,6 +1143,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     key.sigma_v = t->sigma[0];
     key.sigma_k = t->sigma[1];
     key.shrink = t->shrink;
+    key.from_map = from_map ? t->centreline_points : 0;
     for (int g = 0; g < acmpc_ctx::kOptGraphs; ++g)
       if (c->tick_graph[g] != nullptr && key == c->tick_key[g]) slot = g;
     if (slot < 0) {
@@ -1152,7 +1202,12 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   h->qp_check_every = t->qp_check_every;
   h->seed_lo = static_cast<uint32_t>(t->seed);
   h->seed_hi = static_cast<uint32_t>(t->seed >> 32);
-  std::memcpy(c->h_tick + in.coords, coords, static_cast<size_t>(H) * 3 * sizeof(double));
+  h->use_map = from_map ? 1 : 0;
+  h->map_index = t->map_index;
+  h->pose_x = t->pose_x;
+  h->pose_y = t->pose_y;
+  h->lateral_offset = t->lateral_offset;
+  if (!from_map) std::memcpy(c->h_tick + in.coords, coords, static_cast<size_t>(H) * 3 * sizeof(double));
   if (centre != nullptr) std::memcpy(c->h_tick + in.centre_in, centre, static_cast<size_t>(n) * 2 * sizeof(float));
   if (use_graph) {
     ACMPC_HIP(c, hipGraphLaunch(c->tick_graph[slot], s));
@@ -1190,8 +1245,55 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   info[3] = biggest;
   info[4] = status[0];
   info[5] = status[1];
-  info[6] = 0.0;
+  info[6] = from_map ? static_cast<double>(status[2]) : -1.0;   // first map index of the window
   info[7] = 0.0;
+  if (coords_out != nullptr)
+    std::memcpy(coords_out, from_map ? reinterpret_cast<const void*>(c->h_tick_out + out.coords)
+                                     : reinterpret_cast<const void*>(coords),
+                static_cast<size_t>(H) * 3 * sizeof(double));
+  return ACMPC_OK;
+}
+
+int acmpc_bind_map(acmpc_ctx* c, const double* centre, int32_t M, double spacing) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (centre == nullptr || M < 3 || !(spacing > 0.0)) return fail(c, ACMPC_EINVAL, "need a centre line of >= 3 points and a positive spacing");
+  c->h_map.assign(centre, centre + 2 * static_cast<size_t>(M));
+  c->map_spacing = spacing;
+  c->map_dirty = true;
+  return ACMPC_OK;
+}
+
+int acmpc_map_reference_path(acmpc_ctx* c, int32_t map_index, double pose_x, double pose_y, double lateral_offset,
+                             int32_t horizon, int32_t centreline_points, double* coords, int32_t* first_index) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (coords == nullptr) return fail(c, ACMPC_EINVAL, "null output");
+  const int n = horizon - 1;
+  if (horizon < 3 || n > std::min(c->prm.max_steps, acmpc::kPrologueMaxSteps))
+    return fail(c, ACMPC_ECAPACITY, "horizon out of range for this handle");
+  int rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_staging(c);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_tick(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = c->stream;
+  const TickOutLayout out(n);
+  acmpc::MapWindowArgs ma{};
+  rc = map_window_args(c, horizon, centreline_points, out, &ma);
+  if (rc != ACMPC_OK) return rc;
+  rc = upload_map(c, s);
+  if (rc != ACMPC_OK) return rc;
+  ma.centre = c->d_map;
+  acmpc::TickHeader* h = reinterpret_cast<acmpc::TickHeader*>(c->h_tick);
+  h->use_map = 1;
+  h->map_index = map_index;
+  h->pose_x = pose_x;
+  h->pose_y = pose_y;
+  h->lateral_offset = lateral_offset;
+  ACMPC_HIP(c, acmpc::launch_map_window(ma, s));
+  ACMPC_HIP(c, hipStreamSynchronize(s));
+  std::memcpy(coords, c->h_tick_out + out.coords, static_cast<size_t>(horizon) * 3 * sizeof(double));
+  if (first_index != nullptr) *first_index = reinterpret_cast<const int*>(c->h_tick_out + out.status)[2];
   return ACMPC_OK;
 }
 

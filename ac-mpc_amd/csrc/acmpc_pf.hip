@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/acmpc.h"
+#include "acmpc_device.h"  // Philox4x32-10, uniform_open, box_muller: the sampler's generator
 
 namespace {
 
@@ -44,90 +45,145 @@ struct ScoreArgs {
   uint8_t* valid;          // [P]
 };
 
-// (distance^2, index) minimum over the workgroup, lowest index on ties; result broadcast through LDS
-__device__ void block_argmin(double& d2, int& idx, double* s_d, int* s_i) {
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ void take_smaller(double& d, int& i, double od, int oi) {
+  if (od < d || (od == d && oi < i)) {  // lowest index on ties: the first minimum
+    d = od;
+    i = oi;
+  }
+}
+
+// (distance^2, index) minimum over the wavefront, every lane ends with the result
+__device__ __forceinline__ void wave_argmin(double& d, int& i) {
+#pragma unroll
+  for (int mask = 32; mask >= 1; mask >>= 1) {
+    const double od = __shfl_xor(d, mask, 64);
+    const int oi = __shfl_xor(i, mask, 64);
+    take_smaller(d, i, od, oi);
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int mask = 32; mask >= 1; mask >>= 1) v += __shfl_xor(v, mask, 64);  // fixed tree: reproducible
+  return v;
+}
+
+// One workgroup scores PB particles.  Every map point a thread loads is compared against all PB of them, so the
+// map (557 kB for the three 11.6 k-point polylines) crosses the L2 once per workgroup instead of once per particle -
+// at 100 000 particles that read was the bound (55 GB per scoring call).  Reductions are wave shuffles plus one
+// kWaves-entry exchange through LDS per polyline, for all PB particles at once (the first form ran three 256-wide
+// LDS trees of eight barriers each per particle).  PB = 1 keeps one particle per workgroup for the reference's
+// particle counts (500: configs/monza.yaml:47), where the launch has to fill the chip with workgroups.
+template <int PB>
+__global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, const int P) {
+  __shared__ double s_d[3][PB][kWaves];
+  __shared__ int s_i[3][PB][kWaves];
+  __shared__ double s_sum[PB][kWaves];
   const int tid = threadIdx.x;
-  s_d[tid] = d2;
-  s_i[tid] = idx;
-  __syncthreads();
-  for (int half = kBlock / 2; half > 0; half >>= 1) {
-    if (tid < half) {
-      const double od = s_d[tid + half];
-      const int oi = s_i[tid + half];
-      if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) {
-        s_d[tid] = od;
-        s_i[tid] = oi;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int p0 = blockIdx.x * PB;
+  double px[PB], py[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int p = min(p0 + q, P - 1);  // the last workgroup repeats its last particle; only p < P is written
+    px[q] = a.states[3 * p];
+    py[q] = a.states[3 * p + 1];
+  }
+
+  // three nearest-neighbour queries (localiser.py:282-289): first minimum of the float64 squared distance
+  const Track tracks[3] = {a.centre, a.left, a.right};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    double best[PB];
+    int best_i[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      best[q] = INFINITY;
+      best_i[q] = 0x7fffffff;
+    }
+    const double* __restrict__ xy = tracks[t].xy;
+    for (int m = tid; m < tracks[t].m; m += kBlock) {
+      const double mx = xy[2 * m], my = xy[2 * m + 1];
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const double dx = px[q] - mx, dy = py[q] - my;
+        const double d = dx * dx + dy * dy;
+        if (d < best[q]) {  // ascending m per thread: the first minimum stays
+          best[q] = d;
+          best_i[q] = m;
+        }
       }
     }
-    __syncthreads();
-  }
-  d2 = s_d[0];
-  idx = s_i[0];
-  __syncthreads();
-}
-
-__device__ void nearest_on_track(const Track t, double px, double py, double& d2, int& idx, double* s_d, int* s_i) {
-  double best = INFINITY;
-  int best_i = 0x7fffffff;
-  for (int m = threadIdx.x; m < t.m; m += kBlock) {
-    const double dx = px - t.xy[2 * m], dy = py - t.xy[2 * m + 1];
-    const double d = dx * dx + dy * dy;
-    if (d < best) {  // ascending m per thread: the first minimum stays
-      best = d;
-      best_i = m;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      wave_argmin(best[q], best_i[q]);
+      if (lane == 0) {
+        s_d[t][q][wave] = best[q];
+        s_i[t][q][wave] = best_i[q];
+      }
     }
   }
-  block_argmin(best, best_i, s_d, s_i);
-  d2 = best;
-  idx = best_i;
-}
+  __syncthreads();
+  int nearest[3][PB];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      double d = s_d[t][q][0];
+      int i = s_i[t][q][0];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) take_smaller(d, i, s_d[t][q][w], s_i[t][q][w]);
+      nearest[t][q] = i;
+    }
 
-__global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a) {
-  __shared__ double s_d[kBlock];
-  __shared__ int s_i[kBlock];
-  const int p = blockIdx.x;
-  const int tid = threadIdx.x;
-  const double px = a.states[3 * p], py = a.states[3 * p + 1], phi = a.states[3 * p + 2];
-
-  // three nearest-neighbour queries (localiser.py:282-289)
-  double d_centre, d_tmp;
-  int i_centre, i_left, i_right;
-  nearest_on_track(a.centre, px, py, d_centre, i_centre, s_d, s_i);
-  nearest_on_track(a.left, px, py, d_tmp, i_left, s_d, s_i);
-  nearest_on_track(a.right, px, py, d_tmp, i_right, s_d, s_i);
-
-  // observation placed in this particle's frame vs the map limits ahead of the nearest points (:330-410)
+  // observation placed in each particle's frame vs the map limits ahead of the nearest points (:330-410)
   // The reference places the observation in float32 (float32 states and observation, :330-353) and only then
   // subtracts the float64 map: do the same, so that the placed points round the way its do.
-  const float phi32 = a.states[3 * p + 2], px32 = a.states[3 * p], py32 = a.states[3 * p + 1];
-  const float angle = -phi32 + 1.57079632679489661923f;
-  const float ca = cosf(angle), sa = sinf(angle);
   const int K = a.k_left + a.k_right;
-  double sum = 0.0;
-  for (int k = tid; k < K; k += kBlock) {
-    const float ox = a.obs[2 * k], oy = a.obs[2 * k + 1];
-    const double wx = (ca * ox + sa * oy) + px32;   // transpose of [[cos, -sin], [sin, cos]] (:355-364)
-    const double wy = (-sa * ox + ca * oy) + py32;
-    const bool is_left = k < a.k_left;
-    const Track t = is_left ? a.left : a.right;
-    const int i = is_left ? k : k - a.k_left;
-    const int count = is_left ? a.k_left : a.k_right;
-    const int closest = is_left ? i_left : i_right;
-    // np.linspace(closest, closest + count, count, dtype=uint16): closest + i, except the last entry = closest + count
-    const int off = (count > 1 && i == count - 1) ? count : i;
-    const int idx = ((closest + off) & 0xffff) % t.m;
-    const double dx = wx - t.xy[2 * idx], dy = wy - t.xy[2 * idx + 1];
-    sum += sqrt(dx * dx + dy * dy);
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int p = min(p0 + q, P - 1);
+    const float phi32 = a.states[3 * p + 2], px32 = a.states[3 * p], py32 = a.states[3 * p + 1];
+    const float angle = -phi32 + 1.57079632679489661923f;
+    const float ca = cosf(angle), sa = sinf(angle);
+    double sum = 0.0;
+    for (int k = tid; k < K; k += kBlock) {
+      const float ox = a.obs[2 * k], oy = a.obs[2 * k + 1];
+      const double wx = (ca * ox + sa * oy) + px32;   // transpose of [[cos, -sin], [sin, cos]] (:355-364)
+      const double wy = (-sa * ox + ca * oy) + py32;
+      const bool is_left = k < a.k_left;
+      const Track t = is_left ? a.left : a.right;
+      const int i = is_left ? k : k - a.k_left;
+      const int count = is_left ? a.k_left : a.k_right;
+      const int closest = is_left ? nearest[1][q] : nearest[2][q];
+      // np.linspace(closest, closest + count, count, dtype=uint16): closest + i, except the last entry = closest + count
+      const int off = (count > 1 && i == count - 1) ? count : i;
+      const int idx = ((closest + off) & 0xffff) % t.m;
+      const double dx = wx - t.xy[2 * idx], dy = wy - t.xy[2 * idx + 1];
+      sum += sqrt(dx * dx + dy * dy);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) s_sum[q][wave] = sum;
   }
-  s_d[tid] = sum;
   __syncthreads();
-  for (int half = kBlock / 2; half > 0; half >>= 1) {  // fixed tree: reproducible
-    if (tid < half) s_d[tid] += s_d[tid + half];
-    __syncthreads();
-  }
 
-  if (tid == 0) {
-    const double error = s_d[0] / static_cast<double>(K);
+  if (tid < PB && p0 + tid < P) {
+    const int q = tid, p = p0 + tid;
+    double total = s_sum[q][0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) total += s_sum[q][w];
+    const double error = total / static_cast<double>(K);
+    const double phi = a.states[3 * p + 2];
+    // nearest[...][q] with a run-time q: read them back from LDS (the registers are indexed statically)
+    int i_centre = s_i[0][q][0], i_left = s_i[1][q][0], i_right = s_i[2][q][0];
+    double dc = s_d[0][q][0], dl = s_d[1][q][0], dr = s_d[2][q][0];
+    for (int w = 1; w < kWaves; ++w) {
+      take_smaller(dc, i_centre, s_d[0][q][w], s_i[0][q][w]);
+      take_smaller(dl, i_left, s_d[1][q][w], s_i[1][q][w]);
+      take_smaller(dr, i_right, s_d[2][q][w], s_i[2][q][w]);
+    }
     // heading of the centreline at the nearest point, indices mod (len - 1) (:291-318)
     const int m1 = a.centre.m - 1;
     const int here = i_centre % m1, next = (i_centre + 1) % m1;
@@ -135,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a) {
                                        a.centre.xy[2 * next] - a.centre.xy[2 * here]);
     const double raw = track_heading - phi + kPi;
     const double heading = fabs(raw - floor(raw / (2 * kPi)) * (2 * kPi) - kPi);
-    const double offset = sqrt(d_centre);
+    const double offset = sqrt(dc);
     const double z = (error - a.mean) / a.sigma;
     const double score = exp(-z * z / 2.0) / sqrt(2.0 * kPi) / a.sigma / a.scale;
     a.track_indices[3 * p] = i_centre;
@@ -222,6 +278,192 @@ __global__ void __launch_bounds__(kBlock) pf_estimate_kernel(const float* states
   }
 }
 
+
+// ---- device-resident filter (one host round trip per update) ----------------------------------------------------------
+// The reference's update cycle (localiser.py:41-77,234-239,420-579) with its random part restated on counter-based
+// draws, so that it can run where the particles live:
+//   step      every particle moves with its own noisy control (yaw noise on the tyre angle, |velocity + noise|)
+//   update    score -> keep the valid particles in order -> too few left: reset along the centre line; otherwise top up
+//             to the desired count with copies of kept particles drawn in proportion to their score (inverse CDF on a
+//             prefix sum) plus Gaussian noise -> score-weighted estimate and the two convergence numbers
+// The reference draws from NumPy's global Mersenne Twister in a fixed call order, which a parallel kernel cannot
+// follow; `particle_filter.ParticleFilter` (NumPy resampling, the reference's draw order) therefore stays the parity
+// mode, and this path is pinned by its own restatement (oracle pf_resample_counter_based): the weights are integers
+// (floor(score * 2^40)), so the prefix sums, the draws (mulhi of a 64-bit Philox word with the total) and the picked
+// indices are exact in any summation order.
+constexpr int kScanBlock = 1024;
+constexpr uint32_t kTagResample = 0x52534d50u;  // "RSMP"
+constexpr uint32_t kTagControl = 0x4354524cu;   // "CTRL"
+
+struct FilterArgs {
+  const float* states_in;   // [n_live][3]
+  const float* scores_in;   // [n_live]  (float32 scores of this update)
+  const double* score;      // [n_live]  float64 scores of this update
+  const uint8_t* valid;     // [n_live]
+  float* states_out;        // [capacity][3]
+  float* scores_out;        // [capacity]
+  unsigned long long* cdf;  // [n_live] workspace: inclusive prefix sums of the kept weights
+  int* kept;                // [n_live] workspace: source index of kept particle k
+  int* counts;              // [4]: n_live (in/out), n_valid (out), was_reset (out), spare
+  const double* centre;     // map centre line [m][2] (reset pattern)
+  int m_centre;
+  int capacity;             // max_particles
+  int n_desired, minimum_particles;
+  double sigma_x, sigma_y, sigma_yaw;
+  uint32_t seed_lo, seed_hi, counter;
+};
+
+__device__ __forceinline__ unsigned long long weight_of(double score) {
+  // floor(score * 2^40) for finite positive scores, 0 otherwise (NaN, negative); scores are <= 1 by construction
+  if (!(score > 0.0)) return 0ull;
+  const double scaled = score * 1099511627776.0;
+  return scaled >= 1.8446744073709552e19 ? 0xffffffffffffffffull : static_cast<unsigned long long>(scaled);
+}
+
+// exclusive prefix sum of one value per thread over the workgroup (kScanBlock threads); returns the offset, *total
+__device__ unsigned long long block_exclusive_scan(unsigned long long v, unsigned long long* s_scan,
+                                                   unsigned long long* total) {
+  const int tid = threadIdx.x;
+  s_scan[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < kScanBlock; off <<= 1) {
+    const unsigned long long add = (tid >= off) ? s_scan[tid - off] : 0ull;
+    __syncthreads();
+    s_scan[tid] += add;
+    __syncthreads();
+  }
+  *total = s_scan[kScanBlock - 1];
+  const unsigned long long inclusive = s_scan[tid];
+  __syncthreads();
+  return inclusive - v;
+}
+
+__global__ void __launch_bounds__(kScanBlock) pf_resample_kernel(const FilterArgs a) {
+  __shared__ unsigned long long s_scan[kScanBlock];
+  const int tid = threadIdx.x;
+  const int n = a.counts[0];
+  const int chunk = (n + kScanBlock - 1) / kScanBlock;
+  const int begin = min(tid * chunk, n), end = min(begin + chunk, n);
+  // 1. stable compaction of the valid particles
+  unsigned long long local = 0ull, total = 0ull;
+  for (int p = begin; p < end; ++p) local += a.valid[p] ? 1ull : 0ull;
+  unsigned long long offset = block_exclusive_scan(local, s_scan, &total);
+  const int n_valid = static_cast<int>(total);
+  for (int p = begin; p < end; ++p)
+    if (a.valid[p]) a.kept[offset++] = p;
+  __syncthreads();
+  __threadfence_block();
+  if (n_valid < a.minimum_particles) {
+    // _reset_filter (localiser.py:468-485): spread evenly along the centre line, heading along it, uniform scores
+    const int count = a.capacity;
+    for (int k = tid; k < count; k += kScanBlock) {
+      // np.linspace(0, m - 3, count).astype(int32)
+      const double pos = (count > 1) ? static_cast<double>(k) * (static_cast<double>(a.m_centre - 3) / static_cast<double>(count - 1))
+                                     : 0.0;
+      int idx = static_cast<int>((k == count - 1 && count > 1) ? static_cast<double>(a.m_centre - 3) : pos);
+      const double x = a.centre[2 * idx], y = a.centre[2 * idx + 1];
+      const double yaw = atan2(a.centre[2 * (idx + 1) + 1] - y, a.centre[2 * (idx + 1)] - x);
+      a.states_out[3 * k] = static_cast<float>(x);
+      a.states_out[3 * k + 1] = static_cast<float>(y);
+      a.states_out[3 * k + 2] = static_cast<float>(yaw);
+      a.scores_out[k] = 1.0f / static_cast<float>(count);
+    }
+    if (tid == 0) {
+      a.counts[0] = count;
+      a.counts[1] = n_valid;
+      a.counts[2] = 1;
+    }
+    return;
+  }
+  // 2. integer weights of the kept particles and their inclusive prefix sums (exact: order does not matter)
+  const int kchunk = (n_valid + kScanBlock - 1) / kScanBlock;
+  const int kb = min(tid * kchunk, n_valid), ke = min(kb + kchunk, n_valid);
+  local = 0ull;
+  for (int k = kb; k < ke; ++k) local += weight_of(a.score[a.kept[k]]);
+  unsigned long long wtotal = 0ull;
+  offset = block_exclusive_scan(local, s_scan, &wtotal);
+  const bool uniform = wtotal == 0ull;   // all scores zero / NaN: uniform weights (localiser.py:523-526)
+  if (uniform) {
+    offset = static_cast<unsigned long long>(kb);
+    wtotal = static_cast<unsigned long long>(n_valid);
+  }
+  for (int k = kb; k < ke; ++k) {
+    offset += uniform ? 1ull : weight_of(a.score[a.kept[k]]);
+    a.cdf[k] = offset;
+  }
+  __syncthreads();
+  __threadfence_block();
+  // 3. kept particles first, in order
+  for (int k = tid; k < n_valid; k += kScanBlock) {
+    const int p = a.kept[k];
+    a.states_out[3 * k] = a.states_in[3 * p];
+    a.states_out[3 * k + 1] = a.states_in[3 * p + 1];
+    a.states_out[3 * k + 2] = a.states_in[3 * p + 2];
+    a.scores_out[k] = a.scores_in[p];
+  }
+  // 4. top up: new particle j = kept[upper_bound(cdf, mulhi(r, total))] + noise
+  const int n_new = max(0, min(a.n_desired, a.capacity) - n_valid);
+  const uint32_t key[2] = {a.seed_lo, a.seed_hi};
+  for (int j = tid; j < n_new; j += kScanBlock) {
+    const uint32_t c_pick[4] = {static_cast<uint32_t>(j), a.counter, kTagResample, 0u};
+    const uint32_t c_noise[4] = {static_cast<uint32_t>(j), a.counter, kTagResample, 1u};
+    uint32_t r[4], q[4];
+    acmpc::philox4x32_10(c_pick, key, r);
+    acmpc::philox4x32_10(c_noise, key, q);
+    const unsigned long long word = (static_cast<unsigned long long>(r[0]) << 32) | r[1];
+    const unsigned long long target = __umul64hi(word, wtotal);   // uniform in [0, total)
+    int lo = 0, hi = n_valid - 1;                                   // first k with cdf[k] > target
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (a.cdf[mid] > target) hi = mid; else lo = mid + 1;
+    }
+    const int p = a.kept[lo];
+    float z0, z1, z2, z3;
+    acmpc::box_muller(acmpc::uniform_open(q[0]), acmpc::uniform_open(q[1]), z0, z1);
+    acmpc::box_muller(acmpc::uniform_open(q[2]), acmpc::uniform_open(q[3]), z2, z3);
+    (void)z3;
+    const int k = n_valid + j;
+    a.states_out[3 * k] = static_cast<float>(static_cast<double>(a.states_in[3 * p]) + a.sigma_x * static_cast<double>(z0));
+    a.states_out[3 * k + 1] =
+        static_cast<float>(static_cast<double>(a.states_in[3 * p + 1]) + a.sigma_y * static_cast<double>(z1));
+    a.states_out[3 * k + 2] =
+        static_cast<float>(static_cast<double>(a.states_in[3 * p + 2]) + a.sigma_yaw * static_cast<double>(z2));
+    a.scores_out[k] = a.scores_in[p];
+  }
+  if (tid == 0) {
+    a.counts[0] = n_valid + n_new;
+    a.counts[1] = n_valid;
+    a.counts[2] = 0;
+  }
+}
+
+// Localiser.step (localiser.py:41-77): delta = tyre_angle + N(0, sigma_yaw), speed = |velocity + N(0, sigma_v)| per
+// particle from Philox (counter = particle, step), then the float32 kinematic step of pf_advance_kernel
+__global__ void pf_step_kernel(float* states, const int* counts, float tyre_angle, float velocity, float sigma_yaw,
+                               float sigma_v, float wheelbase, float dt, uint32_t seed_lo, uint32_t seed_hi,
+                               uint32_t counter) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= counts[0]) return;
+  const uint32_t ctr[4] = {static_cast<uint32_t>(p), counter, kTagControl, 0u};
+  const uint32_t key[2] = {seed_lo, seed_hi};
+  uint32_t r[4];
+  acmpc::philox4x32_10(ctr, key, r);
+  float z0, z1;
+  acmpc::box_muller(acmpc::uniform_open(r[0]), acmpc::uniform_open(r[1]), z0, z1);
+  const float delta = tyre_angle + sigma_yaw * z0;
+  const float v = fabsf(velocity + sigma_v * z1);
+  const float phi = states[3 * p + 2];
+  states[3 * p] += (v * cosf(phi)) * dt;
+  states[3 * p + 1] += (v * sinf(phi)) * dt;
+  states[3 * p + 2] += (v * tanf(delta) / wheelbase) * dt;
+}
+
+// float64 score -> the float32 score the reference publishes (_update_particle_scores), for the n live particles
+__global__ void pf_publish_scores_kernel(const double* score, float* scores, const int* counts) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < counts[0]) scores[p] = static_cast<float>(score[p]);
+}
+
 thread_local std::string g_pf_create_error;
 
 }  // namespace
@@ -233,13 +475,16 @@ struct acmpc_pf {
   bool device_ready = false;
   double* d_track[3] = {nullptr, nullptr, nullptr};
   hipStream_t stream = nullptr;
-  // staging for the host-pointer entry points
-  float* d_states = nullptr;
+  // staging for the host-pointer entry points: ONE pinned block up (states | observation) and ONE down (all
+  // per-particle results) per scoring call - at the reference's 500 particles the call is a handful of microseconds
+  // of kernel and otherwise transfer round trips (it used to make nine of them)
+  unsigned char* h_up = nullptr;    // pinned
+  unsigned char* h_down = nullptr;  // pinned
+  unsigned char* d_down = nullptr;  // [4 P doubles | 3 P int32 | P bytes]
+  float* d_states = nullptr;        // [P][3] then the observation [K][2] directly behind it
   float* d_obs = nullptr;
   float* d_aux = nullptr;      // 2 * max_particles floats: delta / velocity, or scores
-  int32_t* d_indices = nullptr;
-  double* d_out = nullptr;     // 4 * max_particles doubles + 8
-  uint8_t* d_valid = nullptr;
+  double* d_out = nullptr;     // 8 doubles: result of the estimate kernel
   mutable std::string err;
 };
 
@@ -276,12 +521,14 @@ int pf_ensure_device(acmpc_pf* h) {
                         hipMemcpyHostToDevice));
   }
   const size_t P = h->prm.max_particles, K = h->prm.max_observation_points;
-  PF_HIP(h, hipMalloc(&h->d_states, P * 3 * sizeof(float)));
-  PF_HIP(h, hipMalloc(&h->d_obs, K * 2 * sizeof(float)));
+  PF_HIP(h, hipMalloc(&h->d_states, (P * 3 + K * 2) * sizeof(float)));
+  h->d_obs = nullptr;  // placed behind the states of each call
+  PF_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_up), (P * 3 + K * 2) * sizeof(float), hipHostMallocDefault));
+  const size_t down = P * (4 * sizeof(double) + 3 * sizeof(int32_t) + 1);
+  PF_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_down), down, hipHostMallocDefault));
+  PF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_down), down));
   PF_HIP(h, hipMalloc(&h->d_aux, P * 2 * sizeof(float)));
-  PF_HIP(h, hipMalloc(&h->d_indices, P * 3 * sizeof(int32_t)));
-  PF_HIP(h, hipMalloc(&h->d_out, (P * 4 + 8) * sizeof(double)));
-  PF_HIP(h, hipMalloc(&h->d_valid, P));
+  PF_HIP(h, hipMalloc(&h->d_out, 8 * sizeof(double)));
   h->device_ready = true;
   return ACMPC_OK;
 }
@@ -325,11 +572,11 @@ void acmpc_pf_destroy(acmpc_pf* h) {
     if (h->prm.device >= 0) (void)hipSetDevice(h->prm.device);
     for (int t = 0; t < 3; ++t) (void)hipFree(h->d_track[t]);
     (void)hipFree(h->d_states);
-    (void)hipFree(h->d_obs);
+    (void)hipFree(h->d_down);
+    if (h->h_up != nullptr) (void)hipHostFree(h->h_up);
+    if (h->h_down != nullptr) (void)hipHostFree(h->h_down);
     (void)hipFree(h->d_aux);
-    (void)hipFree(h->d_indices);
     (void)hipFree(h->d_out);
-    (void)hipFree(h->d_valid);
     if (h->stream != nullptr) (void)hipStreamDestroy(h->stream);
   }
   delete h;
@@ -352,15 +599,19 @@ int acmpc_pf_score(acmpc_pf* h, const float* states, int32_t P, const float* obs
   const int rc = pf_ensure_device(h);
   if (rc != ACMPC_OK) return rc;
   hipStream_t s = h->stream;
-  PF_HIP(h, hipMemcpyAsync(h->d_states, states, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-  if (k_left > 0)
-    PF_HIP(h, hipMemcpyAsync(h->d_obs, obs_left, static_cast<size_t>(k_left) * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+  const int K = k_left + k_right;
+  const size_t up_floats = static_cast<size_t>(P) * 3 + static_cast<size_t>(K) * 2;
+  float* up = reinterpret_cast<float*>(h->h_up);
+  std::memcpy(up, states, static_cast<size_t>(P) * 3 * sizeof(float));
+  if (k_left > 0) std::memcpy(up + 3 * static_cast<size_t>(P), obs_left, static_cast<size_t>(k_left) * 2 * sizeof(float));
   if (k_right > 0)
-    PF_HIP(h, hipMemcpyAsync(h->d_obs + 2 * k_left, obs_right, static_cast<size_t>(k_right) * 2 * sizeof(float),
-                             hipMemcpyHostToDevice, s));
+    std::memcpy(up + 3 * static_cast<size_t>(P) + 2 * static_cast<size_t>(k_left), obs_right,
+                static_cast<size_t>(k_right) * 2 * sizeof(float));
+  PF_HIP(h, hipMemcpyAsync(h->d_states, up, up_floats * sizeof(float), hipMemcpyHostToDevice, s));
+  const size_t pd = static_cast<size_t>(P) * sizeof(double);
   ScoreArgs a{};
   a.states = h->d_states;
-  a.obs = h->d_obs;
+  a.obs = h->d_states + 3 * static_cast<size_t>(P);
   a.k_left = k_left;
   a.k_right = k_right;
   a.centre = Track{h->d_track[0], static_cast<int>(h->h_track[0].size() / 2)};
@@ -372,23 +623,30 @@ int acmpc_pf_score(acmpc_pf* h, const float* states, int32_t P, const float* obs
   a.thr_rotation = h->prm.threshold_rotation;
   a.thr_offset = h->prm.threshold_offset;
   a.thr_error = h->prm.threshold_error;
-  a.track_indices = h->d_indices;
-  a.minimum_offset = h->d_out;
-  a.heading_offset = h->d_out + P;
-  a.error = h->d_out + 2 * static_cast<size_t>(P);
-  a.score = h->d_out + 3 * static_cast<size_t>(P);
-  a.valid = h->d_valid;
+  a.minimum_offset = reinterpret_cast<double*>(h->d_down);
+  a.heading_offset = a.minimum_offset + P;
+  a.error = a.heading_offset + P;
+  a.score = a.error + P;
+  a.track_indices = reinterpret_cast<int32_t*>(h->d_down + 4 * pd);
+  a.valid = reinterpret_cast<uint8_t*>(h->d_down + 4 * pd + static_cast<size_t>(P) * 3 * sizeof(int32_t));
   (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
-  hipLaunchKernelGGL(pf_score_kernel, dim3(P), dim3(kBlock), 0, s, a);
+  if (P >= 4096) {
+    constexpr int PB = 8;
+    hipLaunchKernelGGL(pf_score_kernel<PB>, dim3((P + PB - 1) / PB), dim3(kBlock), 0, s, a, P);
+  } else {
+    hipLaunchKernelGGL(pf_score_kernel<1>, dim3(P), dim3(kBlock), 0, s, a, P);
+  }
   PF_HIP(h, hipGetLastError());
-  const size_t pd = static_cast<size_t>(P) * sizeof(double);
-  PF_HIP(h, hipMemcpyAsync(track_indices, h->d_indices, static_cast<size_t>(P) * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  PF_HIP(h, hipMemcpyAsync(minimum_offset, a.minimum_offset, pd, hipMemcpyDeviceToHost, s));
-  PF_HIP(h, hipMemcpyAsync(heading_offset, a.heading_offset, pd, hipMemcpyDeviceToHost, s));
-  PF_HIP(h, hipMemcpyAsync(observation_error, a.error, pd, hipMemcpyDeviceToHost, s));
-  PF_HIP(h, hipMemcpyAsync(score, a.score, pd, hipMemcpyDeviceToHost, s));
-  PF_HIP(h, hipMemcpyAsync(valid, h->d_valid, static_cast<size_t>(P), hipMemcpyDeviceToHost, s));
+  const size_t down = 4 * pd + static_cast<size_t>(P) * (3 * sizeof(int32_t) + 1);
+  PF_HIP(h, hipMemcpyAsync(h->h_down, h->d_down, down, hipMemcpyDeviceToHost, s));
   PF_HIP(h, hipStreamSynchronize(s));
+  const unsigned char* dn = h->h_down;
+  std::memcpy(minimum_offset, dn, pd);
+  std::memcpy(heading_offset, dn + pd, pd);
+  std::memcpy(observation_error, dn + 2 * pd, pd);
+  std::memcpy(score, dn + 3 * pd, pd);
+  std::memcpy(track_indices, dn + 4 * pd, static_cast<size_t>(P) * 3 * sizeof(int32_t));
+  std::memcpy(valid, dn + 4 * pd + static_cast<size_t>(P) * 3 * sizeof(int32_t), static_cast<size_t>(P));
   return ACMPC_OK;
 }
 
@@ -422,7 +680,7 @@ int acmpc_pf_estimate(acmpc_pf* h, const float* states, const float* scores, int
   hipStream_t s = h->stream;
   PF_HIP(h, hipMemcpyAsync(h->d_states, states, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
   PF_HIP(h, hipMemcpyAsync(h->d_aux, scores, static_cast<size_t>(P) * sizeof(float), hipMemcpyHostToDevice, s));
-  double* d_res = h->d_out + 4 * static_cast<size_t>(h->prm.max_particles);
+  double* d_res = h->d_out;
   (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
   hipLaunchKernelGGL(pf_estimate_kernel, dim3(1), dim3(kBlock), 0, s, h->d_states, h->d_aux, P, d_res);
   PF_HIP(h, hipGetLastError());

@@ -22,6 +22,24 @@ struct TickHeader {
   int32_t centre_is_reference;            // sample round the reference controls (no previous plan)
   int32_t qp_max_iter, qp_check_every;
   uint32_t seed_lo, seed_hi;              // Philox key of this solve (read by the rollout kernels through seed_ptr)
+  // reference path taken from the bound map instead of from `coords` (acmpc_bind_map)
+  int32_t use_map;                        // != 0: the window kernel in front of the prologue produces the H x 3 path
+  int32_t map_index;                      // first waypoint of the window, or < 0: the map point nearest to the pose
+  double pose_x, pose_y;                  // map frame; only read when map_index < 0
+  double lateral_offset;                  // subtracted from the window's lateral coordinate (car off the centre line)
+};
+
+// The window kernel's arguments: map polyline resident on the device, output = the H x 3 path the prologue reads.
+struct MapWindowArgs {
+  const TickHeader* header;   // pinned host memory (use_map fields)
+  const double* centre;       // [M][2] map centre line, device
+  int M;
+  int count;                  // map points in the look-ahead window: round(150 m / spacing) + 1 (perception/tracks.py:14)
+  int points;                 // length of the resampled centre line perception publishes (500; controller.py:102-108)
+  int H;                      // rows of the reference path: points / H must be an integer stride (controller.py:256-267)
+  double* coords;             // [H][3] out, device
+  double* coords_out;         // [H][3] out, pinned host memory (or nullptr)
+  int* index_out;             // [1] out, pinned host memory: the window's first map index
 };
 
 struct PrologueArgs {
@@ -47,6 +65,7 @@ constexpr int kPrologueMaxSteps = admm::kPcrMaxN;  // LDS budget of the single-w
 
 size_t prologue_lds_bytes(int n);
 hipError_t launch_prologue(const PrologueArgs& args, int n, hipStream_t s);
+hipError_t launch_map_window(const MapWindowArgs& args, hipStream_t s);
 
 // test hook: the device ADMM alone (device pointers; v / y are read when warm != 0 and always written)
 hipError_t launch_admm(const double* d_v_hi, const double* d_ds, int n, const admm::Settings& s, double* d_v, double* d_y,

@@ -183,6 +183,98 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   (void)m;
 }
 
+// ---- reference path from the map ----------------------------------------------------------------------
+// What the perception stack and ControlProcess._reference_path do between the map and get_control, for a pose on a
+// known map: the map point nearest to the pose (first minimum, what the localiser's KD-tree query returns,
+// localiser.py:282-289), the next 150 m of centre line (perception/tracks.py:14) moved into the vehicle frame (car at the
+// origin, heading +y), resampled to the 500 points perception publishes as float32 (controller.py:102-108), every
+// (500 / H)-th of them kept and given widths linspace(10, 6, H) (controller.py:256-267).  One workgroup; row r of the
+// path only needs the two window points that bracket its sample, so nothing but the nearest-point search is more than
+// a handful of operations per lane.  float64 like the NumPy statement (workloads.local_centreline), rounded to float32
+// where perception's shared memory does.
+__global__ void __launch_bounds__(256) map_window_kernel(const MapWindowArgs a) {
+  __shared__ double s_d[4];
+  __shared__ int s_i[4];
+  __shared__ int s_first;
+  const int tid = static_cast<int>(threadIdx.x);
+  const TickHeader h = *a.header;
+  int first = h.map_index;
+  if (first < 0) {  // nearest map point: per-thread scan, wave shuffles, four partial results through LDS
+    double best = __builtin_inf();
+    int best_i = 0x7fffffff;
+    for (int m = tid; m < a.M; m += 256) {
+      const double dx = h.pose_x - a.centre[2 * m], dy = h.pose_y - a.centre[2 * m + 1];
+      const double d = dx * dx + dy * dy;
+      if (d < best) {  // ascending m per thread: the first minimum stays
+        best = d;
+        best_i = m;
+      }
+    }
+#pragma unroll
+    for (int mask = 32; mask >= 1; mask >>= 1) {
+      const double od = __shfl_xor(best, mask, 64);
+      const int oi = __shfl_xor(best_i, mask, 64);
+      if (od < best || (od == best && oi < best_i)) {
+        best = od;
+        best_i = oi;
+      }
+    }
+    if ((tid & 63) == 0) {
+      s_d[tid >> 6] = best;
+      s_i[tid >> 6] = best_i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int q = 1; q < 4; ++q)
+        if (s_d[q] < best || (s_d[q] == best && s_i[q] < best_i)) {
+          best = s_d[q];
+          best_i = s_i[q];
+        }
+      s_first = best_i;
+    }
+    __syncthreads();
+    first = s_first;
+  }
+  first = ((first % a.M) + a.M) % a.M;
+  // vehicle frame: origin at the window's first point, +y along its first segment
+  const double* w0 = a.centre + 2 * first;
+  const double* w1 = a.centre + 2 * ((first + 1) % a.M);
+  const double heading = atan2(w1[1] - w0[1], w1[0] - w0[0]);
+  const double rot = kPi / 2.0 - heading;
+  const double c = cos(rot), sn = sin(rot);
+  const int stride = a.points / a.H;
+  const double step = static_cast<double>(a.count - 1) / static_cast<double>(a.points - 1);  // np.linspace's step
+  for (int r = tid; r < a.H; r += 256) {
+    const int q = r * stride;                                   // sample of the resampled centre line kept for row r
+    const double t = (q == a.points - 1) ? static_cast<double>(a.count - 1) : static_cast<double>(q) * step;
+    int j = static_cast<int>(t);                                // np.interp: the bracket [j, j + 1] with xp = arange
+    if (j > a.count - 2) j = a.count - 2;
+    double local[2][2];
+    for (int e = 0; e < 2; ++e) {
+      const double* wp = a.centre + 2 * ((first + j + e) % a.M);
+      const double dx = wp[0] - w0[0], dy = wp[1] - w0[1];
+      local[e][0] = (dx * c + dy * (-sn)) - h.lateral_offset;   // (window - window[0]) @ [[c, s], [-s, c]]
+      local[e][1] = dx * sn + dy * c;
+    }
+    const double frac = t - static_cast<double>(j);
+    const double x = (t >= static_cast<double>(a.count - 1)) ? local[1][0] : (local[1][0] - local[0][0]) * frac + local[0][0];
+    const double y = (t >= static_cast<double>(a.count - 1)) ? local[1][1] : (local[1][1] - local[0][1]) * frac + local[0][1];
+    const double width = (r == a.H - 1) ? 6.0 : 10.0 + static_cast<double>(r) * ((6.0 - 10.0) / static_cast<double>(a.H - 1));
+    const double row[3] = {static_cast<double>(static_cast<float>(x)), static_cast<double>(static_cast<float>(y)), width};
+    for (int e = 0; e < 3; ++e) {
+      a.coords[3 * r + e] = row[e];
+      if (a.coords_out != nullptr) a.coords_out[3 * r + e] = row[e];
+    }
+  }
+  if (tid == 0 && a.index_out != nullptr) a.index_out[0] = first;
+}
+
+hipError_t launch_map_window(const MapWindowArgs& args, hipStream_t s) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(map_window_kernel, dim3(1), dim3(256), 0, s, args);
+  return hipGetLastError();
+}
+
 size_t prologue_lds_bytes(int n) {
   return static_cast<size_t>(7 * n + n + (n + 1) + n + 2 * n + admm::workspace_doubles(n)) * sizeof(double);  // < 64 kB
 }

@@ -229,9 +229,26 @@ typedef struct acmpc_tick {
   double shrink;
   double qp_eps_abs, qp_eps_rel;
   uint64_t seed;
+  /* reference path from the map bound with acmpc_bind_map instead of from `coords` (pass coords = NULL) */
+  int32_t map_index;           /* first map waypoint of the look-ahead window; < 0: the map point nearest to the pose  */
+  int32_t centreline_points;   /* length of the resampled centre line (500, controller.py:102-108); multiple of horizon */
+  double pose_x, pose_y;       /* map frame; read when map_index < 0                                                  */
+  double lateral_offset;       /* subtracted from the window's lateral coordinate (the car's offset from the line)    */
 } acmpc_tick;
 
-/* coords [H][3] float64 (x, y, width) in the vehicle frame; centre [n][2] float32 (v, kappa) or NULL.
+/* Replaces: the path from the map to get_control's argument for a pose on a known map - nearest map
+ * point (what the localiser's KD-tree query returns, localiser.py:282-289), the next 150 m of centre line
+ * (perception/tracks.py:14) in the vehicle frame, resampled to `centreline_points` float32 points (controller.py:102-108),
+ * every (points / H)-th kept with widths linspace(10, 6, H) (ControlProcess._reference_path, controller.py:256-267).
+ * acmpc_bind_map copies the centre polyline [M][2] float64 (utils/load.py:9-35 order x, y; `spacing` = metres between map
+ * points, mapping/map_maker.py:203); no device work.  acmpc_control_tick with coords = NULL then runs the window kernel
+ * in front of the prologue; acmpc_map_reference_path runs it alone (blocking; coords [H][3] out, *first_index out). */
+int acmpc_bind_map(acmpc_ctx* ctx, const double* centre, int32_t M, double spacing);
+int acmpc_map_reference_path(acmpc_ctx* ctx, int32_t map_index, double pose_x, double pose_y, double lateral_offset,
+                             int32_t horizon, int32_t centreline_points, double* coords, int32_t* first_index);
+
+/* coords [H][3] float64 (x, y, width) in the vehicle frame, or NULL with a bound map (then `coords_out` [H][3], if not
+ * NULL, receives the path the device built); centre [n][2] float32 (v, kappa) or NULL.
  * Outputs (all required): table [7][n] float64 (rows x, y, psi, kappa, ds, width, v); record
  * [acmpc_record_floats(n)]; decision [5n + 3] = dec.x ([x_0..x_n ; u_0..u_{n-1}], control.py:121-158);
  * projected_control [2][n], prediction [n][2], cum_time [n], times / accelerations / steer_rates [n - 1] as
@@ -239,7 +256,8 @@ typedef struct acmpc_tick {
  * 1 = maximum iterations), QP iterations, 0, 0}. */
 int acmpc_control_tick(acmpc_ctx* ctx, const acmpc_tick* tick, const double* coords, const float* centre, double* table,
                        float* record, double* decision, double* projected_control, double* prediction,
-                       double* cum_time, double* times, double* accelerations, double* steer_rates, double* info);
+                       double* cum_time, double* times, double* accelerations, double* steer_rates, double* info,
+                       double* coords_out);
 
 /* Test hooks of the tick path.  acmpc_tick_read_device_tables copies what the last tick's prologue left on the device
  * for the rollout - x0 [3], u_ref [n][2], the packed table [n][ACMPC_COEF_STRIDE_SPATIAL] - back to the host.
