@@ -104,6 +104,20 @@ class Tick(C.Structure):
     ]
 
 
+class PfResample(C.Structure):
+    """acmpc_pf_resample: the resampling parameters of one device-resident filter update."""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n_desired", C.c_int32),
+        ("minimum_particles", C.c_int32),
+        ("counter", C.c_uint32),
+        ("seed", C.c_uint64),
+        ("sigma_x", C.c_double),
+        ("sigma_y", C.c_double),
+        ("sigma_yaw", C.c_double),
+    ]
+
+
 _F32P = C.POINTER(C.c_float)
 _F64P = C.POINTER(C.c_double)
 _I32P = C.POINTER(C.c_int32)
@@ -164,6 +178,13 @@ SIGNATURES = {
                        [C.c_void_p] * 6),
     "acmpc_pf_advance": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double]),
     "acmpc_pf_estimate": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, _F64P, _F64P]),
+    "acmpc_pf_filter_reset": (C.c_int, [_CTX, C.c_int32]),
+    "acmpc_pf_filter_set": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32]),
+    "acmpc_pf_filter_get": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, _I32P]),
+    "acmpc_pf_filter_step": (C.c_int, [_CTX, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64,
+                                       C.c_uint32]),
+    "acmpc_pf_filter_update": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(PfResample),
+                                         C.c_void_p]),
     "acmpc_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "acmpc_profile_collect": (C.c_int, [_CTX, _F32P, C.c_int32, _I32P]),
     "acmpc_pack_key": (C.c_int64, [C.c_float, C.c_uint32]),

@@ -197,3 +197,88 @@ class ParticleFilter:
     def estimated_location(self) -> np.ndarray:
         return self.scorer.estimate_location(self.scores, self.states)[0]
 
+
+
+class DeviceParticleFilter:
+    """The same update cycle with the particles LIVING on the GPU: `step` and `update` are one launch sequence each and
+    `update` is one host round trip (the observation goes up, eight numbers come back) instead of the two of
+    `ParticleFilter` (score down, resample on the host, estimate up and down).  The random draws are counter-based
+    (Philox4x32-10, key = `seed`, counter = update / step number) and made on the device - not NumPy's global stream,
+    whose call order a kernel cannot follow - so this class reproduces `ParticleFilter` statistically, not draw for
+    draw; `ParticleFilter` stays the mode that is pinned to the reference's own resampling under a shared seed, this one
+    is pinned by the oracle's restatement of its draws (oracle `pf_resample_counter_based`)."""
+
+    def __init__(self, config: Dict, track_map: Dict[str, np.ndarray], wheelbase: float = 2.65, seed: int = 0,
+                 **scorer_kwargs):
+        self.scorer = ParticleScorer(config, track_map, wheelbase=wheelbase, **scorer_kwargs)
+        self._lib, self._handle = self.scorer._lib, self.scorer._handle
+        self._max_n_particles = int(config["n_particles"])
+        self._n_converged_particles = int(config["n_converged_particles"])
+        noise, control, criteria = config["sampling_noise"], config["control_noise"], config["convergence_criteria"]
+        self._control_sigma = (float(control["yaw"]) * np.pi / 180, float(control["velocity"]))
+        self._convergence_distance = float(criteria["maximum_distance"])
+        self._convergence_angle = float(criteria["maximum_angle"])
+        self._rs = _capi.PfResample()
+        self._rs.struct_size = C.sizeof(_capi.PfResample)
+        self._rs.minimum_particles = int(config["thresholds"]["minimum_particles"])
+        self._rs.seed = int(seed)
+        self._rs.sigma_x, self._rs.sigma_y = float(noise["x"]), float(noise["y"])
+        self._rs.sigma_yaw = float(noise["yaw"]) * np.pi / 180
+        self._seed, self._steps, self._updates = int(seed), 0, 0
+        self._result = np.zeros(8)
+        self.is_converged = False
+        self.was_reset = False
+        self.reset()
+
+    def _check(self, rc: int):
+        self.scorer._check(rc)
+
+    def reset(self):
+        self._check(self._lib.acmpc_pf_filter_reset(self._handle, self._max_n_particles))
+        self.is_converged = False
+
+    def set_particles(self, states: np.ndarray, scores: np.ndarray):
+        states = np.ascontiguousarray(states, dtype=np.float32)
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        self._check(self._lib.acmpc_pf_filter_set(self._handle, states.ctypes.data, scores.ctypes.data, states.shape[0]))
+
+    def particles(self):
+        """(states [n, 3], scores [n]) downloaded from the device."""
+        states = np.empty((self._max_n_particles, 3), dtype=np.float32)
+        scores = np.empty(self._max_n_particles, dtype=np.float32)
+        n = C.c_int32(0)
+        self._check(self._lib.acmpc_pf_filter_get(self._handle, states.ctypes.data, scores.ctypes.data,
+                                                  self._max_n_particles, C.byref(n)))
+        return states[:n.value].copy(), scores[:n.value].copy()
+
+    @property
+    def states(self) -> np.ndarray:
+        return self.particles()[0]
+
+    @property
+    def scores(self) -> np.ndarray:
+        return self.particles()[1]
+
+    def step(self, tyre_angle: float, velocity: float, dt: float):
+        self._steps += 1
+        self._check(self._lib.acmpc_pf_filter_step(self._handle, float(tyre_angle), float(velocity), float(dt),
+                                                   self._control_sigma[0], self._control_sigma[1], self._seed,
+                                                   self._steps))
+
+    def update(self, observations: Dict[str, np.ndarray]) -> Dict:
+        left, right = (np.ascontiguousarray(o[o[:, 1] < 50], dtype=np.float32)
+                       for o in self.scorer.downsample_observations(observations))
+        self._updates += 1
+        self._rs.counter = self._updates
+        self._rs.n_desired = self._n_converged_particles if self.is_converged else self._max_n_particles
+        self._check(self._lib.acmpc_pf_filter_update(self._handle, left.ctypes.data, left.shape[0], right.ctypes.data,
+                                                     right.shape[0], C.byref(self._rs), self._result.ctypes.data))
+        r = self._result
+        self.was_reset = bool(r[7])
+        self.is_converged = bool(r[3] < self._convergence_distance and r[4] < self._convergence_angle)
+        return dict(estimate=r[:3].copy(), max_distance=float(r[3]), max_angle=float(r[4]), n_particles=int(r[5]),
+                    n_valid=int(r[6]), was_reset=self.was_reset)
+
+    @property
+    def estimated_location(self) -> np.ndarray:
+        return self._result[:3].copy()

@@ -6,25 +6,27 @@
 // programs", Math. Prog. Comp. 2020: over-relaxed ADMM, per-row step sizes, heavier weight on equality rows,
 // residual-balancing step-size updates, the package's 1e-3 absolute / relative stopping test) specialised to this
 // problem's structure: the constraint matrix is [D1; I] with D1 bidiagonal, so the linear system of every iteration
-// is symmetric tridiagonal and is solved in O(n) by an LDL' sweep.
+// is symmetric tridiagonal.
 //
 // ONE statement of the algorithm for the host (acmpc_speed_profile_qp: the whole-lap profile of the race start and
-// the CPU tests) and for the device (prologue_kernel: the horizon profile of every control tick, inside the solve's
-// hipGraph).  A "team" of T workers runs it: on the host T = 1; on the device T = 64, the lanes of one wavefront.
-// Element-wise statements are split over the team, the two sequential sweeps of the tridiagonal solve are run by
-// worker 0, norms are max-reductions (exact in any order).  Every element therefore sees the same float64 operations
-// in the same order on both sides, which is what makes the device iterate bit-identical to the host's.  Both
-// translation units are built with -ffp-contract=off (no implicit fused multiply-add); the three sequential sweeps
-// (LDL' factorisation, forward and backward substitution) spell their update as ONE fused multiply-add per step
-// (fma_() below: IEEE fma, v_fma_f64 on the device, vfmadd on the host).
+// the CPU tests) and for the device (prologue_kernel: the horizon profile of every control tick).  A "team" of T
+// workers runs it: on the host T = 1; on the device T = 64, the lanes of one wavefront.  Worker r owns the elements
+// r, r + T, r + 2T, ...; element-wise statements touch only the worker's own elements, values of neighbouring
+// elements travel through an exchange buffer between two team barriers, norms are max-reductions (exact in any
+// order).  Every element therefore sees the same float64 operations in the same order on both sides, which is what
+// makes the device iterate bit-identical to the host's.  Both translation units are built with -ffp-contract=off (no
+// implicit fused multiply-add); where an update is spelt fma_() it is ONE IEEE fused multiply-add on both sides
+// (v_fma_f64 / vfmadd).
 //
 // The tridiagonal system K x = b is solved in one of two ways, chosen by n alone (so host and device always agree):
 //   n >  kPcrMaxN  LDL' sweeps (Thomas): O(n) work, two sequential chains of n steps - the whole-lap profile;
 //   n <= kPcrMaxN  parallel cyclic reduction: ceil(log2 n) levels, every element updated independently at each
 //                  level from its neighbours i - s and i + s (s = 1, 2, 4, ...) with multipliers that depend only
-//                  on K and are therefore computed once per factorisation; an iteration then costs 2 FMAs per
-//                  element and level plus one multiply.  On a wavefront that is ~7 short parallel phases instead of
-//                  two 50-step dependent chains (measured: the horizon's 10 warm iterations took 35 us as sweeps).
+//                  on K and are computed once per factorisation; an iteration then costs 2 FMAs per element and level
+//                  plus one multiply.  In that form a worker keeps everything it owns in local variables (registers
+//                  on the device) for the whole solve: an iteration on a wavefront is eight barrier-separated
+//                  exchanges of one double per lane (measured: 10 warm iterations of the 49-point horizon took 35 us
+//                  as sweeps through LDS arrays, 21 us as cyclic reduction through LDS arrays).
 // Both are exact solvers of the same SPD, diagonally dominant system; their roundings differ, which is why the
 // choice is part of the specification and not a launch decision.
 #pragma once
@@ -37,14 +39,21 @@
 #define ACMPC_HD inline
 #endif
 
+// worker-local loops run over K slots: 2 on the device (unrolled, the slots are registers), 128 on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ACMPC_SLOTS _Pragma("unroll")
+#else
+#define ACMPC_SLOTS
+#endif
+
 namespace acmpc {
 namespace admm {
 
-constexpr int kPcrMaxN = 128;   // systems up to this size use parallel cyclic reduction
+constexpr int kPcrMaxN = 128;     // systems up to this size use parallel cyclic reduction
 constexpr int kPcrMaxLevels = 7;  // ceil(log2(kPcrMaxN))
 
 // Doubles of workspace the solver needs for a problem of n points (see Workspace::bind).
-ACMPC_HD constexpr int workspace_doubles(int n) { return (n <= kPcrMaxN ? 36 : 16) * n; }
+ACMPC_HD constexpr int workspace_doubles(int n) { return (n <= kPcrMaxN ? 8 : 16) * n + 8; }
 
 struct Settings {
   double a_min, a_max, v_min;
@@ -54,11 +63,18 @@ struct Settings {
 };
 
 struct Workspace {
-  double *g, *ra, *rb, *d, *e, *l, *x, *ya, *yb, *za, *zb, *xt;  // n doubles each (the m = n - 1 row arrays too)
-  double* red;                                                    // >= 8 doubles: reductions / broadcast scalars
-  // cyclic reduction (n <= kPcrMaxN only): multipliers of every level, reciprocal of the final diagonal, scratch
-  double *pa, *pg, *binv, *tmp, *ca, *cb, *cc, *na, *nb, *nc;
+  // n > kPcrMaxN: the solver's arrays, n doubles each (the m = n - 1 row arrays too)
+  double *g, *ra, *rb, *d, *e, *l, *x, *ya, *yb, *za, *zb, *xt;
+  // n <= kPcrMaxN: exchange buffers only (values of neighbouring elements between two barriers), n doubles each
+  double* ex[8];
+  double* red;  // 8 doubles: reductions / broadcast scalars
   ACMPC_HD void bind(double* base, int n) {
+    if (n <= kPcrMaxN) {
+      for (int q = 0; q < 8; ++q) ex[q] = base + q * n;
+      red = base + 8 * n;
+      g = ra = rb = d = e = l = x = ya = yb = za = zb = xt = nullptr;
+      return;
+    }
     g = base;
     ra = base + n;
     rb = base + 2 * n;
@@ -72,19 +88,7 @@ struct Workspace {
     zb = base + 10 * n;
     xt = base + 11 * n;
     red = base + 12 * n;
-    pa = pg = binv = tmp = ca = cb = cc = na = nb = nc = nullptr;
-    if (n <= kPcrMaxN) {
-      pa = base + 14 * n;                       // [kPcrMaxLevels][n]
-      pg = pa + kPcrMaxLevels * n;              // [kPcrMaxLevels][n]
-      binv = pg + kPcrMaxLevels * n;
-      tmp = binv + n;
-      ca = tmp + n;
-      cb = ca + n;
-      cc = cb + n;
-      na = cc + n;
-      nb = na + n;
-      nc = nb + n;
-    }
+    for (int q = 0; q < 8; ++q) ex[q] = nullptr;
   }
 };
 
@@ -105,6 +109,268 @@ struct HostTeam {
 constexpr double kSigma = 1e-6;
 constexpr double kAlpha = 1.6;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// n <= kPcrMaxN: cyclic reduction, worker-local state
+// ---------------------------------------------------------------------------------------------------------------------
+// K = elements per worker: ceil(n / team size) rounded up to what is instantiated (1 or 2 on a wavefront - an
+// instruction issued for an empty slot costs the lone wavefront as much as one for a full slot - kPcrMaxN on the host)
+template <class Team, int K_>
+struct Small {
+  static constexpr int K = K_;
+  // per owned element (slot k <-> element rank + k * size)
+  double g[K], gm[K];            // 1 / (2 ds_i) of row i and of row i - 1
+  double ra[K], rb[K], ira[K], irb[K];
+  double vh[K];
+  double x[K], ya[K], yb[K], za[K], zb[K];
+  double pa[kPcrMaxLevels][K], pg[kPcrMaxLevels][K], binv[K];
+};
+
+// Everything below is written without data-dependent branches: a worker's slot that holds no element (index >= n)
+// computes on clamped indices and simply never stores, and an element without a neighbour at distance s has a zero
+// multiplier for it by construction (a_i = 0 for i < s, c_i = 0 for i + s >= n, g = 0 for the row that does not
+// exist), so the fused multiply-add with the clamped neighbour adds nothing.  On a lone wavefront every exec-mask
+// branch costs as much as the arithmetic it guards (the branching form of these loops was 1 300 instructions per
+// iteration, 3 us; this one is a few hundred).
+ACMPC_HD int clamp_index(int i, int n) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); }
+
+// K = diag(1 + sigma + rb) + D1' diag(ra) D1, D1 rows (-g_i, +g_i), reduced level by level: the equation of element i
+//     a_i x_{i-s} + b_i x_i + c_i x_{i+s} = r_i
+// sheds its two neighbours by adding alpha_i = -a_i / b_{i-s} times equation i - s and gamma_i = -c_i / b_{i+s} times
+// equation i + s; after ceil(log2 n) levels only b_i x_i = r_i is left.  Kept: alpha, gamma of every level, 1 / b_i of
+// the last, and the reciprocals of the step sizes (the iteration multiplies by them instead of dividing).
+template <class Team, int K>
+ACMPC_HD void factor_small(const Team& team, const Workspace& w, Small<Team, K>& st, int n, double rho,
+                           const Settings& s) {
+  const int m = n - 1;
+  double a[K], b[K], c[K];
+ACMPC_SLOTS
+  for (int k = 0; k < K; ++k) {
+    const int i = team.rank() + k * Team::size;
+    if (Team::size == 1 && i >= n) break;
+    st.ra[k] = (s.a_min == s.a_max) ? 1e3 * rho : rho;
+    st.rb[k] = (s.v_min == st.vh[k]) ? 1e3 * rho : rho;
+    st.ira[k] = 1.0 / st.ra[k];
+    st.irb[k] = 1.0 / st.rb[k];
+    // off-diagonal towards i + 1 (row i of D1) and towards i - 1 (row i - 1: the same step size, ra is uniform);
+    // g = 0 for the row m that does not exist and gm = 0 for element 0
+    const double up = st.ra[k] * st.g[k] * st.g[k];
+    const double down = st.ra[k] * st.gm[k] * st.gm[k];
+    a[k] = -down;
+    b[k] = ((1.0 + kSigma + st.rb[k]) + down) + up;   // the two rank-one terms in the order of the row index
+    c[k] = -up;
+  }
+  (void)m;
+ACMPC_SLOTS   // (unrolled on the device: `level` indexes worker-local arrays, which must stay in registers)
+  for (int level = 0; level < kPcrMaxLevels; ++level) {
+    const int sft = 1 << level;
+    if (sft >= n) break;
+    double* ea = w.ex[(level & 1) * 3 + 0];
+    double* eb = w.ex[(level & 1) * 3 + 1];
+    double* ec = w.ex[(level & 1) * 3 + 2];
+ACMPC_SLOTS
+    for (int k = 0; k < K; ++k) {
+      const int i = team.rank() + k * Team::size;
+      if (i < n) {
+        ea[i] = a[k];
+        eb[i] = b[k];
+        ec[i] = c[k];
+      }
+    }
+    team.sync();
+ACMPC_SLOTS
+    for (int k = 0; k < K; ++k) {
+      const int i = team.rank() + k * Team::size;
+      if (Team::size == 1 && i >= n) break;
+      const int lo = clamp_index(i - sft, n), hi = clamp_index(i + sft, n);
+      const double al = -a[k] / eb[lo];   // a_i = 0 when there is no element i - s: alpha = 0
+      const double ga = -c[k] / eb[hi];
+      st.pa[level][k] = al;
+      st.pg[level][k] = ga;
+      b[k] = fma_(ga, ea[hi], fma_(al, ec[lo], b[k]));
+      a[k] = al * ea[lo];
+      c[k] = ga * ec[hi];
+    }
+    // (the next level writes the other set of buffers; the one after that comes behind the next barrier)
+  }
+ACMPC_SLOTS
+  for (int k = 0; k < K; ++k) st.binv[k] = 1.0 / b[k];
+  team.sync();  // the exchange buffers are free again
+}
+
+template <class Team, int K>
+ACMPC_HD int solve_small(const Team& team, const Workspace& w, const double* v_hi, const double* ds, int n,
+                         const Settings& s, double* v, double* y, int warm, int* iterations) {
+  const int m = n - 1;  // acceleration rows; then n box rows
+  Small<Team, K> st;
+  double rho = 0.1;
+ACMPC_SLOTS
+  for (int k = 0; k < K; ++k) {
+    const int i = team.rank() + k * Team::size;
+    if (Team::size == 1 && i >= n) break;
+    const int ic = clamp_index(i, n);
+    // a slot without an element copies element n - 1 and never stores; the last element has no row (g = 0), the first
+    // no row behind it (gm = 0)
+    st.g[k] = (i < m) ? 1.0 / (2.0 * ds[clamp_index(i, m)]) : 0.0;
+    st.gm[k] = (i > 0 && i < n) ? 1.0 / (2.0 * ds[clamp_index(i - 1, m)]) : 0.0;
+    st.vh[k] = v_hi[ic];
+    st.x[k] = warm != 0 ? v[ic] : 0.0;
+    st.yb[k] = warm != 0 ? y[m + ic] : 0.0;
+    st.ya[k] = (warm != 0 && i < m) ? y[clamp_index(i, m)] : 0.0;
+    st.za[k] = st.zb[k] = 0.0;
+  }
+  factor_small(team, w, st, n, rho, s);
+  // z = clamp(A x): the rows need x_{i+1}
+ACMPC_SLOTS
+  for (int k = 0; k < K; ++k) {
+    const int i = team.rank() + k * Team::size;
+    if (i < n) w.ex[6][i] = st.x[k];
+  }
+  team.sync();
+ACMPC_SLOTS
+  for (int k = 0; k < K; ++k) {
+    const int i = team.rank() + k * Team::size;
+    if (Team::size == 1 && i >= n) break;
+    const double za = clamp(st.g[k] * (w.ex[6][clamp_index(i + 1, n)] - st.x[k]), s.a_min, s.a_max);
+    st.za[k] = (i < m) ? za : 0.0;
+    st.zb[k] = clamp(st.x[k], s.v_min, st.vh[k]);
+  }
+
+  int status = 1;
+  int it = 0;
+  for (it = 1; it <= s.max_iter; ++it) {
+    // rhs = sigma x - q + A'(rho z - y),  q = -v_hi,  A' u = D1' u_a + u_b: row i's u_a reaches elements i and i + 1
+    double ua[K], cur[K];
+ACMPC_SLOTS
+    for (int k = 0; k < K; ++k) {
+      const int i = team.rank() + k * Team::size;
+      ua[k] = st.ra[k] * st.za[k] - st.ya[k];
+      if (i < n) w.ex[7][i] = ua[k];
+    }
+    team.sync();
+ACMPC_SLOTS
+    for (int k = 0; k < K; ++k) {
+      const int i = team.rank() + k * Team::size;
+      if (Team::size == 1 && i >= n) break;
+      double r = kSigma * st.x[k] + st.vh[k] + (st.rb[k] * st.zb[k] - st.yb[k]);
+      r += st.gm[k] * w.ex[7][clamp_index(i - 1, n)];
+      r -= st.g[k] * ua[k];
+      cur[k] = r;
+    }
+    // K xt = rhs by cyclic reduction: r_i += alpha_i r_{i-s} + gamma_i r_{i+s} level by level, then xt = r / b
+ACMPC_SLOTS
+    for (int level = 0; level < kPcrMaxLevels; ++level) {
+      const int sft = 1 << level;
+      if (sft >= n) break;
+      double* buf = w.ex[level & 1];
+ACMPC_SLOTS
+      for (int k = 0; k < K; ++k) {
+        const int i = team.rank() + k * Team::size;
+        if (i < n) buf[i] = cur[k];
+      }
+      team.sync();
+ACMPC_SLOTS
+      for (int k = 0; k < K; ++k) {
+        const int i = team.rank() + k * Team::size;
+        if (Team::size == 1 && i >= n) break;
+        cur[k] = fma_(st.pg[level][k], buf[clamp_index(i + sft, n)],
+                      fma_(st.pa[level][k], buf[clamp_index(i - sft, n)], cur[k]));
+      }
+    }
+    double xt[K];
+ACMPC_SLOTS
+    for (int k = 0; k < K; ++k) {
+      const int i = team.rank() + k * Team::size;
+      xt[k] = cur[k] * st.binv[k];
+      if (i < n) w.ex[2][i] = xt[k];
+    }
+    team.sync();
+    // over-relaxation, projection, dual update
+ACMPC_SLOTS
+    for (int k = 0; k < K; ++k) {
+      const int i = team.rank() + k * Team::size;
+      if (Team::size == 1 && i >= n) break;
+      {
+        const double zt = st.g[k] * (w.ex[2][clamp_index(i + 1, n)] - xt[k]);
+        const double mix = kAlpha * zt + (1.0 - kAlpha) * st.za[k];
+        const double zn = clamp(mix + st.ya[k] * st.ira[k], s.a_min, s.a_max);
+        const double ya = st.ya[k] + st.ra[k] * (mix - zn);
+        st.ya[k] = (i < m) ? ya : 0.0;   // the row m that does not exist keeps z = y = 0
+        st.za[k] = (i < m) ? zn : 0.0;
+      }
+      const double mix = kAlpha * xt[k] + (1.0 - kAlpha) * st.zb[k];
+      const double zn = clamp(mix + st.yb[k] * st.irb[k], s.v_min, st.vh[k]);
+      st.yb[k] += st.rb[k] * (mix - zn);
+      st.zb[k] = zn;
+      st.x[k] = kAlpha * xt[k] + (1.0 - kAlpha) * st.x[k];
+    }
+    if (it % s.check_every != 0) continue;
+    // residuals (infinity norms) and OSQP's stopping test: rows need x_{i+1}, the dual residual ya_{i-1}
+ACMPC_SLOTS
+    for (int k = 0; k < K; ++k) {
+      const int i = team.rank() + k * Team::size;
+      if (i < n) {
+        w.ex[3][i] = st.x[k];
+        w.ex[4][i] = st.ya[k];
+      }
+    }
+    team.sync();
+    double r_prim = 0, r_dual = 0, s_ax = 0, s_z = 0, s_px = 0, s_aty = 0, s_q = 0;
+ACMPC_SLOTS
+    for (int k = 0; k < K; ++k) {
+      const int i = team.rank() + k * Team::size;
+      if (Team::size == 1 && i >= n) break;
+      const double live = (i < n) ? 1.0 : 0.0;   // a slot without an element contributes zeros to the norms
+      const double ax = st.g[k] * (w.ex[3][clamp_index(i + 1, n)] - st.x[k]);   // 0 for the row that does not exist
+      r_prim = dmax(r_prim, live * dabs(ax - st.za[k]));
+      s_ax = dmax(s_ax, live * dabs(ax));
+      s_z = dmax(s_z, live * dabs(st.za[k]));
+      r_prim = dmax(r_prim, live * dabs(st.x[k] - st.zb[k]));
+      s_ax = dmax(s_ax, live * dabs(st.x[k]));
+      s_z = dmax(s_z, live * dabs(st.zb[k]));
+      double aty = st.yb[k];
+      aty -= st.g[k] * st.ya[k];
+      aty += st.gm[k] * w.ex[4][clamp_index(i - 1, n)];
+      r_dual = dmax(r_dual, live * dabs(st.x[k] - st.vh[k] + aty));
+      s_px = dmax(s_px, live * dabs(st.x[k]));
+      s_aty = dmax(s_aty, live * dabs(aty));
+      s_q = dmax(s_q, live * dabs(st.vh[k]));
+    }
+    r_prim = team.max(r_prim, w.red);
+    r_dual = team.max(r_dual, w.red);
+    const double s_prim = team.max(dmax(s_ax, s_z), w.red);
+    const double s_dual = team.max(dmax(dmax(s_px, s_aty), s_q), w.red);
+    if (r_prim <= s.eps_abs + s.eps_rel * s_prim && r_dual <= s.eps_abs + s.eps_rel * s_dual) {
+      status = 0;
+      break;
+    }
+    team.sync();  // every worker has read the exchange buffers of the residuals before they are written again
+    if (it % 50 == 0) {
+      const double ratio =
+          __builtin_sqrt((r_prim / dmax(s_prim, 1e-12)) / dmax(r_dual / dmax(s_dual, 1e-12), 1e-12));
+      if (ratio > 5.0 || ratio < 0.2) {
+        rho = clamp(rho * ratio, 1e-6, 1e6);
+        factor_small(team, w, st, n, rho, s);
+      }
+    }
+  }
+  team.sync();
+ACMPC_SLOTS
+  for (int k = 0; k < K; ++k) {
+    const int i = team.rank() + k * Team::size;
+    if (i < n) {
+      v[i] = st.x[k];
+      y[m + i] = st.yb[k];
+      if (i < m) y[i] = st.ya[k];
+    }
+  }
+  team.sync();
+  if (iterations != nullptr) *iterations = it < s.max_iter ? it : s.max_iter;
+  return status;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// n > kPcrMaxN: LDL' sweeps on workspace arrays
+// ---------------------------------------------------------------------------------------------------------------------
 // K = diag(1 + sigma + rb) + D1' diag(ra) D1, D1 rows (-g_i, +g_i); LDL' factors into d (pivots), l (multipliers)
 template <class Team>
 ACMPC_HD void refactor(const Team& team, const Workspace& w, int n, double rho, const double* v_hi,
@@ -127,43 +393,6 @@ ACMPC_HD void refactor(const Team& team, const Workspace& w, int n, double rho, 
     w.d[i] = di;
   }
   team.sync();
-  if (n <= kPcrMaxN) {
-    // cyclic reduction of K (diagonal d, off-diagonals e): level by level the equation of element i
-    //     a_i x_{i-s} + b_i x_i + c_i x_{i+s} = r_i
-    // sheds its two neighbours by adding alpha_i = -a_i / b_{i-s} times equation i - s and gamma_i = -c_i / b_{i+s}
-    // times equation i + s; after ceil(log2 n) levels only b_i x_i = r_i is left.  Kept: alpha, gamma of every level
-    // and 1 / b_i of the last.
-    for (int i = team.rank(); i < n; i += Team::size) {
-      w.ca[i] = (i > 0) ? w.e[i - 1] : 0.0;
-      w.cb[i] = w.d[i];
-      w.cc[i] = (i < m) ? w.e[i] : 0.0;
-    }
-    team.sync();
-    double *a = w.ca, *b = w.cb, *c = w.cc, *a2 = w.na, *b2 = w.nb, *c2 = w.nc;
-    int level = 0;
-    for (int s = 1; s < n; s <<= 1, ++level) {
-      for (int i = team.rank(); i < n; i += Team::size) {
-        const bool lo = i - s >= 0, hi = i + s < n;
-        const double al = lo ? -a[i] / b[i - s] : 0.0;
-        const double ga = hi ? -c[i] / b[i + s] : 0.0;
-        w.pa[level * n + i] = al;
-        w.pg[level * n + i] = ga;
-        a2[i] = lo ? al * a[i - s] : 0.0;
-        c2[i] = hi ? ga * c[i + s] : 0.0;
-        double bi = b[i];
-        if (lo) bi = fma_(al, c[i - s], bi);
-        if (hi) bi = fma_(ga, a[i + s], bi);
-        b2[i] = bi;
-      }
-      team.sync();
-      double* t = a; a = a2; a2 = t;
-      t = b; b = b2; b2 = t;
-      t = c; c = c2; c2 = t;
-    }
-    for (int i = team.rank(); i < n; i += Team::size) w.binv[i] = 1.0 / b[i];
-    team.sync();
-    return;
-  }
   if (team.rank() == 0) {
     // l[i] = e[i] / d[i]; d[i + 1] = fma(-l[i], e[i], d[i + 1]) - with the running pivot in a register, and the
     // arrays behind restrict-qualified pointers so that their loads do not wait for the stores of earlier steps
@@ -187,6 +416,13 @@ ACMPC_HD void refactor(const Team& team, const Workspace& w, int n, double rho, 
 template <class Team>
 ACMPC_HD int solve(const Team& team, const Workspace& w, const double* v_hi, const double* ds, int n,
                    const Settings& s, double* v, double* y, int warm, int* iterations) {
+  if (n <= kPcrMaxN) {
+    constexpr int kSlots = (kPcrMaxN + Team::size - 1) / Team::size;
+    if constexpr (kSlots > 1 && Team::size > 1) {
+      if (n <= Team::size) return solve_small<Team, 1>(team, w, v_hi, ds, n, s, v, y, warm, iterations);
+    }
+    return solve_small<Team, kSlots>(team, w, v_hi, ds, n, s, v, y, warm, iterations);
+  }
   const int m = n - 1;  // acceleration rows; then n box rows
   double rho = 0.1;
   for (int i = team.rank(); i < m; i += Team::size) w.g[i] = 1.0 / (2.0 * ds[i]);
@@ -215,29 +451,6 @@ ACMPC_HD int solve(const Team& team, const Workspace& w, const double* v_hi, con
       w.xt[i] = r;
     }
     team.sync();
-    if (n <= kPcrMaxN) {
-      // K xt = rhs by cyclic reduction: r_i += alpha_i r_{i-s} + gamma_i r_{i+s} level by level, then xt = r / b
-      double *cur = w.xt, *nxt = w.tmp;
-      int level = 0;
-      for (int s2 = 1; s2 < n; s2 <<= 1, ++level) {
-        const double* __restrict__ al = w.pa + level * n;
-        const double* __restrict__ ga = w.pg + level * n;
-        for (int i = team.rank(); i < n; i += Team::size) {
-          double r = cur[i];
-          if (i - s2 >= 0) r = fma_(al[i], cur[i - s2], r);
-          if (i + s2 < n) r = fma_(ga[i], cur[i + s2], r);
-          nxt[i] = r;
-        }
-        team.sync();
-        double* t = cur; cur = nxt; nxt = t;
-      }
-      for (int i = team.rank(); i < n; i += Team::size) {
-        const double xi = cur[i] * w.binv[i];
-        nxt[i] = xi;          // both buffers end up holding the solution: whichever of them is `xt` is right
-        cur[i] = xi;
-      }
-      team.sync();
-    } else {
     // K xt = rhs: forward sweep, pivots, backward sweep
     // (xt[i + 1] = fma(-l[i], xt[i], xt[i + 1]) and xt[i] = fma(-l[i], xt[i + 1], xt[i]), the running value kept in
     // a register: only it is on the dependent chain, the loads of l and xt are not)
@@ -265,7 +478,6 @@ ACMPC_HD int solve(const Team& team, const Workspace& w, const double* v_hi, con
       }
     }
     team.sync();
-    }
     // over-relaxation, projection, dual update (rows first read their neighbours' xt, then every x is replaced)
     for (int i = team.rank(); i < m; i += Team::size) {
       const double zt = w.g[i] * (w.xt[i + 1] - w.xt[i]);

@@ -1034,7 +1034,7 @@ int map_window_args(acmpc_ctx* c, int H, int points, const TickOutLayout& out, a
   a->H = H;
   a->coords = c->d_coords;
   a->coords_out = reinterpret_cast<double*>(c->h_tick_out + out.coords);
-  a->index_out = reinterpret_cast<int*>(c->h_tick_out + out.status) + 2;
+  a->first_out = reinterpret_cast<int*>(c->h_tick_out + out.status) + 2;
   return ACMPC_OK;
 }
 
@@ -1099,7 +1099,19 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
 
   acmpc::PrologueArgs pa{};
   pa.header = reinterpret_cast<const acmpc::TickHeader*>(c->h_tick);   // read in place over the host link
-  pa.coords = from_map ? c->d_coords : reinterpret_cast<const double*>(c->h_tick + in.coords);
+  pa.coords = reinterpret_cast<const double*>(c->h_tick + in.coords);
+  if (from_map) {
+    pa.map_centre = c->d_map;
+    pa.map_M = ma.M;
+    pa.map_count = ma.count;
+    pa.map_points = ma.points;
+    pa.map_first = reinterpret_cast<const int*>(c->d_coords);   // (the search kernel leaves the index here)
+    pa.coords_out = ma.coords_out;
+    pa.index_out = ma.first_out;
+    ma.coords = nullptr;                                         // the search launch only needs to leave `first`
+    ma.coords_out = nullptr;
+    ma.first_out = reinterpret_cast<int*>(c->d_coords);
+  }
   pa.centre_in = reinterpret_cast<const float*>(c->h_tick + in.centre_in);
   pa.x0 = reinterpret_cast<float*>(c->d_tick + in.x0);
   pa.u_ref = reinterpret_cast<float*>(c->d_tick + in.uref);
@@ -1119,7 +1131,8 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   const bool direct = use_fused_finalize(c, n);
   // prologue -> rounds (-> copy of the record when the fused finalize cannot write it to the host itself)
   auto enqueue = [&](hipStream_t q, int* rc_rounds) -> hipError_t {
-    hipError_t e = from_map ? acmpc::launch_map_window(ma, q) : hipSuccess;
+    // (a pose instead of a map index: the nearest-point search runs in front, as its own 256-thread launch)
+    hipError_t e = (from_map && t->map_index < 0) ? acmpc::launch_map_window(ma, q) : hipSuccess;
     if (e == hipSuccess) e = acmpc::launch_prologue(pa, n, q);
     if (e != hipSuccess) return e;
     const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef};
@@ -1143,7 +1156,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     key.sigma_v = t->sigma[0];
     key.sigma_k = t->sigma[1];
     key.shrink = t->shrink;
-    key.from_map = from_map ? t->centreline_points : 0;
+    key.from_map = from_map ? (t->map_index < 0 ? -t->centreline_points : t->centreline_points) : 0;
     for (int g = 0; g < acmpc_ctx::kOptGraphs; ++g)
       if (c->tick_graph[g] != nullptr && key == c->tick_key[g]) slot = g;
     if (slot < 0) {
@@ -1212,6 +1225,8 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   if (use_graph) {
     ACMPC_HIP(c, hipGraphLaunch(c->tick_graph[slot], s));
   } else {
+    pa.header_by_value = 1;
+    pa.header_value = *h;
     int rc_rounds = ACMPC_OK;
     const hipError_t e = enqueue(s, &rc_rounds);
     if (rc_rounds != ACMPC_OK) return rc_rounds;

@@ -43,6 +43,7 @@ struct ScoreArgs {
   double* error;           // [P]
   double* score;           // [P]
   uint8_t* valid;          // [P]
+  const int* live;         // when not null: the number of particles is read from the device (resident filter)
 };
 
 constexpr int kWaves = kBlock / 64;
@@ -77,13 +78,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 // LDS trees of eight barriers each per particle).  PB = 1 keeps one particle per workgroup for the reference's
 // particle counts (500: configs/monza.yaml:47), where the launch has to fill the chip with workgroups.
 template <int PB>
-__global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, const int P) {
+__global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, const int P_arg) {
   __shared__ double s_d[3][PB][kWaves];
   __shared__ int s_i[3][PB][kWaves];
   __shared__ double s_sum[PB][kWaves];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int p0 = blockIdx.x * PB;
+  if (a.live != nullptr) {   // wave-uniform
+    if (p0 >= a.live[0]) return;
+  }
+  const int P = (a.live != nullptr) ? a.live[0] : P_arg;
   double px[PB], py[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
@@ -220,9 +225,11 @@ __global__ void pf_advance_kernel(float* states, const float* delta, const float
 // sum(state * score) / sum(score) with the NaN -> uniform fallback, then max distance / max |yaw difference| to the
 // estimate (localiser.py:561-579).  One workgroup; float64 accumulation in a fixed order.
 __global__ void __launch_bounds__(kBlock) pf_estimate_kernel(const float* states, const float* scores, int P,
-                                                             double* out /*[5]: x, y, yaw, max_dist, max_angle*/) {
+                                                             double* out /*[5]: x, y, yaw, max_dist, max_angle*/,
+                                                             const int* live = nullptr) {
   __shared__ double s[4][kBlock];
   const int tid = threadIdx.x;
+  if (live != nullptr) P = live[0];
   double acc[4] = {0, 0, 0, 0}, plain[3] = {0, 0, 0};
   for (int p = tid; p < P; p += kBlock) {
     const double w = scores[p];
@@ -485,6 +492,16 @@ struct acmpc_pf {
   float* d_obs = nullptr;
   float* d_aux = nullptr;      // 2 * max_particles floats: delta / velocity, or scores
   double* d_out = nullptr;     // 8 doubles: result of the estimate kernel
+  // device-resident filter: ping-pong particle buffers, this update's results, workspace of the resampling
+  bool filter_ready = false;
+  float* f_states[2] = {nullptr, nullptr};  // [max_particles][3] (+ room for the observation behind buffer 0 / 1)
+  float* f_scores[2] = {nullptr, nullptr};
+  int f_cur = 0;
+  float* f_obs = nullptr;                   // [K][2]
+  unsigned long long* f_cdf = nullptr;
+  int* f_kept = nullptr;
+  int* f_counts = nullptr;                  // [4] n_live, n_valid, was_reset
+  double* h_result = nullptr;               // pinned [8 doubles + 4 ints]
   mutable std::string err;
 };
 
@@ -577,6 +594,15 @@ void acmpc_pf_destroy(acmpc_pf* h) {
     if (h->h_down != nullptr) (void)hipHostFree(h->h_down);
     (void)hipFree(h->d_aux);
     (void)hipFree(h->d_out);
+    for (int b = 0; b < 2; ++b) {
+      (void)hipFree(h->f_states[b]);
+      (void)hipFree(h->f_scores[b]);
+    }
+    (void)hipFree(h->f_obs);
+    (void)hipFree(h->f_cdf);
+    (void)hipFree(h->f_kept);
+    (void)hipFree(h->f_counts);
+    if (h->h_result != nullptr) (void)hipHostFree(h->h_result);
     if (h->stream != nullptr) (void)hipStreamDestroy(h->stream);
   }
   delete h;
@@ -682,7 +708,8 @@ int acmpc_pf_estimate(acmpc_pf* h, const float* states, const float* scores, int
   PF_HIP(h, hipMemcpyAsync(h->d_aux, scores, static_cast<size_t>(P) * sizeof(float), hipMemcpyHostToDevice, s));
   double* d_res = h->d_out;
   (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
-  hipLaunchKernelGGL(pf_estimate_kernel, dim3(1), dim3(kBlock), 0, s, h->d_states, h->d_aux, P, d_res);
+  hipLaunchKernelGGL(pf_estimate_kernel, dim3(1), dim3(kBlock), 0, s, h->d_states, h->d_aux, P, d_res,
+                     static_cast<const int*>(nullptr));
   PF_HIP(h, hipGetLastError());
   double res[5];
   PF_HIP(h, hipMemcpyAsync(res, d_res, sizeof res, hipMemcpyDeviceToHost, s));
@@ -692,6 +719,199 @@ int acmpc_pf_estimate(acmpc_pf* h, const float* states, const float* scores, int
   estimate[2] = res[2];
   if (max_distance != nullptr) *max_distance = res[3];
   if (max_angle != nullptr) *max_angle = res[4];
+  return ACMPC_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int pf_ensure_filter(acmpc_pf* h) {
+  if (h->filter_ready) return ACMPC_OK;
+  const int rc = pf_ensure_device(h);
+  if (rc != ACMPC_OK) return rc;
+  const size_t P = h->prm.max_particles, K = h->prm.max_observation_points;
+  for (int b = 0; b < 2; ++b) {
+    PF_HIP(h, hipMalloc(&h->f_states[b], P * 3 * sizeof(float)));
+    PF_HIP(h, hipMalloc(&h->f_scores[b], P * sizeof(float)));
+  }
+  PF_HIP(h, hipMalloc(&h->f_obs, K * 2 * sizeof(float)));
+  PF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->f_cdf), P * sizeof(unsigned long long)));
+  PF_HIP(h, hipMalloc(&h->f_kept, P * sizeof(int)));
+  PF_HIP(h, hipMalloc(&h->f_counts, 4 * sizeof(int)));
+  PF_HIP(h, hipMemset(h->f_counts, 0, 4 * sizeof(int)));
+  PF_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_result), 8 * sizeof(double) + 4 * sizeof(int), hipHostMallocDefault));
+  PF_HIP(h, hipStreamSynchronize(nullptr));
+  h->filter_ready = true;
+  return ACMPC_OK;
+}
+
+FilterArgs filter_args(acmpc_pf* h, const acmpc_pf_resample* rs) {
+  FilterArgs f{};
+  const size_t P = h->prm.max_particles;
+  f.states_in = h->f_states[h->f_cur];
+  f.scores_in = h->f_scores[h->f_cur];
+  f.score = reinterpret_cast<const double*>(h->d_down) + 3 * P;
+  f.valid = reinterpret_cast<const uint8_t*>(h->d_down + 4 * P * sizeof(double) + P * 3 * sizeof(int32_t));
+  f.states_out = h->f_states[1 - h->f_cur];
+  f.scores_out = h->f_scores[1 - h->f_cur];
+  f.cdf = h->f_cdf;
+  f.kept = h->f_kept;
+  f.counts = h->f_counts;
+  f.centre = h->d_track[0];
+  f.m_centre = static_cast<int>(h->h_track[0].size() / 2);
+  f.capacity = h->prm.max_particles;
+  if (rs != nullptr) {
+    f.n_desired = rs->n_desired;
+    f.minimum_particles = rs->minimum_particles;
+    f.sigma_x = rs->sigma_x;
+    f.sigma_y = rs->sigma_y;
+    f.sigma_yaw = rs->sigma_yaw;
+    f.seed_lo = static_cast<uint32_t>(rs->seed);
+    f.seed_hi = static_cast<uint32_t>(rs->seed >> 32);
+    f.counter = rs->counter;
+  }
+  return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int acmpc_pf_filter_reset(acmpc_pf* h, int32_t n) {
+  if (h == nullptr) return ACMPC_EINVAL;
+  if (n < 1 || n > h->prm.max_particles) return pf_fail(h, ACMPC_ECAPACITY, "particle count out of range");
+  const int rc = pf_ensure_filter(h);
+  if (rc != ACMPC_OK) return rc;
+  // the resampling kernel's reset branch with nothing valid: n_live = 0, minimum = 1, capacity = n
+  hipStream_t s = h->stream;
+  const int zero[4] = {0, 0, 0, 0};
+  PF_HIP(h, hipMemcpyAsync(h->f_counts, zero, sizeof zero, hipMemcpyHostToDevice, s));
+  FilterArgs f = filter_args(h, nullptr);
+  f.capacity = n;
+  f.minimum_particles = 1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(pf_resample_kernel, dim3(1), dim3(kScanBlock), 0, s, f);
+  PF_HIP(h, hipGetLastError());
+  PF_HIP(h, hipStreamSynchronize(s));
+  h->f_cur = 1 - h->f_cur;
+  return ACMPC_OK;
+}
+
+int acmpc_pf_filter_set(acmpc_pf* h, const float* states, const float* scores, int32_t n) {
+  if (h == nullptr) return ACMPC_EINVAL;
+  if (states == nullptr || scores == nullptr) return pf_fail(h, ACMPC_EINVAL, "null argument");
+  if (n < 1 || n > h->prm.max_particles) return pf_fail(h, ACMPC_ECAPACITY, "particle count out of range");
+  const int rc = pf_ensure_filter(h);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = h->stream;
+  const int counts[4] = {n, 0, 0, 0};
+  PF_HIP(h, hipMemcpyAsync(h->f_states[h->f_cur], states, static_cast<size_t>(n) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  PF_HIP(h, hipMemcpyAsync(h->f_scores[h->f_cur], scores, static_cast<size_t>(n) * sizeof(float), hipMemcpyHostToDevice, s));
+  PF_HIP(h, hipMemcpyAsync(h->f_counts, counts, sizeof counts, hipMemcpyHostToDevice, s));
+  PF_HIP(h, hipStreamSynchronize(s));
+  return ACMPC_OK;
+}
+
+int acmpc_pf_filter_get(acmpc_pf* h, float* states, float* scores, int32_t capacity, int32_t* n) {
+  if (h == nullptr) return ACMPC_EINVAL;
+  if (states == nullptr || scores == nullptr || n == nullptr) return pf_fail(h, ACMPC_EINVAL, "null argument");
+  if (!h->filter_ready) return pf_fail(h, ACMPC_ESTATE, "no particles on the device yet");
+  hipStream_t s = h->stream;
+  int counts[4];
+  PF_HIP(h, hipMemcpyAsync(counts, h->f_counts, sizeof counts, hipMemcpyDeviceToHost, s));
+  PF_HIP(h, hipStreamSynchronize(s));
+  if (counts[0] > capacity) return pf_fail(h, ACMPC_ECAPACITY, "output buffers too small");
+  PF_HIP(h, hipMemcpyAsync(states, h->f_states[h->f_cur], static_cast<size_t>(counts[0]) * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+  PF_HIP(h, hipMemcpyAsync(scores, h->f_scores[h->f_cur], static_cast<size_t>(counts[0]) * sizeof(float), hipMemcpyDeviceToHost, s));
+  PF_HIP(h, hipStreamSynchronize(s));
+  *n = counts[0];
+  return ACMPC_OK;
+}
+
+int acmpc_pf_filter_step(acmpc_pf* h, double tyre_angle, double velocity, double dt, double sigma_yaw,
+                         double sigma_velocity, uint64_t seed, uint32_t counter) {
+  if (h == nullptr) return ACMPC_EINVAL;
+  if (!h->filter_ready) return pf_fail(h, ACMPC_ESTATE, "no particles on the device yet");
+  const int P = h->prm.max_particles;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(pf_step_kernel, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->f_states[h->f_cur], h->f_counts,
+                     static_cast<float>(tyre_angle), static_cast<float>(velocity), static_cast<float>(sigma_yaw),
+                     static_cast<float>(sigma_velocity), static_cast<float>(h->prm.wheelbase), static_cast<float>(dt),
+                     static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), counter);
+  PF_HIP(h, hipGetLastError());
+  return ACMPC_OK;
+}
+
+int acmpc_pf_filter_update(acmpc_pf* h, const float* obs_left, int32_t k_left, const float* obs_right,
+                           int32_t k_right, const acmpc_pf_resample* rs, double* result) {
+  if (h == nullptr) return ACMPC_EINVAL;
+  if (rs == nullptr || result == nullptr) return pf_fail(h, ACMPC_EINVAL, "null argument");
+  if (rs->struct_size != sizeof(acmpc_pf_resample)) return pf_fail(h, ACMPC_EINVAL, "acmpc_pf_resample size mismatch");
+  if (k_left < 0 || k_right < 0 || k_left + k_right < 1) return pf_fail(h, ACMPC_EINVAL, "empty observation");
+  if ((k_left > 0 && obs_left == nullptr) || (k_right > 0 && obs_right == nullptr))
+    return pf_fail(h, ACMPC_EINVAL, "null observation");
+  if (k_left + k_right > h->prm.max_observation_points) return pf_fail(h, ACMPC_ECAPACITY, "too many observation points");
+  if (!h->filter_ready) return pf_fail(h, ACMPC_ESTATE, "no particles on the device yet");
+  hipStream_t s = h->stream;
+  const size_t Pmax = h->prm.max_particles;
+  // observation up (one pinned block), everything else is already there
+  float* up = reinterpret_cast<float*>(h->h_up);
+  if (k_left > 0) std::memcpy(up, obs_left, static_cast<size_t>(k_left) * 2 * sizeof(float));
+  if (k_right > 0) std::memcpy(up + 2 * static_cast<size_t>(k_left), obs_right, static_cast<size_t>(k_right) * 2 * sizeof(float));
+  PF_HIP(h, hipMemcpyAsync(h->f_obs, up, static_cast<size_t>(k_left + k_right) * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+  ScoreArgs a{};
+  a.states = h->f_states[h->f_cur];
+  a.obs = h->f_obs;
+  a.k_left = k_left;
+  a.k_right = k_right;
+  a.centre = Track{h->d_track[0], static_cast<int>(h->h_track[0].size() / 2)};
+  a.left = Track{h->d_track[1], static_cast<int>(h->h_track[1].size() / 2)};
+  a.right = Track{h->d_track[2], static_cast<int>(h->h_track[2].size() / 2)};
+  a.mean = h->prm.score_mean;
+  a.sigma = h->prm.score_sigma;
+  a.scale = h->scale;
+  a.thr_rotation = h->prm.threshold_rotation;
+  a.thr_offset = h->prm.threshold_offset;
+  a.thr_error = h->prm.threshold_error;
+  const size_t pd = Pmax * sizeof(double);
+  a.minimum_offset = reinterpret_cast<double*>(h->d_down);
+  a.heading_offset = a.minimum_offset + Pmax;
+  a.error = a.heading_offset + Pmax;
+  a.score = a.error + Pmax;
+  a.track_indices = reinterpret_cast<int32_t*>(h->d_down + 4 * pd);
+  a.valid = reinterpret_cast<uint8_t*>(h->d_down + 4 * pd + Pmax * 3 * sizeof(int32_t));
+  a.live = h->f_counts;   // the particle count is on the device
+  (void)hipGetLastError();
+  {
+    constexpr int PB = 8;
+    const int P = h->prm.max_particles;   // workgroups beyond the live count return at once
+    if (P >= 4096) {
+      hipLaunchKernelGGL(pf_score_kernel<PB>, dim3((P + PB - 1) / PB), dim3(kBlock), 0, s, a, P);
+    } else {
+      hipLaunchKernelGGL(pf_score_kernel<1>, dim3(P), dim3(kBlock), 0, s, a, P);
+    }
+  }
+  PF_HIP(h, hipGetLastError());
+  hipLaunchKernelGGL(pf_publish_scores_kernel, dim3((h->prm.max_particles + 255) / 256), dim3(256), 0, s, a.score,
+                     h->f_scores[h->f_cur], h->f_counts);
+  PF_HIP(h, hipGetLastError());
+  const FilterArgs f = filter_args(h, rs);
+  hipLaunchKernelGGL(pf_resample_kernel, dim3(1), dim3(kScanBlock), 0, s, f);
+  PF_HIP(h, hipGetLastError());
+  h->f_cur = 1 - h->f_cur;
+  double* res = h->h_result;
+  hipLaunchKernelGGL(pf_estimate_kernel, dim3(1), dim3(kBlock), 0, s, h->f_states[h->f_cur], h->f_scores[h->f_cur], -1,
+                     h->d_out, h->f_counts);
+  PF_HIP(h, hipGetLastError());
+  PF_HIP(h, hipMemcpyAsync(res, h->d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
+  PF_HIP(h, hipMemcpyAsync(res + 8, h->f_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  PF_HIP(h, hipStreamSynchronize(s));
+  const int* counts = reinterpret_cast<const int*>(res + 8);
+  for (int i = 0; i < 5; ++i) result[i] = res[i];
+  result[5] = counts[0];
+  result[6] = counts[1];
+  result[7] = counts[2];
   return ACMPC_OK;
 }
 

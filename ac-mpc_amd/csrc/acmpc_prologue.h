@@ -37,12 +37,16 @@ struct MapWindowArgs {
   int count;                  // map points in the look-ahead window: round(150 m / spacing) + 1 (perception/tracks.py:14)
   int points;                 // length of the resampled centre line perception publishes (500; controller.py:102-108)
   int H;                      // rows of the reference path: points / H must be an integer stride (controller.py:256-267)
-  double* coords;             // [H][3] out, device
+  double* coords;             // [H][3] out, device (or nullptr)
   double* coords_out;         // [H][3] out, pinned host memory (or nullptr)
-  int* index_out;             // [1] out, pinned host memory: the window's first map index
+  int* first_out;             // [1] out: the window's first map index (device or pinned host memory; or nullptr)
 };
 
 struct PrologueArgs {
+  // the head of the tick block: read in place from pinned host memory - or, when the kernel is launched directly (not
+  // replayed from a captured graph), carried in the kernel arguments themselves, which saves the read over the host link
+  int header_by_value;
+  TickHeader header_value;
   const TickHeader* header;   // pinned host memory
   const double* coords;       // [H][3] (x, y, width), pinned host memory
   const float* centre_in;     // [n][2] pinned host memory (ignored when header->centre_is_reference)
@@ -58,6 +62,12 @@ struct PrologueArgs {
   int warm_capacity;          // largest n a slot can hold
   double margin;              // vehicle width / 2 (dynamics.py:14)
   double u_lo0, u_lo1, u_hi0, u_hi1;  // QP input box incl. the 0.1 m/s slack (control.py:130-139)
+  // header.use_map: the H x 3 path is cut out of the map by this kernel's own lanes (see map_window_kernel)
+  const double* map_centre;   // [M][2] device
+  int map_M, map_count, map_points;
+  const int* map_first;       // device: the window's first index when header.map_index < 0 (written by map_window_kernel)
+  double* coords_out;         // [H][3] pinned host memory: the path used (map mode)
+  int* index_out;             // pinned host memory
 };
 
 constexpr int kPrologueMaxSteps = admm::kPcrMaxN;  // LDS budget of the single-workgroup prologue (~390 n bytes) and the

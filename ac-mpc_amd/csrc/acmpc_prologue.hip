@@ -53,9 +53,45 @@ struct WaveTeam {
 
 }  // namespace
 
+// Row r of the H x 3 reference path for the window that starts at map point `first` (see map_window_kernel)
+struct MapFrame {
+  double x0, y0, c, sn;
+};
+__device__ __forceinline__ MapFrame map_frame(const double* centre, int M, int first) {
+  const double* w0 = centre + 2 * first;
+  const double* w1 = centre + 2 * ((first + 1) % M);
+  const double heading = atan2(w1[1] - w0[1], w1[0] - w0[0]);
+  const double rot = kPi / 2.0 - heading;
+  return MapFrame{w0[0], w0[1], cos(rot), sin(rot)};
+}
+__device__ __forceinline__ void map_path_row(const double* centre, int M, int first, int count, int points, int H, int r,
+                                             double lateral_offset, const MapFrame& f, double (&row)[3]) {
+  const int stride = points / H;
+  const double step = static_cast<double>(count - 1) / static_cast<double>(points - 1);  // np.linspace's step
+  const int q = r * stride;                                   // sample of the resampled centre line kept for row r
+  const double t = (q == points - 1) ? static_cast<double>(count - 1) : static_cast<double>(q) * step;
+  int j = static_cast<int>(t);                                // np.interp: the bracket [j, j + 1] with xp = arange
+  if (j > count - 2) j = count - 2;
+  double local[2][2];
+  for (int e = 0; e < 2; ++e) {
+    const double* wp = centre + 2 * ((first + j + e) % M);
+    const double dx = wp[0] - f.x0, dy = wp[1] - f.y0;
+    local[e][0] = (dx * f.c + dy * (-f.sn)) - lateral_offset;   // (window - window[0]) @ [[c, s], [-s, c]]
+    local[e][1] = dx * f.sn + dy * f.c;
+  }
+  const double frac = t - static_cast<double>(j);
+  const bool last = t >= static_cast<double>(count - 1);
+  const double x = last ? local[1][0] : (local[1][0] - local[0][0]) * frac + local[0][0];
+  const double y = last ? local[1][1] : (local[1][1] - local[0][1]) * frac + local[0][1];
+  row[0] = static_cast<double>(static_cast<float>(x));         // perception publishes float32
+  row[1] = static_cast<double>(static_cast<float>(y));
+  row[2] = (r == H - 1) ? 6.0 : 10.0 + static_cast<double>(r) * ((6.0 - 10.0) / static_cast<double>(H - 1));
+}
+
 __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
-  const TickHeader h = *a.header;  // ONE read of the head over the host link; everything below uses the copy
+  // ONE read of the head (kernel arguments, or the pinned block over the host link); everything below uses the copy
+  const TickHeader h = (a.header_by_value != 0) ? a.header_value : *a.header;
   const int lane = static_cast<int>(threadIdx.x);
   const int H = h.horizon;
   const int n = H - 1;
@@ -71,8 +107,26 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   double* qy = qv + n;
   admm::Workspace ws;
   ws.bind(qy + 2 * n, n);
+  double* s_coords = qy + 2 * n + admm::workspace_doubles(n);   // [H][3]: the path when it comes from the map
   const double* __restrict__ coords = a.coords;
   const WaveTeam team;
+  if (h.use_map != 0) {
+    // the reference path cut out of the bound map by this wavefront itself (no launch in front of the prologue)
+    int first = (h.map_index < 0) ? a.map_first[0] : h.map_index;
+    first = ((first % a.map_M) + a.map_M) % a.map_M;
+    const MapFrame frame = map_frame(a.map_centre, a.map_M, first);
+    for (int r = lane; r < H; r += 64) {
+      double row[3];
+      map_path_row(a.map_centre, a.map_M, first, a.map_count, a.map_points, H, r, h.lateral_offset, frame, row);
+      for (int e = 0; e < 3; ++e) {
+        s_coords[3 * r + e] = row[e];
+        a.coords_out[3 * r + e] = row[e];
+      }
+    }
+    if (lane == 0) a.index_out[0] = first;
+    team.sync();
+    coords = s_coords;
+  }
 
   // ---- construct_waypoints (spatial_mpc.py:125-154) ------------------------------------------------------------
   // headings of the n forward segments and of the segment that closes the loop from the last point to point 0
@@ -236,37 +290,16 @@ __global__ void __launch_bounds__(256) map_window_kernel(const MapWindowArgs a) 
     first = s_first;
   }
   first = ((first % a.M) + a.M) % a.M;
-  // vehicle frame: origin at the window's first point, +y along its first segment
-  const double* w0 = a.centre + 2 * first;
-  const double* w1 = a.centre + 2 * ((first + 1) % a.M);
-  const double heading = atan2(w1[1] - w0[1], w1[0] - w0[0]);
-  const double rot = kPi / 2.0 - heading;
-  const double c = cos(rot), sn = sin(rot);
-  const int stride = a.points / a.H;
-  const double step = static_cast<double>(a.count - 1) / static_cast<double>(a.points - 1);  // np.linspace's step
+  const MapFrame frame = map_frame(a.centre, a.M, first);
   for (int r = tid; r < a.H; r += 256) {
-    const int q = r * stride;                                   // sample of the resampled centre line kept for row r
-    const double t = (q == a.points - 1) ? static_cast<double>(a.count - 1) : static_cast<double>(q) * step;
-    int j = static_cast<int>(t);                                // np.interp: the bracket [j, j + 1] with xp = arange
-    if (j > a.count - 2) j = a.count - 2;
-    double local[2][2];
-    for (int e = 0; e < 2; ++e) {
-      const double* wp = a.centre + 2 * ((first + j + e) % a.M);
-      const double dx = wp[0] - w0[0], dy = wp[1] - w0[1];
-      local[e][0] = (dx * c + dy * (-sn)) - h.lateral_offset;   // (window - window[0]) @ [[c, s], [-s, c]]
-      local[e][1] = dx * sn + dy * c;
-    }
-    const double frac = t - static_cast<double>(j);
-    const double x = (t >= static_cast<double>(a.count - 1)) ? local[1][0] : (local[1][0] - local[0][0]) * frac + local[0][0];
-    const double y = (t >= static_cast<double>(a.count - 1)) ? local[1][1] : (local[1][1] - local[0][1]) * frac + local[0][1];
-    const double width = (r == a.H - 1) ? 6.0 : 10.0 + static_cast<double>(r) * ((6.0 - 10.0) / static_cast<double>(a.H - 1));
-    const double row[3] = {static_cast<double>(static_cast<float>(x)), static_cast<double>(static_cast<float>(y)), width};
+    double row[3];
+    map_path_row(a.centre, a.M, first, a.count, a.points, a.H, r, h.lateral_offset, frame, row);
     for (int e = 0; e < 3; ++e) {
-      a.coords[3 * r + e] = row[e];
+      if (a.coords != nullptr) a.coords[3 * r + e] = row[e];
       if (a.coords_out != nullptr) a.coords_out[3 * r + e] = row[e];
     }
   }
-  if (tid == 0 && a.index_out != nullptr) a.index_out[0] = first;
+  if (tid == 0 && a.first_out != nullptr) a.first_out[0] = first;
 }
 
 hipError_t launch_map_window(const MapWindowArgs& args, hipStream_t s) {
@@ -276,7 +309,7 @@ hipError_t launch_map_window(const MapWindowArgs& args, hipStream_t s) {
 }
 
 size_t prologue_lds_bytes(int n) {
-  return static_cast<size_t>(7 * n + n + (n + 1) + n + 2 * n + admm::workspace_doubles(n)) * sizeof(double);  // < 64 kB
+  return static_cast<size_t>(7 * n + n + (n + 1) + n + 2 * n + admm::workspace_doubles(n) + 3 * (n + 1)) * sizeof(double);  // < 64 kB
 }
 
 hipError_t launch_prologue(const PrologueArgs& args, int n, hipStream_t s) {

@@ -354,6 +354,39 @@ int acmpc_pf_advance(acmpc_pf* handle, float* states, const float* delta, const 
 int acmpc_pf_estimate(acmpc_pf* handle, const float* states, const float* scores, int32_t P, double estimate[3],
                       double* max_distance, double* max_angle);
 
+/* ---- device-resident particle filter: one host round trip per update ------------------------------------------------
+ * The reference's update cycle with the particles living on the GPU: Localiser.step (localiser.py:41-77: every particle
+ * moves with its own noisy control), then _score_particles (localiser.py:234-239): score, publish the scores, resample
+ * (keep the valid particles in order; fewer than `minimum_particles` left -> _reset_filter, localiser.py:468-485;
+ * otherwise top up to `n_desired` with copies of kept particles drawn in proportion to their score, plus Gaussian
+ * noise, localiser.py:486-545), estimate and convergence numbers (localiser.py:561-579).  The random draws are
+ * Philox4x32-10 at counter (index, `counter`, tag, draw) with key `seed` - NOT NumPy's global stream, whose call order a
+ * kernel cannot follow: the host-side ParticleFilter (NumPy resampling, the reference's draw order) stays the parity
+ * mode, this path is pinned by the oracle's restatement of these draws (exact picked indices: integer weights
+ * floor(score 2^40), integer prefix sums, mulhi of a 64-bit word with the total). */
+typedef struct acmpc_pf_resample {
+  uint32_t struct_size;
+  int32_t n_desired;          /* n_particles, or n_converged_particles once converged (localiser.py:497-500)         */
+  int32_t minimum_particles;  /* thresholds.minimum_particles                                                       */
+  uint32_t counter;           /* update number: a fresh set of draws per update                                     */
+  uint64_t seed;
+  double sigma_x, sigma_y, sigma_yaw;  /* sampling_noise (yaw in radians)                                           */
+} acmpc_pf_resample;
+
+/* _reset_filter on the device: `n` particles evenly along the centre line, uniform scores. */
+int acmpc_pf_filter_reset(acmpc_pf* handle, int32_t n);
+/* Upload / download the live particles (states [n][3], scores [n] float32). */
+int acmpc_pf_filter_set(acmpc_pf* handle, const float* states, const float* scores, int32_t n);
+int acmpc_pf_filter_get(acmpc_pf* handle, float* states, float* scores, int32_t capacity, int32_t* n);
+/* Localiser.step: delta = tyre_angle + N(0, sigma_yaw), speed = |velocity + N(0, sigma_velocity)|, kinematic Euler step.
+ * Asynchronous (ordered before the next update on the handle's stream). */
+int acmpc_pf_filter_step(acmpc_pf* handle, double tyre_angle, double velocity, double dt, double sigma_yaw,
+                         double sigma_velocity, uint64_t seed, uint32_t counter);
+/* One _score_particles.  result [8] = {estimate x, y, yaw, max distance, max |yaw difference| to the estimate,
+ * live particles after the update, valid particles of this scoring, 1 if the filter was reset}. */
+int acmpc_pf_filter_update(acmpc_pf* handle, const float* obs_left, int32_t k_left, const float* obs_right,
+                           int32_t k_right, const acmpc_pf_resample* resample, double* result);
+
 /* Library identification: "acmpc-hip <version> gfx950". */
 const char* acmpc_version(void);
 

@@ -829,3 +829,56 @@ def pf_resample(states: np.ndarray, scores: np.ndarray, score: np.ndarray, valid
     new_scores = np.concatenate((kept_scores, kept_scores[idx]), axis=0).astype(np.float32)
     return new_states, new_scores
 
+
+
+PF_TAG_RESAMPLE = 0x52534D50  # "RSMP"
+PF_TAG_CONTROL = 0x4354524C   # "CTRL"
+
+
+def pf_weights_fixed_point(score: np.ndarray) -> np.ndarray:
+    """floor(score * 2^40) as Python integers for finite positive scores, 0 otherwise (csrc weight_of)."""
+    out = []
+    for v in np.asarray(score, dtype=np.float64):
+        out.append(int(np.floor(v * 2.0**40)) if v > 0.0 else 0)
+    return out
+
+
+def pf_resample_counter_based(states, scores, score, valid, n_desired, minimum_particles, noise_sigma, seed, counter):
+    """Restates csrc/acmpc_pf.hip pf_resample_kernel (the device-resident filter's resampling; BUILD-DEFINED draws - the
+    reference's own come from NumPy's global stream, see `pf_resample`): keep the valid particles in order; with fewer
+    than `minimum_particles` return None (the caller resets); otherwise particle j of the top-up is a copy of kept
+    particle  upper_bound(cdf, (r_j * total) >> 64)  with r_j the first 64 bits of Philox4x32-10 at counter
+    (j, counter, "RSMP", 0), integer weights floor(score 2^40), plus sigma * Box-Muller normals from the draw at
+    (j, counter, "RSMP", 1).  Returns (new_states float32, new_scores float32, picked indices into the kept set) -
+    the indices are exact, the noise is float64 here and fast float32 transcendental on the device (~1e-6)."""
+    states = np.asarray(states, dtype=np.float32)
+    keep = np.flatnonzero(np.asarray(valid, dtype=bool))
+    n_valid = keep.shape[0]
+    if n_valid < minimum_particles:
+        return None
+    weights = pf_weights_fixed_point(np.asarray(score, dtype=np.float64)[keep])
+    if sum(weights) == 0:
+        weights = [1] * n_valid
+    cdf = np.cumsum(np.array(weights, dtype=object))
+    total = int(cdf[-1])
+    n_new = max(0, n_desired - n_valid)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    j = np.arange(n_new, dtype=np.uint32)
+    ctr = lambda draw: np.stack([j, np.full_like(j, counter), np.full_like(j, PF_TAG_RESAMPLE), np.full_like(j, draw)], 1)
+    r = philox4x32_10(ctr(0), np.broadcast_to(key, (n_new, 2)))
+    q = philox4x32_10(ctr(1), np.broadcast_to(key, (n_new, 2)))
+    picked = np.empty(n_new, dtype=np.int64)
+    cdf_list = [int(c) for c in cdf]
+    import bisect
+    for i in range(n_new):
+        word = (int(r[i, 0]) << 32) | int(r[i, 1])
+        picked[i] = bisect.bisect_right(cdf_list, (word * total) >> 64)
+    u = ((q >> 8).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)).astype(np.float64)
+    z = np.empty((n_new, 3))
+    rad0, ang0 = np.sqrt(-2.0 * np.log(u[:, 0])), 2.0 * np.pi * u[:, 1]
+    rad1, ang1 = np.sqrt(-2.0 * np.log(u[:, 2])), 2.0 * np.pi * u[:, 3]
+    z[:, 0], z[:, 1], z[:, 2] = rad0 * np.cos(ang0), rad0 * np.sin(ang0), rad1 * np.cos(ang1)
+    kept_states = states[keep]
+    fresh = (kept_states[picked].astype(np.float64) + z * np.asarray(noise_sigma, dtype=np.float64)).astype(np.float32)
+    kept_scores = np.asarray(scores, dtype=np.float32)[keep]
+    return (np.concatenate([kept_states, fresh]), np.concatenate([kept_scores, kept_scores[picked]]), picked)

@@ -126,3 +126,110 @@ def test_filter_cycle_tracks_a_moving_car(golden):
     assert pf.is_converged
     assert max(errors) < 3.0 and np.mean(errors[20:]) < 2.0, (max(errors), np.mean(errors[20:]))
 
+
+
+def _scene(golden, n, seed=21):
+    """A cluster of particles round a pose on the golden map and an observation of both track limits from there."""
+    g = golden
+    centre, left, right = g["pf/centre"], g["pf/left"], g["pf/right"]
+    M = len(centre)
+    rng = np.random.default_rng(seed)
+    tangent = np.roll(centre, -1, axis=0) - np.roll(centre, 1, axis=0)
+    heading = np.unwrap(np.arctan2(tangent[:, 1], tangent[:, 0]))
+    idx = 700
+    pose = np.array([centre[idx, 0], centre[idx, 1], heading[idx]])
+    states = (pose + rng.normal(0, [1.5, 1.5, 0.08], (n, 3))).astype(np.float32)
+    states[::7, :2] += 40.0                                    # some particles far off the track: invalid
+    a = np.pi / 2 - heading[idx]
+    rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    obs = {k: ((t[(idx + np.arange(c)) % M] - centre[idx]) @ rot.T + rng.normal(0, 0.15, (c, 2))).astype(np.float32)
+           for k, t, c in (("left", left, 230), ("right", right, 210))}
+    return dict(centre=centre, left=left, right=right), states, obs, idx, heading
+
+
+@pytest.mark.parametrize("n,n_desired", [(300, 300), (5000, 6000), (300, 200)])
+def test_device_resampling_matches_its_restatement(golden, n, n_desired):
+    """One update of the device-resident filter against the oracle's restatement of its counter-based resampling:
+    the same particles kept in the same order, the SAME picked indices for every new particle (integer weights and
+    prefix sums: exact), the noise to the accuracy of the device's fast float32 transcendentals, and the estimate of
+    the weighted mean."""
+    from acmpc_amd.particle_filter import DeviceParticleFilter, ParticleScorer
+    track, states, obs, _, _ = _scene(golden, n)
+    cfg = dict(LOCALISATION, n_particles=max(n, n_desired), n_converged_particles=n_desired,
+               sampling_noise=dict(x=1.1, y=1.1, yaw=3.0), control_noise=dict(velocity=0.25, yaw=2.0),
+               convergence_criteria=dict(maximum_distance=50, maximum_angle=90))
+    pf = DeviceParticleFilter(cfg, track, seed=1234)
+    scores0 = np.full(n, 1.0 / n, dtype=np.float32)
+    pf.set_particles(states, scores0)
+    out = pf.update(obs)
+    got_states, got_scores = pf.particles()
+    # the scoring the update used, through the host-pointer seam (pinned to the reference above)
+    scorer = ParticleScorer(cfg, track)
+    scored = scorer.update_particles(states, scorer.downsample_observations(obs))
+    sigma = (1.1, 1.1, 3.0 * np.pi / 180)
+    want = orc.pf_resample_counter_based(states, scored["score"].astype(np.float32), scored["score"], scored["valid_mask"],
+                                         max(n, n_desired), cfg["thresholds"]["minimum_particles"], sigma, 1234, 1)
+    assert want is not None and not out["was_reset"]
+    want_states, want_scores, picked = want
+    n_valid = int(scored["valid_mask"].sum())
+    assert out["n_valid"] == n_valid and out["n_particles"] == want_states.shape[0] == got_states.shape[0]
+    np.testing.assert_array_equal(got_states[:n_valid], want_states[:n_valid])          # kept, in order
+    np.testing.assert_array_equal(got_scores, want_scores)                                # scores follow the picks exactly
+    np.testing.assert_allclose(got_states[n_valid:], want_states[n_valid:], rtol=0, atol=2e-4)
+    assert len(np.unique(picked)) > 1
+    est, max_d, max_a = scorer.estimate_location(got_scores, got_states)
+    np.testing.assert_allclose(out["estimate"], est, rtol=1e-9)
+    np.testing.assert_allclose([out["max_distance"], out["max_angle"]], [max_d, max_a], rtol=1e-9)
+    scorer.close()
+
+
+def test_device_filter_resets_when_too_few_particles_are_valid(golden):
+    from acmpc_amd.particle_filter import DeviceParticleFilter
+    track, states, obs, _, _ = _scene(golden, 300)
+    cfg = dict(LOCALISATION, n_particles=300, n_converged_particles=300, sampling_noise=dict(x=1.1, y=1.1, yaw=3.0),
+               control_noise=dict(velocity=0.25, yaw=2.0), convergence_criteria=dict(maximum_distance=50, maximum_angle=90))
+    pf = DeviceParticleFilter(cfg, track, seed=5)
+    reset_states, reset_scores = pf.particles()                      # _reset_filter on the device ...
+    want_states, want_scores = orc.pf_reset(track["centre"], 300)     # ... against the reference's (G: pf_reset)
+    np.testing.assert_array_equal(reset_states, want_states)
+    np.testing.assert_array_equal(reset_scores, want_scores)
+    far = states.copy()
+    far[:, :2] += 500.0                                               # nothing near the track: everything invalid
+    pf.set_particles(far, np.full(300, 1 / 300, dtype=np.float32))
+    out = pf.update(obs)
+    assert out["was_reset"] and out["n_valid"] < cfg["thresholds"]["minimum_particles"] and out["n_particles"] == 300
+    np.testing.assert_array_equal(pf.particles()[0], want_states)
+
+
+def test_device_filter_tracks_a_moving_car(golden):
+    """The cycle of test_filter_cycle_tracks_a_moving_car with the particles living on the GPU: one round trip per
+    update, counter-based draws on the device."""
+    from acmpc_amd.particle_filter import DeviceParticleFilter
+    track, states, _, idx, heading = _scene(golden, 300, seed=11)
+    states[::7, :2] -= 40.0
+    centre, left, right = track["centre"], track["left"], track["right"]
+    M = len(centre)
+    cfg = dict(LOCALISATION, n_particles=300, n_converged_particles=300, sampling_noise=dict(x=1.1, y=1.1, yaw=3.0),
+               control_noise=dict(velocity=0.25, yaw=2.0), convergence_criteria=dict(maximum_distance=50, maximum_angle=90))
+    pf = DeviceParticleFilter(cfg, track, seed=99)
+    pf.set_particles(states, np.full(300, 1 / 300, dtype=np.float32))
+    rng = np.random.default_rng(11)
+    spacing = float(np.mean(np.linalg.norm(np.diff(centre, axis=0), axis=1)))
+    step, dt = 3, 0.05
+    speed = step * spacing / dt
+
+    def observe(t, count, at, yaw):
+        a = np.pi / 2 - yaw
+        rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        return ((t[(at + np.arange(count)) % M] - centre[at]) @ rot.T + rng.normal(0, 0.15, (count, 2))).astype(np.float32)
+
+    errors = []
+    for _ in range(40):
+        yaw_rate = (heading[(idx + step) % M] - heading[idx]) / dt
+        pf.step(float(np.arctan(yaw_rate * 2.65 / speed)), speed, dt)
+        idx = (idx + step) % M
+        out = pf.update({"left": observe(left, 230, idx, heading[idx]), "right": observe(right, 210, idx, heading[idx])})
+        assert not out["was_reset"] and out["n_particles"] == 300
+        errors.append(np.linalg.norm(out["estimate"][:2] - centre[idx]))
+    assert pf.is_converged
+    assert max(errors) < 3.0 and np.mean(errors[20:]) < 2.0, (max(errors), np.mean(errors[20:]))
