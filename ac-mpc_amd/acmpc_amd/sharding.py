@@ -182,7 +182,9 @@ class ShardedOptimizer:
     """The closed-loop solve (`acmpc_optimize`'s rounds) with the candidates of every round spread over the ranks:
     each rank draws and rolls out its own slice of global candidate indices, ONE all-reduce(MIN) of the keys per
     round picks the global winner, every rank re-draws that winner from its index and uses it as the next round's
-    centre.  All ranks end every round with identical records, so no other exchange is needed."""
+    centre.  All ranks end every round with identical records - except column 2 (`n_feasible`), which is each rank's
+    count over its own slice - so no other exchange is needed.  `stream` must be the stream torch.distributed enqueues
+    on (torch's current stream): the engine calls and the collective are ordered by stream order alone."""
 
     def __init__(self, engine, n_problems: int, n_local: int, n_steps: int, index_offset: int, device: torch.device,
                  group: Optional[dist.ProcessGroup] = None, host_collectives: bool = False):
@@ -198,6 +200,8 @@ class ShardedOptimizer:
               shrink: float = 0.5, seed: int = 0, stream: int = 0) -> torch.Tensor:
         """x0 [P,3], centre / u_ref [P,n,2] device tensors -> records [P, R] (identical on every rank)."""
         shard, n = self.shard, self.shard.n
+        if stream not in (0, torch.cuda.current_stream().cuda_stream) and not shard.host_collectives:
+            raise ValueError("ShardedOptimizer.solve: `stream` must be torch's current stream (the collective runs there)")
         scale = 1.0
         for r in range(rounds):
             if r == 0:

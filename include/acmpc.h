@@ -23,8 +23,10 @@
  *     (src/acmpc/control/solvers/control.py:26-28); steering angle = atan(kappa * wheelbase)
  *     (spatial_mpc.py:195-196).
  *
- * Arithmetic is float32 in a fixed operation order with no FMA contraction, so that results are
- * bit-identical to oracle/acmpc_oracle.{py,c}.
+ * Rollout arithmetic is float32 in one fixed operation order with no implicit FMA contraction: mode S uses no
+ * fused multiply-add at all, mode T uses exactly the ones its specification names (the
+ * oracle calls fmaf / emulates it exactly), so results are bit-identical to oracle/acmpc_oracle.{py,c}.
+ * The per-tick prologue (acmpc_control_tick) is float64; its tolerances are stated in DESIGN.md section 2.
  */
 #ifndef ACMPC_H
 #define ACMPC_H

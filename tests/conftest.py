@@ -17,12 +17,12 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """A fresh checkout has no built artefacts (they are git-ignored): compile the HIP library for gfx950 once, as
-    `__graft_entry__.build()` does.  Only when it is MISSING - the product itself never builds or falls back at
-    run time, and an existing library is used as it is (the one that travelled to the GPU box)."""
+    """A fresh checkout has no built artefacts (they are git-ignored): compile the HIP library for gfx950, as
+    `__graft_entry__.build()` does - also when a source is newer than the library, so that the suite never runs
+    against a binary of code that has since changed (`_build.build_library()` checks the time stamps).  The product
+    itself never builds or falls back at run time."""
     from acmpc_amd import _build
-    if not os.path.exists(_build.LIB_PATH):
-        _build.build_library()
+    _build.build_library()
 
 
 @pytest.fixture(scope="session")

@@ -226,3 +226,33 @@ def test_two_controllers_in_two_threads():
             assert bad == bad0 == 0
             np.testing.assert_array_equal(pc, pc0)
             np.testing.assert_array_equal(pred, pred0)
+
+
+def test_a_car_outside_the_corridor_is_reported_infeasible():
+    """The acceptance test is per row, like OSQP's (infinity norm against eps_abs + eps_rel |z|): a start 0.5 m outside
+    the corridor violates the first corridor row by more than that whatever the controls, so the solve must come back
+    not "solved", the previous plan stays and the counter goes up (spatial_mpc.py:212-217) - it used to pass as
+    "solved" under a tolerance summed over the rows."""
+    import copy
+    from acmpc_amd.mpc import build_mpc
+    from acmpc_amd.sampling_solver import SOLVED
+    cfg = copy.deepcopy(RACING["monza"])
+    cfg["speed_profile_constraints"]["v_max"] = 28.0
+    mpc = build_mpc(cfg, PlaceholderVehicle())
+    H = 50
+    path = _reference_path(H, "straight")
+    path[:, 2] = 6.0                                   # corridor half-width 3.0 - 0.97 = 2.03 m
+    mpc.get_control(path, offset=0.0)
+    assert mpc.infeasibility_counter == 0
+    before = mpc.projected_control.copy()
+    mpc.get_control(path, offset=2.6)                  # 0.57 m outside, heading along the path: x_1 is outside too
+    assert mpc.infeasibility_counter == 1
+    np.testing.assert_array_equal(mpc.projected_control, before)
+    # the seam reports it the same way
+    solver = mpc._control_solver
+    table = mpc.construct_waypoints(path)
+    table = mpc.compute_speed_profile(table, False, end_vel=cfg["speed_profile_constraints"]["end_velocity"])
+    dec = solver.solve(mpc.model.t2s(table.get_state(0), np.array([2.6, 0.0, np.pi / 2])), table)
+    assert dec.info.status != SOLVED and dec.info.violation > 0.25
+    dec = solver.solve(mpc.model.t2s(table.get_state(0), np.array([0.0, 0.0, np.pi / 2])), table)
+    assert dec.info.status == SOLVED

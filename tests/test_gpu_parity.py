@@ -326,7 +326,15 @@ def test_device_allocation_failure_is_an_error_not_a_crash():
     with pytest.raises(EngineError) as e:
         huge.rollout_device(x0.data_ptr(), U.data_ptr(), 2, 64, 19, LAYOUT_SM, 0, 0, 0, 0)
     assert e.value.code == -2 and "memory" in str(e.value).lower()
+    # a retry on the same handle fails the same way without allocating again what the first attempt already obtained,
+    # and closing the handle gives everything back (the failed bring-up used to leak)
+    free_after_first = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        with pytest.raises(EngineError):
+            huge.rollout_device(x0.data_ptr(), U.data_ptr(), 2, 64, 19, LAYOUT_SM, 0, 0, 0, 0)
+    assert abs(torch.cuda.mem_get_info()[0] - free_after_first) < (8 << 20)
     huge.close()
+    assert torch.cuda.mem_get_info()[0] >= free_after_first
     eng = _engine([prob], 0, 64, 19)
     out = eng.solve(prob["x0"][None], prob["U"][None])
     cost = _oracle(prob, eng.coefficients(0), 0)[0]

@@ -479,3 +479,56 @@ def test_sharded_optimizer_two_ranks_equal_the_unsharded_solve():
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, (proc.stdout + proc.stderr)[-3000:]
     assert "sharded optimizer ok" in proc.stdout
+
+
+def test_mode_t_softmin_optimize_on_a_fresh_handle_and_after_new_paths():
+    """Mode T with the exhaustive (verified-window) search and centre_update="softmin": acmpc_optimize's captured graph
+    runs the three-kernel rounds, whose rollout reads the verified-search thresholds - they must be on the device when
+    the graph runs on a handle that has never made another device call, and be the NEW paths' thresholds after a
+    second set_paths.  Oracle: the same rounds through sample / solve / softmin device calls."""
+    import torch
+    from acmpc_amd import Engine, _capi
+    P, H, N, rounds = 2, 50, 1024, 3
+    n = H - 1
+    dev = torch.device("cuda", 0)
+    sigma, seed = (3.0, 0.01), 47
+
+    def manual(eng, x0, u_ref):
+        R = _capi.record_floats(n)
+        d_x0, d_ref = torch.tensor(x0, device=dev), torch.tensor(u_ref, device=dev)
+        U = torch.empty(P, n, 2, N, device=dev)
+        rec = torch.empty(P, R, device=dev)
+        keys = torch.empty(P, dtype=torch.int64, device=dev)
+        cost = torch.empty(P, N, device=dev)
+        mean = d_ref.clone()
+        s = torch.cuda.current_stream().cuda_stream
+        for r in range(rounds):
+            ref = d_ref if r == 0 else rec[:, _capi.REC_HEADER:_capi.REC_HEADER + 2 * n].contiguous()
+            eng.sample_device(mean.data_ptr(), 2 * n, ref.data_ptr(), P, N, n, 1, 0,
+                              (sigma[0] * 0.5**r, sigma[1] * 0.5**r), seed, r, U.data_ptr(), s)
+            eng.solve_device(d_x0.data_ptr(), U.data_ptr(), P, N, n, 1, cost.data_ptr(), keys.data_ptr(), rec.data_ptr(), s)
+            eng.softmin_device(cost.data_ptr(), keys.data_ptr(), U.data_ptr(), P, N, n, 1, mean.data_ptr(), 0, s)
+            torch.cuda.synchronize()
+        return rec.cpu().numpy()
+
+    def inputs(seed0):
+        problems = [make_problem(orc, "silverstone", H, 4, seed=seed0 + p) for p in range(P)]
+        tables = np.stack([p["table"] for p in problems])
+        u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1)
+                          for p in problems]).astype(np.float32)
+        return problems, tables, u_ref, np.stack([p["pose0"] for p in problems])
+
+    problems, tables, u_ref, x0 = inputs(560)
+    fresh = Engine(**engine_kwargs(problems[0], 1, P, N, n, centre_update="softmin"))   # exhaustive search: thresholds
+    fresh.set_paths(tables)
+    first = fresh.optimize(x0, u_ref, u_ref, N, rounds, sigma, shrink=0.5, seed=seed)["records"].copy()   # FIRST device call
+    checker = Engine(**engine_kwargs(problems[0], 1, P, N, n, centre_update="softmin"))
+    checker.set_paths(tables)
+    np.testing.assert_array_equal(first, manual(checker, x0, u_ref))
+    # new paths on the same handle: the graph is replayed, the thresholds must be the new ones
+    problems2, tables2, u_ref2, x02 = inputs(590)
+    fresh.set_paths(tables2)
+    second = fresh.optimize(x02, u_ref2, u_ref2, N, rounds, sigma, shrink=0.5, seed=seed)["records"].copy()
+    checker.set_paths(tables2)
+    np.testing.assert_array_equal(second, manual(checker, x02, u_ref2))
+    assert not np.array_equal(first, second)
