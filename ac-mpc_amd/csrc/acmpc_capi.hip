@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <limits>
 #include <new>
 #include <string>
@@ -23,6 +25,7 @@ namespace {
 thread_local std::string g_create_error;
 
 constexpr double kEps = 1e-12;  // dynamics.py:21
+constexpr int kTraceBlocks = 1024;  // workgroups per launch the traced fused finalize has room for (64 candidates each)
 
 }  // namespace
 
@@ -43,6 +46,7 @@ struct acmpc_ctx {
   float* d_coef = nullptr;
   int64_t* d_partial_keys = nullptr;
   int* d_partial_feas = nullptr;
+  size_t partial_slots = 0;  // slots of ONE set of partial keys / feasible counts (there are two)
   double* d_soft_partial = nullptr;
   size_t soft_partial_doubles = 0;
 
@@ -61,7 +65,9 @@ struct acmpc_ctx {
   float* d_costs = nullptr;
   float* d_records = nullptr;
   int64_t* d_keys = nullptr;
-  int* d_tickets = nullptr;  // [max_problems] last-workgroup counters of the fused finalize; zero between launches
+  int* d_tickets = nullptr;  // [max_problems][kTicketGroups + 1] last-workgroup counters of the fused finalize; zero between launches
+  unsigned tick_sequence = 0;   // completion flag values of acmpc_control_tick
+  float* d_trace = nullptr;  // [2][kTraceBlocks][trace_floats(max_steps)] best-candidate traces of the fused rounds' workgroups
   // mode T with exhaustive search: thresholds of the verified window search (acmpc_device.h: nearest_verified)
   std::vector<float> h_nn_thr;  // [P][n][kVerifiedWindow], empty when not applicable
   float* d_nn_thr = nullptr;
@@ -222,8 +228,10 @@ int ensure_device(acmpc_ctx* c) {
   c->soft_partial_doubles = static_cast<size_t>(p.max_problems) * acmpc::softmin_chunks(p.max_candidates) *
                             (4 * static_cast<size_t>(p.max_steps) + 1);
   ACMPC_HIP(c, alloc_once(&c->d_coef, coef_floats * sizeof(float)));
-  ACMPC_HIP(c, alloc_once(&c->d_partial_keys, partials * sizeof(int64_t)));
-  ACMPC_HIP(c, alloc_once(&c->d_partial_feas, partials * sizeof(int)));
+  // (two sets: chained optimisation rounds alternate, a round reads the keys its predecessor wrote while it writes its own)
+  ACMPC_HIP(c, alloc_once(&c->d_partial_keys, 2 * partials * sizeof(int64_t)));
+  ACMPC_HIP(c, alloc_once(&c->d_partial_feas, 2 * partials * sizeof(int)));
+  c->partial_slots = partials;
   ACMPC_HIP(c, alloc_once(&c->d_soft_partial, c->soft_partial_doubles * sizeof(double)));
   ACMPC_HIP(c, alloc_once(&c->d_segments, static_cast<size_t>(p.max_steps) * 2 * sizeof(float)));
   if (p.mode == ACMPC_MODE_TEMPORAL && p.nn_ahead < 0)
@@ -418,8 +426,10 @@ int ensure_staging(acmpc_ctx* c) {
   ACMPC_HIP(c, alloc_once(&c->d_records,
                           static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float)));
   ACMPC_HIP(c, alloc_once(&c->d_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
-  ACMPC_HIP(c, alloc_once(&c->d_tickets, static_cast<size_t>(p.max_problems) * sizeof(int)));
-  ACMPC_HIP(c, hipMemset(c->d_tickets, 0, static_cast<size_t>(p.max_problems) * sizeof(int)));
+  const size_t ticket_ints = static_cast<size_t>(p.max_problems) * (acmpc::kTicketGroups + 1);
+  ACMPC_HIP(c, alloc_once(&c->d_tickets, ticket_ints * sizeof(int)));
+  ACMPC_HIP(c, hipMemset(c->d_tickets, 0, ticket_ints * sizeof(int)));
+  ACMPC_HIP(c, alloc_once(&c->d_trace, 2 * static_cast<size_t>(kTraceBlocks) * acmpc::trace_floats(p.max_steps) * sizeof(float)));
   ACMPC_HIP(c, hipStreamSynchronize(nullptr));  // the handle's own stream does not order against the null stream
   ACMPC_HIP(c, host_alloc_once(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
   c->staging_ready = true;
@@ -514,6 +524,7 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_keys);
     (void)hipFree(c->d_tickets);
+    (void)hipFree(c->d_trace);
     (void)hipFree(c->d_nn_thr);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
     for (hipGraphExec_t g : c->opt_graph)
@@ -744,11 +755,18 @@ bool use_fused_finalize(const acmpc_ctx* c, int n) {
   return std::getenv("ACMPC_NO_FUSED_FINALIZE") == nullptr && acmpc::fused_finalize_fits(c->prm.mode, n);
 }
 
+// The fused finalize copies the record out of the winning workgroup's trace when the launch is small enough for the
+// trace buffer (closed-loop rounds are: 256 workgroups) and the trace fits the LDS; else it re-draws and re-rolls.
+bool use_traced_finalize(const acmpc_ctx* c, int P, int N, int n) {
+  return std::getenv("ACMPC_NO_TRACED_FINALIZE") == nullptr && acmpc::traced_finalize_fits(c->prm.mode, n) &&
+         static_cast<long long>(P) * ((N + 63) / 64) <= kTraceBlocks;
+}
+
 // `final_records`: where the LAST round's records go when the fused finalize writes them (device memory, or pinned
 // host memory - then the winner lands in the caller's staging buffer without a copy node); nullptr = c->d_records
 int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int rounds, double sigma_v, double sigma_k,
                    double shrink, uint64_t seed, const uint32_t* d_seed, hipStream_t s, bool fused,
-                   float* final_records = nullptr) {
+                   float* final_records = nullptr, unsigned* done = nullptr, unsigned done_value = 0) {
   const bool has_uref = in.uref != nullptr;
   const bool fused_finalize = use_fused_finalize(c, n);
   const int layout = ACMPC_LAYOUT_STEP_MAJOR;
@@ -797,11 +815,22 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     }
     int rc = upload_segments(c, n, s);
     if (rc != ACMPC_OK) return rc;
+    // Traced rounds are chained: a round that is not the last ends without a finalize - its workgroups leave their
+    // partial keys and the trace of their best candidate - and the NEXT launch finds the winner itself (argmin over
+    // those keys while its Philox draws run) and samples round that workgroup's trace.  Only the last round pays the
+    // last-workgroup tail (six dependent device-scope round trips, ~10 us).  Keys, counts and traces alternate between
+    // two sets, since a round reads its predecessor's while it writes its own.
+    const int blocks = (N + 63) / 64;
+    const bool traced = fused_finalize && use_traced_finalize(c, P, N, n);
+    const bool chain = traced && blocks <= acmpc::kChainBlocks && std::getenv("ACMPC_NO_CHAINED_ROUNDS") == nullptr;
+    const size_t set = (chain && (r & 1)) ? 1 : 0;
+    const size_t trace_set_floats = static_cast<size_t>(kTraceBlocks) * acmpc::trace_floats(c->prm.max_steps);
+    float* d_trace = c->d_trace + set * trace_set_floats;
     acmpc::RolloutArgs ra{};
     ra.x0 = in.x0;
     ra.coef = in.coef;
-    ra.partial_keys = c->d_partial_keys;
-    ra.partial_feas = c->d_partial_feas;
+    ra.partial_keys = c->d_partial_keys + set * c->partial_slots;
+    ra.partial_feas = c->d_partial_feas + set * c->partial_slots;
     ra.P = P;
     ra.N = N;
     ra.n = n;
@@ -816,17 +845,26 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     sa.n = n;
     sa.spec = make_spec(c, sigma_v * scale, sigma_k * scale, seed, static_cast<uint32_t>(r));
     sa.spec.seed_ptr = d_seed;
+    if (chain && r > 0) {
+      sa.prev_keys = c->d_partial_keys + (set ^ 1) * c->partial_slots;
+      sa.prev_trace = c->d_trace + (set ^ 1) * trace_set_floats;
+      sa.prev_blocks = blocks;
+      sa.prev_pitch = acmpc::trace_floats(n);
+    }
     // NB: the finalize of round r reads its centre from the records it is about to overwrite; it copies the
     // controls it needs into registers/LDS before lane 0..63 write the new record, and one wave owns one record
     if (fused_finalize) {
       // one launch per round: the last workgroup of each problem also reduces the partial keys and writes the
       // record; rounds before the last only need the winner's controls (the next centre), not its re-roll
       const bool last = r + 1 == rounds;
-      const acmpc::FusedFinalize ff{c->d_tickets, (last && final_records != nullptr) ? final_records : c->d_records,
-                                    !last};
+      const bool tail = last || !chain;
+      const acmpc::FusedFinalize ff{tail ? c->d_tickets : nullptr,
+                                    (last && final_records != nullptr) ? final_records : c->d_records, !last,
+                                    traced ? d_trace : nullptr, acmpc::trace_floats(n),
+                                    last ? done : nullptr, done_value};
       ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, ff, s));
     } else {
-      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, acmpc::FusedFinalize{nullptr, nullptr, false}, s));
+      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, acmpc::FusedFinalize{nullptr, nullptr, false, nullptr, 0, nullptr, 0}, s));
       Regenerate regen{d_c, stride, d_ref, sa.spec};
       rc = finalize(c, nullptr, nullptr, in.x0, nullptr, P, N, n, layout, 0, c->d_records, (N + 63) / 64, s, &regen,
                     in.coef);
@@ -1000,13 +1038,14 @@ struct TickLayout {
 
 // layout of the pinned result block
 struct TickOutLayout {
-  size_t record, table, status, coords, total;
+  size_t record, table, status, coords, done, total;
   explicit TickOutLayout(int n) {
     record = 0;
     table = align16(static_cast<size_t>(acmpc_record_floats(n)) * sizeof(float));
     status = align16(table + static_cast<size_t>(7) * n * sizeof(double));   // QP status, iterations, map index
     coords = status + 16;
-    total = coords + static_cast<size_t>(n + 1) * 3 * sizeof(double);
+    done = align16(coords + static_cast<size_t>(n + 1) * 3 * sizeof(double));   // completion flag of the last round
+    total = done + 16;
   }
 };
 
@@ -1045,6 +1084,7 @@ int ensure_tick(acmpc_ctx* c) {
   ACMPC_HIP(c, host_alloc_once(&c->h_tick, TickLayout(n_cap).host_total));
   ACMPC_HIP(c, alloc_once(&c->d_tick, TickLayout(n_cap).total));
   ACMPC_HIP(c, host_alloc_once(&c->h_tick_out, TickOutLayout(n_cap).total));
+  std::memset(c->h_tick_out, 0, TickOutLayout(n_cap).total);   // completion flags start below every sequence number
   ACMPC_HIP(c, alloc_once(&c->d_coords, static_cast<size_t>(n_cap + 1) * 3 * sizeof(double)));
   c->warm_stride = 2 + 3 * n_cap;
   const size_t warm_bytes = static_cast<size_t>(2) * c->warm_stride * sizeof(double);
@@ -1129,6 +1169,14 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   pa.u_hi0 = c->prm.u_max[0];
   pa.u_hi1 = c->prm.u_max[1];
   const bool direct = use_fused_finalize(c, n);
+  // Completion: with direct launches the last round's tail stores a sequence number behind the record, both in pinned
+  // host memory, and this call polls it - the record is here a microsecond after it was written, where the launch's
+  // completion signal (hipStreamSynchronize) takes the driver's path.  The stream is only synchronised when the flag
+  // does not come (a fault), and before a host buffer the kernels read is rewritten by a DIFFERENT kind of call.
+  static const bool use_graph = std::getenv("ACMPC_TICK_GRAPH") != nullptr;
+  const bool flagged = direct && !use_graph && std::getenv("ACMPC_TICK_NO_FLAG") == nullptr;
+  unsigned* done_flag = reinterpret_cast<unsigned*>(c->h_tick_out + out.done);
+  const unsigned done_value = ++c->tick_sequence;
   // prologue -> rounds (-> copy of the record when the fused finalize cannot write it to the host itself)
   auto enqueue = [&](hipStream_t q, int* rc_rounds) -> hipError_t {
     // (a pose instead of a map index: the nearest-point search runs in front, as its own 256-thread launch)
@@ -1137,7 +1185,8 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     if (e != hipSuccess) return e;
     const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef};
     *rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink, 0, pa.seed, q, true,
-                                direct ? reinterpret_cast<float*>(c->h_tick_out + out.record) : nullptr);
+                                direct ? reinterpret_cast<float*>(c->h_tick_out + out.record) : nullptr,
+                                flagged ? done_flag : nullptr, done_value);
     if (*rc_rounds == ACMPC_OK && !direct)
       e = hipMemcpyAsync(c->h_tick_out + out.record, c->d_records, static_cast<size_t>(rec_floats) * sizeof(float),
                          hipMemcpyDeviceToHost, q);
@@ -1146,7 +1195,6 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   // Three short kernels behind one another: launched directly they start sooner than a graph replay does (the
   // replay's fixed cost is ~10 us on this runtime, a launch on an idle stream ~4 us, and the later launches overlap
   // the prologue's execution).  ACMPC_TICK_GRAPH=1 replays a captured graph instead.
-  static const bool use_graph = std::getenv("ACMPC_TICK_GRAPH") != nullptr;
   int slot = -1;
   if (use_graph) {
     acmpc_ctx::TickKey key;
@@ -1232,7 +1280,22 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     if (rc_rounds != ACMPC_OK) return rc_rounds;
     ACMPC_HIP(c, e);
   }
-  ACMPC_HIP(c, hipStreamSynchronize(s));
+  if (flagged) {
+    volatile unsigned* flag = done_flag;
+    const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+    unsigned spins = 0;
+    while (*flag != done_value) {
+      __builtin_ia32_pause();
+      if ((++spins & 0x3fffu) == 0 && std::chrono::steady_clock::now() > give_up) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*flag != done_value) {   // no flag: wait the ordinary way, which also reports what went wrong
+      ACMPC_HIP(c, hipStreamSynchronize(s));
+      if (*flag != done_value) return fail(c, ACMPC_EHIP, "the tick finished without its completion flag");
+    }
+  } else {
+    ACMPC_HIP(c, hipStreamSynchronize(s));
+  }
   c->tick_last_n = n;
 
   const float* rec = reinterpret_cast<const float*>(c->h_tick_out + out.record);

@@ -67,7 +67,14 @@ struct SampleArgs {
   int P, N, n;
   int64_t index_offset;    // global index of local candidate 0 (the counter of the generator)
   SampleSpec spec;
+  // rollout_sampled_kernel only - the centre taken straight from the PREVIOUS round's launch instead of `centre`: the
+  // argmin over that launch's partial keys names a workgroup, and the head of its trace is the winner's controls
+  const int64_t* prev_keys;  // [P][prev_blocks] or nullptr
+  const float* prev_trace;   // [P][prev_blocks][prev_pitch]
+  int prev_blocks;           // <= kChainBlocks
+  int prev_pitch;
 };
+constexpr int kChainBlocks = 256;   // four keys per lane
 
 struct LaunchShape {
   int block;              // threads per workgroup
@@ -91,19 +98,31 @@ hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const Rollout
                                          hipEvent_t start, hipEvent_t stop);
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s);
-// Optional tail of the fused launch: the workgroup that finishes a problem LAST (a ticket counter per problem)
-// also runs the finalize for it, in the same launch - argmin over the partial keys, winner re-drawn from its index,
-// record written.  `tickets` [P] must be zero before the launch and is left zero by it.
+// Optional tail of the fused launch: the workgroup that finishes a problem LAST (two levels of ticket counters per
+// problem) also runs the finalize for it, in the same launch - argmin over the partial keys, record written.  With
+// `trace` the record is copied out of what the winning workgroup left there (every workgroup writes the controls,
+// states, violation and cost of its best candidate: [P][workgroups][trace_pitch] floats); without, the winner is
+// re-drawn from its index and rolled again.  `tickets` [P][kTicketGroups + 1] must be zero before the launch and is
+// left zero by it.
+constexpr int kTicketGroups = 8;
 struct FusedFinalize {
   int* tickets;        // nullptr: no fused finalize
   float* records;      // [P][record_floats]
   bool controls_only;  // see FinalizeArgs
+  float* trace;        // nullptr: re-draw and re-roll the winner
+  int trace_pitch;     // floats per workgroup in `trace` (>= trace_floats(n))
+  // completion flag (pinned host memory) or nullptr: `done_value` is stored there, at system scope, AFTER problem 0's
+  // record - a host that polls it has the record without waiting for the launch's completion signal
+  unsigned* done;
+  unsigned done_value;
 };
 
 // sample + rollout + cost (+ finalize) fused: candidates are drawn inside the rollout kernel and never touch memory
 // (the closed-loop solve, where every launch is ~10 us of latency-bound work)
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
                                   const FusedFinalize& fused, hipStream_t s);
+int trace_floats(int n);
+bool traced_finalize_fits(int mode, int n);
 // whether rollout + fused finalize fit one workgroup's 64 KB of LDS (mode T at the longest horizons does not)
 bool fused_finalize_fits(int mode, int n);
 int softmin_chunks(int N);

@@ -79,11 +79,30 @@ __device__ __forceinline__ void load_controls(const float* __restrict__ U, int p
 // which the caller keeps reserved until scalar_touch_wait() - the compiler does not know these loads are in flight.
 __device__ __forceinline__ uint32_t scalar_touch(const void* base, int bytes, uint32_t sink) {
   for (int off = 0; off < bytes; off += 64)
-    asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(base), "s"(off) : "memory");
+    asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(base), "s"(off));
   return sink;
 }
 __device__ __forceinline__ void scalar_touch_wait(uint32_t& sink) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink) : : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink));
+}
+
+// Publishing between workgroups of ONE launch without fences.  An agent-scope fence is an L2 write-back (release) or an
+// L2 invalidate (acquire) on this multi-die part - microseconds each, and the fused finalize needed three per
+// workgroup.  Instead the few values that cross workgroups (partial keys, traces, tickets) are written and read with
+// agent-scope atomic stores / loads, which go to the memory-side coherence point past the per-die L2, and a writer
+// only has to wait until its stores have been acknowledged (vmcnt = 0) before it takes its ticket.
+template <typename T>
+__device__ __forceinline__ void publish(T* where, T value) {
+  __hip_atomic_store(where, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T observe(const T* where) {
+  return __hip_atomic_load(where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void published() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every store of this wave has been acknowledged
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
 
 // PACK = candidates per arithmetic state: 2 = pairs in v_pk_* instructions, 1 = plain float32 instructions.
@@ -414,8 +433,30 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
 // controls are drawn (same Philox counters, same blend_control arithmetic: bit-identical to sample_kernel) and
 // consumed step by step without ever being written to memory.  Output: the per-workgroup partial keys, as usual;
 // the winner's controls are re-drawn by finalize_kernel in regenerate mode.
+//
+// `s_trace` (LDS, [5n + 2][64] floats, or nullptr): every lane also leaves what it computed - controls and state of
+// each step, violation, cost - in its column, and the workgroup copies the column of its best candidate to
+// `trace_out` (global, [5n + 2]): the fused finalize then assembles the winner's record out of the winning workgroup's
+// trace instead of drawing and rolling that candidate a second time (one wave, ~8 us of serial work, per round).
+// Returns nothing; rows: 2i, 2i + 1 = (v, kappa) of step i | 2n + 3i .. + 2 = state after step i | 5n = V | 5n + 1 = cost.
+// The tables the step loop reads at wave-uniform addresses come in as `restrict` kernel parameters (UniformTables):
+// the loop contains compiler markers (asm) and LDS stores, and only a pointer the compiler knows to be unaliased keeps
+// a read behind them on the scalar unit.
+struct UniformTables {
+  const float* __restrict__ coef;        // RolloutArgs::coef
+  const float* __restrict__ centre;      // SampleArgs::centre
+  const float* __restrict__ u_ref;       // SampleArgs::u_ref or nullptr
+  const float* __restrict__ weights;     // SampleSpec::segments
+  const float* __restrict__ prev_trace;  // SampleArgs::prev_trace
+};
+
 template <int MODE>
-__device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const SampleArgs& smp, float* s_fused) {
+__device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const SampleArgs& smp, const UniformTables& tab,
+                                                     float* s_fused, const bool traced = false,
+                                                     const int trace_lds_floats = 0, float* trace_out = nullptr) {
+  // (the trace is addressed off `s_fused` itself, not through a pointer that may be null: a select of pointers would
+  // lose the LDS address space, its stores could then alias the tables, and the table reads would leave the scalar unit)
+  float* s_trace = s_fused + trace_lds_floats;
   const int p = blockIdx.y;
   const int lane = threadIdx.x;
   const int c = blockIdx.x * kWave + lane;
@@ -423,12 +464,12 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   const Weights w = a.w;
   const SampleSpec sp = smp.spec;
   constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
-  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
+  const float* __restrict__ coef = tab.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
   // centre, reference controls and knot weights sit at wave-uniform addresses: scalar loads, operands in SGPRs
-  const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
-  const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : centre;
-  const float* __restrict__ knot_weight = sp.segments;
+  const float* __restrict__ centre = tab.centre + static_cast<size_t>(p) * smp.centre_stride;
+  const float* __restrict__ ref = (tab.u_ref != nullptr) ? tab.u_ref + static_cast<size_t>(p) * n * 2 : centre;
+  const float* __restrict__ knot_weight = tab.weights;
   float* s_wp = s_fused;
   float* s_xy = s_wp + n * kCoefT;
   if constexpr (MODE == 1) {
@@ -440,11 +481,17 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     __syncthreads();
   }
 
-  uint32_t sink = 0;
-  if constexpr (MODE == 0) sink = scalar_touch(coef, n * kStride * static_cast<int>(sizeof(float)), sink);
-  sink = scalar_touch(centre, 2 * n * static_cast<int>(sizeof(float)), sink);
-  sink = scalar_touch(ref, 2 * n * static_cast<int>(sizeof(float)), sink);
-  sink = scalar_touch(knot_weight, 2 * n * static_cast<int>(sizeof(float)), sink);
+  // chained rounds: the previous launch's partial keys, four per lane, requested before the Philox draws below and
+  // reduced after them - the draws (a few microseconds of arithmetic that needs no centre) cover the round trip
+  int64_t prev_key[kChainBlocks / kWave];
+  const bool chained = smp.prev_keys != nullptr;   // wave-uniform
+  if (chained) {
+#pragma unroll
+    for (int q = 0; q < kChainBlocks / kWave; ++q) {
+      const int b = lane + q * kWave;
+      prev_key[q] = smp.prev_keys[static_cast<size_t>(p) * smp.prev_blocks + min(b, smp.prev_blocks - 1)];
+    }
+  }
 
   const bool active = c < a.N;
   float cost = __builtin_inff();
@@ -452,28 +499,83 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   float z[kKnots][2] = {};
   const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
   if (active) draw_normals(sp, gidx, static_cast<uint32_t>(p), z);
-  scalar_touch_wait(sink);
+  if (chained) {
+    int64_t best = kKeyMax;
+    int block = 0;
+#pragma unroll
+    for (int q = 0; q < kChainBlocks / kWave; ++q) {
+      const int b = lane + q * kWave;
+      const int64_t kb = (b < smp.prev_blocks) ? prev_key[q] : kKeyMax;
+      block = (kb < best) ? b : block;
+      best = (kb < best) ? kb : best;
+    }
+    const int64_t winner = wave_min_key(best);
+    const unsigned long long holder = __ballot(best == winner);   // keys are distinct (they carry the index)
+    block = __builtin_amdgcn_readlane(block, __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1));
+    centre = tab.prev_trace + (static_cast<size_t>(p) * smp.prev_blocks + block) * smp.prev_pitch;
+    if (tab.u_ref == nullptr) ref = centre;
+  }
   if (active) {
     const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     StateS ss{x0[0], x0[1], x0[2], 0.0f, 0.0f};
     StateT ts{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
     int nearest = 0;
+    // The wave-uniform operands of a step - centre and reference controls, knot weight, the table row - are scalar
+    // loads, and a lone wave has nothing to hide their latency behind: three waits per step were 55 % of this kernel's
+    // wave-cycles.  So step i + 1's operands are requested before step i's arithmetic: arrived() marks where a set must
+    // be there (the one s_waitcnt, for everything outstanding, sits before the next set is requested - its index passes
+    // through the marker), and the arithmetic of the step then covers the next set's round trip.
+    constexpr int kRowS = 9;   // floats of a mode-S table row a step reads (the stride pads to 12)
+    struct StepOperands {
+      float centre_v, centre_k, ref_v, ref_k, weight;
+      float row[kRowS];
+    };
+    auto request = [&](int i, StepOperands& o) {
+      asm volatile("" : "+s"(i));                        // not before the marker of the set in use
+      const int j = min(i, n - 1);                        // the request behind the last step repeats it
+      o.centre_v = centre[2 * j];                         // both loaded, then selected:
+      o.centre_k = centre[2 * j + 1];                     // a select of ADDRESSES would go flat
+      o.ref_v = ref[2 * j];
+      o.ref_k = ref[2 * j + 1];
+      o.weight = knot_weight[2 * j + 1];
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < kRowS; ++e) o.row[e] = coef[j * kCoefS + e];
+      }
+    };
+    auto arrived = [&](StepOperands& o) {
+      asm volatile("" : "+s"(o.centre_v), "+s"(o.centre_k), "+s"(o.ref_v), "+s"(o.ref_k), "+s"(o.weight));
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < kRowS; ++e) asm volatile("" : "+s"(o.row[e]));
+      }
+    };
+    StepOperands now, next;
+    request(sp.knot_begin[0], now);
 #pragma unroll
     for (int knot = 0; knot < kKnots - 1; ++knot) {
-#pragma unroll 4
+#pragma unroll 2
       for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
+        arrived(now);
+        request(i + 1, next);
         float v, k;
-        const float centre_v = centre[2 * i], centre_k = centre[2 * i + 1];  // both loaded (scalar), then selected:
-        const float ref_v = ref[2 * i], ref_k = ref[2 * i + 1];              // a select of ADDRESSES would go flat
-        const float cv = use_ref ? ref_v : centre_v;
-        const float ck = use_ref ? ref_k : centre_k;
-        blend_control(sp, amp, knot_weight[2 * i + 1], cv, ck, z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1],
-                      v, k);
+        const float cv = use_ref ? now.ref_v : now.centre_v;
+        const float ck = use_ref ? now.ref_k : now.centre_k;
+        blend_control(sp, amp, now.weight, cv, ck, z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1], v, k);
         if constexpr (MODE == 0) {
-          step_spatial<float>(ss, coef + i * kCoefS, v, k, w);
+          step_spatial<float>(ss, now.row, v, k, w);
         } else {
           nearest = step_temporal(ts, s_wp, s_xy, n, v, k, w, nearest);
+        }
+        now = next;
+        if (traced) {   // wave-uniform
+          float* col = s_trace + lane;
+          col[(2 * i) * kWave] = v;
+          col[(2 * i + 1) * kWave] = k;
+          col[(2 * n + 3 * i) * kWave] = (MODE == 0) ? ss.ey : ts.X;
+          col[(2 * n + 3 * i + 1) * kWave] = (MODE == 0) ? ss.ep : ts.Y;
+          col[(2 * n + 3 * i + 2) * kWave] = (MODE == 0) ? ss.t : ts.phi;
         }
       }
     }
@@ -484,16 +586,27 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
       cost = finish_temporal<float>(ts, n, w);
       feas = ts.V == 0.0f;
     }
+    if (traced) {
+      s_trace[(5 * n) * kWave + lane] = (MODE == 0) ? ss.V : ts.V;
+      s_trace[(5 * n + 1) * kWave + lane] = cost;
+    }
     if (a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c] = cost;
   }
-  int64_t key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
+  const int64_t own_key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
   int nfeas = (active && feas) ? 1 : 0;
-  key = wave_min_key(key);
+  const int64_t key = wave_min_key(own_key);
   nfeas = wave_sum_int(nfeas);
+  if (traced) {
+    // keys carry the candidate index: exactly one lane holds the workgroup's minimum
+    const unsigned long long holder = __ballot(own_key == key);
+    const int best_lane = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1);
+    __syncthreads();   // one wave: orders the column writes above before the row reads
+    for (int e = lane; e < 5 * n + 2; e += kWave) publish(&trace_out[e], s_trace[e * kWave + best_lane]);
+  }
   if (lane == 0) {
     const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;
-    a.partial_keys[slot] = key;
-    a.partial_feas[slot] = nfeas;
+    publish(&a.partial_keys[slot], key);
+    publish(&a.partial_feas[slot], nfeas);
   }
 }
 
@@ -763,23 +876,103 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   finalize_problem<MODE, LAYOUT>(a, blockIdx.x, s_finalize);
 }
 
-// LDS: [rollout part: mode T tables] [finalize part: record image (+ mode T table)]
+// Record of problem p out of the winning workgroup's trace (see rollout_sampled_body): argmin over the partial keys,
+// then a copy - no arithmetic, so the record holds exactly the bits the winning lane computed, which are the bits a
+// re-roll of that candidate computes.  One wave.
+__device__ __forceinline__ void finalize_from_trace(const RolloutArgs& a, const FusedFinalize& fused, const int p) {
+  const int lane = threadIdx.x;
+  const int n = a.n;
+  const int blocks = static_cast<int>(gridDim.x);
+  int nfeas = 0;
+  int64_t key = kKeyMax;
+  int block = 0;
+  for (int b = lane; b < blocks; b += kWave) {
+    const size_t slot = static_cast<size_t>(p) * blocks + b;
+    nfeas += observe(&a.partial_feas[slot]);
+    const int64_t kb = observe(&a.partial_keys[slot]);
+    block = (kb < key) ? b : block;
+    key = (kb < key) ? kb : key;
+  }
+  nfeas = wave_sum_int(nfeas);
+  const int64_t best = wave_min_key(key);
+  const unsigned long long holder = __ballot(key == best);   // keys are distinct: one lane (all of them: nothing finite)
+  block = __builtin_amdgcn_readlane(block, __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1));
+  const float* trace = fused.trace + (static_cast<size_t>(p) * blocks + block) * fused.trace_pitch;
+  const int rec_floats = 4 + 2 * n + 3 * (n + 1);
+  float* __restrict__ rec = fused.records + static_cast<size_t>(p) * rec_floats;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+  const int count = fused.controls_only ? 4 + 2 * n : rec_floats;
+  for (int e = lane; e < count; e += kWave) {
+    float value;
+    if (e == 0) {            // between rounds the cost is read back from the key (non-finite -> +inf), as the
+      value = fused.controls_only ? key_cost(best)   // separate finalize does; the last record carries the lane's own
+                                  : observe(&trace[5 * n + 1]);
+    } else if (e == 1) {
+      value = fused.controls_only ? 0.0f
+                                  : observe(&trace[5 * n]);
+    } else if (e == 2) {
+      value = static_cast<float>(nfeas);
+    } else if (e == 3) {
+      value = 1.0f;
+    } else if (e < 4 + 2 * n) {
+      value = observe(&trace[e - 4]);
+    } else if (e < 4 + 2 * n + 3) {
+      value = x0[e - (4 + 2 * n)];
+    } else {
+      value = observe(&trace[e - 7]);   // 2n + (e - 4 - 2n - 3)
+    }
+    rec[e] = value;
+  }
+}
+
+// LDS: [rollout part: mode T tables] [trace [5n + 2][64], or - no trace - the finalize's record image (+ mode T table)]
 template <int MODE>
 __global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArgs a, const SampleArgs smp,
-                                                                const FusedFinalize fused, const int rollout_lds_floats) {
+                                                                const FusedFinalize fused, const int rollout_lds_floats,
+                                                                const float* __restrict__ coef,
+                                                                const float* __restrict__ centre,
+                                                                const float* __restrict__ u_ref,
+                                                                const float* __restrict__ weights,
+                                                                const float* __restrict__ prev_trace) {
   extern __shared__ __attribute__((aligned(16))) float s_fused[];
-  rollout_sampled_body<MODE>(a, smp, s_fused);
-  if (fused.tickets == nullptr) return;
-  // Last-workgroup-done: publish this workgroup's partials device-wide, take a ticket; whoever draws the last
-  // ticket of its problem knows every other workgroup's partials are visible (each fenced before its increment).
   const int p = blockIdx.y;
-  __threadfence();
+  const bool traced = fused.trace != nullptr;
+  const UniformTables tab{coef, centre, u_ref, weights, prev_trace};
+  rollout_sampled_body<MODE>(a, smp, tab, s_fused, traced, rollout_lds_floats,
+                             fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch);
+  if (fused.tickets == nullptr) return;
+  // Last-workgroup-done, in two levels: a workgroup publishes its partials (and trace) device-wide and takes a ticket
+  // of its group (workgroup index mod 8); the last of a group takes a ticket of the problem; the last of those knows
+  // every workgroup's results are at the coherence point (each waited for its stores before its increment) and finalizes.  Two levels because a
+  // device-scope atomic on one address takes ~13 ns and they serialise: 256 workgroups finishing together would queue
+  // for 3 us on one counter, and queue for 0.5 us on 8 + 1.  `tickets` [P][9] is zero before the launch and after it.
+  const int blocks = static_cast<int>(gridDim.x);
+  const int group = blockIdx.x & (kTicketGroups - 1);
+  const int group_size = (blocks - group + kTicketGroups - 1) / kTicketGroups;
+  const int groups = min(blocks, kTicketGroups);
+  int* tickets = fused.tickets + p * (kTicketGroups + 1);
+  published();   // partial key, feasible count and trace of this workgroup are at the coherence point
   int ticket = 0;
-  if (threadIdx.x == 0) ticket = atomicAdd(&fused.tickets[p], 1);
+  if (threadIdx.x == 0) ticket = atomicAdd(&tickets[group], 1);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != static_cast<int>(gridDim.x) - 1) return;
-  __threadfence();
-  if (threadIdx.x == 0) fused.tickets[p] = 0;  // the launch leaves the counters as it found them
+  if (ticket != group_size - 1) return;
+  if (threadIdx.x == 0) {
+    publish(&tickets[group], 0);
+    ticket = atomicAdd(&tickets[kTicketGroups], 1);
+  }
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != groups - 1) return;
+  if (threadIdx.x == 0) publish(&tickets[kTicketGroups], 0);  // the launch leaves the counters as it found them
+  auto signal_done = [&]() {   // the record (written by all lanes) before the flag (lane 0), both on their way to the host
+    if (fused.done == nullptr || p != 0) return;
+    __threadfence_system();
+    if (threadIdx.x == 0) __hip_atomic_store(fused.done, fused.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  if (traced) {
+    finalize_from_trace(a, fused, p);
+    signal_done();
+    return;
+  }
   FinalizeArgs f{};
   f.x0 = a.x0;
   f.coef = a.coef;
@@ -799,6 +992,7 @@ __global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArg
   f.index_offset = a.index_offset;
   f.w = a.w;
   finalize_problem<MODE, 1>(f, p, s_fused + rollout_lds_floats);
+  signal_done();
 }
 
 // ---- softmin-weighted mean -------------------------------------------------------------------------------
@@ -1104,22 +1298,49 @@ bool fused_finalize_fits(int mode, int n) {
   return (sampled_rollout_floats(mode, n) + sampled_finalize_floats(mode, n)) * sizeof(float) <= 64 * 1024;
 }
 
+int trace_floats(int n) { return 5 * n + 2; }
+
+// The traced form keeps [5n + 2][64] floats in LDS per workgroup (63 kB at H = 50): up to the CU's 160 kB.
+bool traced_finalize_fits(int mode, int n) {
+  return (sampled_rollout_floats(mode, n) + static_cast<size_t>(trace_floats(n)) * kWave) * sizeof(float) <= 160 * 1024;
+}
+
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
                                   const FusedFinalize& fused, hipStream_t s) {
   clear_stale_error();
   const int n = rollout.n;
   const dim3 grid((rollout.N + kWave - 1) / kWave, rollout.P);
   const size_t rollout_floats = sampled_rollout_floats(mode, n);
-  const size_t finalize_floats = (fused.tickets != nullptr) ? sampled_finalize_floats(mode, n) : 0;
+  const bool traced = fused.trace != nullptr;
+  const size_t finalize_floats = traced                     ? static_cast<size_t>(trace_floats(n)) * kWave
+                                 : fused.tickets != nullptr ? sampled_finalize_floats(mode, n)
+                                                            : 0;
   const size_t lds = (rollout_floats + finalize_floats) * sizeof(float);
-  if (lds > 64 * 1024) return hipErrorInvalidValue;  // callers check fused_finalize_fits() first
+  if (lds > (traced ? 160u : 64u) * 1024u) return hipErrorInvalidValue;  // callers check *_fits() first
+  if (traced && fused.trace_pitch < trace_floats(n)) return hipErrorInvalidValue;
   const int offset = static_cast<int>(rollout_floats);
+  if (mode != 0 && mode != 1) return hipErrorInvalidValue;
+  if (lds > 64 * 1024) {   // more dynamic LDS than a kernel gets by default: raise the kernel's limit once per device
+    static bool raised[2][64] = {};
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+    if (!raised[mode][device]) {
+      e = (mode == 0) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_sampled_kernel<0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                      : hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_sampled_kernel<1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      raised[mode][device] = true;
+    }
+  }
   if (mode == 0) {
-    hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset);
-  } else if (mode == 1) {
-    hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset);
+    hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, rollout.coef,
+                       sample.centre, sample.u_ref, sample.spec.segments, sample.prev_trace);
   } else {
-    return hipErrorInvalidValue;
+    hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, rollout.coef,
+                       sample.centre, sample.u_ref, sample.spec.segments, sample.prev_trace);
   }
   return hipGetLastError();
 }
