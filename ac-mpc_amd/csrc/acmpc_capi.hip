@@ -1184,7 +1184,10 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     if (e == hipSuccess) e = acmpc::launch_prologue(pa, n, q);
     if (e != hipSuccess) return e;
     const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef};
-    *rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink, 0, pa.seed, q, true,
+    // (launched directly the rounds take the seed by value: read from the device block, as a replayed graph must, it is
+    // a dependent load in front of every round's first Philox draw)
+    *rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink,
+                                use_graph ? 0 : t->seed, use_graph ? pa.seed : nullptr, q, true,
                                 direct ? reinterpret_cast<float*>(c->h_tick_out + out.record) : nullptr,
                                 flagged ? done_flag : nullptr, done_value);
     if (*rc_rounds == ACMPC_OK && !direct)

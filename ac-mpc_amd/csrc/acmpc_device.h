@@ -581,12 +581,14 @@ struct SampleSpec {
   float ulo0, ulo1, uhi0, uhi1;
 };
 
-// the 8 x 2 standard normals of one candidate
+// the 8 x 2 standard normals of one candidate; draws Q0 .. Q1 - 1 of the kKnots / 2 (a caller with something to wait
+// for in between takes them in two halves)
+template <int Q0 = 0, int Q1 = kKnots / 2>
 __device__ __forceinline__ void draw_normals(const SampleSpec& sp, uint32_t gidx, uint32_t p, float (&z)[kKnots][2]) {
   const uint32_t key[2] = {sp.seed_ptr != nullptr ? sp.seed_ptr[0] : sp.seed_lo,
                            sp.seed_ptr != nullptr ? sp.seed_ptr[1] : sp.seed_hi};
 #pragma unroll
-  for (int q = 0; q < kKnots / 2; ++q) {
+  for (int q = Q0; q < Q1; ++q) {
     const uint32_t ctr[4] = {gidx, p, sp.round, static_cast<uint32_t>(q)};
     uint32_t r[4];
     philox4x32_10(ctr, key, r);

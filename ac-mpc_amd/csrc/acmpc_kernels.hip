@@ -73,19 +73,6 @@ __device__ __forceinline__ void load_controls(const float* __restrict__ U, int p
   }
 }
 
-// Warms the scalar cache: one s_load per 64-byte line of [base, base + bytes), results discarded.  In the
-// latency-bound kernels every step's table row is otherwise a first-touch miss that the lone wave of a SIMD has to
-// sit out; issued up front, the misses overlap the Philox draws instead.  All loads write the same SGPR (`sink`),
-// which the caller keeps reserved until scalar_touch_wait() - the compiler does not know these loads are in flight.
-__device__ __forceinline__ uint32_t scalar_touch(const void* base, int bytes, uint32_t sink) {
-  for (int off = 0; off < bytes; off += 64)
-    asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(base), "s"(off));
-  return sink;
-}
-__device__ __forceinline__ void scalar_touch_wait(uint32_t& sink) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink));
-}
-
 // Publishing between workgroups of ONE launch without fences.  An agent-scope fence is an L2 write-back (release) or an
 // L2 invalidate (acquire) on this multi-die part - microseconds each, and the fused finalize needed three per
 // workgroup.  Instead the few values that cross workgroups (partial keys, traces, tickets) are written and read with
@@ -431,31 +418,23 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
 
 // sample_kernel and rollout_kernel fused for the latency-bound closed-loop solve: one lane = one candidate whose
 // controls are drawn (same Philox counters, same blend_control arithmetic: bit-identical to sample_kernel) and
-// consumed step by step without ever being written to memory.  Output: the per-workgroup partial keys, as usual;
-// the winner's controls are re-drawn by finalize_kernel in regenerate mode.
+// consumed step by step without ever being written to memory.  Output: the per-workgroup partial keys, as usual.
+// One wave per workgroup and one workgroup per CU at the closed-loop size (16 384 candidates), so nothing hides a
+// wait: what the kernel does about each is said where it is done (operands through LDS, requests before the draws).
 //
-// `s_trace` (LDS, [5n + 2][64] floats, or nullptr): every lane also leaves what it computed - controls and state of
-// each step, violation, cost - in its column, and the workgroup copies the column of its best candidate to
+// `traced`: every lane also leaves what it computed - controls and state of each step, violation, cost - in its column
+// of an LDS block [5n + 2][64] at `trace_lds_floats`, and the workgroup copies the column of its best candidate to
 // `trace_out` (global, [5n + 2]): the fused finalize then assembles the winner's record out of the winning workgroup's
-// trace instead of drawing and rolling that candidate a second time (one wave, ~8 us of serial work, per round).
-// Returns nothing; rows: 2i, 2i + 1 = (v, kappa) of step i | 2n + 3i .. + 2 = state after step i | 5n = V | 5n + 1 = cost.
-// The tables the step loop reads at wave-uniform addresses come in as `restrict` kernel parameters (UniformTables):
-// the loop contains compiler markers (asm) and LDS stores, and only a pointer the compiler knows to be unaliased keeps
-// a read behind them on the scalar unit.
-struct UniformTables {
-  const float* __restrict__ coef;        // RolloutArgs::coef
-  const float* __restrict__ centre;      // SampleArgs::centre
-  const float* __restrict__ u_ref;       // SampleArgs::u_ref or nullptr
-  const float* __restrict__ weights;     // SampleSpec::segments
-  const float* __restrict__ prev_trace;  // SampleArgs::prev_trace
-};
+// trace instead of drawing and rolling that candidate a second time, and a following round finds its centre there.
+// Rows: 2i, 2i + 1 = (v, kappa) of step i | 2n + 3i .. + 2 = state after step i | 5n = V | 5n + 1 = cost.
+// (The trace is addressed off `s_fused` itself, not through a pointer that may be null: a select of pointers would lose
+// the LDS address space.)
+constexpr int kStagedSteps = 128;   // steps whose uniform operands travel through registers (longer horizons: the rest by a loop)
 
 template <int MODE>
-__device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const SampleArgs& smp, const UniformTables& tab,
-                                                     float* s_fused, const bool traced = false,
+__device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const SampleArgs& smp, float* s_fused,
+                                                     const int uniform_lds_floats, const bool traced = false,
                                                      const int trace_lds_floats = 0, float* trace_out = nullptr) {
-  // (the trace is addressed off `s_fused` itself, not through a pointer that may be null: a select of pointers would
-  // lose the LDS address space, its stores could then alias the tables, and the table reads would leave the scalar unit)
   float* s_trace = s_fused + trace_lds_floats;
   const int p = blockIdx.y;
   const int lane = threadIdx.x;
@@ -464,12 +443,11 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   const Weights w = a.w;
   const SampleSpec sp = smp.spec;
   constexpr int kStride = (MODE == 0) ? kCoefS : kCoefT;
-  const float* __restrict__ coef = tab.coef + static_cast<size_t>(p) * n * kStride;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
-  // centre, reference controls and knot weights sit at wave-uniform addresses: scalar loads, operands in SGPRs
-  const float* __restrict__ centre = tab.centre + static_cast<size_t>(p) * smp.centre_stride;
-  const float* __restrict__ ref = (tab.u_ref != nullptr) ? tab.u_ref + static_cast<size_t>(p) * n * 2 : centre;
-  const float* __restrict__ knot_weight = tab.weights;
+  const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
+  const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
+  const float* __restrict__ knot_weight = sp.segments;
   float* s_wp = s_fused;
   float* s_xy = s_wp + n * kCoefT;
   if constexpr (MODE == 1) {
@@ -481,10 +459,36 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     __syncthreads();
   }
 
-  // chained rounds: the previous launch's partial keys, four per lane, requested before the Philox draws below and
-  // reduced after them - the draws (a few microseconds of arithmetic that needs no centre) cover the round trip
-  int64_t prev_key[kChainBlocks / kWave];
+  // The wave-uniform operands of the steps - table rows, centre and reference controls, knot weights: 17 floats per
+  // step - go through LDS.  Read where they are needed they are scalar loads that miss this CU's cold scalar cache
+  // (58 lines at H = 50), and a lone wave has nothing to hide a miss behind: half of this kernel's wave-cycles were
+  // such waits.  Here the lanes fetch them side by side (one round trip, covered by the Philox draws below), and the
+  // step loop reads them back as broadcast LDS reads one step ahead of the arithmetic.
+  //   s_uni: [n][12] table rows (mode S) | [n][2] centre | [n][2] reference (or the centre again) | [n] knot weights
+  float* s_uni = s_fused + uniform_lds_floats;
+  float* s_row = s_uni;
+  float* s_centre = s_row + ((MODE == 0) ? n * kCoefS : 0);
+  float* s_ref = s_centre + 2 * n;
+  float* s_weight = s_ref + 2 * n;
   const bool chained = smp.prev_keys != nullptr;   // wave-uniform
+  constexpr int kRowQuads = (kStagedSteps * kCoefS / 4 + kWave - 1) / kWave;   // table quads per lane
+  constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;                    // (v, kappa) pairs per lane
+  f32x4 g_row[kRowQuads];
+  f32x2 g_centre[kPairs], g_ref[kPairs], g_weight[kPairs];
+#pragma unroll
+  for (int q = 0; q < kRowQuads; ++q) {
+    if constexpr (MODE == 0)
+      g_row[q] = reinterpret_cast<const f32x4*>(coef)[min(lane + q * kWave, n * (kCoefS / 4) - 1)];
+  }
+#pragma unroll
+  for (int q = 0; q < kPairs; ++q) {
+    const int j = min(lane + q * kWave, n - 1);
+    if (!chained) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[j];
+    if (ref != nullptr) g_ref[q] = reinterpret_cast<const f32x2*>(ref)[j];
+    g_weight[q] = reinterpret_cast<const f32x2*>(knot_weight)[j];   // (knot, weight) pairs: the weight is [1]
+  }
+  // chained rounds: the previous launch's partial keys, four per lane, requested with the rest
+  int64_t prev_key[kChainBlocks / kWave];
   if (chained) {
 #pragma unroll
     for (int q = 0; q < kChainBlocks / kWave; ++q) {
@@ -498,8 +502,10 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   bool feas = false;
   float z[kKnots][2] = {};
   const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
-  if (active) draw_normals(sp, gidx, static_cast<uint32_t>(p), z);
-  if (chained) {
+  // first half of the draws (covers the round trip of the requests above), then - chained - the winner of the previous
+  // round and the request for ITS controls, which the second half of the draws covers
+  if (active) draw_normals<0, kKnots / 4>(sp, gidx, static_cast<uint32_t>(p), z);
+  if (chained) {   // the previous round's winner: argmin over its workgroups' keys; its controls head that workgroup's trace
     int64_t best = kKeyMax;
     int block = 0;
 #pragma unroll
@@ -512,59 +518,78 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     const int64_t winner = wave_min_key(best);
     const unsigned long long holder = __ballot(best == winner);   // keys are distinct (they carry the index)
     block = __builtin_amdgcn_readlane(block, __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1));
-    centre = tab.prev_trace + (static_cast<size_t>(p) * smp.prev_blocks + block) * smp.prev_pitch;
-    if (tab.u_ref == nullptr) ref = centre;
+    centre = smp.prev_trace + (static_cast<size_t>(p) * smp.prev_blocks + block) * smp.prev_pitch;
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[min(lane + q * kWave, n - 1)];
   }
+  if (active) draw_normals<kKnots / 4, kKnots / 2>(sp, gidx, static_cast<uint32_t>(p), z);
+#pragma unroll
+  for (int q = 0; q < kRowQuads; ++q) {
+    if constexpr (MODE == 0) {
+      const int e = lane + q * kWave;
+      if (e < n * (kCoefS / 4)) reinterpret_cast<f32x4*>(s_row)[e] = g_row[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kPairs; ++q) {
+    const int j = lane + q * kWave;
+    if (j < n) {
+      reinterpret_cast<f32x2*>(s_centre)[j] = g_centre[q];
+      reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? g_ref[q] : g_centre[q];
+      s_weight[j] = g_weight[q][1];
+    }
+  }
+  if (n > kStagedSteps) {   // horizons beyond the registers' share: plain copies (a second round trip)
+    if constexpr (MODE == 0)
+      for (int e = lane + kRowQuads * kWave; e < n * (kCoefS / 4); e += kWave)
+        reinterpret_cast<f32x4*>(s_row)[e] = reinterpret_cast<const f32x4*>(coef)[e];
+    for (int j = lane + kPairs * kWave; j < n; j += kWave) {
+      const f32x2 cj = reinterpret_cast<const f32x2*>(centre)[j];
+      reinterpret_cast<f32x2*>(s_centre)[j] = cj;
+      reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? reinterpret_cast<const f32x2*>(ref)[j] : cj;
+      s_weight[j] = knot_weight[2 * j + 1];
+    }
+  }
+  __syncthreads();   // one wave: orders the staging above before the reads below
   if (active) {
     const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     StateS ss{x0[0], x0[1], x0[2], 0.0f, 0.0f};
     StateT ts{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
     int nearest = 0;
-    // The wave-uniform operands of a step - centre and reference controls, knot weight, the table row - are scalar
-    // loads, and a lone wave has nothing to hide their latency behind: three waits per step were 55 % of this kernel's
-    // wave-cycles.  So step i + 1's operands are requested before step i's arithmetic: arrived() marks where a set must
-    // be there (the one s_waitcnt, for everything outstanding, sits before the next set is requested - its index passes
-    // through the marker), and the arithmetic of the step then covers the next set's round trip.
-    constexpr int kRowS = 9;   // floats of a mode-S table row a step reads (the stride pads to 12)
     struct StepOperands {
-      float centre_v, centre_k, ref_v, ref_k, weight;
-      float row[kRowS];
+      f32x2 centre, ref;
+      float weight;
+      f32x4 lo, hi;   // table row (mode S): ds, a21, a31, b31 | f3, v_ref, k_ref, ey_lo
+      float last;     // ey_hi
     };
-    auto request = [&](int i, StepOperands& o) {
-      asm volatile("" : "+s"(i));                        // not before the marker of the set in use
-      const int j = min(i, n - 1);                        // the request behind the last step repeats it
-      o.centre_v = centre[2 * j];                         // both loaded, then selected:
-      o.centre_k = centre[2 * j + 1];                     // a select of ADDRESSES would go flat
-      o.ref_v = ref[2 * j];
-      o.ref_k = ref[2 * j + 1];
-      o.weight = knot_weight[2 * j + 1];
+    // (the request behind the last step reads inside the block - the next array, or the padding - and is never used)
+    auto request = [&](int i) {
+      StepOperands o;
+      o.centre = reinterpret_cast<const f32x2*>(s_centre)[i];
+      o.ref = reinterpret_cast<const f32x2*>(s_ref)[i];
+      o.weight = s_weight[i];
       if constexpr (MODE == 0) {
-#pragma unroll
-        for (int e = 0; e < kRowS; ++e) o.row[e] = coef[j * kCoefS + e];
+        o.lo = *reinterpret_cast<const f32x4*>(s_row + i * kCoefS);
+        o.hi = *reinterpret_cast<const f32x4*>(s_row + i * kCoefS + 4);
+        o.last = s_row[i * kCoefS + 8];
       }
+      return o;
     };
-    auto arrived = [&](StepOperands& o) {
-      asm volatile("" : "+s"(o.centre_v), "+s"(o.centre_k), "+s"(o.ref_v), "+s"(o.ref_k), "+s"(o.weight));
-      if constexpr (MODE == 0) {
-#pragma unroll
-        for (int e = 0; e < kRowS; ++e) asm volatile("" : "+s"(o.row[e]));
-      }
-    };
-    StepOperands now, next;
-    request(sp.knot_begin[0], now);
+    StepOperands now = request(sp.knot_begin[0]);
 #pragma unroll
     for (int knot = 0; knot < kKnots - 1; ++knot) {
 #pragma unroll 2
       for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
-        arrived(now);
-        request(i + 1, next);
+        const StepOperands next = request(i + 1);
         float v, k;
-        const float cv = use_ref ? now.ref_v : now.centre_v;
-        const float ck = use_ref ? now.ref_k : now.centre_k;
+        const float cv = use_ref ? now.ref[0] : now.centre[0];
+        const float ck = use_ref ? now.ref[1] : now.centre[1];
         blend_control(sp, amp, now.weight, cv, ck, z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1], v, k);
         if constexpr (MODE == 0) {
-          step_spatial<float>(ss, now.row, v, k, w);
+          const float row[9] = {now.lo[0], now.lo[1], now.lo[2], now.lo[3], now.hi[0],
+                                now.hi[1], now.hi[2], now.hi[3], now.last};
+          step_spatial<float>(ss, row, v, k, w);
         } else {
           nearest = step_temporal(ts, s_wp, s_xy, n, v, k, w, nearest);
         }
@@ -926,19 +951,15 @@ __device__ __forceinline__ void finalize_from_trace(const RolloutArgs& a, const 
 }
 
 // LDS: [rollout part: mode T tables] [trace [5n + 2][64], or - no trace - the finalize's record image (+ mode T table)]
+//      [uniform operands of the steps: sampled_uniform_floats()]
 template <int MODE>
 __global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArgs a, const SampleArgs smp,
                                                                 const FusedFinalize fused, const int rollout_lds_floats,
-                                                                const float* __restrict__ coef,
-                                                                const float* __restrict__ centre,
-                                                                const float* __restrict__ u_ref,
-                                                                const float* __restrict__ weights,
-                                                                const float* __restrict__ prev_trace) {
+                                                                const int uniform_lds_floats) {
   extern __shared__ __attribute__((aligned(16))) float s_fused[];
   const int p = blockIdx.y;
   const bool traced = fused.trace != nullptr;
-  const UniformTables tab{coef, centre, u_ref, weights, prev_trace};
-  rollout_sampled_body<MODE>(a, smp, tab, s_fused, traced, rollout_lds_floats,
+  rollout_sampled_body<MODE>(a, smp, s_fused, uniform_lds_floats, traced, rollout_lds_floats,
                              fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch);
   if (fused.tickets == nullptr) return;
   // Last-workgroup-done, in two levels: a workgroup publishes its partials (and trace) device-wide and takes a ticket
@@ -1288,6 +1309,11 @@ namespace {
 size_t sampled_rollout_floats(int mode, int n) {
   return (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + 2) + 3) & ~static_cast<size_t>(3)) : 0;
 }
+// uniform operands of the steps staged in LDS: [n][12] table rows (mode S), centre, reference, knot weights (+ padding
+// for the read one step past the end)
+size_t sampled_uniform_floats(int mode, int n) {
+  return static_cast<size_t>(n) * ((mode == 0 ? kCoefS : 0) + 5) + 4;
+}
 size_t sampled_finalize_floats(int mode, int n) {
   const size_t rec_floats = static_cast<size_t>(4 + 2 * n + 3 * (n + 1));
   return ((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? static_cast<size_t>(n) * kCoefT : 0);
@@ -1295,14 +1321,16 @@ size_t sampled_finalize_floats(int mode, int n) {
 }  // namespace
 
 bool fused_finalize_fits(int mode, int n) {
-  return (sampled_rollout_floats(mode, n) + sampled_finalize_floats(mode, n)) * sizeof(float) <= 64 * 1024;
+  return (sampled_rollout_floats(mode, n) + sampled_finalize_floats(mode, n) + sampled_uniform_floats(mode, n)) *
+             sizeof(float) <= 64 * 1024;
 }
 
 int trace_floats(int n) { return 5 * n + 2; }
 
 // The traced form keeps [5n + 2][64] floats in LDS per workgroup (63 kB at H = 50): up to the CU's 160 kB.
 bool traced_finalize_fits(int mode, int n) {
-  return (sampled_rollout_floats(mode, n) + static_cast<size_t>(trace_floats(n)) * kWave) * sizeof(float) <= 160 * 1024;
+  return (sampled_rollout_floats(mode, n) + static_cast<size_t>(trace_floats(n)) * kWave +
+          sampled_uniform_floats(mode, n)) * sizeof(float) <= 160 * 1024;
 }
 
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
@@ -1315,8 +1343,10 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
   const size_t finalize_floats = traced                     ? static_cast<size_t>(trace_floats(n)) * kWave
                                  : fused.tickets != nullptr ? sampled_finalize_floats(mode, n)
                                                             : 0;
-  const size_t lds = (rollout_floats + finalize_floats) * sizeof(float);
-  if (lds > (traced ? 160u : 64u) * 1024u) return hipErrorInvalidValue;  // callers check *_fits() first
+  const size_t uniform_floats = sampled_uniform_floats(mode, n);
+  const size_t lds = (rollout_floats + finalize_floats + uniform_floats) * sizeof(float);
+  if (lds > 160u * 1024u) return hipErrorInvalidValue;  // callers check *_fits() first
+  const int uniform_offset = static_cast<int>(rollout_floats + finalize_floats);
   if (traced && fused.trace_pitch < trace_floats(n)) return hipErrorInvalidValue;
   const int offset = static_cast<int>(rollout_floats);
   if (mode != 0 && mode != 1) return hipErrorInvalidValue;
@@ -1336,11 +1366,9 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
     }
   }
   if (mode == 0) {
-    hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, rollout.coef,
-                       sample.centre, sample.u_ref, sample.spec.segments, sample.prev_trace);
+    hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, uniform_offset);
   } else {
-    hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, rollout.coef,
-                       sample.centre, sample.u_ref, sample.spec.segments, sample.prev_trace);
+    hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, uniform_offset);
   }
   return hipGetLastError();
 }

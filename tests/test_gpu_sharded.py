@@ -216,6 +216,42 @@ def test_optimize_equals_the_manual_round_loop(mode, window, P, H, N, rounds):
         assert (b <= a).all()
 
 
+@pytest.mark.parametrize("mode,window,P,H,N,rounds", [
+    (0, None, 1, 50, 16384, 3),     # the closed-loop shape: 256 workgroups, chained rounds
+    (0, None, 2, 150, 4096, 3),     # horizon beyond the register-staged operands (the loop behind them)
+    (1, (2, 5), 2, 50, 4096, 3),    # mode T: tables + trace need more than the default 64 kB of LDS
+    (0, None, 1, 50, 16448, 2),     # 257 workgroups: traced, but one too many for the chained form
+    (0, None, 3, 80, 1000, 4),      # ragged last wave, several problems
+])
+def test_optimize_forms_agree(mode, window, P, H, N, rounds, monkeypatch):
+    """The fused rounds come in three forms - the record copied out of the winning workgroup's trace with the rounds
+    chained through the previous launch's keys (default), traced but every round finalized, and the winner re-drawn and
+    re-rolled by the last workgroup - and all three write the same records, bit for bit."""
+    from acmpc_amd import Engine
+    n = H - 1
+    problems = [make_problem(orc, "silverstone", H, 4, seed=900 + p) for p in range(P)]
+    u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]).astype(np.float32)
+    x0 = np.stack([p["x0"] if mode == 0 else p["pose0"] for p in problems])
+
+    def solve():
+        eng = Engine(**engine_kwargs(problems[0], mode, P, N, n, nn_window=window))
+        eng.set_paths(np.stack([p["table"] for p in problems]))
+        first = eng.optimize(x0, u_ref, u_ref, N, rounds, (3.0, 0.01), shrink=0.5, seed=7)["records"].copy()
+        again = eng.optimize(x0, u_ref, None, N, rounds, (1.0, 0.005), shrink=0.5, seed=8)["records"].copy()
+        eng.close()
+        return first, again
+
+    default = solve()
+    monkeypatch.setenv("ACMPC_NO_CHAINED_ROUNDS", "1")
+    unchained = solve()
+    monkeypatch.setenv("ACMPC_NO_TRACED_FINALIZE", "1")
+    rerolled = solve()
+    for a, b, c in zip(default, unchained, rerolled):
+        assert np.isfinite(a[:, 0]).all()
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, c)
+
+
 def test_softmin_centre_update_equals_the_manual_round_loop():
     """centre_update="softmin": each round samples round the softmin-weighted mean of the previous round and keeps
     the previous winner as candidate 1; equals the loop built from sample/solve/softmin device calls bit for bit, the
