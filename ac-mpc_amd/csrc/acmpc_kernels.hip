@@ -950,17 +950,11 @@ __device__ __forceinline__ void finalize_from_trace(const RolloutArgs& a, const 
   }
 }
 
-// LDS: [rollout part: mode T tables] [trace [5n + 2][64], or - no trace - the finalize's record image (+ mode T table)]
-//      [uniform operands of the steps: sampled_uniform_floats()]
+// Optional tail of a fused round (one wave, threadIdx.x = its lanes): see FusedFinalize.
 template <int MODE>
-__global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArgs a, const SampleArgs smp,
-                                                                const FusedFinalize fused, const int rollout_lds_floats,
-                                                                const int uniform_lds_floats) {
-  extern __shared__ __attribute__((aligned(16))) float s_fused[];
+__device__ __forceinline__ void fused_tail(const RolloutArgs& a, const SampleArgs& smp, const FusedFinalize& fused,
+                                           const bool traced, float* s_finalize) {
   const int p = blockIdx.y;
-  const bool traced = fused.trace != nullptr;
-  rollout_sampled_body<MODE>(a, smp, s_fused, uniform_lds_floats, traced, rollout_lds_floats,
-                             fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch);
   if (fused.tickets == nullptr) return;
   // Last-workgroup-done, in two levels: a workgroup publishes its partials (and trace) device-wide and takes a ticket
   // of its group (workgroup index mod 8); the last of a group takes a ticket of the problem; the last of those knows
@@ -1012,8 +1006,222 @@ __global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArg
   f.n = a.n;
   f.index_offset = a.index_offset;
   f.w = a.w;
-  finalize_problem<MODE, 1>(f, p, s_fused + rollout_lds_floats);
+  finalize_problem<MODE, 1>(f, p, s_finalize);
   signal_done();
+}
+
+// LDS: [rollout part: mode T tables] [trace [5n + 2][64], or - no trace - the finalize's record image (+ mode T table)]
+//      [uniform operands of the steps: sampled_uniform_floats()]
+template <int MODE>
+__global__ void __launch_bounds__(kWave) rollout_sampled_kernel(const RolloutArgs a, const SampleArgs smp,
+                                                                const FusedFinalize fused, const int rollout_lds_floats,
+                                                                const int uniform_lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float s_fused[];
+  const int p = blockIdx.y;
+  const bool traced = fused.trace != nullptr;
+  rollout_sampled_body<MODE>(a, smp, s_fused, uniform_lds_floats, traced, rollout_lds_floats,
+                             fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch);
+  fused_tail<MODE>(a, smp, fused, traced, s_fused + rollout_lds_floats);
+}
+
+// The traced mode-S round on TWO waves per workgroup.  A round at the closed-loop size is one wave per CU walking a serial
+// stream of ~5 700 instructions, three SIMDs of its CU idle, and the stream falls into two parts that only meet in
+// (v, kappa): drawing the normals and blending them into the controls of each step, and rolling those controls.  Here
+// wave 1 - the producer - draws and blends, running ahead through the horizon and handing (v, kappa) per step and lane
+// over through LDS in chunks of kPairChunk steps, two buffers; wave 0 - the consumer - rolls them (step_spatial, the
+// same call) one chunk behind, one barrier per chunk, and then reduces, publishes and runs the tail as the single-wave
+// kernel does.  Same operations on the same operands: same bits (test_optimize_forms_agree).
+// LDS: [trace [5n + 2][64]] [uniform operands] [exchange [2][kPairChunk][2][64]].
+constexpr int kPairChunk = 7;
+constexpr int kPairValues = 2;
+
+__global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const RolloutArgs a, const SampleArgs smp,
+                                                                         const FusedFinalize fused,
+                                                                         const int uniform_lds_floats,
+                                                                         const int exchange_lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float s_fused[];
+  float* s_trace = s_fused;
+  float* s_row = s_fused + uniform_lds_floats;
+  const int p = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool consumer = threadIdx.x < kWave;   // wave 0 (so that the tail's threadIdx.x are its lanes)
+  const int n = a.n;
+  float* s_centre = s_row + n * kCoefS;
+  float* s_ref = s_centre + 2 * n;
+  float* s_weight = s_ref + 2 * n;
+  float* s_exchange = s_fused + exchange_lds_floats + lane;   // [buffer][step of the chunk][v | kappa][lane]
+  constexpr int kStepFloats = kPairValues * kWave, kBufferFloats = kPairChunk * kStepFloats;
+  const int c = blockIdx.x * kWave + lane;
+  const bool active = c < a.N;
+  const Weights w = a.w;
+
+  if (!consumer) {
+    // ---- producer: requests, draws, the uniform operands of ITS half into LDS, then the controls chunk by chunk ----
+    const SampleSpec sp = smp.spec;
+    const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
+    const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ knot_weight = sp.segments;
+    const bool chained = smp.prev_keys != nullptr;
+    constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
+    f32x2 g_centre[kPairs], g_ref[kPairs], g_weight[kPairs];
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q) {
+      const int j = min(lane + q * kWave, n - 1);
+      if (!chained) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[j];
+      if (ref != nullptr) g_ref[q] = reinterpret_cast<const f32x2*>(ref)[j];
+      g_weight[q] = reinterpret_cast<const f32x2*>(knot_weight)[j];
+    }
+    int64_t prev_key[kChainBlocks / kWave];
+    if (chained) {
+#pragma unroll
+      for (int q = 0; q < kChainBlocks / kWave; ++q)
+        prev_key[q] = smp.prev_keys[static_cast<size_t>(p) * smp.prev_blocks + min(lane + q * kWave, smp.prev_blocks - 1)];
+    }
+    float z[kKnots][2] = {};
+    const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
+    draw_normals<0, kKnots / 4>(sp, gidx, static_cast<uint32_t>(p), z);
+    if (chained) {
+      int64_t best = kKeyMax;
+      int block = 0;
+#pragma unroll
+      for (int q = 0; q < kChainBlocks / kWave; ++q) {
+        const int b = lane + q * kWave;
+        const int64_t kb = (b < smp.prev_blocks) ? prev_key[q] : kKeyMax;
+        block = (kb < best) ? b : block;
+        best = (kb < best) ? kb : best;
+      }
+      const int64_t winner = wave_min_key(best);
+      const unsigned long long holder = __ballot(best == winner);
+      block = __builtin_amdgcn_readlane(block, __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1));
+      centre = smp.prev_trace + (static_cast<size_t>(p) * smp.prev_blocks + block) * smp.prev_pitch;
+#pragma unroll
+      for (int q = 0; q < kPairs; ++q) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[min(lane + q * kWave, n - 1)];
+    }
+    draw_normals<kKnots / 4, kKnots / 2>(sp, gidx, static_cast<uint32_t>(p), z);
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q) {
+      const int j = lane + q * kWave;
+      if (j < n) {
+        reinterpret_cast<f32x2*>(s_centre)[j] = g_centre[q];
+        reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? g_ref[q] : g_centre[q];
+        s_weight[j] = g_weight[q][1];
+      }
+    }
+    for (int j = lane + kPairs * kWave; j < n; j += kWave) {   // horizons beyond the registers' share
+      const f32x2 cj = reinterpret_cast<const f32x2*>(centre)[j];
+      reinterpret_cast<f32x2*>(s_centre)[j] = cj;
+      reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? reinterpret_cast<const f32x2*>(ref)[j] : cj;
+      s_weight[j] = knot_weight[2 * j + 1];
+    }
+    __syncthreads();   // (0) the consumer has put the table rows in, this wave the rest
+    const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
+    const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
+    struct Operands {
+      f32x2 centre, ref;
+      float weight;
+    };
+    auto request = [&](int i) {   // (one step past the end is read - inside the block - and never used)
+      Operands o;
+      o.centre = reinterpret_cast<const f32x2*>(s_centre)[i];
+      o.ref = reinterpret_cast<const f32x2*>(s_ref)[i];
+      o.weight = s_weight[i];
+      return o;
+    };
+    Operands now = request(sp.knot_begin[0]);
+    float* out = s_exchange;          // slot of the step being produced
+    float* u_out = s_trace + lane;    // its place in the trace (rows 2i, 2i + 1)
+    int in_chunk = 0, buffer = 0;
+#pragma unroll
+    for (int knot = 0; knot < kKnots - 1; ++knot) {
+      for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
+        const Operands next = request(i + 1);
+        float v, k;
+        const float cv = use_ref ? now.ref[0] : now.centre[0];
+        const float ck = use_ref ? now.ref[1] : now.centre[1];
+        blend_control(sp, amp, now.weight, cv, ck, z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1], v, k);
+        out[0] = v;
+        out[kWave] = k;
+        u_out[0] = v;
+        u_out[kWave] = k;
+        now = next;
+        out += kStepFloats;
+        u_out += 2 * kWave;
+        if (++in_chunk == kPairChunk || i == n - 1) {   // chunk handed over (wave-uniform)
+          __syncthreads();
+          in_chunk = 0;
+          buffer ^= 1;
+          out = s_exchange + buffer * kBufferFloats;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- consumer: table rows into LDS, then the rollout one chunk behind the producer ----
+  {
+    const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kCoefS;
+    for (int q = lane; q < n * (kCoefS / 4); q += kWave)
+      reinterpret_cast<f32x4*>(s_row)[q] = reinterpret_cast<const f32x4*>(coef)[q];
+  }
+  const float* __restrict__ x0 = a.x0 + p * 3;
+  StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+  __syncthreads();   // (0)
+  struct StepInputs {
+    float v, k;
+    f32x4 lo, hi;
+    float last;
+  };
+  auto inputs_of = [&](const float* in, int i) {
+    StepInputs s;
+    s.v = in[0];
+    s.k = in[kWave];
+    const float* t = s_row + i * kCoefS;
+    s.lo = *reinterpret_cast<const f32x4*>(t);
+    s.hi = *reinterpret_cast<const f32x4*>(t + 4);
+    s.last = t[8];
+    return s;
+  };
+  auto advance = [&](int i, const StepInputs& in) {
+    const float row[9] = {in.lo[0], in.lo[1], in.lo[2], in.lo[3], in.hi[0], in.hi[1], in.hi[2], in.hi[3], in.last};
+    step_spatial<float>(st, row, in.v, in.k, w);
+    s_trace[(2 * n + 3 * i) * kWave + lane] = st.ey;
+    s_trace[(2 * n + 3 * i + 1) * kWave + lane] = st.ep;
+    s_trace[(2 * n + 3 * i + 2) * kWave + lane] = st.t;
+  };
+  for (int first = 0, buffer = 0; first < n; first += kPairChunk, buffer ^= 1) {
+    __syncthreads();   // this chunk is in its buffer (and the producer may start on the other one)
+    const float* in = s_exchange + buffer * kBufferFloats;
+    if (first + kPairChunk <= n) {   // a full chunk, straight-line: every step's reads can move ahead of the arithmetic
+      StepInputs steps[kPairChunk];
+#pragma unroll
+      for (int j = 0; j < kPairChunk; ++j) steps[j] = inputs_of(in + j * kStepFloats, first + j);
+#pragma unroll
+      for (int j = 0; j < kPairChunk; ++j) advance(first + j, steps[j]);
+    } else {
+      for (int j = 0; first + j < n; ++j) advance(first + j, inputs_of(in + j * kStepFloats, first + j));
+    }
+  }
+  const float cost = finish_spatial<float>(st, w);
+  s_trace[(5 * n) * kWave + lane] = st.V;
+  s_trace[(5 * n + 1) * kWave + lane] = cost;
+  if (active && a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c] = cost;
+  const int64_t own_key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
+  int nfeas = (active && st.V == 0.0f) ? 1 : 0;
+  const int64_t key = wave_min_key(own_key);
+  nfeas = wave_sum_int(nfeas);
+  {
+    const unsigned long long holder = __ballot(own_key == key);
+    const int best_lane = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1);
+    __syncthreads();   // this wave alone by now: orders its column writes before the row reads
+    float* trace_out = fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch;
+    for (int e = lane; e < 5 * n + 2; e += kWave) publish(&trace_out[e], s_trace[e * kWave + best_lane]);
+  }
+  if (lane == 0) {
+    const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;
+    publish(&a.partial_keys[slot], key);
+    publish(&a.partial_feas[slot], nfeas);
+  }
+  fused_tail<0>(a, smp, fused, true, nullptr);
 }
 
 // ---- softmin-weighted mean -------------------------------------------------------------------------------
@@ -1333,6 +1541,22 @@ bool traced_finalize_fits(int mode, int n) {
           sampled_uniform_floats(mode, n)) * sizeof(float) <= 160 * 1024;
 }
 
+// More dynamic LDS than a kernel gets by default (64 kB): raise the kernel's limit, once per kernel and device.
+static hipError_t raise_lds_limit(const void* kernel, int which, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  static bool raised[3][64] = {};
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+  if (!raised[which][device]) {
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    raised[which][device] = true;
+  }
+  return hipSuccess;
+}
+
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
                                   const FusedFinalize& fused, hipStream_t s) {
   clear_stale_error();
@@ -1350,19 +1574,23 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
   if (traced && fused.trace_pitch < trace_floats(n)) return hipErrorInvalidValue;
   const int offset = static_cast<int>(rollout_floats);
   if (mode != 0 && mode != 1) return hipErrorInvalidValue;
-  if (lds > 64 * 1024) {   // more dynamic LDS than a kernel gets by default: raise the kernel's limit once per device
-    static bool raised[2][64] = {};
-    int device = 0;
-    hipError_t e = hipGetDevice(&device);
+  {
+    const hipError_t e = raise_lds_limit(mode == 0 ? reinterpret_cast<const void*>(&rollout_sampled_kernel<0>)
+                                                   : reinterpret_cast<const void*>(&rollout_sampled_kernel<1>),
+                                         mode, lds);
     if (e != hipSuccess) return e;
-    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
-    if (!raised[mode][device]) {
-      e = (mode == 0) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_sampled_kernel<0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                      : hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_sampled_kernel<1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  if (mode == 0 && traced && std::getenv("ACMPC_NO_PAIR_ROUNDS") == nullptr) {
+    // two waves per workgroup: trace | uniform operands | exchange buffers (no mode T tables, no record image)
+    const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
+    const size_t exchange = static_cast<size_t>(2) * kPairChunk * kPairValues * kWave;
+    const size_t pair_lds = (trace + uniform_floats + exchange) * sizeof(float);
+    if (pair_lds <= 160u * 1024u) {
+      hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&rollout_sampled_pair_kernel), 2, pair_lds);
       if (e != hipSuccess) return e;
-      raised[mode][device] = true;
+      hipLaunchKernelGGL(rollout_sampled_pair_kernel, grid, dim3(2 * kWave), pair_lds, s, rollout, sample, fused,
+                         static_cast<int>(trace), static_cast<int>(trace + uniform_floats));
+      return hipGetLastError();
     }
   }
   if (mode == 0) {

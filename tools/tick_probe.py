@@ -1,12 +1,15 @@
+"""Development probe (GPU box): closed-loop get_control latency on consecutive poses (TICK_H = horizon, default 50)."""
 import copy, os, sys, time
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, os.path.join(ROOT, "ac-mpc_amd"))
 from acmpc_amd import workloads
 from acmpc_amd.mpc import build_mpc
+H = int(os.environ.get("TICK_H", "50"))
 track = workloads.synthetic_track("silverstone")
-paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % len(track["centre"])), 50) for i in range(1520)]
+paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % len(track["centre"])), H) for i in range(1520)]
 cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"])
+cfg["horizon"] = H
 cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
 mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
 for p in paths[:20]: mpc.get_control(p)
