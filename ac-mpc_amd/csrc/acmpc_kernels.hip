@@ -678,6 +678,20 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
   const int lane = threadIdx.x;
   const int n = a.n;
 
+  // (mode S) lane l's table row of the first 64 steps and the start state do not depend on who won: requested first,
+  // they travel together with the partial keys instead of after the argmin
+  float row_first[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  float x0_first[3] = {0.0f, 0.0f, 0.0f};
+  if constexpr (MODE == 0) {
+    if (a.records != nullptr) {
+      const float* __restrict__ coef_p = a.coef + static_cast<size_t>(p) * n * kCoefS;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) row_first[q] = coef_p[min(lane, n - 1) * kCoefS + q];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) x0_first[q] = a.x0[p * 3 + q];
+    }
+  }
+
   int nfeas = 0;
   int64_t key = kKeyMax;
   for (int b = lane; b < a.blocks_per_problem; b += kWave) {
@@ -755,7 +769,7 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
     // lock-step on broadcast inputs); everything that hangs off a state - stage cost, the four bound terms - is
     // evaluated by lane i for step i in parallel, and the partial results are then accumulated in step order so
     // that J and V see exactly the additions of step_spatial(), in the same order.
-    float ey = x0[0], ep = x0[1], t = x0[2], J = 0.0f, V = 0.0f;
+    float ey = x0_first[0], ep = x0_first[1], t = x0_first[2], J = 0.0f, V = 0.0f;
     for (int base = 0; base < n; base += kWave) {
       const int mine = base + lane;
       const bool valid = mine < n;
@@ -764,7 +778,7 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
       if (valid) {
         winner_control(mine, v[0], k[0]);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) row[q] = coef[mine * kCoefS + q];
+        for (int q = 0; q < 9; ++q) row[q] = (base == 0) ? row_first[q] : coef[mine * kCoefS + q];
         su[2 * mine] = v[0];
         su[2 * mine + 1] = k[0];
       }
