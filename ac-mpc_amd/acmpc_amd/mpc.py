@@ -170,16 +170,14 @@ class SpatialMPC:
         """The same solve as one round trip (`acmpc_control_tick`): waypoints, speed profile, Frenet start state and
         linearisation run on the device in front of the sampling rounds; this method only keeps the reference's
         bookkeeping (spatial_mpc.py:98-122,193-217)."""
-        coords = None
-        if reference_path is not None:
-            coords = np.ascontiguousarray(reference_path, dtype=np.float64)
-            if coords.shape != (self.MPC_horizon, 3):
-                raise ValueError("reference_path must be %d x 3" % self.MPC_horizon)
+        coords = reference_path
+        if coords is not None and np.shape(coords) != (self.MPC_horizon, 3):
+            raise ValueError("reference_path must be %d x 3" % self.MPC_horizon)
         out, status, _ = self._control_solver.solve_tick(coords, float(offset), self.speed_profile_constraints,
                                                          is_localised, qp_max_iter=MAX_SOLVER_ITERATIONS,
                                                          qp_check_every=self._qp_check_every, **from_map)
         self.reference_coordinates = out["coords"]
-        path = ReferencePath.from_table(out["table"])
+        path = ReferencePath.adopt(out["table"])   # a view of this tick's own snapshot
         if out["info"][4] == 0.0:
             self.speed_profile = path.velocities.copy()
         else:  # the path keeps the velocities it was built with (spatial_mpc.py:119-122)

@@ -34,6 +34,15 @@ class ReferencePath:
         path._reference_path[:] = table
         return path
 
+    @classmethod
+    def adopt(cls, table: np.ndarray) -> "ReferencePath":
+        """A path that takes `table` (7 x n float64, C-contiguous) as its storage without copying it: for a table
+        nobody else writes to."""
+        path = cls.__new__(cls)
+        path._n_positions = table.shape[1]
+        path._reference_path = table
+        return path
+
     @property
     def table(self) -> np.ndarray:
         return self._reference_path
