@@ -145,6 +145,40 @@ def test_tick_equals_set_paths_plus_optimize():
     eng.close()
 
 
+def test_tick_forms_agree(monkeypatch):
+    """However the tick is run - completion flag polled in pinned memory (default) or the stream synchronised, rounds on
+    two waves per workgroup or one, chained or each finalized, the winner copied from its trace or rolled again - a
+    sequence of warm-started ticks returns the same numbers."""
+    cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=28.0)
+    n = 49
+    paths = [np.stack([0.004 * (1 + 0.1 * j) * np.linspace(0, 120, 50) ** 2, np.linspace(0, 120, 50),
+                       np.linspace(10, 6, 50)], axis=1) for j in range(4)]
+
+    def run():
+        eng, _, _ = _engine(n, n_candidates=16384)
+        outs, centre = [], None
+        for j, coords in enumerate(paths):
+            t = _tick(50, cons, n_candidates=16384, rounds=2, offset=0.1 * j, seed=5 + j)
+            t.centre_is_reference = 1 if centre is None else 0
+            out = eng.control_tick(t, coords, centre)
+            centre = out["decision"][3 * (n + 1):].reshape(n, 2).astype(np.float32)
+            outs.append(out)
+        eng.close()
+        return outs
+
+    reference = run()
+    for switches in (("ACMPC_TICK_NO_FLAG",), ("ACMPC_NO_PAIR_ROUNDS",), ("ACMPC_NO_PAIR_ROUNDS", "ACMPC_NO_CHAINED_ROUNDS"),
+                     ("ACMPC_NO_TRACED_FINALIZE",)):
+        for name in switches:
+            monkeypatch.setenv(name, "1")
+        for want, got in zip(reference, run()):
+            for key in ("record", "table", "decision", "projected_control", "prediction", "cum_time", "coords"):
+                np.testing.assert_array_equal(want[key], got[key], err_msg="%s with %s" % (key, switches))
+            np.testing.assert_array_equal(want["info"][:6], got["info"][:6])
+        for name in switches:
+            monkeypatch.delenv(name)
+
+
 def test_warm_state_lives_on_the_device_per_solver():
     """Second tick of the same solver warm-starts from the first (10 iterations instead of ~100); the localised
     solver has its own state; an iteration cap the solve cannot meet leaves the velocities at zero, as the reference
