@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development probe (GPU box): SQ counter passes of ONE tools/sweep.py spec (any kernel), plus the un-profiled timing.
-# usage: tools/pmc_sweep.sh <name> <spec>      (environment switches such as ACMPC_NO_STREAM_TILE=1 are inherited)
+# usage: tools/pmc_sweep.sh <name> <spec>      (environment switches such as ACMPC_NO_TILE=1 are inherited)
 # -> gpurun_out/pmc_<name>_{a,b,c}/ (raw), gpurun_out/pmc_<name>.log
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -10,6 +10,8 @@ track = workloads.synthetic_track("silverstone")
 paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % len(track["centre"])), H) for i in range(1520)]
 cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"])
 cfg["horizon"] = H
+if "TICK_CHECK" in os.environ:
+    cfg["speed_profile_check_every"] = int(os.environ["TICK_CHECK"])
 cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
 mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
 for p in paths[:20]: mpc.get_control(p)
