@@ -110,6 +110,24 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   double* s_coords = qy + 2 * n + admm::workspace_doubles(n);   // [H][3]: the path when it comes from the map
   const double* __restrict__ coords = a.coords;
   const WaveTeam team;
+  // Requested now, used at the end: the previous plan (pinned host memory: a trip over the host link) and the previous
+  // iterate of the speed-profile solver (device memory).  Read where they are needed, each was a wait of its own on the
+  // one wavefront's critical path; this way they arrive while the waypoints are built.  (Lane i holds entries i, i + 64.)
+  constexpr int kPerLane = (kPrologueMaxSteps + 63) / 64;
+  float centre_in_v[kPerLane], centre_in_k[kPerLane];
+  double warm_v[kPerLane], warm_y[2 * kPerLane];
+  double* state = a.warm_state + static_cast<size_t>(h.localised != 0 ? 1 : 0) * a.warm_stride;
+  const double warm_flag = state[0], warm_n = state[1];
+#pragma unroll
+  for (int q = 0; q < kPerLane; ++q) {
+    const int i = min(lane + 64 * q, n - 1);
+    centre_in_v[q] = (h.centre_is_reference != 0) ? 0.0f : a.centre_in[2 * i];
+    centre_in_k[q] = (h.centre_is_reference != 0) ? 0.0f : a.centre_in[2 * i + 1];
+    warm_v[q] = (a.warm_capacity >= n) ? state[2 + i] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 2 * kPerLane; ++q)
+    warm_y[q] = (a.warm_capacity >= n) ? state[2 + n + min(lane + 64 * q, 2 * n - 2)] : 0.0;
   if (h.use_map != 0) {
     // the reference path cut out of the bound map by this wavefront itself (no launch in front of the prologue)
     int first = (h.map_index < 0) ? a.map_first[0] : h.map_index;
@@ -171,12 +189,15 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     v_hi[i] = c;
   }
   // ---- speed-profile QP, warm-started from the previous tick's iterate of the same solver ----------------------------
-  double* state = a.warm_state + static_cast<size_t>(h.localised != 0 ? 1 : 0) * a.warm_stride;
   // state: [valid, n] [v n] [y 2n - 1]
-  const bool warm = state[0] == 1.0 && state[1] == static_cast<double>(n) && a.warm_capacity >= n;
+  const bool warm = warm_flag == 1.0 && warm_n == static_cast<double>(n) && a.warm_capacity >= n;
   if (warm) {
-    for (int i = lane; i < n; i += 64) qv[i] = state[2 + i];
-    for (int i = lane; i < 2 * n - 1; i += 64) qy[i] = state[2 + n + i];
+#pragma unroll
+    for (int q = 0; q < kPerLane; ++q)
+      if (lane + 64 * q < n) qv[lane + 64 * q] = warm_v[q];
+#pragma unroll
+    for (int q = 0; q < 2 * kPerLane; ++q)
+      if (lane + 64 * q < 2 * n - 1) qy[lane + 64 * q] = warm_y[q];
   }
   team.sync();
   const admm::Settings settings{h.a_min, h.a_max, h.v_min, h.qp_max_iter, h.qp_check_every > 0 ? h.qp_check_every : 10,
@@ -208,7 +229,10 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     a.seed[1] = h.seed_hi;
   }
   // ---- linearise + corridor rows + reference controls, rounded once to float32 (as acmpc_set_paths does) --------------
-  for (int i = lane; i < n; i += 64) {
+#pragma unroll
+  for (int q = 0; q < kPerLane; ++q) {
+    const int i = lane + 64 * q;
+    if (i >= n) break;
     const double v = tv[i], ds = tds[i], kappa = tkappa[i], width = twidth[i];
     const double vds = v * ds + 1e-12;
     float* out = a.coef + static_cast<size_t>(i) * 12;
@@ -229,8 +253,8 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     a.u_ref[2 * i] = static_cast<float>(uv);
     a.u_ref[2 * i + 1] = static_cast<float>(uk);
     // a solve without a previous plan samples round the reference controls
-    a.centre[2 * i] = (h.centre_is_reference != 0) ? static_cast<float>(uv) : a.centre_in[2 * i];
-    a.centre[2 * i + 1] = (h.centre_is_reference != 0) ? static_cast<float>(uk) : a.centre_in[2 * i + 1];
+    a.centre[2 * i] = (h.centre_is_reference != 0) ? static_cast<float>(uv) : centre_in_v[q];
+    a.centre[2 * i + 1] = (h.centre_is_reference != 0) ? static_cast<float>(uk) : centre_in_k[q];
   }
   // the 7 x n table for the caller (pinned host memory: posted writes, visible once the stream has drained)
   for (int e = lane; e < 7 * n; e += 64) a.table_out[e] = table[e];
