@@ -416,6 +416,47 @@ def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
     return out
 
 
+def sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_rank, device, backend, solves=200):
+    """The second half of BASELINE.json's metric at N > 1 GPUs: BASELINE configs[3] as ONE sharded solve - 262 144
+    candidates x horizon 80 in total, 262 144 / N per rank - one call at a time: this rank's rollout, the all-reduce(MIN)
+    of the packed key over the ranks, the winner's record on every rank; barrier before, drained after, max over the
+    ranks per solve.  Run by every rank (it contains collectives), reported by rank 0."""
+    track, H, total = "nordschleife", 80, 262144
+    n, N = H - 1, total // world
+    batch = workloads.problem_batch(track, 1, H, seed=0)
+    engine = Engine(**workloads.engine_kwargs(batch, 0, N, device=local_rank))
+    engine.set_paths(batch.tables)
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.sync_tables(stream)
+    x0 = torch.tensor(batch.x0, device=device)
+    u_ref = torch.tensor(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=torch.float32,
+                         device=device).contiguous()
+    U = torch.empty((1, n, 2, N), dtype=torch.float32, device=device)
+    engine.sample_device(u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), 1, N, n, 1, rank * N, SAMPLE_SIGMA, 1000, 0,
+                         U.data_ptr(), stream)
+    slot = ShardedRollout(engine, 1, N, n, 1, index_offset=rank * N, device=device, host_collectives=backend == "gloo")
+    slot.use_sampler(u_ref, u_ref, SAMPLE_SIGMA, 1000, 0)
+    warm = 10
+    lat = np.empty(warm + solves)
+    for i in range(lat.shape[0]):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        slot.rollout(x0, U, stream)
+        slot.select(x0, U, stream, seed=1000)
+        torch.cuda.synchronize()
+        lat[i] = time.perf_counter() - t0
+    t = torch.tensor(lat[warm:], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    lat = t.cpu().numpy()
+    engine.close()
+    return {"workload": "%s (synthetic circuit), BASELINE configs[3] as one sharded solve: %d candidates x horizon %d in "
+                        "total, %d per GPU over %d GPUs" % (track, total, H, N, world),
+            "solve_us_p50": float(np.percentile(lat, 50) * 1e6), "solve_us_p99": float(np.percentile(lat, 99) * 1e6),
+            "includes": "rollout of this rank's slice + all-reduce(MIN) of the packed key + winner record on every rank; "
+                        "max over ranks per solve"}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -578,6 +619,11 @@ def main():
         assert len(kernel_times) == args.steps, "every rollout launch of the timed region carries an event pair"
         kernel_ms = float(kernel_times.mean())
 
+    sharded_solve = None
+    if world > 1 and args.scaling == "weak" and not args.no_single_solve:
+        # (every rank: it contains collectives; after the timed region, so it cannot disturb the headline)
+        sharded_solve = sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_rank, device,
+                                              args.backend)
     if rank == 0:
         algorithmic_bytes = P * N * (8 * n + 4)  # 8n B of controls read + 4 B of cost written
         achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
@@ -624,6 +670,12 @@ def main():
             out["step_latency"] = step_latency
         if collective is not None:
             out["collective"] = collective
+        if sharded_solve is not None:
+            # "+ MPC solve p50 latency" of the metric at this GPU count: one problem's candidates split over the ranks
+            out["sharded_solve"] = sharded_solve
+            out["mpc_solve_latency_ms"] = {"p50": sharded_solve["solve_us_p50"] * 1e-3,
+                                           "p99": sharded_solve["solve_us_p99"] * 1e-3,
+                                           "of": "one sharded solve (sharded_solve workload)"}
         if world == 1 and not args.no_single_solve and args.scaling == "weak":
             out["single_solve"] = single_solve(workloads, Engine, args.track, H, N, mode, args.layout, device)
             out["closed_loop_replay"] = closed_loop_replay(workloads)

@@ -84,3 +84,7 @@ def test_two_rank_rehearsal_agrees_across_ranks():
     out = _last_json(proc.stdout)
     assert out["n_gpus"] == 2 and out["value"] > 1e6
     assert "one all-reduce(MIN)" in out["config"]["parallelism"]
+    # at N > 1 the line also carries the latency half of the metric: config 4 as one solve sharded over the ranks
+    sharded = out["sharded_solve"]
+    assert "131072 per GPU over 2 GPUs" in sharded["workload"] and 0 < sharded["solve_us_p50"] <= sharded["solve_us_p99"]
+    assert out["mpc_solve_latency_ms"]["p50"] == pytest.approx(sharded["solve_us_p50"] * 1e-3)
