@@ -10,8 +10,10 @@
 // observation points) the kernel is latency-bound; the map stays resident in device memory.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -44,6 +46,9 @@ struct ScoreArgs {
   double* score;           // [P]
   uint8_t* valid;          // [P]
   const int* live;         // when not null: the number of particles is read from the device (resident filter)
+  // nearest points found by pf_nearest_kernel (the grid search) - the scoring kernel then skips its own scan
+  const int32_t* given_index;   // [P][3] or nullptr
+  const double* given_d2;       // [P][3]
 };
 
 constexpr int kWaves = kBlock / 64;
@@ -69,6 +74,124 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int mask = 32; mask >= 1; mask >>= 1) v += __shfl_xor(v, mask, 64);  // fixed tree: reproducible
   return v;
+}
+
+// ---- nearest map point through a uniform grid ------------------------------------------------------------------------
+// The reference answers its three nearest-point queries per particle with KD-trees (localiser.py:282-289); scanning the
+// whole map per particle, as pf_score_kernel does on its own, is 3 x 34 758 distance evaluations each.  The map's points
+// are binned once (host, at create) into square cells of `cell` metres, one index per polyline over a common box:
+// `start` [cells + 1] and the points themselves in cell order (x, y, index in the polyline).  A query visits the cell of the particle,
+// then ring after ring of cells round it; after ring r every point not yet seen lies outside the block of
+// (2r + 1)^2 cells, i.e. at least `margin` = the particle's distance to the nearest side of that block away (sides on
+// the box's own border do not count: nothing lies beyond them), so the search stops as soon as the best squared
+// distance is below margin^2.  Same float64 distance expression, ties to the lower index: the answer is the
+// exhaustive scan's, bit for bit.  A particle whose search is not settled after kMaxRings rings (far from the track,
+// or outside the box) is scanned exhaustively by its whole wavefront.
+struct GridIndex {
+  const int* start;     // [nx * ny + 1]: cell c holds entries [start[c], start[c + 1]) of the three arrays below
+  const double* x;      // the points in cell order (row-major cells, ascending point index inside a cell) ...
+  const double* y;
+  const int* index;     // ... and the index each has in the polyline
+};
+struct GridArgs {
+  const float* states;   // [P][3]
+  const int* live;       // or nullptr
+  Track track[3];
+  GridIndex grid[3];
+  double x0, y0, cell;
+  int nx, ny;
+  int32_t* index_out;    // [P][3]
+  double* d2_out;        // [P][3]
+};
+constexpr int kMaxRings = 4;
+
+// One lane per (particle, polyline): the search is a chain of dependent loads, and three short chains side by side
+// finish sooner than one long one.
+__global__ void __launch_bounds__(64) pf_nearest_kernel(const GridArgs a, const int P_arg) {
+  const int lane = threadIdx.x;
+  const int P = (a.live != nullptr) ? a.live[0] : P_arg;
+  const int first = blockIdx.x * 64;
+  if (first >= 3 * P) return;   // wave-uniform
+  const int query = first + lane;
+  const bool active = query < 3 * P;
+  const int p = active ? query / 3 : P - 1;
+  const int t = active ? query - 3 * p : 0;
+  const double px = a.states[3 * p], py = a.states[3 * p + 1];
+  const int ix = min(max(static_cast<int>(floor((px - a.x0) / a.cell)), 0), a.nx - 1);
+  const int iy = min(max(static_cast<int>(floor((py - a.y0) / a.cell)), 0), a.ny - 1);
+  const int* __restrict__ start = (t == 0) ? a.grid[0].start : (t == 1) ? a.grid[1].start : a.grid[2].start;
+  const double* __restrict__ gx = (t == 0) ? a.grid[0].x : (t == 1) ? a.grid[1].x : a.grid[2].x;
+  const double* __restrict__ gy = (t == 0) ? a.grid[0].y : (t == 1) ? a.grid[1].y : a.grid[2].y;
+  const int* __restrict__ gi = (t == 0) ? a.grid[0].index : (t == 1) ? a.grid[1].index : a.grid[2].index;
+  double best = INFINITY;
+  int best_i = 0x7fffffff;
+  bool settled = false;
+  for (int r = 0; r <= kMaxRings && !settled; ++r) {
+    // the whole block of (2r + 1)^2 cells again (a second ring is rare): a row of cells is ONE run of the cell-ordered
+    // arrays, walked eight points at a time so that the loads of a batch are in flight together - a lane has nothing
+    // else to hide a load behind
+    const int x_lo = max(ix - r, 0), x_hi = min(ix + r, a.nx - 1);
+    const int y_lo = max(iy - r, 0), y_hi = min(iy + r, a.ny - 1);
+    best = INFINITY;
+    best_i = 0x7fffffff;
+    for (int cy = y_lo; cy <= y_hi; ++cy) {
+      const int j0 = start[cy * a.nx + x_lo], j1 = start[cy * a.nx + x_hi + 1];
+      for (int j = j0; j < j1; j += 8) {
+        double bx[8], by[8];
+        int bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int jj = min(j + k, j1 - 1);   // past the run: its last point again (harmless: same distance, same index)
+          bx[k] = gx[jj];
+          by[k] = gy[jj];
+          bi[k] = gi[jj];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const double dx = px - bx[k], dy = py - by[k];
+          take_smaller(best, best_i, dx * dx + dy * dy, bi[k]);
+        }
+      }
+    }
+    // distance to the nearest side of the block that has cells beyond it
+    double margin = INFINITY;
+    if (ix - r > 0) margin = fmin(margin, px - (a.x0 + (ix - r) * a.cell));
+    if (ix + r < a.nx - 1) margin = fmin(margin, (a.x0 + (ix + r + 1) * a.cell) - px);
+    if (iy - r > 0) margin = fmin(margin, py - (a.y0 + (iy - r) * a.cell));
+    if (iy + r < a.ny - 1) margin = fmin(margin, (a.y0 + (iy + r + 1) * a.cell) - py);
+    // (1 - 1e-9: the comparison must hold for the exact values; strictly below, so that a point outside the block at
+    // exactly the same distance, which could carry a lower index, is still looked at)
+    settled = margin > 0.0 && best < margin * margin * (1.0 - 1e-9);
+    if (margin == INFINITY) settled = true;   // the block covers the whole box
+  }
+  // the rest: all 64 lanes scan the polyline side by side for each unsettled query of the wave
+  unsigned long long pending = __ballot(!settled);
+  while (pending != 0ull) {
+    const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(pending)) - 1);
+    pending &= pending - 1ull;
+    const double qx = __shfl(px, src, 64), qy = __shfl(py, src, 64);
+    const int qt = __builtin_amdgcn_readlane(t, src);
+    const Track track = a.track[qt];
+    double d = INFINITY;
+    int i = 0x7fffffff;
+    for (int m = lane; m < track.m; m += 64) {
+      const double dx = qx - track.xy[2 * m], dy = qy - track.xy[2 * m + 1];
+      const double dd = dx * dx + dy * dy;
+      if (dd < d) {   // ascending m per lane: the first minimum stays
+        d = dd;
+        i = m;
+      }
+    }
+    wave_argmin(d, i);
+    if (lane == src) {
+      best = d;
+      best_i = i;
+    }
+  }
+  if (active) {
+    a.index_out[3 * p + t] = best_i;
+    a.d2_out[3 * p + t] = best;
+  }
 }
 
 // One workgroup scores PB particles.  Every map point a thread loads is compared against all PB of them, so the
@@ -97,10 +220,20 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
     py[q] = a.states[3 * p + 1];
   }
 
-  // three nearest-neighbour queries (localiser.py:282-289): first minimum of the float64 squared distance
+  // three nearest-neighbour queries (localiser.py:282-289): first minimum of the float64 squared distance - found
+  // already by the grid search, or scanned here
   const Track tracks[3] = {a.centre, a.left, a.right};
+  const bool given = a.given_index != nullptr;   // wave-uniform
+  if (given) {
+    for (int e = tid; e < 3 * PB * kWaves; e += kBlock) {
+      const int w = e % kWaves, q = (e / kWaves) % PB, t = e / (kWaves * PB);
+      const int p = min(p0 + q, P - 1);
+      s_d[t][q][w] = (w == 0) ? a.given_d2[3 * p + t] : INFINITY;
+      s_i[t][q][w] = (w == 0) ? a.given_index[3 * p + t] : 0x7fffffff;
+    }
+  }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < 3 && !given; ++t) {
     double best[PB];
     int best_i[PB];
 #pragma unroll
@@ -140,7 +273,7 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
       int i = s_i[t][q][0];
 #pragma unroll
       for (int w = 1; w < kWaves; ++w) take_smaller(d, i, s_d[t][q][w], s_i[t][q][w]);
-      nearest[t][q] = i;
+      nearest[t][q] = (i == 0x7fffffff) ? 0 : i;   // a non-finite position is nearest to nothing: point 0, like np.argmin
     }
 
   // observation placed in each particle's frame vs the map limits ahead of the nearest points (:330-410)
@@ -189,6 +322,9 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
       take_smaller(dl, i_left, s_d[1][q][w], s_i[1][q][w]);
       take_smaller(dr, i_right, s_d[2][q][w], s_i[2][q][w]);
     }
+    i_centre = (i_centre == 0x7fffffff) ? 0 : i_centre;
+    i_left = (i_left == 0x7fffffff) ? 0 : i_left;
+    i_right = (i_right == 0x7fffffff) ? 0 : i_right;
     // heading of the centreline at the nearest point, indices mod (len - 1) (:291-318)
     const int m1 = a.centre.m - 1;
     const int here = i_centre % m1, next = (i_centre + 1) % m1;
@@ -481,6 +617,17 @@ struct acmpc_pf {
   double scale = 1.0;
   bool device_ready = false;
   double* d_track[3] = {nullptr, nullptr, nullptr};
+  // the grid over the map's points (see pf_nearest_kernel): built on the host at create, uploaded with the polylines
+  std::vector<int> h_grid_start[3], h_grid_index[3];
+  std::vector<double> h_grid_x[3], h_grid_y[3];
+  double grid_x0 = 0.0, grid_y0 = 0.0, grid_cell = 0.0;
+  int grid_nx = 0, grid_ny = 0;
+  int* d_grid_start[3] = {nullptr, nullptr, nullptr};
+  int* d_grid_index[3] = {nullptr, nullptr, nullptr};
+  double* d_grid_x[3] = {nullptr, nullptr, nullptr};
+  double* d_grid_y[3] = {nullptr, nullptr, nullptr};
+  int32_t* d_near_index = nullptr;   // [max_particles][3]
+  double* d_near_d2 = nullptr;       // [max_particles][3]
   hipStream_t stream = nullptr;
   // staging for the host-pointer entry points: ONE pinned block up (states | observation) and ONE down (all
   // per-particle results) per scoring call - at the reference's 500 particles the call is a handful of microseconds
@@ -524,6 +671,99 @@ int pf_fail(const acmpc_pf* h, int code, const std::string& msg) {
                      std::string(#call) + ": " + hipGetErrorString(e_));                                  \
   } while (0)
 
+// Bins the three polylines into one grid geometry: cells of kGridCell metres over the box of all points (fewer, larger
+// cells when that would be more than kGridMaxCells).  Non-finite points are left out (the exhaustive scan never picks
+// them either: a NaN distance is never smaller); a map without a finite point gets no grid.
+constexpr double kGridCell = 8.0;
+constexpr long long kGridMaxCells = 1 << 20;
+
+void build_grid(acmpc_pf* h) {
+  double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+  for (int t = 0; t < 3; ++t)
+    for (size_t m = 0; m + 1 < h->h_track[t].size(); m += 2) {
+      const double x = h->h_track[t][m], y = h->h_track[t][m + 1];
+      if (!std::isfinite(x) || !std::isfinite(y)) continue;
+      lo[0] = std::min(lo[0], x);
+      hi[0] = std::max(hi[0], x);
+      lo[1] = std::min(lo[1], y);
+      hi[1] = std::max(hi[1], y);
+    }
+  h->grid_nx = h->grid_ny = 0;
+  if (!(lo[0] <= hi[0])) return;
+  double cell = kGridCell;
+  for (;;) {
+    const double nx = std::floor((hi[0] - lo[0]) / cell) + 1.0, ny = std::floor((hi[1] - lo[1]) / cell) + 1.0;
+    if (nx * ny <= static_cast<double>(kGridMaxCells)) {
+      h->grid_nx = static_cast<int>(nx);
+      h->grid_ny = static_cast<int>(ny);
+      break;
+    }
+    cell *= 2.0;
+  }
+  h->grid_x0 = lo[0];
+  h->grid_y0 = lo[1];
+  h->grid_cell = cell;
+  const size_t cells = static_cast<size_t>(h->grid_nx) * h->grid_ny;
+  for (int t = 0; t < 3; ++t) {
+    const size_t M = h->h_track[t].size() / 2;
+    std::vector<int> cell_of(M, -1);
+    std::vector<int>& start = h->h_grid_start[t];
+    start.assign(cells + 1, 0);
+    for (size_t m = 0; m < M; ++m) {
+      const double x = h->h_track[t][2 * m], y = h->h_track[t][2 * m + 1];
+      if (!std::isfinite(x) || !std::isfinite(y)) continue;
+      // the same expression the kernel uses for a particle: a point and a particle at the same place share a cell
+      const int ix = std::min(std::max(static_cast<int>(std::floor((x - lo[0]) / cell)), 0), h->grid_nx - 1);
+      const int iy = std::min(std::max(static_cast<int>(std::floor((y - lo[1]) / cell)), 0), h->grid_ny - 1);
+      cell_of[m] = iy * h->grid_nx + ix;
+      ++start[cell_of[m] + 1];
+    }
+    for (size_t c = 0; c < cells; ++c) start[c + 1] += start[c];
+    const size_t kept = std::max<size_t>(static_cast<size_t>(start[cells]), 1);
+    h->h_grid_index[t].assign(kept, 0);
+    h->h_grid_x[t].assign(kept, 0.0);
+    h->h_grid_y[t].assign(kept, 0.0);
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (size_t m = 0; m < M; ++m) {   // ascending m: ascending indices inside a cell
+      if (cell_of[m] < 0) continue;
+      const size_t j = static_cast<size_t>(fill[cell_of[m]]++);
+      h->h_grid_index[t][j] = static_cast<int>(m);
+      h->h_grid_x[t][j] = h->h_track[t][2 * m];
+      h->h_grid_y[t][j] = h->h_track[t][2 * m + 1];
+    }
+  }
+}
+
+// (below kGridParticles the scan is faster: a few hundred particles cannot hide the grid search's dependent loads,
+// while the scan spreads every particle over a whole workgroup)
+constexpr int kGridParticles = 4096;
+bool use_grid(const acmpc_pf* h, int P) {
+  return h->grid_nx > 0 && P >= kGridParticles && std::getenv("ACMPC_PF_NO_GRID") == nullptr;
+}
+
+// the grid search in front of a scoring launch; fills `a.given_*`
+hipError_t launch_nearest(acmpc_pf* h, ScoreArgs& a, int P, hipStream_t s) {
+  if (!use_grid(h, P)) return hipSuccess;
+  GridArgs g{};
+  g.states = a.states;
+  g.live = a.live;
+  g.track[0] = a.centre;
+  g.track[1] = a.left;
+  g.track[2] = a.right;
+  for (int t = 0; t < 3; ++t) g.grid[t] = GridIndex{h->d_grid_start[t], h->d_grid_x[t], h->d_grid_y[t], h->d_grid_index[t]};
+  g.x0 = h->grid_x0;
+  g.y0 = h->grid_y0;
+  g.cell = h->grid_cell;
+  g.nx = h->grid_nx;
+  g.ny = h->grid_ny;
+  g.index_out = h->d_near_index;
+  g.d2_out = h->d_near_d2;
+  hipLaunchKernelGGL(pf_nearest_kernel, dim3((3 * P + 63) / 64), dim3(64), 0, s, g, P);
+  a.given_index = h->d_near_index;
+  a.given_d2 = h->d_near_d2;
+  return hipGetLastError();
+}
+
 int pf_ensure_device(acmpc_pf* h) {
   if (h->device_ready) return ACMPC_OK;
   int count = 0;
@@ -538,6 +778,22 @@ int pf_ensure_device(acmpc_pf* h) {
                         hipMemcpyHostToDevice));
   }
   const size_t P = h->prm.max_particles, K = h->prm.max_observation_points;
+  if (h->grid_nx > 0) {
+    for (int t = 0; t < 3; ++t) {
+      PF_HIP(h, hipMalloc(&h->d_grid_start[t], h->h_grid_start[t].size() * sizeof(int)));
+      PF_HIP(h, hipMemcpy(h->d_grid_start[t], h->h_grid_start[t].data(), h->h_grid_start[t].size() * sizeof(int),
+                          hipMemcpyHostToDevice));
+      const size_t kept = h->h_grid_index[t].size();
+      PF_HIP(h, hipMalloc(&h->d_grid_index[t], kept * sizeof(int)));
+      PF_HIP(h, hipMemcpy(h->d_grid_index[t], h->h_grid_index[t].data(), kept * sizeof(int), hipMemcpyHostToDevice));
+      PF_HIP(h, hipMalloc(&h->d_grid_x[t], kept * sizeof(double)));
+      PF_HIP(h, hipMemcpy(h->d_grid_x[t], h->h_grid_x[t].data(), kept * sizeof(double), hipMemcpyHostToDevice));
+      PF_HIP(h, hipMalloc(&h->d_grid_y[t], kept * sizeof(double)));
+      PF_HIP(h, hipMemcpy(h->d_grid_y[t], h->h_grid_y[t].data(), kept * sizeof(double), hipMemcpyHostToDevice));
+    }
+    PF_HIP(h, hipMalloc(&h->d_near_index, P * 3 * sizeof(int32_t)));
+    PF_HIP(h, hipMalloc(&h->d_near_d2, P * 3 * sizeof(double)));
+  }
   PF_HIP(h, hipMalloc(&h->d_states, (P * 3 + K * 2) * sizeof(float)));
   h->d_obs = nullptr;  // placed behind the states of each call
   PF_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_up), (P * 3 + K * 2) * sizeof(float), hipHostMallocDefault));
@@ -571,6 +827,7 @@ int acmpc_pf_create(const acmpc_pf_params* params, const double* centre, int32_t
   h->h_track[0].assign(centre, centre + 2 * static_cast<size_t>(m_centre));
   h->h_track[1].assign(left, left + 2 * static_cast<size_t>(m_left));
   h->h_track[2].assign(right, right + 2 * static_cast<size_t>(m_right));
+  build_grid(h);
   // score normaliser: max of the pdf over linspace(-10, 10, 100) (localiser.py:655-661)
   double best = 0.0;
   for (int i = 0; i < 100; ++i) {
@@ -587,7 +844,15 @@ void acmpc_pf_destroy(acmpc_pf* h) {
   if (h == nullptr) return;
   if (h->device_ready) {
     if (h->prm.device >= 0) (void)hipSetDevice(h->prm.device);
-    for (int t = 0; t < 3; ++t) (void)hipFree(h->d_track[t]);
+    for (int t = 0; t < 3; ++t) {
+      (void)hipFree(h->d_track[t]);
+      (void)hipFree(h->d_grid_start[t]);
+      (void)hipFree(h->d_grid_index[t]);
+      (void)hipFree(h->d_grid_x[t]);
+      (void)hipFree(h->d_grid_y[t]);
+    }
+    (void)hipFree(h->d_near_index);
+    (void)hipFree(h->d_near_d2);
     (void)hipFree(h->d_states);
     (void)hipFree(h->d_down);
     if (h->h_up != nullptr) (void)hipHostFree(h->h_up);
@@ -656,6 +921,7 @@ int acmpc_pf_score(acmpc_pf* h, const float* states, int32_t P, const float* obs
   a.track_indices = reinterpret_cast<int32_t*>(h->d_down + 4 * pd);
   a.valid = reinterpret_cast<uint8_t*>(h->d_down + 4 * pd + static_cast<size_t>(P) * 3 * sizeof(int32_t));
   (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
+  PF_HIP(h, launch_nearest(h, a, P, s));
   if (P >= 4096) {
     constexpr int PB = 8;
     hipLaunchKernelGGL(pf_score_kernel<PB>, dim3((P + PB - 1) / PB), dim3(kBlock), 0, s, a, P);
@@ -886,6 +1152,7 @@ int acmpc_pf_filter_update(acmpc_pf* h, const float* obs_left, int32_t k_left, c
   {
     constexpr int PB = 8;
     const int P = h->prm.max_particles;   // workgroups beyond the live count return at once
+    PF_HIP(h, launch_nearest(h, a, P, s));
     if (P >= 4096) {
       hipLaunchKernelGGL(pf_score_kernel<PB>, dim3((P + PB - 1) / PB), dim3(kBlock), 0, s, a, P);
     } else {

@@ -243,10 +243,16 @@ def particle_filter_block(workloads, iters=20):
             scorer.update_particles(states, [left, right])
             t.append(time.perf_counter() - t0)
         us = float(np.median(t) * 1e6)
-        pairs = P * 3 * len(centre)   # particle x map-point distance evaluations (5 float64 flops + a compare each)
-        out["particles_%d" % P] = {"update_us": us, "particles_per_s": P / (us * 1e-6),
-                                   "distance_evaluations_per_s": pairs / (us * 1e-6),
-                                   "fp64_TFLOPs": pairs * 5 / (us * 1e-6) / 1e12}
+        entry = {"update_us": us, "particles_per_s": P / (us * 1e-6)}
+        if P < 4096:
+            # below 4 096 particles every query scans its whole polyline (a workgroup per particle): particle x map-point
+            # distance evaluations, 5 float64 flops + a compare each; from 4 096 up the grid search looks at ~150 points
+            pairs = P * 3 * len(centre)
+            entry.update(nearest_point_search="exhaustive scan", distance_evaluations_per_s=pairs / (us * 1e-6),
+                         fp64_TFLOPs=pairs * 5 / (us * 1e-6) / 1e12)
+        else:
+            entry.update(nearest_point_search="uniform grid, exact (certified rings, wave-wide scan for the rest)")
+        out["particles_%d" % P] = entry
     scorer.close()
     return out
 

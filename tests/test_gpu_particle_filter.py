@@ -56,6 +56,38 @@ def test_scoring_matches_the_oracle_on_other_inputs(golden):
     np.testing.assert_array_equal(out["valid_mask"], want["valid"])
 
 
+@pytest.mark.parametrize("P", [4096, 9001])
+def test_grid_search_equals_the_exhaustive_scan(golden, P, monkeypatch):
+    """The nearest map points come from a grid search (pf_nearest_kernel) - the exhaustive scan's answer, bit for bit:
+    particles on the track, metres off it, far outside the map's box, exactly on cell borders of the grid, duplicates,
+    and a non-finite one; both launch shapes of the scoring kernel."""
+    g = golden
+    centre = g["pf/centre"]
+    rng = np.random.default_rng(17)
+    lo = np.minimum(np.minimum(g["pf/centre"].min(0), g["pf/left"].min(0)), g["pf/right"].min(0))
+    hi = np.maximum(np.maximum(g["pf/centre"].max(0), g["pf/left"].max(0)), g["pf/right"].max(0))
+    seeds = rng.integers(0, len(centre), P)
+    xy = centre[seeds] + rng.normal(0, 6.0, (P, 2))
+    xy[:50] = centre[seeds[:50]] + rng.normal(0, 60.0, (50, 2))                    # tens of metres off: later rings
+    xy[50:80] = rng.uniform(lo - 3000.0, hi + 3000.0, (30, 2))                       # outside the box: the wave's scan
+    cells = rng.integers(0, 40, (40, 2))
+    xy[80:120] = lo + 8.0 * cells                                                     # on the grid's lines
+    xy[120:125] = centre[100]                                                         # on a map point, five times
+    states = np.concatenate([xy, rng.uniform(-np.pi, np.pi, (P, 1))], axis=1).astype(np.float32)
+    states[125, 0] = np.nan
+    left = np.stack([-4.5 + rng.normal(0, 0.2, 90), np.linspace(0, 60, 90)], axis=1).astype(np.float32)
+    right = np.stack([4.5 + rng.normal(0, 0.2, 70), np.linspace(0, 45, 70)], axis=1).astype(np.float32)
+    grid = _scorer(g, n_particles=P).update_particles(states, [left, right])
+    monkeypatch.setenv("ACMPC_PF_NO_GRID", "1")
+    scan = _scorer(g, n_particles=P).update_particles(states, [left, right])
+    for key in ("track_indices", "minimum_offset", "heading_offset", "observation_error", "score", "valid_mask"):
+        np.testing.assert_array_equal(grid[key], scan[key], err_msg=key)
+    # and the brute-force statement itself on the finite ones
+    some = np.r_[0:125, 126:600]   # (all but the non-finite one of the special cases, and a few hundred ordinary ones)
+    d2 = ((states[some, None, :2].astype(np.float64) - centre[None]) ** 2).sum(-1)
+    np.testing.assert_array_equal(grid["track_indices"][some, 0], d2.argmin(1))
+
+
 def test_advance_and_estimate_match_the_reference(golden):
     g = golden
     scorer = _scorer(g)
