@@ -628,8 +628,11 @@ def main():
     sharded_solve = None
     if world > 1 and args.scaling == "weak" and not args.no_single_solve:
         # (every rank: it contains collectives; after the timed region, so it cannot disturb the headline)
-        sharded_solve = sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_rank, device,
-                                              args.backend)
+        try:
+            sharded_solve = sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_rank, device,
+                                                  args.backend)
+        except Exception as error:   # (the same on every rank, or the collectives above would not have returned)
+            sharded_solve = {"error": "%s: %s" % (type(error).__name__, error)}
     if rank == 0:
         algorithmic_bytes = P * N * (8 * n + 4)  # 8n B of controls read + 4 B of cost written
         achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
@@ -679,6 +682,7 @@ def main():
         if sharded_solve is not None:
             # "+ MPC solve p50 latency" of the metric at this GPU count: one problem's candidates split over the ranks
             out["sharded_solve"] = sharded_solve
+        if sharded_solve is not None and "error" not in sharded_solve:
             out["mpc_solve_latency_ms"] = {"p50": sharded_solve["solve_us_p50"] * 1e-3,
                                            "p99": sharded_solve["solve_us_p99"] * 1e-3,
                                            "of": "one sharded solve (sharded_solve workload)"}
