@@ -158,10 +158,13 @@ class ControlSolver:
             centre = self._incumbent if warm else None
             out = engine.control_tick(tick, coords, centre)
             info = out["info"]
-            self._incumbent = out["decision"][3 * (n + 1):].reshape(n, 2)
-            warm = True
+            finite = info[7] == 0.0                     # cost, violation and every entry of the plan
+            # (a plan with a NaN in it is no warm start: the next solve samples round the reference controls again)
+            self._incumbent = out["decision"][3 * (n + 1):].reshape(n, 2) if finite else None
+            warm = finite
             tolerance = 1e-3 + 1e-3 * info[3]           # eps_abs + eps_rel * |z|_inf, as in `solve`
-            status = SOLVED if info[1] <= tolerance**2 else INFEASIBLE
+            # (the violation sums NaN-ignoring maxima: a path with an infinite coordinate can give 0 next to a NaN cost)
+            status = SOLVED if finite and info[1] <= tolerance**2 else INFEASIBLE
             if status == SOLVED or explore:
                 break
             explore = True
@@ -190,14 +193,16 @@ class ControlSolver:
                                    seed=self._seed + self._solves)
             u_star = best["u"][0].astype(np.float64)
             x_star = best["x"][0].astype(np.float64)
-            self._incumbent, warm = u_star, True
+            finite = bool(np.isfinite(u_star).all() and np.isfinite(x_star).all() and np.isfinite(best["cost"][0])
+                          and np.isfinite(best["violation"][0]))
+            self._incumbent, warm = (u_star, True) if finite else (None, False)
             # accept a residual bound violation the way the reference's solver does: every row within
             # eps_abs + eps_rel * |z| (OSQP's test is the infinity norm over the rows).  `violation` is the SUM of the
             # squared row excesses, so `violation <= tolerance^2` bounds every single row by the tolerance
             # (conservative: several rows violated at once are rejected a little earlier than OSQP would).
             tolerance = 1e-3 + 1e-3 * max(np.abs(x_star).max(), np.abs(u_star).max())
             violation = float(best["violation"][0])
-            status = SOLVED if violation <= tolerance**2 else INFEASIBLE
+            status = SOLVED if finite and violation <= tolerance**2 else INFEASIBLE
             if status == SOLVED or explore:
                 break
             explore = True    # the refining schedule failed (the path jumped under the old plan): explore once, now

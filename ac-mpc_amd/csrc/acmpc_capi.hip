@@ -1309,13 +1309,16 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   const float* ru = rec + ACMPC_REC_HEADER;
   const float* rx = ru + 2 * n;
   double biggest = 0.0;
+  bool finite = std::isfinite(rec[ACMPC_REC_COST]) && std::isfinite(rec[ACMPC_REC_VIOLATION]);
   for (int i = 0; i < 3 * (n + 1); ++i) {
     decision[i] = static_cast<double>(rx[i]);
     biggest = std::max(biggest, std::fabs(decision[i]));
+    finite = finite && std::isfinite(rx[i]);
   }
   for (int i = 0; i < 2 * n; ++i) {
     decision[3 * (n + 1) + i] = static_cast<double>(ru[i]);
     biggest = std::max(biggest, std::fabs(static_cast<double>(ru[i])));
+    finite = finite && std::isfinite(ru[i]);
   }
   rc = acmpc_unpack_decision(decision, n, table, c->prm.wheelbase, projected_control, prediction, cum_time, times,
                              accelerations, steer_rates);
@@ -1327,7 +1330,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   info[4] = status[0];
   info[5] = status[1];
   info[6] = from_map ? static_cast<double>(status[2]) : -1.0;   // first map index of the window
-  info[7] = 0.0;
+  info[7] = finite ? 0.0 : 1.0;   // a non-finite cost, violation or plan entry (max |dec.x| above skips NaNs)
   if (coords_out != nullptr)
     std::memcpy(coords_out, from_map ? reinterpret_cast<const void*>(c->h_tick_out + out.coords)
                                      : reinterpret_cast<const void*>(coords),

@@ -255,7 +255,8 @@ int acmpc_map_reference_path(acmpc_ctx* ctx, int32_t map_index, double pose_x, d
  * [acmpc_record_floats(n)]; decision [5n + 3] = dec.x ([x_0..x_n ; u_0..u_{n-1}], control.py:121-158);
  * projected_control [2][n], prediction [n][2], cum_time [n], times / accelerations / steer_rates [n - 1] as
  * acmpc_unpack_decision writes them; info [8] = {cost, violation, n_feasible, max |dec.x|, QP status (0 = solved,
- * 1 = maximum iterations), QP iterations, 0, 0}. */
+ * 1 = maximum iterations), QP iterations, first map index of the window or -1, 1 when the cost, the violation or an
+ * entry of the plan is not finite (the reference's solver would not report such a solve as solved) else 0}. */
 int acmpc_control_tick(acmpc_ctx* ctx, const acmpc_tick* tick, const double* coords, const float* centre, double* table,
                        float* record, double* decision, double* projected_control, double* prediction,
                        double* cum_time, double* times, double* accelerations, double* steer_rates, double* info,

@@ -256,3 +256,41 @@ def test_a_car_outside_the_corridor_is_reported_infeasible():
     assert dec.info.status != SOLVED and dec.info.violation > 0.25
     dec = solver.solve(mpc.model.t2s(table.get_state(0), np.array([0.0, 0.0, np.pi / 2])), table)
     assert dec.info.status == SOLVED
+
+
+def test_non_finite_inputs_are_rejected_not_fatal():
+    """A reference path with a NaN in it (a perception glitch), or a NaN pose on the bound map: the solve comes back
+    not "solved", the previous plan stays, the counter goes up - and the controller carries on with the next good
+    path as if nothing had happened (nothing indexed by a non-finite number, nothing left poisoned on the device)."""
+    import copy
+    from acmpc_amd import workloads
+    from acmpc_amd.mpc import build_mpc
+    cfg = copy.deepcopy(RACING["monza"])
+    cfg["speed_profile_constraints"]["v_max"] = 28.0
+    mpc = build_mpc(cfg, PlaceholderVehicle())
+    H = 50
+    good = _reference_path(H, "straight")
+    mpc.get_control(good)
+    assert mpc.infeasibility_counter == 0
+    before = mpc.projected_control.copy()
+    bad = good.copy()
+    bad[17, 0] = np.nan
+    mpc.get_control(bad)
+    assert mpc.infeasibility_counter == 1
+    np.testing.assert_array_equal(mpc.projected_control, before)
+    bad[17, 0] = np.inf
+    mpc.get_control(bad)
+    assert mpc.infeasibility_counter == 2
+    mpc.get_control(good)
+    assert mpc.infeasibility_counter == 0 and np.isfinite(mpc.projected_control).all()
+    # the same through the map
+    track = workloads.synthetic_track("monza")
+    mpc.bind_map(track)
+    mpc.get_control_at(pose=(float(track["centre"][40, 0]), float(track["centre"][40, 1]), 0.0))
+    assert mpc.infeasibility_counter == 0
+    kept = mpc.projected_control.copy()
+    mpc.get_control_at(pose=(float("nan"), 0.0, 0.0))
+    assert np.isfinite(mpc.reference_coordinates).all()      # the window of map point 0: a NaN pose is nearest to nothing
+    mpc.get_control_at(pose=(float(track["centre"][41, 0]), float(track["centre"][41, 1]), 0.0))
+    assert mpc.infeasibility_counter == 0 and np.isfinite(mpc.projected_control).all()
+    assert kept.shape == mpc.projected_control.shape
