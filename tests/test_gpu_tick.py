@@ -145,6 +145,33 @@ def test_tick_equals_set_paths_plus_optimize():
     eng.close()
 
 
+@pytest.mark.parametrize("H,N,rounds", [(3, 100, 2), (4, 64, 1), (65, 8192, 3), (129, 4096, 2)])
+def test_tick_at_the_horizon_limits(H, N, rounds):
+    """The shortest horizon the controller can pose (two control steps), one step more, the first horizon whose
+    operands need a second register set, and the longest the device prologue takes (128 steps: the record is re-rolled
+    there, a trace would not fit the LDS): each tick equals the two-call path on the tables the prologue made."""
+    n = H - 1
+    y = np.linspace(0, 2.5 * H, H)
+    coords = np.stack([0.002 * y ** 2, y, np.linspace(10, 6, H)], axis=1)
+    cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=28.0)
+    eng, _, _ = _engine(n, n_candidates=N)
+    t = _tick(H, cons, n_candidates=N, rounds=rounds, offset=0.1, seed=11)
+    out = eng.control_tick(t, coords, None)
+    assert out["info"][4] == 0 and out["info"][7] == 0 and np.isfinite(out["record"]).all()
+    x0, u_ref, coef = eng.tick_device_tables(n)
+    eng.set_paths(out["table"])
+    if np.array_equal(eng.coefficients(0), coef):   # (the host table can differ in a last float32 bit: then skip)
+        best = eng.optimize(x0[None], u_ref[None], u_ref[None], N, rounds, (0.5, 1e-3), shrink=0.5, seed=11)
+        np.testing.assert_array_equal(best["records"][0], out["record"])
+    # a second, warm-started tick on the same handle
+    centre = out["decision"][3 * (n + 1):].reshape(n, 2).astype(np.float32)
+    t2 = _tick(H, cons, n_candidates=N, rounds=rounds, offset=0.12, seed=12)
+    t2.centre_is_reference = 0
+    again = eng.control_tick(t2, coords, centre)
+    assert again["info"][7] == 0 and again["record"][0] <= out["record"][0] * 1.5 + 1.0
+    eng.close()
+
+
 def test_tick_forms_agree(monkeypatch):
     """However the tick is run - completion flag polled in pinned memory (default) or the stream synchronised, rounds on
     two waves per workgroup or one, chained or each finalized, the winner copied from its trace or rolled again - a
