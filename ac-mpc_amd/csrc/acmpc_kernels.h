@@ -74,6 +74,7 @@ struct SampleArgs {
   int prev_blocks;           // <= kChainBlocks
   int prev_pitch;
 };
+constexpr int kTileRowsMaxSteps = 64;   // longest horizon of rollout_tile_rows_kernel (2 VGPRs per step)
 constexpr int kChainBlocks = 256;   // four keys per lane
 
 struct LaunchShape {
@@ -81,6 +82,7 @@ struct LaunchShape {
   int cpt;                // candidates per thread
   int blocks_per_problem;
   bool tile;              // candidate-major LDS-tile kernel
+  int tile_waves;         // tile kernel with the rows in registers: waves per workgroup sharing one LDS tile (0: not used)
   int pack;               // mode T, cpt >= 2: candidates per arithmetic state (2 = v_pk_* pairs, 1 = plain float32)
 };
 

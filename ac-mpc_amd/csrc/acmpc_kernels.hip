@@ -1386,6 +1386,111 @@ hipError_t launch_rollout_tile(const LaunchShape& shape, const RolloutArgs& args
 }
 
 #ifndef ACMPC_TEMPORAL_TU
+// Candidate-major, mode S, horizons of at most NMAX steps: the tile is only PASSED THROUGH the LDS.  rollout_tile_kernel
+// keeps its 8n * 64 bytes of LDS for the whole walk, which caps a CU at six waves on four SIMDs.  Here a wave loads its
+// span into registers (16-byte pieces, every line once), and the WAVES waves of a workgroup take turns at ONE tile
+// buffer: write the pieces, read the own row back (ds_read_b64, conflict-free for odd n) into 2n registers, hand the
+// buffer on.  The walk then runs out of registers with no LDS instruction in it, at the occupancy the registers allow
+// (four waves per SIMD at H = 50), while other waves of the CU are still loading.
+template <int NMAX, int WAVES>
+__global__ void __launch_bounds__(WAVES * kWave) rollout_tile_rows_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_tile[];  // ONE [64][2n] tile, used by the waves in turn
+  const int p = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave);
+  const int tiles = (a.N + kWave - 1) / kWave;
+  const int tile = blockIdx.x * WAVES + wave;
+  const bool live = tile < tiles;  // (wave-uniform; a workgroup's spare waves still take their turns at the barrier)
+  const int c0 = tile * kWave;
+  const int rows = live ? min(kWave, a.N - c0) : 0;
+  const int n = a.n;
+  const int row_floats = 2 * n;
+  const Weights w = a.w;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kCoefS;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+
+  // the span starts on a 16-byte boundary (the launcher checks 2 N n % 4 == 0 or P == 1)
+  const float* __restrict__ src = a.U + (static_cast<size_t>(p) * a.N + c0) * row_floats;
+  const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(src);
+  const int total = rows * row_floats;
+  const int quads = total >> 2;
+  constexpr int kQuads = (2 * NMAX + 3) / 4;  // 16-byte pieces per lane of a [64][2 NMAX] tile
+  f32x4 raw[kQuads];
+#pragma unroll
+  for (int k = 0; k < kQuads; ++k) {
+    const int q = lane + k * kWave;
+    if (q < quads) raw[k] = __builtin_nontemporal_load(src4 + q);
+  }
+  f32x2 rest = {0.0f, 0.0f};
+  const bool has_rest = (total & 2) != 0 && lane == 0;  // rows * n odd: one (v, kappa) pair past the last full piece
+  if (has_rest) rest = *reinterpret_cast<const f32x2*>(src + (quads << 2));
+
+  // turns at the one buffer: wave t goes after t barriers and leaves WAVES - 1 - t behind it (every wave passes the
+  // same WAVES - 1 barriers; the loads above are in flight while a wave waits for its turn)
+  auto handover = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  for (int t = 0; t < wave; ++t) handover();
+  {
+    f32x4* dst4 = reinterpret_cast<f32x4*>(s_tile);
+#pragma unroll
+    for (int k = 0; k < kQuads; ++k) {
+      const int q = lane + k * kWave;
+      if (q < quads) dst4[q] = raw[k];
+    }
+    if (has_rest) *reinterpret_cast<f32x2*>(s_tile + (quads << 2)) = rest;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  f32x2 u[NMAX];
+  {
+    const f32x2* row = reinterpret_cast<const f32x2*>(s_tile + lane * row_floats);
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i)
+      if (i < n) u[i] = row[i];
+  }
+  for (int t = wave; t < WAVES - 1; ++t) handover();
+
+  const bool active = lane < rows;
+  float cost = __builtin_inff();
+  bool feas = false;
+  if (active) {
+    StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i)
+      if (i < n) step_spatial(st, coef + i * kCoefS, u[i][0], u[i][1], w);
+    cost = finish_spatial(st, w);
+    feas = st.V == 0.0f;
+    if (a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c0 + lane] = cost;
+  }
+  int64_t key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c0 + lane)) : kKeyMax;
+  int nfeas = (active && feas) ? 1 : 0;
+  key = wave_min_key(key);
+  nfeas = wave_sum_int(nfeas);
+  if (lane == 0 && live) {
+    const size_t slot = static_cast<size_t>(p) * tiles + tile;
+    a.partial_keys[slot] = key;
+    a.partial_feas[slot] = nfeas;
+  }
+}
+
+template <int NMAX, int WAVES>
+hipError_t launch_rollout_tile_rows(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
+                                    hipEvent_t e1) {
+  const dim3 grid((shape.blocks_per_problem + WAVES - 1) / WAVES, args.P);
+  const size_t lds = tile_lds_bytes(0, args.n);
+  if (e0 != nullptr && e1 != nullptr) {
+    hipExtLaunchKernelGGL((rollout_tile_rows_kernel<NMAX, WAVES>), grid, dim3(WAVES * kWave),
+                          static_cast<std::uint32_t>(lds), s, e0, e1, 0, args);
+  } else {
+    hipLaunchKernelGGL((rollout_tile_rows_kernel<NMAX, WAVES>), grid, dim3(WAVES * kWave), lds, s, args);
+  }
+  return hipGetLastError();
+}
+
 template <int MODE, int LAYOUT>
 hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                              hipEvent_t e1) {
@@ -1394,6 +1499,13 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
     if (shape.pack == 1) return launch_rollout_temporal_plain(shape, args, s, e0, e1);
   }
   if constexpr (LAYOUT == 0) {
+    if constexpr (MODE == 0) {
+      if (shape.tile && shape.tile_waves == 4) {
+        if (args.n <= 32) return launch_rollout_tile_rows<32, 4>(shape, args, s, e0, e1);
+        if (args.n <= 50) return launch_rollout_tile_rows<50, 4>(shape, args, s, e0, e1);
+        return launch_rollout_tile_rows<kTileRowsMaxSteps, 4>(shape, args, s, e0, e1);
+      }
+    }
     if (shape.tile) return launch_rollout_tile<MODE>(shape, args, s, e0, e1);
   }
   if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<MODE, LAYOUT, 1, 64>(shape, args, s, e0, e1);
@@ -1440,6 +1552,7 @@ LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
   // per-lane work so that each wave load moves 16 B per lane (large step-major batches).
   LaunchShape s;
   s.tile = false;
+  s.tile_waves = 0;
   s.pack = (mode == 1) ? 1 : 2;  // mode T: plain float32 states (see launch_rollout_temporal_plain)
   if (const char* env = std::getenv("ACMPC_T_PACK")) s.pack = (env[0] == '1') ? 1 : 2;
   const long long total = static_cast<long long>(P) * N;
@@ -1449,6 +1562,14 @@ LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
     s.block = kWave;
     s.cpt = 1;
     s.blocks_per_problem = (N + kWave - 1) / kWave;
+    // mode S up to kTileRowsMaxSteps steps: rows in registers, the LDS tile shared by the waves of a workgroup in turn
+    // (needs every problem's span on a 16-byte boundary)
+    // - from 2 048 tiles up: below that the four-wave workgroups leave CUs idle (16 x 320 x 49: 19 us against 12)
+    if (mode == 0 && n <= kTileRowsMaxSteps && (P == 1 || (2LL * N * n) % 4 == 0) &&
+        static_cast<long long>(P) * s.blocks_per_problem >= 2048) {
+      s.tile_waves = 4;
+      if (const char* env = std::getenv("ACMPC_TILE_ROWS")) s.tile_waves = (std::atoi(env) == 4) ? 4 : 0;
+    }
     return s;
   }
   // tuning override for experiments: ACMPC_SHAPE="<block>,<cpt>"
