@@ -98,6 +98,8 @@ hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const 
 // (defined in acmpc_kernels_temporal.hip, the translation unit built without the SLP vectoriser)
 hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                                          hipEvent_t start, hipEvent_t stop);
+hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
+                                          hipEvent_t start, hipEvent_t stop);
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s);
 // Optional tail of the fused launch: the workgroup that finishes a problem LAST (two levels of ticket counters per

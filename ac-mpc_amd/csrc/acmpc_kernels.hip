@@ -1385,7 +1385,6 @@ hipError_t launch_rollout_tile(const LaunchShape& shape, const RolloutArgs& args
   return hipGetLastError();
 }
 
-#ifndef ACMPC_TEMPORAL_TU
 // Candidate-major, mode S, horizons of at most NMAX steps: the tile is only PASSED THROUGH the LDS.  rollout_tile_kernel
 // keeps its 8n * 64 bytes of LDS for the whole walk, which caps a CU at six waves on four SIMDs.  Here a wave loads its
 // span into registers (16-byte pieces, every line once), and the WAVES waves of a workgroup take turns at ONE tile
@@ -1491,6 +1490,7 @@ hipError_t launch_rollout_tile_rows(const LaunchShape& shape, const RolloutArgs&
   return hipGetLastError();
 }
 
+#ifndef ACMPC_TEMPORAL_TU
 template <int MODE, int LAYOUT>
 hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                              hipEvent_t e1) {
@@ -1500,11 +1500,7 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
   }
   if constexpr (LAYOUT == 0) {
     if constexpr (MODE == 0) {
-      if (shape.tile && shape.tile_waves == 4) {
-        if (args.n <= 32) return launch_rollout_tile_rows<32, 4>(shape, args, s, e0, e1);
-        if (args.n <= 50) return launch_rollout_tile_rows<50, 4>(shape, args, s, e0, e1);
-        return launch_rollout_tile_rows<kTileRowsMaxSteps, 4>(shape, args, s, e0, e1);
-      }
+      if (shape.tile && shape.tile_waves == 4) return launch_rollout_tile_rows_plain(shape, args, s, e0, e1);
     }
     if (shape.tile) return launch_rollout_tile<MODE>(shape, args, s, e0, e1);
   }
@@ -1526,6 +1522,15 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
 // MI355X (1 M candidates per launch) the compiler's SLP re-packing of neighbouring candidates into v_pk_* pairs costs
 // 15 % at the 8-waypoint window (183 -> 155 us), because a packed instruction issues at half the rate of a plain one
 // and the packing adds moves - so this translation unit is compiled with -fno-slp-vectorize (ac-mpc_amd/acmpc_amd/_build.py).
+// (the candidate-major rows kernel gains the same way: its walk is one candidate per lane, and the SLP vectoriser's
+// ten packed instructions + five moves per step cost more than the twenty plain ones they replace)
+hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
+                                          hipEvent_t e0, hipEvent_t e1) {
+  if (args.n <= 32) return launch_rollout_tile_rows<32, 4>(shape, args, s, e0, e1);
+  if (args.n <= 50) return launch_rollout_tile_rows<50, 4>(shape, args, s, e0, e1);
+  return launch_rollout_tile_rows<kTileRowsMaxSteps, 4>(shape, args, s, e0, e1);
+}
+
 hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                                          hipEvent_t e0, hipEvent_t e1) {
   if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<1, 1, 1, 64, 1>(shape, args, s, e0, e1);
