@@ -55,8 +55,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     from concurrent.futures import ThreadPoolExecutor
     objects = [os.path.join(obj_dir, os.path.splitext(src)[0] + ".o") for src in SOURCES]
+    experiment = tuple(os.environ.get("ACMPC_HIPCC_EXTRA", "").split())   # flags of a one-off A/B build, all sources
     with ThreadPoolExecutor(max_workers=4) as pool:   # one hipcc per source (they carry different flags), then one link
-        list(pool.map(lambda so: run([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(so[0], ()), "-c",
+        list(pool.map(lambda so: run([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(so[0], ()), *experiment, "-c",
                                       os.path.join(CSRC_DIR, so[0]), "-o", so[1]]), zip(SOURCES, objects)))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objects, "-o", LIB_PATH])
     return LIB_PATH
