@@ -74,7 +74,7 @@ struct SampleArgs {
   int prev_blocks;           // <= kChainBlocks
   int prev_pitch;
 };
-constexpr int kTileRowsMaxSteps = 64;   // longest horizon of rollout_tile_rows_kernel (2 VGPRs per step)
+constexpr int kTileRowsMaxSteps = 80;   // longest horizon of rollout_tile_rows_kernel (2 VGPRs per step)
 constexpr int kChainBlocks = 256;   // four keys per lane
 
 struct LaunchShape {

@@ -1528,6 +1528,7 @@ hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const Rollou
                                           hipEvent_t e0, hipEvent_t e1) {
   if (args.n <= 32) return launch_rollout_tile_rows<32, 4>(shape, args, s, e0, e1);
   if (args.n <= 50) return launch_rollout_tile_rows<50, 4>(shape, args, s, e0, e1);
+  if (args.n <= 64) return launch_rollout_tile_rows<64, 4>(shape, args, s, e0, e1);
   return launch_rollout_tile_rows<kTileRowsMaxSteps, 4>(shape, args, s, e0, e1);
 }
 
