@@ -96,6 +96,34 @@ def test_large_step_major_batch_uses_vector_loads(mode):
         np.testing.assert_array_equal(out["costs"][p, sub], cost)
 
 
+@pytest.mark.parametrize("H", [20, 34, 50, 52, 66, 81, 82])
+def test_candidate_major_rows_kernel_at_every_register_size(H):
+    """Candidate-major launches of 2 048 tiles and more take the kernel that walks its rows out of registers, in one of
+    four register sizes (32 / 50 / 64 / 80 steps; 81 steps fall back to the LDS-resident tile).  Ragged N (a partial
+    last tile in every problem): costs, winner and record equal the step-major layout's bit for bit, and a subset
+    equals the oracle."""
+    N, P = 6700, 20
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 8, seed=300 + p) for p in range(P)]
+    rng = np.random.default_rng(H)
+    u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems])
+    U = (u_ref[:, None] + rng.standard_normal((P, N, n, 2)) * np.array([2.0, 0.01])).astype(np.float32)
+    eng = _engine(problems, 0, N, n)
+    x0 = np.stack([p["x0"] for p in problems])
+    out_sm = eng.solve(x0, _as_layout(U, LAYOUT_SM), layout=LAYOUT_SM)
+    out = eng.solve(x0, U, layout=LAYOUT_CM)
+    np.testing.assert_array_equal(out["costs"], out_sm["costs"])
+    np.testing.assert_array_equal(out["best_idx"], out_sm["best_idx"])
+    np.testing.assert_array_equal(out["records"], out_sm["records"])
+    sub = np.concatenate([rng.choice(N, 96, replace=False), np.arange(N - 48, N)])   # (the partial tile included)
+    for p in (0, P - 1):
+        cost = _oracle(dict(problems[p], U=U[p, sub]), eng.coefficients(p), 0)[0]
+        np.testing.assert_array_equal(out["costs"][p, sub], cost)
+        best, best_cost = orc.pick_best(out["costs"][p])
+        assert out["best_idx"][p] == best and out["cost"][p] == np.float32(best_cost)
+    eng.close()
+
+
 def test_nonfinite_costs_rank_last():
     prob = make_problem(orc, "monza", 20, 64, seed=3)
     prob["U"][5, 3, 0] = np.nan
