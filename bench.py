@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import copy
 import json
 import os
 import sys
@@ -388,18 +389,25 @@ def closed_loop_replay(workloads, track_name="silverstone", poses=2000):
 def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
     """The other kernels of the path on the same kind of batch, timed alone with dispatch-attached HIP events:
     mode T (Cartesian rollout + nearest-waypoint projection; exhaustive and windowed search) and the
-    candidate-major layout.  256 poses x N candidates each (1 M candidates per launch)."""
-    P, n = 256, H - 1
-    batch = workloads.problem_batch(track, P, H, seed=0)
-    u_ref = torch.tensor(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=torch.float32,
-                         device=device).contiguous()
+    candidate-major layout.  256 poses x N candidates each (1 M candidates per launch: one generation of waves, launch
+    ramp and tail included), and - `*_16M` - the two that are furthest from the roofline again at the headline's own
+    batch of 4 096 poses (their steady state)."""
+    n = H - 1
+    base = workloads.problem_batch(track, 256, H, seed=0)
     stream = torch.cuda.current_stream().cuda_stream
-    costs = torch.empty(P, N, device=device)
     out = {}
-    cases = [("mode_S_candidate_major", 0, 0, None), ("mode_T_exhaustive_search", 1, 1, None),
-             ("mode_T_window_2_5", 1, 1, (2, 5)), ("mode_T_window_1_2", 1, 1, (1, 2)),
-             ("mode_S_step_major_1M", 0, 1, None)]
-    for name, mode, layout, window in cases:
+    cases = [("mode_S_candidate_major", 0, 0, None, 256), ("mode_T_exhaustive_search", 1, 1, None, 256),
+             ("mode_T_window_2_5", 1, 1, (2, 5), 256), ("mode_T_window_1_2", 1, 1, (1, 2), 256),
+             ("mode_S_step_major_1M", 0, 1, None, 256),
+             ("mode_T_window_2_5_16M", 1, 1, (2, 5), 4096), ("mode_S_candidate_major_16M", 0, 0, None, 4096)]
+    for name, mode, layout, window, P in cases:
+        batch = copy.copy(base)
+        reps = P // 256
+        batch.tables, batch.x0, batch.pose0 = (np.tile(base.tables, (reps, 1, 1)), np.tile(base.x0, (reps, 1)),
+                                               np.tile(base.pose0, (reps, 1)))
+        u_ref = torch.tensor(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=torch.float32,
+                             device=device).contiguous()
+        costs = torch.empty(P, N, device=device)
         eng = Engine(**workloads.engine_kwargs(batch, mode, N, device=device.index, nn_window=window))
         eng.set_paths(batch.tables)
         eng.sync_tables(stream)
@@ -418,7 +426,7 @@ def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
         out[name] = {"kernel_us": ms * 1e3, "candidate_trajectories_per_s": P * N / (ms * 1e-3),
                      "algorithmic_GBps": byts / (ms * 1e-3) / 1e9, "frac_of_hbm_roofline": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         eng.close()
-        del U
+        del U, costs
     return out
 
 
