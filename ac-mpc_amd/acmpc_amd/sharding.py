@@ -47,17 +47,47 @@ def global_select_sampled(local_keys: torch.Tensor, regenerate_records: Callable
     return local_keys, regenerate_records(local_keys)
 
 
+def softmin_payload(mean: torch.Tensor, weight_sum: torch.Tensor, count: int) -> torch.Tensor:
+    """What one shard contributes to the softmin mean of all shards: [P][2n + 2] float64 = its own weighted mean, the
+    sum of its weights (relative to the GLOBAL minimum cost) and its candidate count."""
+    P = mean.shape[0]
+    return torch.cat([mean.double().reshape(P, -1), weight_sum.double().reshape(P, 1),
+                      torch.full((P, 1), float(count), dtype=torch.float64, device=mean.device)], dim=1)
+
+
+def combine_softmin(payloads, n_steps: int):
+    """Shard payloads in rank order -> (mean [P][n][2] float32, weight_sum [P] float64).  mean = sum_r w_r mean_r /
+    sum_r w_r in float64, accumulated in the order given (deterministic); a problem whose weights are all zero (no
+    finite cost on any shard) gets the plain average of the candidates, as the single-GPU kernel gives it."""
+    num = torch.zeros_like(payloads[0][:, :-2])
+    uni = torch.zeros_like(num)
+    den = torch.zeros_like(payloads[0][:, -2:-1])
+    cnt = torch.zeros_like(den)
+    for t in payloads:
+        m, w, c = t[:, :-2], t[:, -2:-1], t[:, -1:]
+        num = num + m * w
+        den = den + w
+        uni = uni + m * c
+        cnt = cnt + c
+    usable = den > 0
+    mean = torch.where(usable, num / torch.where(usable, den, torch.ones_like(den)), uni / cnt)
+    return mean.float().reshape(-1, n_steps, 2), den[:, 0].clone()
+
+
 class ShardedRollout:
     """Binds an `Engine` to this rank's slice of the candidates.  All tensors are torch CUDA tensors; the engine
     is handed raw pointers and the current stream, RCCL runs on the same stream through torch.distributed."""
 
     def __init__(self, engine, n_problems: int, n_local: int, n_steps: int, layout: int, index_offset: int,
                  device: torch.device, group: Optional[dist.ProcessGroup] = None, want_costs: bool = True,
-                 host_collectives: bool = False):
-        """`host_collectives=True` stages the (tiny) collective payloads through the CPU - for process groups whose
+                 host_collectives: bool = False, want_keys: bool = False):
+        """`want_keys=True` makes a single-rank rollout export its reduced keys too (softmin() needs them; with several
+        ranks they are exported anyway).  `host_collectives=True` stages the (tiny) collective payloads through the CPU - for process groups whose
         backend cannot reduce GPU tensors (gloo rehearsals of the multi-rank path on a single GPU)."""
         from ._capi import record_floats
         self.host_collectives = host_collectives
+        self.want_keys = want_keys
+        self._soft = None
 
         self.engine, self.group = engine, group
         self.P, self.N, self.n, self.layout, self.offset = n_problems, n_local, n_steps, layout, index_offset
@@ -86,7 +116,7 @@ class ShardedRollout:
         """The dominant kernel alone: controls in, costs and per-workgroup partial keys out."""
         self.engine.rollout_device(x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n, self.layout, self.offset,
                                    self.costs.data_ptr() if self.costs is not None else 0,
-                                   self.keys.data_ptr() if self.distributed else 0, stream)
+                                   self.keys.data_ptr() if (self.distributed or self.want_keys) else 0, stream)
 
     def select(self, x0: torch.Tensor, U: torch.Tensor, stream: int, seed: Optional[int] = None,
                round_: Optional[int] = None):
@@ -117,6 +147,38 @@ class ShardedRollout:
     def step(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
         self.rollout(x0, U, stream)
         return self.select(x0, U, stream)
+
+    def softmin(self, U: torch.Tensor, stream: int):
+        """Softmin-weighted mean control sequence over the candidates of ALL ranks (the weighted-reduction form of
+        localiser.py:572-579 across shards; SURVEY 8e's softmin variant).  Call after select(): the weights are
+        exp(-(cost - min) / lambda) with the GLOBAL minimum, which the all-reduced keys carry.  Every rank runs the
+        softmin kernels on its own slice, ONE all-gather moves [P][2n + 2] float64 per rank (local mean, local weight sum,
+        local count), and every rank combines them in rank order - the same bits on every rank, run after run.
+        Returns (mean [P][n][2] float32, weight_sum [P] float64)."""
+        if self.costs is None:
+            raise RuntimeError("softmin() needs the per-candidate costs: construct with want_costs=True")
+        if not (self.distributed or self.want_keys):
+            raise RuntimeError("softmin() needs the reduced keys: construct with want_keys=True")
+        if self._soft is None:
+            dev = self.keys.device
+            self._soft = (torch.empty(self.P, self.n, 2, dtype=torch.float32, device=dev),
+                          torch.empty(self.P, dtype=torch.float64, device=dev))
+        mean, wsum = self._soft
+        self.engine.softmin_device(self.costs.data_ptr(), self.keys.data_ptr(), U.data_ptr(), self.P, self.N, self.n,
+                                   self.layout, mean.data_ptr(), wsum.data_ptr(), stream)
+        if not self.distributed:
+            return mean, wsum
+        mine = softmin_payload(mean, wsum, self.N)
+        world = dist.get_world_size(self.group)
+        if self.host_collectives:
+            staged = mine.cpu()                # synchronises with the stream that produced it
+            parts = [torch.empty_like(staged) for _ in range(world)]
+            dist.all_gather(parts, staged, group=self.group)
+            parts = [t.to(mine.device) for t in parts]
+        else:
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=self.group)
+        return combine_softmin(parts, self.n)
 
     def _all_reduce(self, tensor: torch.Tensor, op):
         if self.host_collectives:

@@ -61,6 +61,24 @@ def main():
     dist.all_gather_object(gathered, rec.tobytes())
     if any(g != gathered[0] for g in gathered):
         raise SystemExit("ranks disagree")
+    # softmin variant: the weighted mean over BOTH ranks' candidates, one all-gather; the same bits on every
+    # rank, and the unsharded kernel's mean to float32 rounding
+    mean, wsum = shard.softmin(U, stream)
+    want_mean = torch.empty(1, n, 2, device=dev)
+    want_wsum = torch.empty(1, dtype=torch.float64, device=dev)
+    costs_full = torch.empty(1, N, device=dev)
+    full.rollout_device(x0.data_ptr(), U_full.data_ptr(), 1, N, n, 1, 0, costs_full.data_ptr(), keys.data_ptr(), stream)
+    full.softmin_device(costs_full.data_ptr(), keys.data_ptr(), U_full.data_ptr(), 1, N, n, 1, want_mean.data_ptr(),
+                        want_wsum.data_ptr(), stream)
+    torch.cuda.synchronize()
+    if not torch.allclose(mean, want_mean, rtol=2e-6, atol=1e-7):
+        raise SystemExit("rank %d: the sharded softmin mean differs from the unsharded one by %g"
+                         % (rank, float((mean - want_mean).abs().max())))
+    if abs(float(wsum[0]) - float(want_wsum[0])) > 1e-9 * float(want_wsum[0]):
+        raise SystemExit("rank %d: softmin weight sums differ" % rank)
+    dist.all_gather_object(gathered, mean.cpu().numpy().tobytes())
+    if any(g != gathered[0] for g in gathered):
+        raise SystemExit("ranks disagree on the softmin mean")
     dist.barrier()
     if rank == 0:
         print("config 4 in two ranks ok")

@@ -130,6 +130,59 @@ def test_softmin_weighted_mean(layout, N, H):
         np.testing.assert_allclose(wsum[p].item(), w.sum(), rtol=1e-5)
 
 
+def test_softmin_over_shards_equals_the_unsharded_mean():
+    """SURVEY 8e's softmin variant on one card: three uneven shards, the keys' minimum as the all-reduce would leave it,
+    each shard's softmin kernels on its own slice, the payloads combined in shard order - equal to the unsharded
+    kernel's mean to float32 rounding and to the oracle; a problem with no finite cost falls back to the plain mean."""
+    import torch
+    from acmpc_amd import Engine
+    from acmpc_amd.sharding import combine_softmin, softmin_payload
+    P, H, N, lam = 3, 30, 5000, 0.5
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, N, seed=610 + p) for p in range(P)]
+    problems[2]["U"][:, 0, 0] = np.nan   # problem 2: every candidate non-finite -> every weight zero
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    U_h = np.ascontiguousarray(np.stack([p["U"] for p in problems]).transpose(0, 2, 3, 1))   # step-major
+    x0 = torch.tensor(np.stack([p["x0"] for p in problems]), device=dev)
+    tables = np.stack([p["table"] for p in problems])
+
+    def run(offset, count, gkeys=None):
+        eng = Engine(**engine_kwargs(problems[0], 0, P, count, n, softmin_lambda=lam))
+        eng.set_paths(tables)
+        U = torch.tensor(np.ascontiguousarray(U_h[..., offset:offset + count]), device=dev)
+        costs = torch.empty(P, count, device=dev)
+        keys = torch.empty(P, dtype=torch.int64, device=dev)
+        eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, count, n, 1, offset, costs.data_ptr(), keys.data_ptr(), s)
+        return eng, U, costs, keys
+
+    full = run(0, N)
+    mean_full = torch.empty(P, n, 2, device=dev)
+    wsum_full = torch.empty(P, dtype=torch.float64, device=dev)
+    full[0].softmin_device(full[2].data_ptr(), full[3].data_ptr(), full[1].data_ptr(), P, N, n, 1, mean_full.data_ptr(),
+                           wsum_full.data_ptr(), s)
+    shards = [run(0, 2100), run(2100, 1900), run(4000, 1000)]
+    gkeys = torch.stack([sh[3] for sh in shards]).min(dim=0).values.contiguous()
+    assert torch.equal(gkeys, full[3])
+    payloads = []
+    for (eng, U, costs, _), count in zip(shards, (2100, 1900, 1000)):
+        mean = torch.empty(P, n, 2, device=dev)
+        wsum = torch.empty(P, dtype=torch.float64, device=dev)
+        eng.softmin_device(costs.data_ptr(), gkeys.data_ptr(), U.data_ptr(), P, count, n, 1, mean.data_ptr(),
+                           wsum.data_ptr(), s)
+        payloads.append(softmin_payload(mean, wsum, count))
+    mean, wsum = combine_softmin(payloads, n)
+    again = combine_softmin(payloads, n)
+    torch.cuda.synchronize()
+    assert torch.equal(mean.view(torch.int32), again[0].view(torch.int32)) and torch.equal(wsum, again[1])   # bits
+    np.testing.assert_allclose(mean.cpu().numpy(), mean_full.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(wsum.cpu().numpy(), wsum_full.cpu().numpy(), rtol=1e-12)
+    assert wsum[2].item() == 0.0 and wsum[0].item() > 0.0
+    for p in range(2):
+        want = orc.softmin_mean(full[2][p].cpu().numpy(), np.moveaxis(U_h[p], -1, 0), lam)
+        np.testing.assert_allclose(mean[p].cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_device_sampler_matches_its_restatement(layout):
     """acmpc_sample_device vs the oracle's float64 restatement (integer stream exact, transform to 1e-6),

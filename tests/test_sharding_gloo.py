@@ -176,3 +176,31 @@ def test_single_collective_protocol_for_counter_based_candidates(tmp_path):
     full = np.load(tmp_path / "sfull.npy")
     assert [_capi.key_index(int(k)) for k in keys[0]] == list(full)
     assert (recs[0][:, _capi.REC_OWNER] == 1.0).all()
+
+
+def test_softmin_combine_over_shards_is_the_global_weighted_mean():
+    """combine_softmin (softmin variant): per-shard (mean, weight sum, count) payloads in rank order give
+    sum(w u) / sum(w) over all candidates; with every weight zero, the plain mean.  Host logic only (torch on CPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "ac-mpc_amd"))
+    from acmpc_amd.sharding import combine_softmin, softmin_payload
+    rng = np.random.default_rng(8)
+    P, n, counts = 3, 7, (40, 25, 60)
+    U = [rng.standard_normal((P, c, n, 2)) for c in counts]
+    w = [rng.random((P, c)) for c in counts]
+    for k in range(len(counts)):
+        w[k][2] = 0.0                                     # problem 2: no finite cost anywhere
+    w[1][0] = 0.0                                          # problem 0: one shard contributes nothing
+    payloads = []
+    for Uk, wk, c in zip(U, w, counts):
+        ws = wk.sum(axis=1)
+        local = np.where(ws[:, None, None] > 0, np.einsum("pc,pcij->pij", wk, Uk) / np.where(ws > 0, ws, 1)[:, None, None],
+                         Uk.mean(axis=1))
+        payloads.append(softmin_payload(torch.tensor(local, dtype=torch.float32), torch.tensor(ws), c))
+    mean, wsum = combine_softmin(payloads, n)
+    Uall, wall = np.concatenate(U, axis=1), np.concatenate(w, axis=1)
+    for p in range(2):
+        want = np.einsum("c,cij->ij", wall[p], Uall[p]) / wall[p].sum()
+        np.testing.assert_allclose(mean[p].numpy(), want, rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(wsum[p].item(), wall[p].sum(), rtol=1e-12)
+    np.testing.assert_allclose(mean[2].numpy(), Uall[2].mean(axis=0), rtol=2e-6, atol=1e-6)
+    assert wsum[2].item() == 0.0 and mean.dtype == torch.float32 and tuple(mean.shape) == (P, n, 2)
