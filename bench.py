@@ -170,6 +170,54 @@ def numpy_baseline(batch, U_dev, layout, N, n, gpu_costs, seconds=3.0):
                       "(NumPy float32, one process), costs bit-identical to the GPU's" % (N, n + 1, repeats, elapsed)}
 
 
+_NUMPY_WORKER = r"""
+import sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import acmpc_oracle as orc
+d = np.load(sys.argv[2])
+lo, hi, seconds = int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
+args = (d["x0"], d["coef"], np.ascontiguousarray(d["U"][lo:hi]), d["Q"], d["R"], d["QN"], d["u_lo"], d["u_hi"], 1.0e6)
+best = orc.pick_best(orc.rollout_spatial(*args, dtype=np.float32)[0])
+repeats, t0 = 0, time.perf_counter()
+while time.perf_counter() - t0 < seconds:
+    best = orc.pick_best(orc.rollout_spatial(*args, dtype=np.float32)[0])
+    repeats += 1
+print(repeats, time.perf_counter() - t0, best[0] + lo, repr(float(best[1])))
+"""
+
+
+def numpy_all_cores_baseline(batch, U_dev, layout, N, n, seconds=3.0):
+    """SURVEY.md 8(d)'s second NumPy figure: as many processes as this job has cores, each rolling out its share of one
+    pose's candidates with the oracle's NumPy restatement and taking its own argmin; the parent takes the argmin of
+    those.  The workers are plain Python processes (no torch, no GPU)."""
+    import subprocess
+    import tempfile
+    cores = min(16, len(os.sched_getaffinity(0)))
+    U = U_dev[0].cpu().numpy()
+    if layout == 1:
+        U = np.ascontiguousarray(U.transpose(2, 0, 1))    # [N, n, 2]
+    cfg = batch.cfg
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "pose.npz")
+        np.savez(path, x0=batch.x0[0], coef=batch.coef_host[0], U=U, Q=np.asarray(cfg["step_cost"]),
+                 R=np.asarray(cfg["r_term"]), QN=np.asarray(cfg["final_cost"]), u_lo=batch.u_lo, u_hi=batch.u_hi)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        bounds = [N * k // cores for k in range(cores + 1)]
+        procs = [subprocess.Popen([sys.executable, "-c", _NUMPY_WORKER, os.path.join(ROOT, "oracle"), path,
+                                   str(bounds[k]), str(bounds[k + 1]), str(seconds)], stdout=subprocess.PIPE, text=True,
+                                  env=env) for k in range(cores)]
+        outs = [p.communicate(timeout=120)[0].split() for p in procs]
+    if any(p.returncode != 0 for p in procs):
+        raise SystemExit("bench: a NumPy baseline worker failed")
+    rate = sum((bounds[k + 1] - bounds[k]) * int(o[0]) / float(o[1]) for k, o in enumerate(outs))
+    winner = min((float(o[3]), int(o[2])) for o in outs)
+    return {"value": rate, "unit": "candidate-trajectories/s", "cores": cores, "kind": "port",
+            "sample": "1 pose x %d candidates x horizon %d split over %d processes for %.1f s each; "
+                      "oracle/acmpc_oracle.py rollout_spatial (NumPy float32) + argmin per process, argmin of those in "
+                      "the parent (winner %d)" % (N, n + 1, cores, seconds, winner[1])}
+
+
 def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50):
     """BASELINE.json configs[4] exactly as SURVEY.md 8(d) defines it: 10 000 consecutive poses along the synthetic
     Silverstone circuit, one solve each of N = 4 096 candidates through the host-pointer `acmpc_solve` (H2D of the
@@ -715,6 +763,8 @@ def main():
             if mode == 0:
                 out["cpu_baseline"]["numpy"] = numpy_baseline(batch, controls[(args.steps - 1) % args.buffers],
                                                               args.layout, N, n, gpu_costs)
+                out["cpu_baseline"]["numpy_all_cores"] = numpy_all_cores_baseline(
+                    batch, controls[(args.steps - 1) % args.buffers], args.layout, N, n)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
