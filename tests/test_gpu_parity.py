@@ -124,6 +124,28 @@ def test_candidate_major_rows_kernel_at_every_register_size(H):
     eng.close()
 
 
+@pytest.mark.parametrize("H", [50, 34])
+def test_candidate_major_rows_kernel_single_problem_odd_last_tile(H):
+    """One problem of 131 109 candidates: 2 049 tiles, the last of 37 rows - with an odd step count its span ends on a
+    lone (v, kappa) pair past the last 16-byte piece (a path only a single-problem launch can reach: with several
+    problems an odd N puts every second span off the 16-byte boundary and the LDS-resident kernel runs instead)."""
+    N, n = 131072 + 37, H - 1
+    prob = make_problem(orc, "spa", H, 8, seed=77)
+    rng = np.random.default_rng(3)
+    u_ref = np.stack([prob["table"][orc.ROW_V], prob["table"][orc.ROW_KAPPA]], axis=1)
+    U = (u_ref[None, None] + rng.standard_normal((1, N, n, 2)) * np.array([2.0, 0.01])).astype(np.float32)
+    eng = _engine([prob], 0, N, n)
+    x0 = prob["x0"][None]
+    out_sm = eng.solve(x0, _as_layout(U, LAYOUT_SM), layout=LAYOUT_SM)
+    out = eng.solve(x0, U, layout=LAYOUT_CM)
+    np.testing.assert_array_equal(out["costs"], out_sm["costs"])
+    np.testing.assert_array_equal(out["records"], out_sm["records"])
+    sub = np.concatenate([rng.choice(N, 64, replace=False), np.arange(N - 40, N)])
+    cost = _oracle(dict(prob, U=U[0, sub]), eng.coefficients(0), 0)[0]
+    np.testing.assert_array_equal(out["costs"][0, sub], cost)
+    eng.close()
+
+
 def test_nonfinite_costs_rank_last():
     prob = make_problem(orc, "monza", 20, 64, seed=3)
     prob["U"][5, 3, 0] = np.nan
