@@ -15,6 +15,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -1500,7 +1501,10 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
   }
   if constexpr (LAYOUT == 0) {
     if constexpr (MODE == 0) {
-      if (shape.tile && shape.tile_waves == 4) return launch_rollout_tile_rows_plain(shape, args, s, e0, e1);
+      // (the rows kernel moves 16-byte pieces: a control matrix that does not start on a 16-byte boundary - a view
+      // into a caller's buffer - takes the other kernel)
+      if (shape.tile && shape.tile_waves == 4 && (reinterpret_cast<uintptr_t>(args.U) & 15u) == 0)
+        return launch_rollout_tile_rows_plain(shape, args, s, e0, e1);
     }
     if (shape.tile) return launch_rollout_tile<MODE>(shape, args, s, e0, e1);
   }

@@ -146,6 +146,42 @@ def test_candidate_major_rows_kernel_single_problem_odd_last_tile(H):
     eng.close()
 
 
+def test_candidate_major_matrix_off_the_16_byte_boundary():
+    """A device control matrix that is a view 8 bytes into a caller's buffer (candidate-major, a launch large enough
+    for the rows kernel, which moves 16-byte pieces): the same costs and records as the aligned copy."""
+    import torch
+    from acmpc_amd import _capi
+    H, N, P = 50, 6700, 20
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 8, seed=500 + p) for p in range(P)]
+    rng = np.random.default_rng(21)
+    u_ref = np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems])
+    U_h = (u_ref[:, None] + rng.standard_normal((P, N, n, 2)) * np.array([2.0, 0.01])).astype(np.float32)
+    eng = _engine(problems, 0, N, n)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    x0 = torch.tensor(np.stack([p["x0"] for p in problems]), device=dev)
+    flat = torch.zeros(U_h.size + 6, dtype=torch.float32, device=dev)
+    results = []
+    for shift in (0, 2, 4):   # floats: 0 and 16 bytes keep the boundary, 8 bytes does not
+        view = flat[shift:shift + U_h.size]
+        view.copy_(torch.tensor(U_h.reshape(-1)))
+        assert (view.data_ptr() % 16 == 0) == (shift != 2)
+        costs = torch.empty(P, N, device=dev)
+        keys = torch.empty(P, dtype=torch.int64, device=dev)
+        rec = torch.empty(P, _capi.record_floats(n), device=dev)
+        eng.solve_device(x0.data_ptr(), view.data_ptr(), P, N, n, LAYOUT_CM, costs.data_ptr(), keys.data_ptr(),
+                         rec.data_ptr(), stream)
+        torch.cuda.synchronize()
+        results.append((costs.cpu().numpy(), keys.cpu().numpy(), rec.cpu().numpy()))
+    for got in results[1:]:
+        for a, b in zip(results[0], got):
+            np.testing.assert_array_equal(a, b)
+    cost = _oracle(dict(problems[3], U=U_h[3, :64]), eng.coefficients(3), 0)[0]
+    np.testing.assert_array_equal(results[1][0][3, :64], cost)
+    eng.close()
+
+
 def test_nonfinite_costs_rank_last():
     prob = make_problem(orc, "monza", 20, 64, seed=3)
     prob["U"][5, 3, 0] = np.nan
