@@ -139,9 +139,9 @@ int acmpc_solve(acmpc_ctx* ctx, const float* x0, const float* U, int32_t P, int3
 /* Same work with every buffer already resident in device memory, asynchronous on `stream`
  * (a hipStream_t, NULL = the null stream).  `d_keys` [P] receives the packed (cost, index) keys - see
  * acmpc_rollout_device - and `d_records` [P][acmpc_record_floats(n)] the winner records.
- * Device buffers are what hipMalloc returns or views into it on their element type's boundary; the widest loads are
- * only issued where the kernel has checked the boundary itself (a candidate-major `d_U` that starts 16-byte aligned takes
- * the faster of the two tile kernels, any other start the slower one - same results). */
+ * Device buffers are what hipMalloc returns, or views into it on their element type's boundary (gfx950 serves a
+ * 16-byte load on any 4-byte boundary); buffers that start 16-byte aligned are served fastest - e.g. a candidate-major
+ * `d_U` then takes the faster of the two tile kernels, any other start the slower one, with the same results. */
 int acmpc_solve_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, int32_t P, int32_t N, int32_t n,
                        int32_t layout, float* d_costs, int64_t* d_keys, float* d_records, void* stream);
 
