@@ -1392,7 +1392,7 @@ hipError_t launch_rollout_tile(const LaunchShape& shape, const RolloutArgs& args
 // buffer: write the pieces, read the own row back (ds_read_b64, conflict-free for odd n) into 2n registers, hand the
 // buffer on.  The walk then runs out of registers with no LDS instruction in it, at the occupancy the registers allow
 // (four waves per SIMD at H = 50), while other waves of the CU are still loading.
-template <int NMAX, int WAVES>
+template <int NMAX, int WAVES, bool LDS_TABLE>
 __global__ void __launch_bounds__(WAVES * kWave) rollout_tile_rows_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_tile[];  // ONE [64][2n] tile, used by the waves in turn
   const int p = blockIdx.y;
@@ -1432,6 +1432,17 @@ __global__ void __launch_bounds__(WAVES * kWave) rollout_tile_rows_kernel(const 
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
+  // The workgroup's four tiles belong to ONE problem: its table ([n][12] floats) goes into LDS once, behind the tile,
+  // and the walk reads its rows from there one step ahead (every lane the same address: a broadcast).  A scalar load
+  // per step misses the scalar cache (the tables of 256 problems do not fit it) and a wave then waits longer than it
+  // computes: 59 % of the wave-cycles of the scalar-load form are waits.
+  float* const s_table = s_tile + ((kWave * row_floats + 3) & ~3);
+  if constexpr (LDS_TABLE) {
+    const f32x4* __restrict__ coef4 = reinterpret_cast<const f32x4*>(coef);
+    f32x4* table4 = reinterpret_cast<f32x4*>(s_table);
+    for (int q = threadIdx.x; q < 3 * n; q += WAVES * kWave) table4[q] = coef4[q];
+    handover();
+  }
   for (int t = 0; t < wave; ++t) handover();
   {
     f32x4* dst4 = reinterpret_cast<f32x4*>(s_tile);
@@ -1459,9 +1470,26 @@ __global__ void __launch_bounds__(WAVES * kWave) rollout_tile_rows_kernel(const 
   bool feas = false;
   if (active) {
     StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+    if constexpr (LDS_TABLE) {
+      constexpr int kRowUsed = 9;
+      float row_now[kRowUsed], row_next[kRowUsed];
+      auto fetch = [&](float (&dst)[kRowUsed], int i) {   // (rows past n: whatever the LDS holds there, never used)
 #pragma unroll
-    for (int i = 0; i < NMAX; ++i)
-      if (i < n) step_spatial(st, coef + i * kCoefS, u[i][0], u[i][1], w);
+        for (int j = 0; j < kRowUsed; ++j) dst[j] = s_table[i * kCoefS + j];
+      };
+      fetch(row_now, 0);
+#pragma unroll
+      for (int i = 0; i < NMAX; ++i) {
+        if (i + 1 < NMAX) fetch(row_next, i + 1);
+        if (i < n) step_spatial(st, row_now, u[i][0], u[i][1], w);
+#pragma unroll
+        for (int j = 0; j < kRowUsed; ++j) row_now[j] = row_next[j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NMAX; ++i)
+        if (i < n) step_spatial(st, coef + i * kCoefS, u[i][0], u[i][1], w);
+    }
     cost = finish_spatial(st, w);
     feas = st.V == 0.0f;
     if (a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c0 + lane] = cost;
@@ -1477,16 +1505,17 @@ __global__ void __launch_bounds__(WAVES * kWave) rollout_tile_rows_kernel(const 
   }
 }
 
-template <int NMAX, int WAVES>
+template <int NMAX, int WAVES, bool LDS_TABLE>
 hipError_t launch_rollout_tile_rows(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                                     hipEvent_t e1) {
   const dim3 grid((shape.blocks_per_problem + WAVES - 1) / WAVES, args.P);
-  const size_t lds = tile_lds_bytes(0, args.n);
+  // the tile, then (LDS_TABLE) the problem's table with room for NMAX rows (the walk's look-ahead reads that far)
+  const size_t lds = tile_lds_bytes(0, args.n) + (LDS_TABLE ? static_cast<size_t>(NMAX + 1) * kCoefS * sizeof(float) : 0);
   if (e0 != nullptr && e1 != nullptr) {
-    hipExtLaunchKernelGGL((rollout_tile_rows_kernel<NMAX, WAVES>), grid, dim3(WAVES * kWave),
+    hipExtLaunchKernelGGL((rollout_tile_rows_kernel<NMAX, WAVES, LDS_TABLE>), grid, dim3(WAVES * kWave),
                           static_cast<std::uint32_t>(lds), s, e0, e1, 0, args);
   } else {
-    hipLaunchKernelGGL((rollout_tile_rows_kernel<NMAX, WAVES>), grid, dim3(WAVES * kWave), lds, s, args);
+    hipLaunchKernelGGL((rollout_tile_rows_kernel<NMAX, WAVES, LDS_TABLE>), grid, dim3(WAVES * kWave), lds, s, args);
   }
   return hipGetLastError();
 }
@@ -1530,10 +1559,17 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
 // ten packed instructions + five moves per step cost more than the twenty plain ones they replace)
 hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                                           hipEvent_t e0, hipEvent_t e1) {
-  if (args.n <= 32) return launch_rollout_tile_rows<32, 4>(shape, args, s, e0, e1);
-  if (args.n <= 50) return launch_rollout_tile_rows<50, 4>(shape, args, s, e0, e1);
-  if (args.n <= 64) return launch_rollout_tile_rows<64, 4>(shape, args, s, e0, e1);
-  return launch_rollout_tile_rows<kTileRowsMaxSteps, 4>(shape, args, s, e0, e1);
+  // Table rows from LDS (one copy per workgroup) or by scalar loads, measured per register size on 1 M / 4 M candidates:
+  // 33-50 steps 92 / 335 us from LDS against 92 / 389 (with a thousand problems' tables in flight the scalar loads miss
+  // more); up to 32 steps 51.5 against 47.8 us at 1 M, 65 steps 183 against 173 - scalar loads there.
+  if (args.n <= 32) return launch_rollout_tile_rows<32, 4, false>(shape, args, s, e0, e1);
+  if (args.n <= 50) {
+    if (std::getenv("ACMPC_TILE_SCALAR_TABLE") != nullptr)   // (A/B switch)
+      return launch_rollout_tile_rows<50, 4, false>(shape, args, s, e0, e1);
+    return launch_rollout_tile_rows<50, 4, true>(shape, args, s, e0, e1);
+  }
+  if (args.n <= 64) return launch_rollout_tile_rows<64, 4, false>(shape, args, s, e0, e1);
+  return launch_rollout_tile_rows<kTileRowsMaxSteps, 4, false>(shape, args, s, e0, e1);
 }
 
 hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
