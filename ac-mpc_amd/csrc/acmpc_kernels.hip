@@ -1559,15 +1559,20 @@ hipError_t launch_rollout_ml(const LaunchShape& shape, const RolloutArgs& args, 
 // ten packed instructions + five moves per step cost more than the twenty plain ones they replace)
 hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                                           hipEvent_t e0, hipEvent_t e1) {
-  // Table rows from LDS (one copy per workgroup) or by scalar loads, measured per register size on 1 M / 4 M candidates:
-  // 33-50 steps 92 / 335 us from LDS against 92 / 389 (with a thousand problems' tables in flight the scalar loads miss
-  // more); up to 32 steps 51.5 against 47.8 us at 1 M, 65 steps 183 against 173 - scalar loads there.
-  if (args.n <= 32) return launch_rollout_tile_rows<32, 4, false>(shape, args, s, e0, e1);
-  if (args.n <= 50) {
-    if (std::getenv("ACMPC_TILE_SCALAR_TABLE") != nullptr)   // (A/B switch)
-      return launch_rollout_tile_rows<50, 4, false>(shape, args, s, e0, e1);
-    return launch_rollout_tile_rows<50, 4, true>(shape, args, s, e0, e1);
+  // Table rows from LDS (one copy per workgroup) or by scalar loads - measured, 4 096 candidates per problem, LDS / scalar:
+  //   H = 50:  256 problems 92 / 92 us, 1 024: 335 / 389, 4 096: 1 258 / 1 457   (more tables in flight, more scalar misses)
+  //   H = 30:  256: 51.5 / 47.8, 1 024: 212 / 216;   H = 20, 2 048 problems: 297 / 280
+  //   H = 65:  256: 183 / 173, 1 024: 654 / 685;     H = 80: 256: 221 / 220, 1 024: 799 / 1 094
+  const char* ab = std::getenv("ACMPC_TILE_TABLE");   // (A/B switch: "lds" / "scalar")
+  const bool lds = ab != nullptr ? ab[0] == 'l' : (args.n > 32 && (args.n <= 50 || args.P >= 512));
+  if (lds) {
+    if (args.n <= 32) return launch_rollout_tile_rows<32, 4, true>(shape, args, s, e0, e1);
+    if (args.n <= 50) return launch_rollout_tile_rows<50, 4, true>(shape, args, s, e0, e1);
+    if (args.n <= 64) return launch_rollout_tile_rows<64, 4, true>(shape, args, s, e0, e1);
+    return launch_rollout_tile_rows<kTileRowsMaxSteps, 4, true>(shape, args, s, e0, e1);
   }
+  if (args.n <= 32) return launch_rollout_tile_rows<32, 4, false>(shape, args, s, e0, e1);
+  if (args.n <= 50) return launch_rollout_tile_rows<50, 4, false>(shape, args, s, e0, e1);
   if (args.n <= 64) return launch_rollout_tile_rows<64, 4, false>(shape, args, s, e0, e1);
   return launch_rollout_tile_rows<kTileRowsMaxSteps, 4, false>(shape, args, s, e0, e1);
 }

@@ -96,12 +96,15 @@ def test_large_step_major_batch_uses_vector_loads(mode):
         np.testing.assert_array_equal(out["costs"][p, sub], cost)
 
 
+@pytest.mark.parametrize("table", ["default", "lds", "scalar"])
 @pytest.mark.parametrize("H", [20, 34, 50, 52, 66, 81, 82])
-def test_candidate_major_rows_kernel_at_every_register_size(H):
+def test_candidate_major_rows_kernel_at_every_register_size(H, table, monkeypatch):
     """Candidate-major launches of 2 048 tiles and more take the kernel that walks its rows out of registers, in one of
     four register sizes (32 / 50 / 64 / 80 steps; 81 steps fall back to the LDS-resident tile).  Ragged N (a partial
     last tile in every problem): costs, winner and record equal the step-major layout's bit for bit, and a subset
     equals the oracle."""
+    if table != "default":   # both ways the kernel can take its table rows (launch-size rule overridden)
+        monkeypatch.setenv("ACMPC_TILE_TABLE", table)
     N, P = 6700, 20
     n = H - 1
     problems = [make_problem(orc, "monza", H, 8, seed=300 + p) for p in range(P)]
