@@ -36,6 +36,12 @@ def test_single_gpu_line_has_the_contract_fields():
     assert out["closed_loop_replay"]["infeasible_solves"] == 0
     # every number DESIGN.md quotes travels in the driver's line
     assert cpu["numpy"]["cores"] == 1 and 0 < cpu["numpy"]["value"] < cpu["value"]
+    assert cpu["numpy_all_cores"]["cores"] >= 1 and cpu["numpy_all_cores"]["value"] > 0      # SURVEY 8d's second figure
+    second = out["secondary_kernels"]
+    for name in ("mode_S_candidate_major", "mode_T_exhaustive_search", "mode_T_window_2_5", "mode_T_window_1_2",
+                 "mode_S_step_major_1M", "mode_T_window_2_5_16M", "mode_S_candidate_major_16M"):
+        assert 0 < second[name]["frac_of_hbm_roofline"] < 1 and second[name]["kernel_us"] > 0, name
+    assert second["mode_S_candidate_major_16M"]["kernel_us"] > 4 * second["mode_S_candidate_major"]["kernel_us"]
     assert out["config3_single"]["device_resident_us_p50"] > 0 and out["config4_share"]["device_resident_us_p50"] > 0
     five = out["config5_host_pointer"]
     assert "10000 consecutive poses" in five["workload"] and 0 < five["solve_us_p50"] <= five["solve_us_p99"]
