@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the rollout-and-cost hot path (contract: see the task statement / DESIGN.md "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      (N > 1 without torchrun: starts its own N ranks as a child)
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM: P poses round
 the synthetic Monza circuit x 4 096 candidate control sequences x horizon 50 (BASELINE.json configs[1], batched
@@ -519,14 +519,44 @@ def sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_
                         "max over ranks per solve"}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process has not touched the
+    GPU yet (torch.cuda.device_count() does not initialise it) and becomes the launcher - it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <the same arguments>` as a CHILD (never exec: see
+    the pool's rules), lets rank 0's JSON line through on the inherited stdout and returns the child's exit code."""
+    import subprocess
+    visible = torch.cuda.device_count()
+    if args.backend == "nccl" and visible < args.gpus:
+        print("bench: --gpus %d but only %d GPU(s) visible (one rank per device over RCCL); not running a smaller job "
+              "under that label" % (args.gpus, visible), file=sys.stderr)
+        return 2
+    if visible < 1:
+        print("bench: no GPU visible - the rollout path has no CPU fallback", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print("bench: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-              file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench: no GPU visible - the rollout path has no CPU fallback")
     if args.backend == "gloo":

@@ -94,3 +94,27 @@ def test_two_rank_rehearsal_agrees_across_ranks():
     sharded = out["sharded_solve"]
     assert "131072 per GPU over 2 GPUs" in sharded["workload"] and 0 < sharded["solve_us_p50"] <= sharded["solve_us_p99"]
     assert out["mpc_solve_latency_ms"]["p50"] == pytest.approx(sharded["solve_us_p50"] * 1e-3)
+
+
+def test_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun on the command line: the parent starts the two ranks as a child
+    torch.distributed.run before touching the GPU and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--poses",
+                           "32", "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, (proc.stdout + proc.stderr)[-3000:]
+    out = _last_json(proc.stdout)
+    assert out["n_gpus"] == 2 and out["collective"]["world_size"] == 2 and out["steps"] == 5
+    assert len([line for line in proc.stdout.splitlines() if line.startswith("{")]) == 1
+
+
+def test_more_gpus_than_devices_is_refused():
+    """`--gpus 8` over RCCL on a box with fewer devices exits non-zero with one line instead of running a smaller job."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box has 8 devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                          capture_output=True, text=True, timeout=300, env=env)
+    assert proc.returncode != 0 and "GPU(s) visible" in proc.stderr
+    assert not [line for line in proc.stdout.splitlines() if line.startswith("{")]
