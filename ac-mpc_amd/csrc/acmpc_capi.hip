@@ -65,7 +65,7 @@ struct acmpc_ctx {
   float* d_costs = nullptr;
   float* d_records = nullptr;
   int64_t* d_keys = nullptr;
-  int* d_tickets = nullptr;  // [max_problems][kTicketGroups + 1] last-workgroup counters of the fused finalize; zero between launches
+  int* d_tickets = nullptr;  // last-workgroup counters of the in-launch finalizes (ensure_tail_buffers); zero between launches
   unsigned tick_sequence = 0;   // completion flag values of acmpc_control_tick
   float* d_trace = nullptr;  // [2][kTraceBlocks][trace_floats(max_steps)] best-candidate traces of the fused rounds' workgroups
   // mode T with exhaustive search: thresholds of the verified window search (acmpc_device.h: nearest_verified)
@@ -412,6 +412,66 @@ int sample(acmpc_ctx* c, const float* d_centre, int centre_stride, const float* 
   return ACMPC_OK;
 }
 
+// what the in-launch finalize of the fused rounds and of the one-launch solve needs: ticket counters (zero between
+// launches) and the workgroups' traces
+int ensure_tail_buffers(acmpc_ctx* c) {
+  if (c->d_tickets != nullptr && c->d_trace != nullptr) return ACMPC_OK;
+  c->touched_device = true;
+  const acmpc_params& p = c->prm;
+  // [P][kTicketGroups + 1] for the fused rounds, [P][up to kTicketGroupsMax + 1] for the one-launch solve (which takes at
+  // most kSoloBlocks workgroups, so at most that many problems), every counter on a line of its own
+  const size_t ticket_ints =
+      std::max(static_cast<size_t>(p.max_problems) * (acmpc::kTicketGroups + 1),
+               static_cast<size_t>(std::min(p.max_problems, acmpc::kSoloBlocks)) * (acmpc::kTicketGroupsMax + 1)) *
+      acmpc::kTicketStride;
+  if (c->d_tickets == nullptr) {
+    ACMPC_HIP(c, alloc_once(&c->d_tickets, ticket_ints * sizeof(int)));
+    ACMPC_HIP(c, hipMemset(c->d_tickets, 0, ticket_ints * sizeof(int)));
+    ACMPC_HIP(c, hipStreamSynchronize(nullptr));  // the callers' streams do not order against the null stream
+  }
+  ACMPC_HIP(c, alloc_once(&c->d_trace, 2 * static_cast<size_t>(kTraceBlocks) * acmpc::trace_floats(p.max_steps) * sizeof(float)));
+  return ACMPC_OK;
+}
+
+// acmpc_solve_device / acmpc_solve in ONE launch (rollout_solo_kernel) when the problem is small enough for it: rollout,
+// argmin and the winner's record without rolling the winner a second time.  ACMPC_NO_SOLO keeps the two launches.
+bool use_solo(const acmpc_ctx* c, int P, int N, int n, int layout) {
+  static_assert(kTraceBlocks >= acmpc::kSoloBlocks, "the trace buffer holds one trace per workgroup");
+  return c->prm.mode == ACMPC_MODE_SPATIAL && std::getenv("ACMPC_NO_SOLO") == nullptr && acmpc::solo_fits(P, N, n, layout);
+}
+
+int solve_solo(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int n, int layout, float* d_costs,
+               int64_t* d_keys, float* d_records, hipStream_t s) {
+  const int rc = ensure_tail_buffers(c);
+  if (rc != ACMPC_OK) return rc;
+  acmpc::RolloutArgs a{};
+  a.U = d_U;
+  a.x0 = d_x0;
+  a.coef = c->d_coef;
+  a.costs = d_costs;
+  a.partial_keys = c->d_partial_keys;
+  a.partial_feas = c->d_partial_feas;
+  a.P = P;
+  a.N = N;
+  a.n = n;
+  a.index_offset = 0;
+  a.w = c->w;
+  acmpc::FusedFinalize ff{};
+  ff.tickets = c->d_tickets;
+  ff.records = d_records;
+  ff.trace = c->d_trace;
+  ff.trace_pitch = acmpc::solo_trace_floats(n);
+  ff.keys_out = d_keys;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof_used < c->prof_start.size()) {
+    e0 = c->prof_start[c->prof_used];
+    e1 = c->prof_stop[c->prof_used];
+    ++c->prof_used;
+  }
+  ACMPC_HIP(c, acmpc::launch_rollout_solo(layout, a, ff, s, e0, e1));
+  return ACMPC_OK;
+}
+
 int ensure_staging(acmpc_ctx* c) {
   if (c->staging_ready) return ACMPC_OK;
   c->touched_device = true;
@@ -426,11 +486,8 @@ int ensure_staging(acmpc_ctx* c) {
   ACMPC_HIP(c, alloc_once(&c->d_records,
                           static_cast<size_t>(p.max_problems) * acmpc_record_floats(p.max_steps) * sizeof(float)));
   ACMPC_HIP(c, alloc_once(&c->d_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
-  const size_t ticket_ints = static_cast<size_t>(p.max_problems) * (acmpc::kTicketGroups + 1);
-  ACMPC_HIP(c, alloc_once(&c->d_tickets, ticket_ints * sizeof(int)));
-  ACMPC_HIP(c, hipMemset(c->d_tickets, 0, ticket_ints * sizeof(int)));
-  ACMPC_HIP(c, alloc_once(&c->d_trace, 2 * static_cast<size_t>(kTraceBlocks) * acmpc::trace_floats(p.max_steps) * sizeof(float)));
-  ACMPC_HIP(c, hipStreamSynchronize(nullptr));  // the handle's own stream does not order against the null stream
+  const int rc_tail = ensure_tail_buffers(c);
+  if (rc_tail != ACMPC_OK) return rc_tail;
   ACMPC_HIP(c, host_alloc_once(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
   c->staging_ready = true;
   return ACMPC_OK;
@@ -662,6 +719,7 @@ int acmpc_solve_device(acmpc_ctx* c, const float* d_x0, const float* d_U, int32_
   hipStream_t s = static_cast<hipStream_t>(stream);
   rc = upload_tables(c, s);
   if (rc != ACMPC_OK) return rc;
+  if (use_solo(c, P, N, n, layout)) return solve_solo(c, d_x0, d_U, P, N, n, layout, d_costs, d_keys, d_records, s);
   acmpc::LaunchShape shape;
   rc = rollout(c, d_x0, d_U, P, N, n, layout, 0, d_costs, s, &shape);
   if (rc != ACMPC_OK) return rc;
@@ -685,11 +743,16 @@ int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_
   const size_t rec_bytes = static_cast<size_t>(P) * acmpc_record_floats(n) * sizeof(float);
   ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
   ACMPC_HIP(c, hipMemcpyAsync(c->d_U, U, cand * n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
-  acmpc::LaunchShape shape;
-  rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, costs != nullptr ? c->d_costs : nullptr, s, &shape);
-  if (rc != ACMPC_OK) return rc;
-  rc = finalize(c, nullptr, c->d_keys, c->d_x0, c->d_U, P, N, n, layout, 0, records != nullptr ? c->d_records : nullptr,
-                shape.blocks_per_problem, s);
+  if (use_solo(c, P, N, n, layout)) {
+    rc = solve_solo(c, c->d_x0, c->d_U, P, N, n, layout, costs != nullptr ? c->d_costs : nullptr, c->d_keys,
+                    records != nullptr ? c->d_records : nullptr, s);
+  } else {
+    acmpc::LaunchShape shape;
+    rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, costs != nullptr ? c->d_costs : nullptr, s, &shape);
+    if (rc != ACMPC_OK) return rc;
+    rc = finalize(c, nullptr, c->d_keys, c->d_x0, c->d_U, P, N, n, layout, 0, records != nullptr ? c->d_records : nullptr,
+                  shape.blocks_per_problem, s);
+  }
   if (rc != ACMPC_OK) return rc;
   ACMPC_HIP(c, hipMemcpyAsync(c->h_keys, c->d_keys, static_cast<size_t>(P) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
   if (costs != nullptr) ACMPC_HIP(c, hipMemcpyAsync(costs, c->d_costs, cand * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -111,6 +111,44 @@ __device__ __forceinline__ void step_spatial(StateS_<F>& s, const float* __restr
   s.V = s.V + tv * tv;
 }
 
+// step_spatial() in two halves that share nothing but the state recurrence: J never reads V and V never reads J, so a
+// small launch - CUs to spare, one candidate's step a serial stream of ~50 instructions on a lone wave - can roll every
+// candidate on TWO waves, one accumulating the stage cost and one the bound violations, each running the 9-operation
+// recurrence itself (no hand-over inside the loop).  Every operation below is the corresponding line of step_spatial on
+// the same operands in the same order: s.J of the first and s.V of the second are step_spatial's, bit for bit.
+__device__ __forceinline__ void advance_spatial(StateS& s, const float* __restrict__ c, float dv, float dk) {
+  const float ds = c[0];
+  const float ey_n = s.ey + ds * s.ep;
+  const float ep_n = (s.ep + c[1] * s.ey) + ds * dk;
+  const float t_n = ((s.t + c[2] * s.ey) + c[3] * dv) + c[4];
+  s.ey = ey_n;
+  s.ep = ep_n;
+  s.t = t_n;
+}
+
+__device__ __forceinline__ void step_spatial_cost(StateS& s, const float* __restrict__ c, float v, float k,
+                                                  const Weights& w) {
+  const float dv = v - c[5];
+  const float dk = k - c[6];
+  float a = quad(w.q0, s.ey);
+  a = a + quad(w.q1, s.ep);
+  a = a + quad(w.q2, s.t);
+  float r = quad(w.r0, dv);
+  r = r + quad(w.r1, dk);
+  s.J = s.J + 0.5f * (a + r);
+  advance_spatial(s, c, dv, dk);
+}
+
+__device__ __forceinline__ void step_spatial_bounds(StateS& s, const float* __restrict__ c, float v, float k,
+                                                    const Weights& w) {
+  s.V = s.V + hinge2<float>(w.ulo0 - v, v - w.uhi0);
+  s.V = s.V + hinge2<float>(w.ulo1 - k, k - w.uhi1);
+  advance_spatial(s, c, v - c[5], k - c[6]);
+  s.V = s.V + hinge2<float>(c[7] - s.ey, s.ey - c[8]);
+  const float tv = vmax(w.tmin - s.t, 0.0f);
+  s.V = s.V + tv * tv;
+}
+
 template <typename F>
 __device__ __forceinline__ F finish_spatial(const StateS_<F>& s, const Weights& w) {
   F a = quad(w.qn0, s.ey);
@@ -649,6 +687,45 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
   return v;
+}
+
+// The same two reductions on the DPP path (row shifts inside the rows of 16 lanes, then row_bcast:15 / :31 across
+// them; the result is lane 63's): twelve vector instructions where the shuffle forms make eighteen round trips through
+// the LDS crossbar (ds_bpermute) - half a microsecond on a lone wave.  Integers: the same values either way.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ int wave_sum_int_dpp(int v) {
+  v += dpp_move<0x111, 0xf>(0, v);   // row_shr:1
+  v += dpp_move<0x112, 0xf>(0, v);   // row_shr:2
+  v += dpp_move<0x114, 0xf>(0, v);   // row_shr:4
+  v += dpp_move<0x118, 0xf>(0, v);   // row_shr:8   -> lane 15 of every row holds the row's sum
+  v += dpp_move<0x142, 0xa>(0, v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(0, v);   // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ int wave_min_int_dpp(int v) {
+  v = min(v, dpp_move<0x111, 0xf>(v, v));
+  v = min(v, dpp_move<0x112, 0xf>(v, v));
+  v = min(v, dpp_move<0x114, 0xf>(v, v));
+  v = min(v, dpp_move<0x118, 0xf>(v, v));
+  v = min(v, dpp_move<0x142, 0xa>(v, v));
+  v = min(v, dpp_move<0x143, 0xc>(v, v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// min over the wave's (cost, index) keys when the index rises with the lane (index = base + lane): the minimum of the
+// ordered cost words, then the FIRST lane that holds it - the same key wave_min_key() returns.  `lane_out` = that lane.
+__device__ __forceinline__ int64_t wave_min_key_by_lane(int64_t own_key, int& lane_out) {
+  const int hi = static_cast<int>(own_key >> 32);
+  const int best = wave_min_int_dpp(hi);
+  const unsigned long long holders = __ballot(hi == best);
+  lane_out = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holders)) - 1);
+  const int lo = __builtin_amdgcn_readlane(static_cast<int>(own_key & 0xffffffffLL), lane_out);
+  return (static_cast<int64_t>(best) << 32) | static_cast<uint32_t>(lo);
 }
 
 }  // namespace acmpc

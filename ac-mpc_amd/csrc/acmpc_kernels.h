@@ -106,9 +106,14 @@ hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s);
 // problem) also runs the finalize for it, in the same launch - argmin over the partial keys, record written.  With
 // `trace` the record is copied out of what the winning workgroup left there (every workgroup writes the controls,
 // states, violation and cost of its best candidate: [P][workgroups][trace_pitch] floats); without, the winner is
-// re-drawn from its index and rolled again.  `tickets` [P][kTicketGroups + 1] must be zero before the launch and is
-// left zero by it.
+// re-drawn from its index and rolled again.  `tickets` [P][kTicketGroups + 1] counters, kTicketStride ints apart, must be zero before the
+// launch and are left zero by it.
 constexpr int kTicketGroups = 8;
+// every counter on a 256-byte line of its own: device-scope atomics on ONE line serialise at ~6-13 ns each whichever
+// word of it they hit (1 024 workgroups on 33 adjacent counters queued for 6 us), lines of their own do not
+constexpr int kTicketStride = 64;      // ints between two counters
+constexpr int kTicketGroupsMax = 32;   // rollout_solo_kernel's launches of more than 256 workgroups; `tickets` is sized for it
+constexpr int kSoloBlocks = 1024;      // workgroups per launch of rollout_solo_kernel (16 partial keys per lane of the last one)
 struct FusedFinalize {
   int* tickets;        // nullptr: no fused finalize
   float* records;      // [P][record_floats]
@@ -119,12 +124,23 @@ struct FusedFinalize {
   // record - a host that polls it has the record without waiting for the launch's completion signal
   unsigned* done;
   unsigned done_value;
+  // rollout_solo_kernel only
+  int64_t* keys_out;   // [P] winners' keys, or nullptr
+  int ticket_groups;   // power of two <= kTicketGroupsMax (set by the launcher)
 };
 
 // sample + rollout + cost (+ finalize) fused: candidates are drawn inside the rollout kernel and never touch memory
 // (the closed-loop solve, where every launch is ~10 us of latency-bound work)
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
                                   const FusedFinalize& fused, hipStream_t s);
+// acmpc_solve_device in ONE launch (mode S, at most kSoloBlocks workgroups of 64 candidates): rollout, argmin and the
+// winner's record assembled from the winning workgroup's state trace - `fused.trace` [P][workgroups][trace_pitch >=
+// solo_trace_floats(n)], `fused.tickets` [P][ticket_groups + 1] counters (kTicketStride ints apart) zero before and after.  `fused.records` may be
+// null (keys only).
+bool solo_fits(int P, int N, int n, int layout);
+int solo_trace_floats(int n);
+hipError_t launch_rollout_solo(int layout, const RolloutArgs& args, const FusedFinalize& fused, hipStream_t s,
+                               hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 int trace_floats(int n);
 bool traced_finalize_fits(int mode, int n);
 // whether rollout + fused finalize fit one workgroup's 64 KB of LDS (mode T at the longest horizons does not)

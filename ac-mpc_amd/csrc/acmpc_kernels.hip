@@ -28,6 +28,20 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Phase stamps for tools/solo_probe.hip (a standalone build of this file with -DACMPC_STAMPS); nothing in the library.
+#ifdef ACMPC_STAMPS
+__device__ unsigned long long g_stamps[4096 * 16];
+#define ACMPC_STAMP(slot)                                                                                         \
+  do {                                                                                                            \
+    if ((threadIdx.x & 63) == 0)                                                                                  \
+      g_stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define ACMPC_STAMP(slot) \
+  do {                    \
+  } while (0)
+#endif
+
 template <int CPT>
 struct VecOf;
 template <>
@@ -965,34 +979,52 @@ __device__ __forceinline__ void finalize_from_trace(const RolloutArgs& a, const 
   }
 }
 
+// Last-workgroup-done, in two levels: a workgroup publishes its partials (and trace) device-wide and takes a ticket of
+// its group (workgroup index mod `groups`); the last of a group takes a ticket of the problem; the last of those knows
+// every workgroup's results are at the coherence point (each waited for its stores before its increment) and
+// finalizes.  Two levels because a device-scope atomic on one address takes ~13 ns and they serialise: 256 workgroups
+// finishing together would queue for 3 us on one counter, and queue for 0.5 us on 8 + 1.  `tickets` - this problem's
+// [groups + 1] counters, kTicketStride ints apart - is zero before the launch and after it.  Called by one whole wave whose threadIdx.x are its
+// lanes; true (wave-uniform) on the wave that may read what the others published.
+//
+// Memory model: the values that cross workgroups are written and read with relaxed agent-scope atomics and ordered by
+// s_waitcnt vmcnt(0) on the writer's side (published()) and by the ticket's data dependence on the reader's.  That
+// relies on gfx942 / gfx950 hardware - an agent-scope (sc1) store is acknowledged only once it is at the memory-side
+// coherence point, and agent-scope loads are served from there - not on the HSA memory model, under which it is a
+// data race.  The signal fences keep the COMPILER from moving the reader's loads above the ticket.  On any other
+// architecture: ACMPC_NO_CHAINED_ROUNDS / ACMPC_NO_TRACED_FINALIZE / ACMPC_NO_SOLO select the forms without it.
+__device__ __forceinline__ bool last_workgroup_of_problem(int* tickets, const int groups_cfg) {
+  const int blocks = static_cast<int>(gridDim.x);
+  const int group = static_cast<int>(blockIdx.x) & (groups_cfg - 1);   // groups_cfg is a power of two
+  const int group_size = (blocks - group + groups_cfg - 1) / groups_cfg;
+  const int groups = min(blocks, groups_cfg);
+  published();   // partial key, feasible count and trace of this workgroup are at the coherence point
+  ACMPC_STAMP(5);
+  int ticket = 0;
+  if (threadIdx.x == 0) ticket = atomicAdd(&tickets[group * kTicketStride], 1);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  if (ticket != group_size - 1) return false;
+  ACMPC_STAMP(6);
+  if (threadIdx.x == 0) {
+    publish(&tickets[group * kTicketStride], 0);
+    ticket = atomicAdd(&tickets[groups_cfg * kTicketStride], 1);
+  }
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  if (ticket != groups - 1) return false;
+  ACMPC_STAMP(7);
+  if (threadIdx.x == 0) publish(&tickets[groups_cfg * kTicketStride], 0);  // the launch leaves the counters as it found them
+  return true;
+}
+
 // Optional tail of a fused round (one wave, threadIdx.x = its lanes): see FusedFinalize.
 template <int MODE>
 __device__ __forceinline__ void fused_tail(const RolloutArgs& a, const SampleArgs& smp, const FusedFinalize& fused,
                                            const bool traced, float* s_finalize) {
   const int p = blockIdx.y;
   if (fused.tickets == nullptr) return;
-  // Last-workgroup-done, in two levels: a workgroup publishes its partials (and trace) device-wide and takes a ticket
-  // of its group (workgroup index mod 8); the last of a group takes a ticket of the problem; the last of those knows
-  // every workgroup's results are at the coherence point (each waited for its stores before its increment) and finalizes.  Two levels because a
-  // device-scope atomic on one address takes ~13 ns and they serialise: 256 workgroups finishing together would queue
-  // for 3 us on one counter, and queue for 0.5 us on 8 + 1.  `tickets` [P][9] is zero before the launch and after it.
-  const int blocks = static_cast<int>(gridDim.x);
-  const int group = blockIdx.x & (kTicketGroups - 1);
-  const int group_size = (blocks - group + kTicketGroups - 1) / kTicketGroups;
-  const int groups = min(blocks, kTicketGroups);
-  int* tickets = fused.tickets + p * (kTicketGroups + 1);
-  published();   // partial key, feasible count and trace of this workgroup are at the coherence point
-  int ticket = 0;
-  if (threadIdx.x == 0) ticket = atomicAdd(&tickets[group], 1);
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != group_size - 1) return;
-  if (threadIdx.x == 0) {
-    publish(&tickets[group], 0);
-    ticket = atomicAdd(&tickets[kTicketGroups], 1);
-  }
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != groups - 1) return;
-  if (threadIdx.x == 0) publish(&tickets[kTicketGroups], 0);  // the launch leaves the counters as it found them
+  if (!last_workgroup_of_problem(fused.tickets + static_cast<size_t>(p) * (kTicketGroups + 1) * kTicketStride, kTicketGroups)) return;
   auto signal_done = [&]() {   // the record (written by all lanes) before the flag (lane 0), both on their way to the host
     if (fused.done == nullptr || p != 0) return;
     __threadfence_system();
@@ -1237,6 +1269,259 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
     publish(&a.partial_feas[slot], nfeas);
   }
   fused_tail<0>(a, smp, fused, true, nullptr);
+}
+
+// ---- one problem (or a few) of a few thousand candidates per call: ONE launch, the winner never rolled twice ------
+// acmpc_solve_device on a caller's control matrix, mode S.  What rollout_kernel + finalize_kernel do in two launches -
+// the second re-rolling the winner on one wave, which takes as long as the rollout itself at this size - is one launch
+// here: 64 candidates per workgroup; every lane leaves the STATES of its candidate in its row of an LDS block
+// [64][3n | 1] (an odd pitch: the lanes' writes of one step fall on 64 different banks, and a row reads back
+// contiguously; 38 kB at H = 50: four workgroups per CU); the workgroup publishes the row of its best candidate
+// (+ violation and cost) as its trace; the workgroup that finishes a problem last (tickets, as in the fused rounds)
+// takes the argmin over the partial keys and assembles the record out of the winning workgroup's trace and the
+// winner's row of the control matrix - copies only, so the record holds exactly the bits the winning lane computed.
+//
+// SPLIT: two waves per workgroup roll the same 64 candidates, wave 0 the stage cost (step_spatial_cost), wave 1 the
+// bound violations (step_spatial_bounds) and the trace; V crosses once, after the horizon.  A lone wave issues one
+// instruction every ~2 ns whatever it is - scalar ones included - and a second wave on a SIMD issues in the gaps of the
+// first, so a launch takes as long as its longest instruction stream: ~40 instructions per step instead of ~60, also
+// when the launch has two waves for every SIMD (1 024 workgroups: measured 20.4 us against 22.1).
+// Candidate-major matrices (LAYOUT 0): the workgroup's 64 rows are one contiguous span, copied into LDS with 16-byte
+// loads by all its waves and read back row-wise (rollout_tile_kernel's scheme).
+// LDS: [64][3n | 1] states | [64] V | (LAYOUT 0) [64][2n] control tile.
+// NSTEPS > 0: the horizon is the compile-time constant NSTEPS (49 = every racing configuration of the reference,
+// configs/*.yaml: horizon 50) and the states stay in REGISTERS - 3 n of them, the step loop fully unrolled, each
+// state computed into its final register, so the trace costs no instruction at all where the LDS form pays three
+// ds_write per step (0.8 us of a 49-step walk: LDS writes share the wait counter of the scalar row loads).  Only the
+// best lane's states ever reach the LDS: it dumps its registers after the reduction and the wave reads them back side
+// by side.  The roles of SPLIT swap with it: wave 0 rolls the bounds and keeps the states, wave 1 the stage cost.
+__device__ __forceinline__ int solo_pitch(int n) { return (3 * n) | 1; }
+
+template <int LAYOUT, bool SPLIT, int NSTEPS>
+__global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave) rollout_solo_kernel(const RolloutArgs a,
+                                                                                  const FusedFinalize fused) {
+  extern __shared__ __attribute__((aligned(16))) float s_solo[];
+  constexpr bool kRegs = NSTEPS > 0;
+  const int p = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool first = threadIdx.x < kWave;   // wave 0: its threadIdx.x are its lanes (the tail relies on it)
+  const int n = kRegs ? NSTEPS : a.n;
+  const int c = blockIdx.x * kWave + lane;
+  const bool active = c < a.N;
+  const int c_run = active ? c : a.N - 1;   // spare lanes of the last workgroup roll the last candidate; never reported
+  const Weights w = a.w;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kCoefS;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+  const int pitch = solo_pitch(n);
+  // LDS: the states ([64][pitch], or - registers - one row of 3n) | [64] the other wave's sum | the control tile
+  float* s_other = s_solo + (kRegs ? ((3 * n + 3) & ~3) : kWave * pitch);
+  float* s_tile = s_other + kWave;
+  ACMPC_STAMP(0);
+  if constexpr (LAYOUT == 0) {
+    const int c0 = blockIdx.x * kWave;
+    const int rows = min(kWave, a.N - c0);
+    const int total = rows * 2 * n;
+    const size_t span = (static_cast<size_t>(p) * a.N + c0) * 2 * n;  // float index of the span
+    const float* __restrict__ src = a.U + span;
+    constexpr int kThreads = SPLIT ? 2 * kWave : kWave;
+    if (((span & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.U) & 15u) == 0)) {
+      const int quads = total >> 2;
+      for (int q = threadIdx.x; q < quads; q += kThreads)
+        reinterpret_cast<f32x4*>(s_tile)[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + q);
+      for (int e = (quads << 2) + threadIdx.x; e < total; e += kThreads) s_tile[e] = src[e];
+    } else {   // the span starts on an 8-byte boundary only
+      for (int q = threadIdx.x; q < (total >> 1); q += kThreads)
+        reinterpret_cast<f32x2*>(s_tile)[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(src) + q);
+    }
+    __syncthreads();
+  }
+  const f32x2* s_row = reinterpret_cast<const f32x2*>(s_tile + (c_run - blockIdx.x * kWave) * 2 * n);
+  auto controls = [&](int i, float& v, float& k) {
+    if constexpr (LAYOUT == 1) {
+      float vv[1], kk[1];
+      load_controls<1, 1>(a.U, p, a.N, n, i, c_run, vv, kk);
+      v = vv[0];
+      k = kk[0];
+    } else {
+      const f32x2 vk = s_row[i];
+      v = vk[0];
+      k = vk[1];
+    }
+  };
+  StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+  // which wave keeps the trace: LDS form - wave 1 (the bounds wave, the shorter stream without it); registers - wave 0
+  constexpr bool kHelperRollsCost = kRegs;   // the helper (wave 1) rolls the stage cost, else the bounds
+  if (SPLIT && !first) {
+    ACMPC_STAMP(1);
+    float* mine = s_solo + lane * pitch;
+#pragma unroll 7
+    for (int i = 0; i < n; ++i) {
+      float v, k;
+      controls(i, v, k);
+      if constexpr (kHelperRollsCost) {
+        step_spatial_cost(st, coef + i * kCoefS, v, k, w);
+      } else {
+        step_spatial_bounds(st, coef + i * kCoefS, v, k, w);
+        mine[3 * i] = st.ey;
+        mine[3 * i + 1] = st.ep;
+        mine[3 * i + 2] = st.t;
+      }
+    }
+    s_other[lane] = kHelperRollsCost ? st.J : st.V;
+    ACMPC_STAMP(2);
+    __syncthreads();   // (1)
+    return;
+  }
+  ACMPC_STAMP(1);
+  float xs[kRegs ? NSTEPS : 1][3];
+  if constexpr (kRegs) {
+#pragma unroll
+    for (int i = 0; i < NSTEPS; ++i) {
+      float v, k;
+      controls(i, v, k);
+      if constexpr (SPLIT) {
+        step_spatial_bounds(st, coef + i * kCoefS, v, k, w);
+      } else {
+        step_spatial<float>(st, coef + i * kCoefS, v, k, w);
+      }
+      xs[i][0] = st.ey;
+      xs[i][1] = st.ep;
+      xs[i][2] = st.t;
+    }
+  } else {
+    float* mine = s_solo + lane * pitch;
+#pragma unroll 7
+    for (int i = 0; i < n; ++i) {
+      float v, k;
+      controls(i, v, k);
+      if constexpr (SPLIT) {
+        step_spatial_cost(st, coef + i * kCoefS, v, k, w);
+      } else {
+        step_spatial<float>(st, coef + i * kCoefS, v, k, w);
+        mine[3 * i] = st.ey;
+        mine[3 * i + 1] = st.ep;
+        mine[3 * i + 2] = st.t;
+      }
+    }
+  }
+  ACMPC_STAMP(2);
+  __syncthreads();   // (1) split: the other wave's sum (and trace) is in; one wave: orders its own trace writes
+  if constexpr (SPLIT) {
+    if constexpr (kHelperRollsCost) {
+      st.J = s_other[lane];
+    } else {
+      st.V = s_other[lane];
+    }
+  }
+  const float cost = finish_spatial<float>(st, w);
+  if (active && a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c] = cost;
+  const int64_t own_key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
+  int best_lane;
+  const int64_t key = wave_min_key_by_lane(own_key, best_lane);   // (the index rises with the lane)
+  const int nfeas = wave_sum_int_dpp((active && st.V == 0.0f) ? 1 : 0);
+  const int blocks = static_cast<int>(gridDim.x);
+  ACMPC_STAMP(3);
+  const size_t slot = static_cast<size_t>(p) * blocks + blockIdx.x;
+  if (fused.records != nullptr) {
+    const float best_v = bcast(st.V, best_lane), best_cost = bcast(cost, best_lane);
+    const float* row = s_solo + best_lane * pitch;
+    if constexpr (kRegs) {
+      row = s_solo;
+      if (lane == best_lane) {
+#pragma unroll
+        for (int i = 0; i < NSTEPS; ++i) {
+          s_solo[3 * i] = xs[i][0];
+          s_solo[3 * i + 1] = xs[i][1];
+          s_solo[3 * i + 2] = xs[i][2];
+        }
+      }
+      __syncthreads();   // this wave alone by now: orders the one lane's writes before the wave's reads
+    }
+    float* trace_out = fused.trace + slot * fused.trace_pitch;
+    for (int e = lane; e < 3 * n; e += kWave) publish(&trace_out[e], row[e]);
+    if (lane == 0) {
+      publish(&trace_out[3 * n], best_v);
+      publish(&trace_out[3 * n + 1], best_cost);
+    }
+  }
+  if (lane == 0) {
+    publish(&a.partial_keys[slot], key);
+    publish(&a.partial_feas[slot], nfeas);
+  }
+  ACMPC_STAMP(4);
+  if (!last_workgroup_of_problem(fused.tickets + static_cast<size_t>(p) * (fused.ticket_groups + 1) * kTicketStride,
+                                 fused.ticket_groups))
+    return;
+
+  // ---- the problem's last workgroup: argmin over the partial keys, record = copies ----
+  constexpr int kPerLane = kSoloBlocks / kWave;   // every key requested before the first is looked at: one round trip
+  int64_t kb[kPerLane];
+  int fb[kPerLane];
+#pragma unroll
+  for (int q = 0; q < kPerLane; ++q) {
+    kb[q] = kKeyMax;
+    fb[q] = 0;
+    if (q * kWave < blocks) {   // (wave-uniform)
+      const int b = min(lane + q * kWave, blocks - 1);
+      kb[q] = observe(&a.partial_keys[static_cast<size_t>(p) * blocks + b]);
+      fb[q] = observe(&a.partial_feas[static_cast<size_t>(p) * blocks + b]);
+    }
+  }
+  int64_t best = kKeyMax;
+  int total_feas = 0;
+#pragma unroll
+  for (int q = 0; q < kPerLane; ++q) {
+    if (q * kWave < blocks) {
+      const bool mine_too = lane + q * kWave < blocks;   // (a clamped lane re-read the last workgroup's slot)
+      best = (mine_too && kb[q] < best) ? kb[q] : best;
+      total_feas += mine_too ? fb[q] : 0;
+    }
+  }
+  total_feas = wave_sum_int_dpp(total_feas);
+  // min over the lanes' keys: the ordered cost words first, then the index words among the lanes that hold that cost;
+  // workgroup b's candidates are b * 64 .., so the winner's workgroup follows from its index
+  const int best_hi = wave_min_int_dpp(static_cast<int>(best >> 32));
+  const unsigned best_lo_mine = (static_cast<int>(best >> 32) == best_hi) ? static_cast<unsigned>(best & 0xffffffffLL) : 0xffffffffu;
+  // (indices are below 2^32 - 1 and compare as unsigned: flip the sign bit for the signed DPP minimum)
+  const unsigned best_lo = static_cast<unsigned>(wave_min_int_dpp(static_cast<int>(best_lo_mine ^ 0x80000000u))) ^ 0x80000000u;
+  const int64_t winner = (static_cast<int64_t>(best_hi) << 32) | best_lo;
+  ACMPC_STAMP(8);
+  if (fused.keys_out != nullptr && lane == 0) fused.keys_out[p] = winner;
+  if (fused.records == nullptr) return;
+  const int cw = static_cast<int>(static_cast<int64_t>(best_lo) - a.index_offset);
+  const int block = cw / kWave;
+  const float* trace = fused.trace + (static_cast<size_t>(p) * blocks + block) * fused.trace_pitch;
+  const int rec_floats = 4 + 2 * n + 3 * (n + 1);
+  float* __restrict__ rec = fused.records + static_cast<size_t>(p) * rec_floats;
+  // Every entry of the record but two is ONE load from an address that depends on the entry alone: all of a pass are
+  // requested (same instruction for trace, control matrix and start state: an agent-scope load), then all stored.
+  constexpr int kSlots = 8;
+  for (int e0 = 0; e0 < rec_floats; e0 += kSlots * kWave) {
+    float value[kSlots];
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      if (e0 + q * kWave < rec_floats) {   // (wave-uniform)
+        const int e = min(e0 + q * kWave + lane, rec_floats - 1);
+        const int u = e - 4;
+        const float* src = trace + (e - (4 + 2 * n + 3));                                        // states
+        src = (e < 4 + 2 * n + 3) ? x0 + (e - (4 + 2 * n)) : src;                                // start state
+        const float* from_u = (LAYOUT == 1) ? a.U + ((static_cast<size_t>(p) * n + (u >> 1)) * 2 + (u & 1)) * a.N + cw
+                                            : a.U + (static_cast<size_t>(p) * a.N + cw) * 2 * n + u;
+        src = (e < 4 + 2 * n) ? from_u : src;                                                    // controls
+        src = (e < 4) ? trace + 3 * n + (1 - min(e, 1)) : src;                                   // cost, violation
+        value[q] = observe(src);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      const int e = e0 + q * kWave + lane;
+      if (e0 + q * kWave < rec_floats) {
+        const float out = (e == 2) ? static_cast<float>(total_feas) : (e == 3) ? 1.0f : value[q];
+        if (e < rec_floats) rec[e] = out;
+      }
+    }
+  }
+  ACMPC_STAMP(9);
 }
 
 // ---- softmin-weighted mean -------------------------------------------------------------------------------
@@ -1730,7 +2015,7 @@ bool traced_finalize_fits(int mode, int n) {
 // More dynamic LDS than a kernel gets by default (64 kB): raise the kernel's limit, once per kernel and device.
 static hipError_t raise_lds_limit(const void* kernel, int which, size_t lds) {
   if (lds <= 64 * 1024) return hipSuccess;
-  static bool raised[3][64] = {};
+  static bool raised[11][64] = {};
   int device = 0;
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
@@ -1785,6 +2070,74 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
     hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, uniform_offset);
   }
   return hipGetLastError();
+}
+
+// acmpc_solve_device's one-launch form (mode S): see rollout_solo_kernel.
+constexpr int kSoloRegisterSteps = 49;   // the horizon whose states stay in registers (H = 50)
+
+// Registers or LDS for the states, measured (device-resident solve, p50 of 300, three engines each; registers / LDS):
+//   step-major   4 096 x 49: 11.6 / 12.4 us    16 384 x 49: 12.5 / 12.6    65 536 x 49: 17.2 / 15.9
+//   cand.-major  4 096 x 49: 12.7 / 13.9                                    65 536 x 49: 18.7 / (two launches: 26.7)
+// so: registers up to 512 workgroups (no SIMD holds more than one wave), and in the candidate-major layout always -
+// there the 38 kB of states beside the 25 kB control tile would keep a launch of more than 512 workgroups from being
+// resident at once.
+static bool solo_in_registers(long long blocks, int n, int layout) {
+  if (n != kSoloRegisterSteps) return false;
+  if (const char* env = std::getenv("ACMPC_SOLO_REGISTERS")) return env[0] == '1';   // (A/B switch)
+  return blocks <= 512 || layout == 0;
+}
+
+static size_t solo_lds_bytes(long long blocks, int layout, int n) {
+  const size_t states = solo_in_registers(blocks, n, layout) ? static_cast<size_t>((3 * n + 3) & ~3)
+                                                             : static_cast<size_t>((3 * n) | 1) * kWave;
+  return (states + kWave + (layout == 0 ? static_cast<size_t>(kWave) * 2 * n : 0)) * sizeof(float);
+}
+
+bool solo_fits(int P, int N, int n, int layout) {
+  // every workgroup of the launch resident at once (256 CUs x 160 kB of LDS; eight two-wave workgroups per CU): a second
+  // generation of workgroups would cost more than the second launch does
+  const long long blocks = static_cast<long long>(P) * ((N + kWave - 1) / kWave);
+  const size_t lds = solo_lds_bytes(blocks, layout, n);
+  return blocks <= kSoloBlocks && lds <= 160u * 1024u &&
+         blocks <= 256LL * std::min<long long>(8, static_cast<long long>((160u * 1024u) / lds));
+}
+
+int solo_trace_floats(int n) { return 3 * n + 2; }
+
+hipError_t launch_rollout_solo(int layout, const RolloutArgs& args, const FusedFinalize& fused_in, hipStream_t s,
+                               hipEvent_t e0, hipEvent_t e1) {
+  clear_stale_error();
+  const int blocks = (args.N + kWave - 1) / kWave;
+  if (!solo_fits(args.P, args.N, args.n, layout) || fused_in.tickets == nullptr) return hipErrorInvalidValue;
+  if (fused_in.records != nullptr && (fused_in.trace == nullptr || fused_in.trace_pitch < solo_trace_floats(args.n)))
+    return hipErrorInvalidValue;
+  FusedFinalize fused = fused_in;
+  // ticket groups: 8 for launches of up to 256 workgroups, 32 above (a device-scope atomic on one address is ~13 ns)
+  fused.ticket_groups = (args.P * blocks > 256 || blocks > 256) ? kTicketGroupsMax : kTicketGroups;
+  // two waves per workgroup (see the kernel); ACMPC_SOLO_SPLIT=0 keeps one, for the tests' three-way comparison
+  bool split = true;
+  if (const char* env = std::getenv("ACMPC_SOLO_SPLIT")) split = env[0] == '1';
+  const long long all_blocks = static_cast<long long>(args.P) * blocks;
+  const size_t lds = solo_lds_bytes(all_blocks, layout, args.n);
+  const dim3 grid(blocks, args.P);
+  auto go = [&](auto kernel, int which, int threads) -> hipError_t {
+    const hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel), which, lds);
+    if (e != hipSuccess) return e;
+    if (e0 != nullptr && e1 != nullptr) {
+      hipExtLaunchKernelGGL(kernel, grid, dim3(threads), static_cast<std::uint32_t>(lds), s, e0, e1, 0, args, fused);
+    } else {
+      hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, args, fused);
+    }
+    return hipGetLastError();
+  };
+  constexpr int R = kSoloRegisterSteps;
+  if (solo_in_registers(all_blocks, args.n, layout)) {
+    if (layout == 1) return split ? go(&rollout_solo_kernel<1, true, R>, 3, 2 * kWave) : go(&rollout_solo_kernel<1, false, R>, 4, kWave);
+    if (layout == 0) return split ? go(&rollout_solo_kernel<0, true, R>, 5, 2 * kWave) : go(&rollout_solo_kernel<0, false, R>, 6, kWave);
+  }
+  if (layout == 1) return split ? go(&rollout_solo_kernel<1, true, 0>, 7, 2 * kWave) : go(&rollout_solo_kernel<1, false, 0>, 8, kWave);
+  if (layout == 0) return split ? go(&rollout_solo_kernel<0, true, 0>, 9, 2 * kWave) : go(&rollout_solo_kernel<0, false, 0>, 10, kWave);
+  return hipErrorInvalidValue;
 }
 
 int softmin_chunks(int N) { return (N + kSoftChunk - 1) / kSoftChunk; }
