@@ -29,12 +29,29 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found: set HIPCC or install ROCm")
 
 
+FLAGS_PATH = os.path.join(LIB_DIR, "build_flags.txt")
+
+
+def flag_record() -> str:
+    """Everything besides the sources that decides what the library is: the flag sets and a one-off experiment's extras."""
+    lines = ["common: " + " ".join(HIPCC_FLAGS)]
+    lines += ["%s: %s" % (src, " ".join(EXTRA_FLAGS.get(src, ()))) for src in SOURCES]
+    lines.append("experiment: " + " ".join(os.environ.get("ACMPC_HIPCC_EXTRA", "").split()))
+    return "\n".join(lines) + "\n"
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """Sources or headers newer than the library, a build script newer than it, or a library built with other flags
+    (an A/B build with ACMPC_HIPCC_EXTRA left in the tree must not be what the tests and the bench silently run)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(FLAGS_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC_DIR, f) for f in SOURCES + HEADERS]   # (acmpc_kernels_temporal.hip includes acmpc_kernels.hip)
-    return any(os.path.getmtime(d) > built for d in deps)
+    deps.append(os.path.abspath(__file__))
+    if any(os.path.getmtime(d) > built for d in deps):
+        return True
+    with open(FLAGS_PATH) as handle:
+        return handle.read() != flag_record()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -60,6 +77,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         list(pool.map(lambda so: run([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(so[0], ()), *experiment, "-c",
                                       os.path.join(CSRC_DIR, so[0]), "-o", so[1]]), zip(SOURCES, objects)))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objects, "-o", LIB_PATH])
+    with open(FLAGS_PATH, "w") as handle:
+        handle.write(flag_record())
     return LIB_PATH
 
 

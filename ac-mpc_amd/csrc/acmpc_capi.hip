@@ -1115,6 +1115,12 @@ struct TickOutLayout {
 // the bound map -> device (when bound or re-bound since the last upload)
 int upload_map(acmpc_ctx* c, hipStream_t s) {
   if (!c->map_dirty) return ACMPC_OK;
+  // a captured tick graph has the map's address, length and window size in its kernel arguments: none survives a re-bind
+  for (hipGraphExec_t& g : c->tick_graph) {
+    if (g != nullptr) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
+  ACMPC_HIP(c, hipStreamSynchronize(s));   // nothing of an earlier tick still reads the old map
   (void)hipFree(c->d_map);
   c->d_map = nullptr;
   ACMPC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_map), c->h_map.size() * sizeof(double)));
@@ -1343,8 +1349,13 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     pa.header_value = *h;
     int rc_rounds = ACMPC_OK;
     const hipError_t e = enqueue(s, &rc_rounds);
-    if (rc_rounds != ACMPC_OK) return rc_rounds;
-    ACMPC_HIP(c, e);
+    if (rc_rounds != ACMPC_OK || e != hipSuccess) {
+      // part of the sequence may be running: it reads the pinned input block and writes the result block, which the
+      // caller's next tick would overwrite - wait for it (result ignored in favour of the error that brought us here)
+      (void)hipStreamSynchronize(s);
+      if (rc_rounds != ACMPC_OK) return rc_rounds;
+      ACMPC_HIP(c, e);
+    }
   }
   if (flagged) {
     volatile unsigned* flag = done_flag;

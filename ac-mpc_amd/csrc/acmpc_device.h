@@ -666,38 +666,15 @@ __device__ __host__ __forceinline__ int64_t pack_key(float cost, uint32_t index)
 
 constexpr int64_t kKeyMax = INT64_MAX;
 
-__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask) {
-  int lo = static_cast<int>(v & 0xffffffffLL);
-  int hi = static_cast<int>(v >> 32);
-  lo = __shfl_xor(lo, mask, kWave);
-  hi = __shfl_xor(hi, mask, kWave);
-  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
-}
-
-__device__ __forceinline__ int64_t wave_min_key(int64_t v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const int64_t o = shfl_xor_i64(v, m);
-    v = (o < v) ? o : v;
-  }
-  return v;
-}
-
-__device__ __forceinline__ int wave_sum_int(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-  return v;
-}
-
-// The same two reductions on the DPP path (row shifts inside the rows of 16 lanes, then row_bcast:15 / :31 across
-// them; the result is lane 63's): twelve vector instructions where the shuffle forms make eighteen round trips through
-// the LDS crossbar (ds_bpermute) - half a microsecond on a lone wave.  Integers: the same values either way.
+// Wave reductions on the DPP path (row shifts inside the rows of 16 lanes, then row_bcast:15 / :31 across them; the
+// result is lane 63's): six vector instructions per 32-bit reduction where the shuffle forms (ds_bpermute) make six round
+// trips through the LDS crossbar - half a microsecond for a key + a count on a lone wave.  Integers: exact either way.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_move(int identity, int v) {
   return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
 }
 
-__device__ __forceinline__ int wave_sum_int_dpp(int v) {
+__device__ __forceinline__ int wave_sum_int(int v) {
   v += dpp_move<0x111, 0xf>(0, v);   // row_shr:1
   v += dpp_move<0x112, 0xf>(0, v);   // row_shr:2
   v += dpp_move<0x114, 0xf>(0, v);   // row_shr:4
@@ -707,7 +684,7 @@ __device__ __forceinline__ int wave_sum_int_dpp(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-__device__ __forceinline__ int wave_min_int_dpp(int v) {
+__device__ __forceinline__ int wave_min_int(int v) {
   v = min(v, dpp_move<0x111, 0xf>(v, v));
   v = min(v, dpp_move<0x112, 0xf>(v, v));
   v = min(v, dpp_move<0x114, 0xf>(v, v));
@@ -717,11 +694,21 @@ __device__ __forceinline__ int wave_min_int_dpp(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-// min over the wave's (cost, index) keys when the index rises with the lane (index = base + lane): the minimum of the
-// ordered cost words, then the FIRST lane that holds it - the same key wave_min_key() returns.  `lane_out` = that lane.
+// min over the wave's keys = lexicographic (signed cost word, unsigned index word): the minimum of the cost words, then
+// the minimum of the index words (sign bit flipped for the signed instruction) among the lanes that hold that cost
+__device__ __forceinline__ int64_t wave_min_key(int64_t v) {
+  const int hi = static_cast<int>(v >> 32);
+  const int best_hi = wave_min_int(hi);
+  const int lo = (hi == best_hi) ? static_cast<int>(static_cast<uint32_t>(v & 0xffffffffLL) ^ 0x80000000u) : INT32_MAX;
+  const uint32_t best_lo = static_cast<uint32_t>(wave_min_int(lo)) ^ 0x80000000u;
+  return (static_cast<int64_t>(best_hi) << 32) | best_lo;
+}
+
+// the same when the index rises with the lane (index = base + lane): the minimum of the cost words, then the FIRST lane
+// that holds it.  `lane_out` = that lane.
 __device__ __forceinline__ int64_t wave_min_key_by_lane(int64_t own_key, int& lane_out) {
   const int hi = static_cast<int>(own_key >> 32);
-  const int best = wave_min_int_dpp(hi);
+  const int best = wave_min_int(hi);
   const unsigned long long holders = __ballot(hi == best);
   lane_out = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holders)) - 1);
   const int lo = __builtin_amdgcn_readlane(static_cast<int>(own_key & 0xffffffffLL), lane_out);

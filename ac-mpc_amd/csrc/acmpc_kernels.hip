@@ -522,17 +522,14 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   if (active) draw_normals<0, kKnots / 4>(sp, gidx, static_cast<uint32_t>(p), z);
   if (chained) {   // the previous round's winner: argmin over its workgroups' keys; its controls head that workgroup's trace
     int64_t best = kKeyMax;
-    int block = 0;
 #pragma unroll
     for (int q = 0; q < kChainBlocks / kWave; ++q) {
-      const int b = lane + q * kWave;
-      const int64_t kb = (b < smp.prev_blocks) ? prev_key[q] : kKeyMax;
-      block = (kb < best) ? b : block;
+      const int64_t kb = (lane + q * kWave < smp.prev_blocks) ? prev_key[q] : kKeyMax;
       best = (kb < best) ? kb : best;
     }
+    // (workgroup b rolled the candidates b * 64 ..: the winner's workgroup follows from its index)
     const int64_t winner = wave_min_key(best);
-    const unsigned long long holder = __ballot(best == winner);   // keys are distinct (they carry the index)
-    block = __builtin_amdgcn_readlane(block, __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1));
+    const int block = static_cast<int>(static_cast<int64_t>(static_cast<uint32_t>(winner & 0xffffffffLL)) - a.index_offset) / kWave;
     centre = smp.prev_trace + (static_cast<size_t>(p) * smp.prev_blocks + block) * smp.prev_pitch;
 #pragma unroll
     for (int q = 0; q < kPairs; ++q) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[min(lane + q * kWave, n - 1)];
@@ -634,12 +631,10 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   }
   const int64_t own_key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
   int nfeas = (active && feas) ? 1 : 0;
-  const int64_t key = wave_min_key(own_key);
+  int best_lane;
+  const int64_t key = wave_min_key_by_lane(own_key, best_lane);   // (the index rises with the lane)
   nfeas = wave_sum_int(nfeas);
   if (traced) {
-    // keys carry the candidate index: exactly one lane holds the workgroup's minimum
-    const unsigned long long holder = __ballot(own_key == key);
-    const int best_lane = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1);
     __syncthreads();   // one wave: orders the column writes above before the row reads
     for (int e = lane; e < 5 * n + 2; e += kWave) publish(&trace_out[e], s_trace[e * kWave + best_lane]);
   }
@@ -937,45 +932,67 @@ __device__ __forceinline__ void finalize_from_trace(const RolloutArgs& a, const 
   const int lane = threadIdx.x;
   const int n = a.n;
   const int blocks = static_cast<int>(gridDim.x);
+  // every key is requested before the first is looked at (a load per loop iteration with its compare behind it is one
+  // round trip per 64 workgroups: 3 us of a 256-workgroup round's tail); launches beyond the batch go round the loop
+  constexpr int kBatch = 4;
   int nfeas = 0;
   int64_t key = kKeyMax;
-  int block = 0;
-  for (int b = lane; b < blocks; b += kWave) {
-    const size_t slot = static_cast<size_t>(p) * blocks + b;
-    nfeas += observe(&a.partial_feas[slot]);
-    const int64_t kb = observe(&a.partial_keys[slot]);
-    block = (kb < key) ? b : block;
-    key = (kb < key) ? kb : key;
+  for (int b0 = 0; b0 < blocks; b0 += kBatch * kWave) {
+    int64_t kb[kBatch];
+    int fb[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      kb[q] = kKeyMax;
+      fb[q] = 0;
+      if (b0 + q * kWave < blocks) {   // (wave-uniform)
+        const size_t slot = static_cast<size_t>(p) * blocks + min(b0 + q * kWave + lane, blocks - 1);
+        kb[q] = observe(&a.partial_keys[slot]);
+        fb[q] = observe(&a.partial_feas[slot]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const bool mine = b0 + q * kWave + lane < blocks;   // (a clamped lane re-read the last workgroup's slot)
+      key = (mine && kb[q] < key) ? kb[q] : key;
+      nfeas += mine ? fb[q] : 0;
+    }
   }
   nfeas = wave_sum_int(nfeas);
   const int64_t best = wave_min_key(key);
-  const unsigned long long holder = __ballot(key == best);   // keys are distinct: one lane (all of them: nothing finite)
-  block = __builtin_amdgcn_readlane(block, __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1));
+  // workgroup b holds the candidates b * 64 ..: the winner's workgroup follows from its index
+  const int block = static_cast<int>(static_cast<int64_t>(static_cast<uint32_t>(best & 0xffffffffLL)) - a.index_offset) / kWave;
   const float* trace = fused.trace + (static_cast<size_t>(p) * blocks + block) * fused.trace_pitch;
   const int rec_floats = 4 + 2 * n + 3 * (n + 1);
   float* __restrict__ rec = fused.records + static_cast<size_t>(p) * rec_floats;
   const float* __restrict__ x0 = a.x0 + p * 3;
   const int count = fused.controls_only ? 4 + 2 * n : rec_floats;
-  for (int e = lane; e < count; e += kWave) {
-    float value;
-    if (e == 0) {            // between rounds the cost is read back from the key (non-finite -> +inf), as the
-      value = fused.controls_only ? key_cost(best)   // separate finalize does; the last record carries the lane's own
-                                  : observe(&trace[5 * n + 1]);
-    } else if (e == 1) {
-      value = fused.controls_only ? 0.0f
-                                  : observe(&trace[5 * n]);
-    } else if (e == 2) {
-      value = static_cast<float>(nfeas);
-    } else if (e == 3) {
-      value = 1.0f;
-    } else if (e < 4 + 2 * n) {
-      value = observe(&trace[e - 4]);
-    } else if (e < 4 + 2 * n + 3) {
-      value = x0[e - (4 + 2 * n)];
-    } else {
-      value = observe(&trace[e - 7]);   // 2n + (e - 4 - 2n - 3)
+  // every entry but three is ONE load from an address that depends on the entry alone: all of a pass requested, then stored
+  constexpr int kSlots = 8;
+  for (int e0 = 0; e0 < count; e0 += kSlots * kWave) {
+    float value[kSlots];
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      if (e0 + q * kWave < count) {   // (wave-uniform)
+        const int e = min(e0 + q * kWave + lane, count - 1);
+        const float* src = trace + (e - 7);                               // states: 2n + (e - 4 - 2n - 3)
+        src = (e < 4 + 2 * n + 3) ? x0 + (e - (4 + 2 * n)) : src;         // start state
+        src = (e < 4 + 2 * n) ? trace + (e - 4) : src;                    // controls
+        src = (e < 4) ? trace + 5 * n + (1 - min(e, 1)) : src;            // cost, violation
+        value[q] = observe(src);
+      }
     }
-    rec[e] = value;
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      const int e = e0 + q * kWave + lane;
+      if (e0 + q * kWave < count) {
+        float out = value[q];
+        // between rounds the cost is read back from the key (non-finite -> +inf), as the separate finalize does; the
+        // last record carries the lane's own
+        if (fused.controls_only) out = (e == 0) ? key_cost(best) : (e == 1) ? 0.0f : out;
+        out = (e == 2) ? static_cast<float>(nfeas) : (e == 3) ? 1.0f : out;
+        if (e < count) rec[e] = out;
+      }
+    }
   }
 }
 
@@ -1129,17 +1146,13 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
     draw_normals<0, kKnots / 4>(sp, gidx, static_cast<uint32_t>(p), z);
     if (chained) {
       int64_t best = kKeyMax;
-      int block = 0;
 #pragma unroll
       for (int q = 0; q < kChainBlocks / kWave; ++q) {
-        const int b = lane + q * kWave;
-        const int64_t kb = (b < smp.prev_blocks) ? prev_key[q] : kKeyMax;
-        block = (kb < best) ? b : block;
+        const int64_t kb = (lane + q * kWave < smp.prev_blocks) ? prev_key[q] : kKeyMax;
         best = (kb < best) ? kb : best;
       }
       const int64_t winner = wave_min_key(best);
-      const unsigned long long holder = __ballot(best == winner);
-      block = __builtin_amdgcn_readlane(block, __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1));
+      const int block = static_cast<int>(static_cast<int64_t>(static_cast<uint32_t>(winner & 0xffffffffLL)) - a.index_offset) / kWave;
       centre = smp.prev_trace + (static_cast<size_t>(p) * smp.prev_blocks + block) * smp.prev_pitch;
 #pragma unroll
       for (int q = 0; q < kPairs; ++q) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[min(lane + q * kWave, n - 1)];
@@ -1254,11 +1267,10 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
   if (active && a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c] = cost;
   const int64_t own_key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
   int nfeas = (active && st.V == 0.0f) ? 1 : 0;
-  const int64_t key = wave_min_key(own_key);
+  int best_lane;
+  const int64_t key = wave_min_key_by_lane(own_key, best_lane);   // (the index rises with the lane)
   nfeas = wave_sum_int(nfeas);
   {
-    const unsigned long long holder = __ballot(own_key == key);
-    const int best_lane = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holder)) - 1);
     __syncthreads();   // this wave alone by now: orders its column writes before the row reads
     float* trace_out = fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch;
     for (int e = lane; e < 5 * n + 2; e += kWave) publish(&trace_out[e], s_trace[e * kWave + best_lane]);
@@ -1418,7 +1430,7 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave) rollout_solo_kernel
   const int64_t own_key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
   int best_lane;
   const int64_t key = wave_min_key_by_lane(own_key, best_lane);   // (the index rises with the lane)
-  const int nfeas = wave_sum_int_dpp((active && st.V == 0.0f) ? 1 : 0);
+  const int nfeas = wave_sum_int((active && st.V == 0.0f) ? 1 : 0);
   const int blocks = static_cast<int>(gridDim.x);
   ACMPC_STAMP(3);
   const size_t slot = static_cast<size_t>(p) * blocks + blockIdx.x;
@@ -1477,14 +1489,10 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave) rollout_solo_kernel
       total_feas += mine_too ? fb[q] : 0;
     }
   }
-  total_feas = wave_sum_int_dpp(total_feas);
-  // min over the lanes' keys: the ordered cost words first, then the index words among the lanes that hold that cost;
-  // workgroup b's candidates are b * 64 .., so the winner's workgroup follows from its index
-  const int best_hi = wave_min_int_dpp(static_cast<int>(best >> 32));
-  const unsigned best_lo_mine = (static_cast<int>(best >> 32) == best_hi) ? static_cast<unsigned>(best & 0xffffffffLL) : 0xffffffffu;
-  // (indices are below 2^32 - 1 and compare as unsigned: flip the sign bit for the signed DPP minimum)
-  const unsigned best_lo = static_cast<unsigned>(wave_min_int_dpp(static_cast<int>(best_lo_mine ^ 0x80000000u))) ^ 0x80000000u;
-  const int64_t winner = (static_cast<int64_t>(best_hi) << 32) | best_lo;
+  total_feas = wave_sum_int(total_feas);
+  // (workgroup b's candidates are b * 64 .., so the winner's workgroup follows from its index)
+  const int64_t winner = wave_min_key(best);
+  const uint32_t best_lo = static_cast<uint32_t>(winner & 0xffffffffLL);
   ACMPC_STAMP(8);
   if (fused.keys_out != nullptr && lane == 0) fused.keys_out[p] = winner;
   if (fused.records == nullptr) return;

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Benchmark of the rollout-and-cost hot path (contract: see the task statement / DESIGN.md "Measurement").
 
     python bench.py --gpus N --steps K --warmup W      (N > 1 without torchrun: starts its own N ranks as a child)

@@ -82,3 +82,51 @@ def test_get_control_at_equals_get_control_on_the_same_path():
             np.testing.assert_array_equal(a.cum_time, b.cum_time)
         else:
             np.testing.assert_allclose(a.projected_control, b.projected_control, rtol=1e-3, atol=1e-4)
+
+
+_REBIND_SCRIPT = r"""
+import copy, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from acmpc_amd import workloads
+from acmpc_amd.mpc import build_mpc
+from test_support import PlaceholderVehicle
+
+def controller():
+    cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"])
+    cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
+    cfg.update(n_candidates=2048)
+    return build_mpc(cfg, PlaceholderVehicle())
+
+maps = [workloads.synthetic_track("silverstone"), workloads.synthetic_track("monza")]
+assert len(maps[0]["centre"]) != len(maps[1]["centre"])
+a = controller()
+for track in maps + maps[:1]:           # A, then B of another length, then A again
+    a.bind_map(track)
+    fresh = controller()
+    fresh.bind_map(track)
+    for index in (5, 4000, len(track["centre"]) - 40):
+        a.get_control_at(map_index=index)
+        fresh.get_control_at(map_index=index)
+        want = a._control_solver._engine.map_reference_path(50, map_index=index)[0]
+        np.testing.assert_array_equal(a.reference_coordinates, want)
+        np.testing.assert_array_equal(a.reference_coordinates, fresh.reference_coordinates)
+print("rebind ok")
+"""
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_rebinding_a_map_does_not_replay_a_stale_tick_graph(graph):
+    """ACMPC_TICK_GRAPH=1 replays a captured graph whose kernel arguments hold the map's address, length and window size:
+    binding another map must drop it (the switch is read once per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("ACMPC_TICK_GRAPH", None)
+    if graph == "1":
+        env["ACMPC_TICK_GRAPH"] = "1"
+    proc = subprocess.run([sys.executable, "-c", _REBIND_SCRIPT, os.path.join(root, "ac-mpc_amd"), os.path.join(root, "tests")],
+                          capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0 and "rebind ok" in proc.stdout, (proc.stdout + proc.stderr)[-3000:]

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing of the particle-scoring seam (development tool): GPU `ParticleScorer.update_particles` vs the oracle's NumPy
 restatement of the reference (KD-tree replaced by brute force there, so the CPU figure is indicative only)."""
 import os

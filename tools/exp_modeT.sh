@@ -12,9 +12,11 @@ run() { echo "== $1" >> $LOG; shift; env "$@" python3 tools/sweep.py $SPECS >> $
 run "default (256,4 packed pairs)"            ACMPC_X=0
 run "256,4 plain float32 source"               ACMPC_T_PACK=1
 run "256,2 plain"                               ACMPC_SHAPE=256,2 ACMPC_T_PACK=1
-CS=ac-mpc_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize $CS/acmpc_kernels.hip $CS/acmpc_capi.hip \
-  $CS/acmpc_pf.hip $CS/acmpc_speed_profile.cpp $CS/acmpc_host_path.cpp -o /tmp/libacmpc_noslp.so >> $LOG 2>&1 || exit 1
+# the A/B library goes through the package's own build (all sources, their per-source flags + the extra one) into a
+# scratch copy of the package, so that the tree's library stays the default build
+rm -rf /tmp/acmpc_noslp && mkdir -p /tmp/acmpc_noslp && cp -r ac-mpc_amd include /tmp/acmpc_noslp/ && rm -rf /tmp/acmpc_noslp/ac-mpc_amd/acmpc_amd/lib
+(cd /tmp/acmpc_noslp/ac-mpc_amd && ACMPC_HIPCC_EXTRA=-fno-slp-vectorize python3 acmpc_amd/_build.py) >> $LOG 2>&1 || exit 1
+cp /tmp/acmpc_noslp/ac-mpc_amd/acmpc_amd/lib/libacmpc_hip.so /tmp/libacmpc_noslp.so
 run "no-slp: 256,4 plain"                       ACMPC_HIP_LIBRARY=/tmp/libacmpc_noslp.so ACMPC_T_PACK=1
 run "no-slp: 256,2 plain"                       ACMPC_HIP_LIBRARY=/tmp/libacmpc_noslp.so ACMPC_SHAPE=256,2 ACMPC_T_PACK=1
 run "no-slp: 256,1"                             ACMPC_HIP_LIBRARY=/tmp/libacmpc_noslp.so ACMPC_SHAPE=256,1

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development probe: a long run of SpatialMPC.get_control - latency drift and host/device memory growth."""
 import copy, os, sys, time
 import numpy as np

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Kernel-level sweep (development tool): times rollout_kernel alone with HIP events for a list of shapes.
 
     python tools/sweep.py "S,1,256,4096,50" "T,1,64,4096,50" ...      spec = mode,layout,P,N,H

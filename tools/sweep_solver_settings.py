@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development probe: closed-loop solve latency and plan cost over (candidates per round, rounds).  Same replay as
 bench.py's closed_loop_replay (consecutive poses along the synthetic Silverstone circuit, warm-started solves);
 the cost of the returned plan is compared with the best setting's on the same pose."""

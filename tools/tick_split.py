@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development probe (GPU box): how the closed-loop get_control divides between Python and the library call."""
 import copy
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development probe (GPU box): where the tail of the closed-loop latency distribution comes from - percentiles of
 get_control with the garbage collector on and off, and the positions of the slowest calls."""
 import copy

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development probe: wall time of SpatialMPC.get_control and of its stages on the GPU box."""
 import copy
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development probe: where the host time of SpatialMPC.get_control goes (perf_counter around its stages)."""
 import copy, math, os, sys, time
 import numpy as np

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development probe: wall time of one acmpc_optimize call (the closed-loop solve's GPU part) on the GPU box."""
 import os
 import sys

@@ -1,6 +1,8 @@
-#!/usr/bin/env python3
 """Development probe (GPU box): closed-loop get_control with the device prologue vs the host prologue, consecutive
-poses 1 m apart; run under `rocprofv3 --kernel-trace --stats` to see the prologue kernel's own time."""
+poses 1 m apart.  For the prologue kernel's own time run it under the profiler with the interpreter named after `--`
+(a script started through its shebang would go through `env`, which replaces the process after the profiler's preloaded
+library has initialised the GPU - not allowed on this pool):
+    rocprofv3 --kernel-trace --stats -- python3 tools/time_tick.py"""
 import copy
 import os
 import sys
