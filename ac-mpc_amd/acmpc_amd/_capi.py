@@ -166,6 +166,7 @@ SIGNATURES = {
     "acmpc_velocity_ceiling": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                          C.c_int32, C.c_double, C.c_void_p]),
     "acmpc_unpack_decision": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_double] + [C.c_void_p] * 6),
+    "acmpc_unpack_decision_temporal": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double] + [C.c_void_p] * 6),
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "acmpc_speed_profile_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
                                          C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, _I32P]),
@@ -478,10 +479,10 @@ class Engine:
         return coords, first.value
 
     def tick_device_tables(self, n: int):
-        """(x0 [3], u_ref [n,2], coef [n,12]) the last tick's prologue left on the device (test hook)."""
+        """(x0 [3], u_ref [n,2], coef [n,12] - mode T: [n,8]) the last tick's prologue left on the device (test hook)."""
         x0 = np.empty(3, dtype=np.float32)
         u_ref = np.empty((n, 2), dtype=np.float32)
-        coef = np.empty((n, COEF_STRIDE[MODE_SPATIAL]), dtype=np.float32)
+        coef = np.empty((n, COEF_STRIDE[self.mode]), dtype=np.float32)
         self._check(self._lib.acmpc_tick_read_device_tables(self._ctx, x0.ctypes.data, u_ref.ctypes.data, coef.ctypes.data))
         return x0, u_ref, coef
 
@@ -587,6 +588,20 @@ def unpack_decision(z: np.ndarray, n: int, table: np.ndarray, wheelbase: float):
     if rc != OK:
         raise EngineError(rc, "acmpc_unpack_decision: bad arguments")
     return tuple(a.copy() for a in arrays)
+
+
+def unpack_decision_temporal(z: np.ndarray, n: int, dt: float, wheelbase: float):
+    """A mode T plan's dec.x -> the same six arrays (`acmpc_unpack_decision_temporal`: prediction = the rolled poses,
+    cum_time = i dt, derivatives of the plan's own controls)."""
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    if z.shape[0] != 5 * n + 3:
+        raise ValueError("decision vector does not match n = %d" % n)
+    arrays = (np.empty((2, n)), np.empty((n, 2)), np.empty(n), np.empty(n - 1), np.empty(n - 1), np.empty(n - 1))
+    rc = load_library().acmpc_unpack_decision_temporal(z.ctypes.data, n, float(dt), float(wheelbase),
+                                                       *(a.ctypes.data for a in arrays))
+    if rc != OK:
+        raise EngineError(rc, "acmpc_unpack_decision_temporal: bad arguments")
+    return arrays
 
 
 def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: float, v_min: float, max_iter: int = 4000,

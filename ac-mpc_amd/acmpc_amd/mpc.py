@@ -134,6 +134,7 @@ class SpatialMPC:
         path = self.compute_speed_profile(path, is_localised,
                                           end_vel=self.speed_profile_constraints["end_velocity"])
         spatial_state = self.model.t2s(path.get_state(0), np.array([offset, 0.0, math.pi / 2]))
+        self._control_solver.pose = (float(offset), 0.0, math.pi / 2)   # what `rollout_mode: "T"` starts from
         dec = self._control_solver.solve(spatial_state, path)
 
         if dec.info.status != SOLVED:
@@ -142,8 +143,12 @@ class SpatialMPC:
             self.infeasibility_counter += 1
             return
 
-        (self.projected_control, self.current_prediction, self.cum_time, self.times, self.accelerations,
-         self.steer_rates) = _capi.unpack_decision(dec.x, n, path.table, self.model.length)
+        if self._control_solver.temporal:
+            (self.projected_control, self.current_prediction, self.cum_time, self.times, self.accelerations,
+             self.steer_rates) = _capi.unpack_decision_temporal(dec.x, n, self._control_solver._dt, self.model.length)
+        else:
+            (self.projected_control, self.current_prediction, self.cum_time, self.times, self.accelerations,
+             self.steer_rates) = _capi.unpack_decision(dec.x, n, path.table, self.model.length)
         self.reference_path = path
         self.infeasibility_counter = 0
 

@@ -10,6 +10,12 @@ optimum.  Candidates are generated on the device too (Philox counters, smooth pe
 one solve is a single host round trip.  The rounds, the candidate count and the spread are build parameters read
 from optional config keys (`n_candidates`, `sampling_rounds`, `sampling_sigma`, `sampling_cold_rounds`,
 `sampling_cold_sigma`, `sampling_seed`, `w_bound`, `sampling_update`, `softmin_lambda`).
+
+`rollout_mode: "T"` (default "S") scores the candidates with the Cartesian rollout instead - BASELINE.json north_star's
+literal shape: kinematic bicycle (localisation/localiser.py:66-95) advanced by `rollout_dt` seconds per step (0.05),
+nearest waypoint of the path (localiser.py:282-289) within `nn_window: [back, ahead]` waypoints of the previous step's
+(default [2, 5]; `null` = all waypoints), Frenet errors against it (dynamics.py:23-40), the same weights and bounds.
+The plan is then a TIME-indexed one (control i holds from i * dt), which is what `TemporalCommandSelector` consumes.
 """
 from __future__ import annotations
 
@@ -62,6 +68,14 @@ class ControlSolver:
         self._lambda = float(config.get("softmin_lambda", 1.0))
         self._incumbent = None
         self._engine = None  # built on first solve: the input box follows the live velocity limits
+        mode = str(config.get("rollout_mode", "S")).upper()
+        if mode not in ("S", "T"):
+            raise ValueError("rollout_mode must be 'S' or 'T'")
+        self.temporal = mode == "T"
+        self._dt = float(config.get("rollout_dt", 0.05))
+        window = config.get("nn_window", (2, 5))
+        self._nn_window = None if window is None else (int(window[0]), int(window[1]))
+        self.pose = (0.0, 0.0, np.pi / 2)   # mode T start state: set by SpatialMPC before `solve` (spatial_mpc.py:185)
 
     # QP input box, widened by 0.1 m/s like the reference (control.py:130-139)
     def _input_box(self):
@@ -76,10 +90,11 @@ class ControlSolver:
             self._box_key = box
             self._box = (np.array(box[:2]), np.array(box[2:]))
             self._engine = _capi.Engine(
-                mode=_capi.MODE_SPATIAL, max_problems=1, max_candidates=self._n_candidates,
-                max_steps=self._n_horizon, step_cost=self._Q, r_term=self._R, final_cost=self._QN, u_min=self._box[0],
-                u_max=self._box[1], margin=self._dynamics_model.margin, wheelbase=self._dynamics_model.length,
-                w_bound=self._w_bound, centre_update=self._centre_update, softmin_lambda=self._lambda)
+                mode=_capi.MODE_TEMPORAL if self.temporal else _capi.MODE_SPATIAL, max_problems=1,
+                max_candidates=self._n_candidates, max_steps=self._n_horizon, step_cost=self._Q, r_term=self._R,
+                final_cost=self._QN, u_min=self._box[0], u_max=self._box[1], margin=self._dynamics_model.margin,
+                wheelbase=self._dynamics_model.length, w_bound=self._w_bound, centre_update=self._centre_update,
+                softmin_lambda=self._lambda, dt=self._dt, nn_window=self._nn_window if self.temporal else None)
             if getattr(self, "_map", None) is not None:
                 self._engine.bind_map(*self._map)
         return self._engine
@@ -181,7 +196,8 @@ class ControlSolver:
         np.clip(reference_path.kappas, lo[1], hi[1], out=u_ref[:, 1])
         warm = self._incumbent is not None and self._incumbent.shape == u_ref.shape
         explore = self._explore or not warm
-        x0 = np.asarray(spatial_state, dtype=np.float32)[None]
+        # mode T rolls the pose itself (the Frenet state the reference's seam hands over is not used then)
+        x0 = np.asarray(self.pose if self.temporal else spatial_state, dtype=np.float32)[None]
         total_rounds = 0
         while True:
             centre = self._incumbent if warm else u_ref

@@ -1086,7 +1086,7 @@ size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 struct TickLayout {
   size_t coords, centre_in, host_total;            // pinned host block
   size_t seed, x0, centre, uref, coef, total;      // device block
-  explicit TickLayout(int n) {
+  explicit TickLayout(int n, int coef_stride = ACMPC_COEF_STRIDE_SPATIAL) {
     coords = align16(sizeof(acmpc::TickHeader));
     centre_in = align16(coords + static_cast<size_t>(n + 1) * 3 * sizeof(double));
     host_total = align16(centre_in + static_cast<size_t>(n) * 2 * sizeof(float));
@@ -1095,7 +1095,7 @@ struct TickLayout {
     centre = 32;
     uref = align16(centre + static_cast<size_t>(n) * 2 * sizeof(float));
     coef = align16(uref + static_cast<size_t>(n) * 2 * sizeof(float));
-    total = align16(coef + static_cast<size_t>(n) * ACMPC_COEF_STRIDE_SPATIAL * sizeof(float));
+    total = align16(coef + static_cast<size_t>(n) * coef_stride * sizeof(float));
   }
 };
 
@@ -1177,8 +1177,9 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
       accelerations == nullptr || steer_rates == nullptr || info == nullptr)
     return fail(c, ACMPC_EINVAL, "null argument");
   if (t->struct_size != sizeof(acmpc_tick)) return fail(c, ACMPC_EINVAL, "acmpc_tick size mismatch");
-  if (c->prm.mode != ACMPC_MODE_SPATIAL || c->prm.centre_update != 0)
-    return fail(c, ACMPC_ESTATE, "acmpc_control_tick needs a mode S handle with centre_update = 0");
+  if (c->prm.centre_update != 0) return fail(c, ACMPC_ESTATE, "acmpc_control_tick needs a handle with centre_update = 0");
+  const bool temporal = c->prm.mode == ACMPC_MODE_TEMPORAL;
+  if (temporal && !(c->prm.dt > 0.0)) return fail(c, ACMPC_ESTATE, "mode T needs a positive dt");
   const int H = t->horizon, n = H - 1, N = t->n_candidates;
   if (H < 3 || t->rounds < 1 || N < 1) return fail(c, ACMPC_EINVAL, "need horizon >= 3, rounds >= 1, n_candidates >= 1");
   if (n > c->prm.max_steps || N > c->prm.max_candidates) return fail(c, ACMPC_ECAPACITY, "horizon or candidates exceed capacity");
@@ -1193,7 +1194,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   rc = ensure_tick(c);
   if (rc != ACMPC_OK) return rc;
   hipStream_t s = c->stream;
-  const TickLayout in(n);
+  const TickLayout in(n, c->coef_stride);   // (spatial rows are the wider: ensure_tick sized the blocks for them)
   const TickOutLayout out(n);
   const int rec_floats = acmpc_record_floats(n);
   const bool from_map = coords == nullptr;
@@ -1221,6 +1222,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     ma.coords_out = nullptr;
     ma.first_out = reinterpret_cast<int*>(c->d_coords);
   }
+  pa.temporal = temporal ? 1 : 0;
   pa.centre_in = reinterpret_cast<const float*>(c->h_tick + in.centre_in);
   pa.x0 = reinterpret_cast<float*>(c->d_tick + in.x0);
   pa.u_ref = reinterpret_cast<float*>(c->d_tick + in.uref);
@@ -1394,8 +1396,10 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     biggest = std::max(biggest, std::fabs(static_cast<double>(ru[i])));
     finite = finite && std::isfinite(ru[i]);
   }
-  rc = acmpc_unpack_decision(decision, n, table, c->prm.wheelbase, projected_control, prediction, cum_time, times,
-                             accelerations, steer_rates);
+  rc = temporal ? acmpc_unpack_decision_temporal(decision, n, c->prm.dt, c->prm.wheelbase, projected_control, prediction,
+                                                 cum_time, times, accelerations, steer_rates)
+                : acmpc_unpack_decision(decision, n, table, c->prm.wheelbase, projected_control, prediction, cum_time,
+                                        times, accelerations, steer_rates);
   if (rc != ACMPC_OK) return fail(c, rc, "acmpc_unpack_decision");
   info[0] = rec[ACMPC_REC_COST];
   info[1] = rec[ACMPC_REC_VIOLATION];
@@ -1460,10 +1464,10 @@ int acmpc_tick_read_device_tables(acmpc_ctx* c, float* x0, float* u_ref, float* 
   if (x0 == nullptr || u_ref == nullptr || coef == nullptr) return fail(c, ACMPC_EINVAL, "null output");
   if (!c->tick_ready || c->tick_last_n == 0) return fail(c, ACMPC_ESTATE, "acmpc_control_tick has not run");
   const int n = c->tick_last_n;
-  const TickLayout in(n);
+  const TickLayout in(n, c->coef_stride);
   ACMPC_HIP(c, hipMemcpy(x0, c->d_tick + in.x0, 3 * sizeof(float), hipMemcpyDeviceToHost));
   ACMPC_HIP(c, hipMemcpy(u_ref, c->d_tick + in.uref, static_cast<size_t>(n) * 2 * sizeof(float), hipMemcpyDeviceToHost));
-  ACMPC_HIP(c, hipMemcpy(coef, c->d_tick + in.coef, static_cast<size_t>(n) * ACMPC_COEF_STRIDE_SPATIAL * sizeof(float),
+  ACMPC_HIP(c, hipMemcpy(coef, c->d_tick + in.coef, static_cast<size_t>(n) * c->coef_stride * sizeof(float),
                          hipMemcpyDeviceToHost));
   return ACMPC_OK;
 }

@@ -102,3 +102,30 @@ extern "C" int acmpc_unpack_decision(const double* z, int32_t n, const double* t
   }
   return ACMPC_OK;
 }
+
+// Mode T's counterpart: the record's states are the poses (X, Y, phi) after each Euler step of `dt` seconds, so the
+// prediction is read off them, the time of step i is i dt, and - where the reference differentiates its Frenet states
+// (spatial_mpc.py:209-211) - the plan's own controls are differentiated: accelerations = dv / dt, steer_rates =
+// d(delta) / dt (build-defined: the reference has no temporal rollout).
+extern "C" int acmpc_unpack_decision_temporal(const double* z, int32_t n, double dt, double wheelbase,
+                                              double* projected_control, double* prediction, double* cum_time,
+                                              double* times, double* accelerations, double* steer_rates) {
+  if (z == nullptr || projected_control == nullptr || prediction == nullptr || cum_time == nullptr || times == nullptr ||
+      accelerations == nullptr || steer_rates == nullptr || n < 2 || !(dt > 0.0))
+    return ACMPC_EINVAL;
+  const double* states = z;
+  const double* controls = z + 3 * (n + 1);
+  for (int i = 0; i < n; ++i) {
+    projected_control[i] = controls[2 * i];
+    projected_control[n + i] = std::atan(controls[2 * i + 1] * wheelbase);
+    prediction[2 * i] = states[3 * i];
+    prediction[2 * i + 1] = states[3 * i + 1];
+    cum_time[i] = static_cast<double>(i) * dt;
+  }
+  for (int i = 0; i + 1 < n; ++i) {
+    times[i] = dt;
+    accelerations[i] = (projected_control[i + 1] - projected_control[i]) / dt;
+    steer_rates[i] = (projected_control[n + i + 1] - projected_control[n + i]) / dt;
+  }
+  return ACMPC_OK;
+}

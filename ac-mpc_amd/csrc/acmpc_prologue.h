@@ -50,9 +50,11 @@ struct PrologueArgs {
   const TickHeader* header;   // pinned host memory
   const double* coords;       // [H][3] (x, y, width), pinned host memory
   const float* centre_in;     // [n][2] pinned host memory (ignored when header->centre_is_reference)
-  float* x0;                  // [3]        out: Frenet start state
+  int temporal;               // != 0: a mode T handle - x0 is the pose itself and the table the [n][8] waypoint rows
+  float* x0;                  // [3]        out: Frenet start state (mode T: the pose (offset, 0, pi / 2))
   float* u_ref;               // [n][2]     out: reference controls clipped to the input box
-  float* coef;                // [n][12]    out: packed mode-S table
+  float* coef;                // [n][12]    out: packed mode-S table (mode T: [n][8] = x, y, cos psi, sin psi, psi,
+                              //            kappa, v, width / 2 - margin, as acmpc_set_paths packs it)
   float* centre;              // [n][2]     out: the sequence round 0 samples round (centre_in or u_ref)
   uint32_t* seed;             // [2]        out: Philox key of this solve (the rollout kernels' seed_ptr)
   double* table_out;          // [7][n]     out, pinned host memory

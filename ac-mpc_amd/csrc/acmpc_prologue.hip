@@ -220,9 +220,15 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   if (lane == 0) {
     const double wx = tx[0], wy = ty[0], wpsi = tpsi[0];
     const double lateral = cos(wpsi) * (0.0 - wy) - sin(wpsi) * (h.offset - wx);
-    a.x0[0] = static_cast<float>(lateral);
-    a.x0[1] = static_cast<float>(wrap_angle(kPi / 2.0 - wpsi));
-    a.x0[2] = 0.0f;
+    if (a.temporal != 0) {   // mode T rolls the pose itself: (X, Y, phi) = (offset, 0, pi / 2)  (spatial_mpc.py:185)
+      a.x0[0] = static_cast<float>(h.offset);
+      a.x0[1] = 0.0f;
+      a.x0[2] = static_cast<float>(kPi / 2.0);
+    } else {
+      a.x0[0] = static_cast<float>(lateral);
+      a.x0[1] = static_cast<float>(wrap_angle(kPi / 2.0 - wpsi));
+      a.x0[2] = 0.0f;
+    }
     a.status[0] = status;
     a.status[1] = iterations;
     a.seed[0] = h.seed_lo;
@@ -235,19 +241,32 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     if (i >= n) break;
     const double v = tv[i], ds = tds[i], kappa = tkappa[i], width = twidth[i];
     const double vds = v * ds + 1e-12;
-    float* out = a.coef + static_cast<size_t>(i) * 12;
-    out[0] = static_cast<float>(ds);
-    out[1] = static_cast<float>(-(kappa * kappa) * ds);
-    out[2] = static_cast<float>(-kappa / vds);
-    out[3] = static_cast<float>(-1.0 / (v * v * ds + 1e-12));
-    out[4] = static_cast<float>(1.0 / vds);
-    out[5] = static_cast<float>(v);
-    out[6] = static_cast<float>(kappa);
-    out[7] = static_cast<float>(-width / 2.0 + a.margin);
-    out[8] = static_cast<float>(width / 2.0 - a.margin);
-    out[9] = 0.0f;
-    out[10] = 0.0f;
-    out[11] = 0.0f;
+    if (a.temporal != 0) {   // the waypoint rows of mode T (acmpc_set_paths' packing)
+      float* out = a.coef + static_cast<size_t>(i) * 8;
+      const double psi = tpsi[i];
+      out[0] = static_cast<float>(tx[i]);
+      out[1] = static_cast<float>(ty[i]);
+      out[2] = static_cast<float>(cos(psi));
+      out[3] = static_cast<float>(sin(psi));
+      out[4] = static_cast<float>(psi);
+      out[5] = static_cast<float>(kappa);
+      out[6] = static_cast<float>(v);
+      out[7] = static_cast<float>(width / 2.0 - a.margin);
+    } else {
+      float* out = a.coef + static_cast<size_t>(i) * 12;
+      out[0] = static_cast<float>(ds);
+      out[1] = static_cast<float>(-(kappa * kappa) * ds);
+      out[2] = static_cast<float>(-kappa / vds);
+      out[3] = static_cast<float>(-1.0 / (v * v * ds + 1e-12));
+      out[4] = static_cast<float>(1.0 / vds);
+      out[5] = static_cast<float>(v);
+      out[6] = static_cast<float>(kappa);
+      out[7] = static_cast<float>(-width / 2.0 + a.margin);
+      out[8] = static_cast<float>(width / 2.0 - a.margin);
+      out[9] = 0.0f;
+      out[10] = 0.0f;
+      out[11] = 0.0f;
+    }
     const double uv = fmin(fmax(v, a.u_lo0), a.u_hi0);       // np.clip(velocities, lo, hi)
     const double uk = fmin(fmax(kappa, a.u_lo1), a.u_hi1);
     a.u_ref[2 * i] = static_cast<float>(uv);

@@ -215,8 +215,12 @@ int acmpc_optimize(acmpc_ctx* ctx, const float* x0, const float* centre, const f
  *     (dynamics.py:23-40) -> linearise + corridor rows (dynamics.py:65-103, control.py:57-60) -> reference controls,
  *   `rounds` rounds of sample -> rollout + cost -> argmin (as acmpc_optimize),
  * all nodes of one captured hipGraph; the winner's record, the 7 x n table and the QP status come back through pinned
- * host memory, and the tail of get_control (acmpc_unpack_decision) runs before the call returns.  Mode S handles with
- * centre_update = 0 and horizon - 1 <= 128 only (ACMPC_ESTATE otherwise: use acmpc_set_paths + acmpc_optimize). */
+ * host memory, and the tail of get_control (acmpc_unpack_decision) runs before the call returns.  Handles with
+ * centre_update = 0 and horizon - 1 <= 128 only (ACMPC_ESTATE otherwise: use acmpc_set_paths + acmpc_optimize).
+ * Mode T handles (the Cartesian rollout with nearest-waypoint projection, north_star's literal shape) take the same
+ * call: the prologue then leaves the pose (offset, 0, pi / 2) as the start state and the [n][8] waypoint rows as the
+ * table, the rounds roll them with the handle's search window (nn_back / nn_ahead; exhaustive when nn_ahead < 0) and
+ * the plan is unpacked by acmpc_unpack_decision_temporal. */
 typedef struct acmpc_tick {
   uint32_t struct_size;        /* sizeof(acmpc_tick)                                                            */
   int32_t horizon;             /* H = rows of `coords`; n = H - 1                                               */
@@ -266,7 +270,8 @@ int acmpc_control_tick(acmpc_ctx* ctx, const acmpc_tick* tick, const double* coo
                        double* coords_out);
 
 /* Test hooks of the tick path.  acmpc_tick_read_device_tables copies what the last tick's prologue left on the device
- * for the rollout - x0 [3], u_ref [n][2], the packed table [n][ACMPC_COEF_STRIDE_SPATIAL] - back to the host.
+ * for the rollout - x0 [3], u_ref [n][2], the packed table [n][ACMPC_COEF_STRIDE_SPATIAL or _TEMPORAL, by the handle's
+ * mode] - back to the host.
  * acmpc_speed_profile_qp_device runs the prologue's ADMM alone on the GPU (host pointers, blocking): same arguments
  * and, bit for bit, the same results as acmpc_speed_profile_qp. */
 int acmpc_tick_read_device_tables(acmpc_ctx* ctx, float* x0, float* u_ref, float* coef);
@@ -289,6 +294,13 @@ int acmpc_velocity_ceiling(const double* kappa, int32_t n, double ay_max, double
 int acmpc_unpack_decision(const double* z, int32_t n, const double* table, double wheelbase, double* projected_control,
                           double* prediction, double* cum_time, double* times, double* accelerations,
                           double* steer_rates);
+/* The same for a mode T plan (build-defined: the reference has no temporal rollout).  z's states are the poses
+ * (X, Y, phi) after each Euler step of `dt` seconds: prediction [n][2] = the first n of them, cum_time [i] = i dt,
+ * times = dt, and the derivatives are those of the plan's own controls: accelerations = dv / dt, steer_rates =
+ * d(delta) / dt. */
+int acmpc_unpack_decision_temporal(const double* z, int32_t n, double dt, double wheelbase, double* projected_control,
+                                   double* prediction, double* cum_time, double* times, double* accelerations,
+                                   double* steer_rates);
 
 /* The generator itself, on the host (same code as the kernels): lets tests pin the integer stream. */
 void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
