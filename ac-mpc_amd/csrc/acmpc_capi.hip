@@ -158,19 +158,30 @@ int fail_hip(const acmpc_ctx* ctx, hipError_t e, const char* what) {
   } while (0)
 
 // Thresholds of the verified nearest-waypoint search (acmpc_device.h: nearest_verified), from the float32 waypoint
-// positions the kernels use: thr[p][j][o] = (R / (2 (1 + 1e-3)))^2 with R the distance from waypoint j to the
-// nearest waypoint outside the kVerifiedWindow-wide window that starts at j - o (+inf when nothing lies outside; -1 = "always
-// scan" for window positions that cannot occur).  O(n^2) per path through prefix / suffix minima, hence the cap.
+// positions the kernels use.  thr[p][j][o] bounds the squared distance to waypoint j - as the kernel estimates it from
+// the winning key - below which no waypoint OUTSIDE the kVerifiedWindow-wide window that starts at j - o can have a
+// smaller key.  With R = distance from waypoint j to the nearest outside waypoint and r = |p - w_j| < R / 2, every
+// outside waypoint m has |p - w_m|^2 - r^2 >= R (R - 2 r).  The keys carry that difference to within 2 E_key, the
+// estimate of r^2 is good to E_est (bounds below, from the largest coordinate of the path and R), so
+//     thr = ((R - 2 E_key / R) / (2 (1 + 1e-3)))^2 - E_est,
+// rounded down; -inf = "always scan" (nothing to certify with, or window positions that cannot occur).  O(n^2) per path
+// through prefix / suffix minima, hence the cap.
 constexpr int kMaxVerifiedSteps = 256;
 
 void verified_thresholds(const float* coef, int P, int n, std::vector<float>* out) {
   constexpr int W = acmpc::kVerifiedWindow;
-  out->assign(static_cast<size_t>(P) * n * W, -1.0f);
-  std::vector<double> left(static_cast<size_t>(n) + 1), right(static_cast<size_t>(n) + 1);
   const double inf = std::numeric_limits<double>::infinity();
+  const float never = -std::numeric_limits<float>::infinity();
+  out->assign(static_cast<size_t>(P) * n * W, never);
+  std::vector<double> left(static_cast<size_t>(n) + 1), right(static_cast<size_t>(n) + 1);
+  const double ulp = std::ldexp(1.0, -24);   // half an ulp of a float32 of magnitude 1: one rounding's relative error
   for (int p = 0; p < P; ++p) {
     const float* t = coef + static_cast<size_t>(p) * n * acmpc::kCoefT;
     float* thr = out->data() + static_cast<size_t>(p) * n * W;
+    double wc = 0.0;   // largest |coordinate| of the path
+    for (int m = 0; m < n; ++m)
+      wc = std::max(wc, std::max(std::fabs(static_cast<double>(t[m * acmpc::kCoefT])),
+                                 std::fabs(static_cast<double>(t[m * acmpc::kCoefT + 1]))));
     for (int j = 0; j < n; ++j) {
       const double xj = t[j * acmpc::kCoefT], yj = t[j * acmpc::kCoefT + 1];
       // left[a] = min distance to waypoints m < a; right[b] = min distance to waypoints m >= b
@@ -188,10 +199,21 @@ void verified_thresholds(const float* coef, int P, int n, std::vector<float>* ou
         const int lo = j - o;
         if (lo < 0 || lo + W > n) continue;
         const double R = std::min(left[lo], right[lo + W]);
-        const double half = R / (2.0 * (1.0 + 1.0e-3));
-        // rounded towards zero: the test `d2 < thr` must never be more permissive than the real-number one
-        thr[j * W + o] = std::isinf(R) ? std::numeric_limits<float>::infinity()
-                                       : std::nextafter(static_cast<float>(half * half), 0.0f);
+        if (std::isinf(R)) {   // the window is the whole path: its minimum is the global one wherever the candidate is
+          thr[j * W + o] = std::numeric_limits<float>::infinity();
+          continue;
+        }
+        if (!(R > 0.0)) continue;
+        // a certified candidate has |X|, |Y| <= L; every intermediate of a key is below B = 6 L^2 in magnitude:
+        // a key is off by at most 3 B ulp (two roundings in c, two fused multiply-adds), the estimate
+        // fma(Y, Y, fma(X, X, key)) of r^2 by at most 7 B ulp
+        const double L = wc + 0.5 * R, B = 6.0 * L * L;
+        const double e_key = 3.0 * B * ulp, e_est = 7.0 * B * ulp;
+        const double rho = (R - 2.0 * e_key / R) / (2.0 * (1.0 + 1.0e-3));
+        const double bound = rho * rho - e_est;
+        if (!(rho > 0.0) || !(bound > 0.0) || !std::isfinite(bound)) continue;
+        // rounded down: the test `estimate < thr` must never be more permissive than the real-number one
+        thr[j * W + o] = std::nextafter(static_cast<float>(bound), never);
       }
     }
   }
@@ -916,6 +938,13 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     }
     // NB: the finalize of round r reads its centre from the records it is about to overwrite; it copies the
     // controls it needs into registers/LDS before lane 0..63 write the new record, and one wave owns one record
+    // (timing armed - acmpc_profile_enable, eager path only: every round's launch carries an event pair)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->prof_used < c->prof_start.size()) {
+      e0 = c->prof_start[c->prof_used];
+      e1 = c->prof_stop[c->prof_used];
+      ++c->prof_used;
+    }
     if (fused_finalize) {
       // one launch per round: the last workgroup of each problem also reduces the partial keys and writes the
       // record; rounds before the last only need the winner's controls (the next centre), not its re-roll
@@ -925,9 +954,9 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
                                     (last && final_records != nullptr) ? final_records : c->d_records, !last,
                                     traced ? d_trace : nullptr, acmpc::trace_floats(n),
                                     last ? done : nullptr, done_value};
-      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, ff, s));
+      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, ff, s, e0, e1));
     } else {
-      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, acmpc::FusedFinalize{nullptr, nullptr, false, nullptr, 0, nullptr, 0}, s));
+      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, acmpc::FusedFinalize{nullptr, nullptr, false, nullptr, 0, nullptr, 0}, s, e0, e1));
       Regenerate regen{d_c, stride, d_ref, sa.spec};
       rc = finalize(c, nullptr, nullptr, in.x0, nullptr, P, N, n, layout, 0, c->d_records, (N + 63) / 64, s, &regen,
                     in.coef);

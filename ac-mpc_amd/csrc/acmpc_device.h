@@ -16,6 +16,16 @@
 namespace acmpc {
 
 constexpr int kWave = 64;
+
+// window of mode T's verified nearest-waypoint search (exhaustive semantics): waypoints searched per step and how many
+// of them lie behind the previous step's nearest one (A/B builds: ACMPC_HIPCC_EXTRA="-DACMPC_VERIFIED_WINDOW=8 ...")
+#ifndef ACMPC_VERIFIED_WINDOW
+#define ACMPC_VERIFIED_WINDOW 16
+#define ACMPC_VERIFIED_BACK 7
+#endif
+
+__device__ __forceinline__ int wave_min_int(int v);
+__device__ __forceinline__ int wave_sum_int(int v);
 constexpr int kCoefS = 12;  // ACMPC_COEF_STRIDE_SPATIAL
 constexpr int kCoefT = 8;   // ACMPC_COEF_STRIDE_TEMPORAL
 
@@ -206,18 +216,28 @@ __device__ __forceinline__ void sincos_spec(F phi, F& sn, F& cs) {
   cs = __builtin_bit_cast(F, __builtin_bit_cast(I, c) ^ sign);
 }
 
+// angle difference into [-pi, pi]: a - 2 pi rint(a / (2 pi)), the integer read off the magic-number sum like the k of
+// sincos_reduced (three instructions; defined for every input; round 3 - the floor form took five)
 template <typename F>
 __device__ __forceinline__ F wrap_spec(F a) {
-  const F b = a + 3.14159265358979f;
-  const F q = __builtin_elementwise_floor(b * 0.159154943091895f);
-  return fma_(-q, splat<F>(6.28318530717959f), b) - 3.14159265358979f;
+  const F t = fma_(a, splat<F>(0.159154943091895f), splat<F>(12582912.0f));
+  const F q = t - 12582912.0f;
+  return fma_(-q, splat<F>(6.28318530717959f), a);
 }
 
+// S0..S3: the running sums of e_y^2, e_psi^2, dv^2, dkappa^2 - the stage cost's weights are applied once, after the
+// horizon (finish_temporal); V: the summed squared bound violations
 template <typename F>
 struct StateT_ {
-  F X, Y, phi, ey, ep, J, V;
+  F X, Y, phi, ey, ep, S0, S1, S2, S3, V;
 };
 using StateT = StateT_<float>;
+
+template <typename F>
+__device__ __forceinline__ StateT_<F> start_temporal(const float* __restrict__ pose) {
+  const F zero = splat<F>(0.0f);
+  return StateT_<F>{splat<F>(pose[0]), splat<F>(pose[1]), splat<F>(pose[2]), zero, zero, zero, zero, zero, zero, zero};
+}
 
 // explicit Euler on the rear-axle kinematic bicycle (localiser.py:66-95); phi_dot = v * kappa
 template <typename F>
@@ -237,6 +257,28 @@ __device__ __forceinline__ void temporal_advance(StateT_<F>& s, F v, F k, const 
   s.phi = phin;
 }
 
+// ---- nearest waypoint ------------------------------------------------------------------------------------------
+// Specification (round 3): the nearest waypoint is the FIRST minimum, under `<`, of the search key
+//     e_m(p) = fma(Y, b_m, fma(X, a_m, c_m)),   a_m = -2 x_m,  b_m = -2 y_m,  c_m = fma(y_m, y_m, x_m x_m)
+// - the squared distance |p - w_m|^2 less the term |p|^2 that is the same for every waypoint, two fused multiply-adds per
+// waypoint where (X - x)^2 + (Y - y)^2 takes four operations (the rollout is bound by instruction issue, and the search
+// was a third of its instructions).  a, b, c are float32, computed from the float32 waypoint positions once per table
+// (a and b exactly; c with two roundings), so oracle/acmpc_oracle.{py,c} restate the key bit for bit.  In the vehicle
+// frame (|coordinates| <= ~200 m) the key resolves ~0.01 m^2: it moves the boundary between two neighbouring
+// waypoints by a millimetre.  NaN keys never win; when every key is NaN the answer is the first waypoint searched.
+template <typename F, typename G>
+__device__ __forceinline__ F search_key(F X, F Y, G a, G b, G c) {
+  return fma_(Y, F(b), fma_(X, F(a), F(c)));
+}
+// the key's table entries for one waypoint (x, y): a, b, c
+__device__ __forceinline__ void search_entry(float x, float y, float& a, float& b, float& c) {
+  a = -2.0f * x;
+  b = -2.0f * y;
+  c = fma_(y, y, x * x);
+}
+// |p - w_m|^2 back from the key (to ~0.01 m^2): what the verified search tests against its thresholds
+__device__ __forceinline__ float distance2_of_key(float X, float Y, float e) { return fma_(Y, Y, fma_(X, X, e)); }
+
 template <typename F, typename G>
 __device__ __forceinline__ F dist2(F X, F Y, G wx, G wy) {
   const F dx = X - wx;
@@ -244,15 +286,15 @@ __device__ __forceinline__ F dist2(F X, F Y, G wx, G wy) {
   return fma_(dy, dy, dx * dx);
 }
 
-// nearest waypoint, first minimum of the squared distance (localiser.py:282-289); every lane scans the table
-// (wave-uniform addresses: the LDS read is a broadcast and serves both candidates of a packed lane)
+// every lane scans the whole table (wave-uniform addresses: the LDS read is a broadcast and serves both candidates of a
+// packed lane).  `abc` = the key table, (a, b, c) per waypoint side by side (stage_temporal_tables).
 template <typename F>
-__device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const StateT_<F>& s, const float* wp, int n) {
+__device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const StateT_<F>& s, const float* abc, int n) {
   using I = typename IndexOf<F>::type;
   F best = splat<F>(__builtin_inff());
   I j = I(0);
   for (int i = 0; i < n; ++i) {
-    const F d = dist2<F>(s.X, s.Y, wp[i * kCoefT + 0], wp[i * kCoefT + 1]);
+    const F d = search_key<F>(s.X, s.Y, abc[3 * i], abc[3 * i + 1], abc[3 * i + 2]);
     const auto better = d < best;
     best = better ? d : best;
     j = better ? I(i) : j;
@@ -263,26 +305,17 @@ __device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const Stat
 // The same search restricted to W = back + ahead + 1 consecutive waypoints starting at
 // lo = clamp(j_prev - back, 0, n - W): progress along the path is monotone and at most about one waypoint per step,
 // so a short window finds the global minimum on every realistic input at a fraction of the ALU work (tests check
-// equality with the exhaustive scan).  `xy` is a planar copy of the table's positions (x_0..x_{n-1}, y_0..y_{n-1}).
-// W = 8 and W = 4 are unrolled: the distances of two neighbouring waypoints are formed by one packed instruction
-// each (v_pk_add/mul_f32: 2.5 instructions per waypoint instead of 5), the minimum by a min chain, and the FIRST
-// index that attains it by an equality scan from the far end - the same answer as the `d < best` scan, one
-// instruction per waypoint cheaper.
+// equality with the exhaustive scan).  W = 16, 8 and 4 are unrolled: the minimum by a min chain, and the FIRST
+// index that attains it by an equality scan - the same answer as the `d < best` scan, cheaper.
 template <int W>
-__device__ __forceinline__ int nearest_in_window(float X, float Y, const float* xs, const float* ys, int lo,
-                                                 float* best_out = nullptr) {
+__device__ __forceinline__ int nearest_in_window(float X, float Y, const float* abc, int lo, float* best_out = nullptr) {
   float d[W];
+  const float* first = abc + 3 * lo;   // one address; the W entries at constant offsets
 #pragma unroll
-  for (int m = 0; m < W; m += 2) {
-    const f32x2 wx = {xs[lo + m], xs[lo + m + 1]};
-    const f32x2 wy = {ys[lo + m], ys[lo + m + 1]};
-    const f32x2 dd = dist2<f32x2>(splat<f32x2>(X), splat<f32x2>(Y), wx, wy);
-    d[m] = dd[0];
-    d[m + 1] = dd[1];
-  }
+  for (int m = 0; m < W; ++m) d[m] = search_key<float>(X, Y, first[3 * m], first[3 * m + 1], first[3 * m + 2]);
   float best = d[0];
 #pragma unroll
-  for (int m = 1; m < W; ++m) best = __builtin_fminf(best, d[m]);  // NaN distances are skipped, like `d < best`
+  for (int m = 1; m < W; ++m) best = __builtin_fminf(best, d[m]);  // NaN keys are skipped, like `d < best`
   // FIRST index that attains the minimum (0 when nothing compares equal - all NaN - where the `d < best` scan keeps
   // `lo`).  The W compare results are lane masks in scalar registers; which window position holds each lane's first
   // hit is worked out on the scalar unit (prefix ORs, one-hot first hits, one mask per index bit), so the vector unit
@@ -307,47 +340,34 @@ __device__ __forceinline__ int nearest_in_window(float X, float Y, const float* 
   return lo + jm;
 }
 
-// one-lane exhaustive scan on plain coordinates (the fallback of the verified search below)
-__device__ __forceinline__ int nearest_scan(float X, float Y, const float* wp, int n) {
-  float best = __builtin_inff();
-  int j = 0;
-  for (int i = 0; i < n; ++i) {
-    const float d = dist2<float>(X, Y, wp[i * kCoefT + 0], wp[i * kCoefT + 1]);
-    const bool better = d < best;
-    best = better ? d : best;
-    j = better ? i : j;
-  }
-  return j;
-}
-
-// EXHAUSTIVE semantics at windowed cost.  The 16 waypoints from lo = clamp(j_prev - 7, 0, n - 16) are searched as
-// above; the host has tabulated, for every waypoint j and every window position o = j - lo, the threshold
-//     thr[j][o] = (R / (2 (1 + 1e-3)))^2,   R = distance from waypoint j to the nearest waypoint OUTSIDE that window.
-// If the window's minimum d2 is below thr, every outside waypoint m is farther: |p - w_m| >= R - |p - w_j| >
-// (1 + 1.9e-3) |p - w_j| by the triangle inequality - a margin a thousand times the rounding error of the float32
-// distances - so the window's first minimum IS the global first minimum and the scan of all n waypoints is
-// skipped.  Otherwise (a candidate far off the path, a non-finite position) all waypoints are scanned - by the whole
-// wave, see nearest_cooperative_fix().  Either way the index is exactly the exhaustive one, bit for bit.
-constexpr int kVerifiedWindow = 16;  // measured on the bench workload: a wave (256 candidates) has to fall back to the
-constexpr int kVerifiedBack = 7;     // full scan in 44 % of its steps with 8 waypoints from j_prev - 2, in 1.5 % with these
+// EXHAUSTIVE semantics at windowed cost.  The kVerifiedWindow waypoints from lo = clamp(j_prev - kVerifiedBack, 0,
+// n - kVerifiedWindow) are searched as above; the host has tabulated, for every waypoint j and every window position
+// o = j - lo, a threshold thr[j][o] on the squared distance to waypoint j below which no waypoint OUTSIDE that window
+// can have a smaller key: with R = distance from waypoint j to the nearest outside waypoint and r = |p - w_j|, every
+// outside waypoint is at least R - r away, i.e. its squared distance exceeds r^2 by R (R - 2 r); the threshold keeps
+// that gap above twice the rounding error of a key (acmpc_capi.hip: verified_thresholds), so the window's first minimum
+// IS the global first minimum and the scan of all n waypoints is skipped.  Otherwise (a candidate far off the path, a
+// non-finite position) all waypoints are scanned - by the whole wave, see nearest_cooperative_fix().  Either way the
+// index is exactly the exhaustive one, bit for bit.
+constexpr int kVerifiedWindow = ACMPC_VERIFIED_WINDOW;
+constexpr int kVerifiedBack = ACMPC_VERIFIED_BACK;
 
 // The window part: index of the window's first minimum and whether the threshold test certifies it as global.
-__device__ __forceinline__ int nearest_verified_window(float X, float Y, const float* xy, const float* thr, int n,
+__device__ __forceinline__ int nearest_verified_window(float X, float Y, const float* abc, const float* thr, int n,
                                                        int j_prev, bool& certified) {
   const int lo = max(min(j_prev - kVerifiedBack, n - kVerifiedWindow), 0);
   float best;
-  const int j = nearest_in_window<kVerifiedWindow>(X, Y, xy, xy + n, lo, &best);
-  certified = best < thr[j * kVerifiedWindow + (j - lo)];
+  const int j = nearest_in_window<kVerifiedWindow>(X, Y, abc, lo, &best);
+  certified = distance2_of_key(X, Y, best) < thr[j * kVerifiedWindow + (j - lo)];
   return j;
 }
 
 // The fallback, wave-cooperative: for every lane whose window result is not certified (a handful per wave and
-// step), ALL 64 lanes scan the waypoint table side by side for that lane's position and reduce to the first
-// minimum - ~40 instructions per uncertified candidate instead of one lane walking all n waypoints while the other
-// 63 wait.  Must be reached by every lane of the wave (the rollout kernel runs its tail lanes on a valid dummy
-// candidate for this reason).  Same answer as nearest_scan(): NaN distances never win, ties go to the lower index,
-// nothing finite found -> 0.
-__device__ __forceinline__ int nearest_cooperative_fix(float X, float Y, bool certified, int j, const float* xy, int n) {
+// step), ALL 64 lanes scan the key table side by side for that lane's position and reduce to the first minimum
+// instead of one lane walking all n waypoints while the other 63 wait.  Must be reached by every lane of the wave (the
+// rollout kernel runs its tail lanes on a valid dummy candidate for this reason).  Same answer as the one-lane scan:
+// NaN keys never win, ties go to the lower index, nothing finite found -> 0.
+__device__ __forceinline__ int nearest_cooperative_fix(float X, float Y, bool certified, int j, const float* abc, int n) {
   unsigned long long pending = __ballot(!certified);
   const int lane = static_cast<int>(__lane_id());
   while (pending != 0ull) {
@@ -356,31 +376,28 @@ __device__ __forceinline__ int nearest_cooperative_fix(float X, float Y, bool ce
     const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(X), src));
     const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Y), src));
     float best = __builtin_inff();
-    int jj = (lane < n) ? lane : 0x7fffffff;
+    int jj = 0x7fffffff;
     for (int m = lane; m < n; m += kWave) {
-      const float d = dist2<float>(px, py, xy[m], xy[n + m]);
+      const float d = search_key<float>(px, py, abc[3 * m], abc[3 * m + 1], abc[3 * m + 2]);
       const bool better = d < best;
       best = better ? d : best;
       jj = better ? m : jj;
     }
-#pragma unroll
-    for (int mask = 32; mask >= 1; mask >>= 1) {
-      const float ob = __shfl_xor(best, mask, kWave);
-      const int oj = __shfl_xor(jj, mask, kWave);
-      const bool take = (ob < best) || (ob == best && oj < jj);
-      best = take ? ob : best;
-      jj = take ? oj : jj;
-    }
-    const int found = __builtin_amdgcn_readfirstlane(jj);
-    j = (lane == src) ? found : j;
+    // first minimum over the lanes: the smallest key (keys order as their sign-flipped bit patterns; +inf where a lane
+    // found nothing), then the lowest index among the lanes that hold it
+    const int bits = __float_as_int(best);
+    const int ordered = (bits >= 0) ? bits : (bits ^ 0x7fffffff);
+    const int least = wave_min_int(ordered);
+    const int found = wave_min_int((ordered == least) ? jj : 0x7fffffff);
+    j = (lane == src) ? ((found == 0x7fffffff) ? 0 : found) : j;
   }
   return j;
 }
 
-__device__ __forceinline__ int nearest_verified(float X, float Y, const float* xy, const float* thr, int n, int j_prev) {
+__device__ __forceinline__ int nearest_verified(float X, float Y, const float* abc, const float* thr, int n, int j_prev) {
   bool certified;
-  const int j = nearest_verified_window(X, Y, xy, thr, n, j_prev, certified);
-  return nearest_cooperative_fix(X, Y, certified, j, xy, n);
+  const int j = nearest_verified_window(X, Y, abc, thr, n, j_prev, certified);
+  return nearest_cooperative_fix(X, Y, certified, j, abc, n);
 }
 
 // How a kernel searches: decided once per launch (the weights are wave-uniform), so the step loop itself is
@@ -396,18 +413,18 @@ __device__ __forceinline__ int search_kind(const Weights& w, int n, bool has_thr
 }
 
 template <int SEARCH>
-__device__ __forceinline__ int temporal_nearest_window(float X, float Y, const float* xy, int n, int j_prev, int back,
+__device__ __forceinline__ int temporal_nearest_window(float X, float Y, const float* abc, int n, int j_prev, int back,
                                                        int ahead) {
   const int W = (SEARCH > 0) ? SEARCH : back + ahead + 1;
   const int lo = max(min(j_prev - back, n - W), 0);
   if constexpr (SEARCH > 0) {
-    return nearest_in_window<SEARCH>(X, Y, xy, xy + n, lo);
+    return nearest_in_window<SEARCH>(X, Y, abc, lo);
   } else {
     const int hi = min(lo + W, n);
     float best = __builtin_inff();
     int j = lo;
     for (int i = lo; i < hi; ++i) {
-      const float d = dist2<float>(X, Y, xy[i], xy[n + i]);
+      const float d = search_key<float>(X, Y, abc[3 * i], abc[3 * i + 1], abc[3 * i + 2]);
       const bool better = d < best;
       best = better ? d : best;
       j = better ? i : j;
@@ -416,24 +433,53 @@ __device__ __forceinline__ int temporal_nearest_window(float X, float Y, const f
   }
 }
 
-// Frenet errors w.r.t. waypoint row(s) g (dynamics.py:23-40), stage cost and bound violations.  g0..g7 hold the
-// row entries x, y, cos psi, sin psi, psi, k_ref, v_ref, w/2 - margin per element.
+// The waypoint rows as the kernels keep them in LDS, derived from the table's [x, y, cos psi, sin psi, psi, k_ref, v_ref,
+// w/2 - margin] once per workgroup: [s x - c y, -s, c, psi, k_ref, v_ref, w/2 - margin, 0], so that the lateral error
+// e_y = c (Y - y) - s (X - x) (dynamics.py:23-40) is two fused multiply-adds on the pose; and the search key's entries
+// (search_entry), three floats per waypoint side by side.  `threads` lanes of a workgroup cooperate.
+__device__ __forceinline__ void stage_temporal_tables(const float* __restrict__ coef, int n, int tid, int threads,
+                                                      float* rows, float* abc) {
+  for (int m = tid; m < n; m += threads) {
+    const float* g = coef + m * kCoefT;
+    const float x = g[0], y = g[1], c = g[2], sn = g[3];
+    float* r = rows + m * kCoefT;
+    r[0] = fma_(sn, x, -(c * y));
+    r[1] = -sn;
+    r[2] = c;
+    r[3] = g[4];
+    r[4] = g[5];
+    r[5] = g[6];
+    r[6] = g[7];
+    r[7] = 0.0f;
+    search_entry(x, y, abc[3 * m], abc[3 * m + 1], abc[3 * m + 2]);
+  }
+}
+
+__device__ __forceinline__ float med3_(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ f32x2 med3_(f32x2 x, f32x2 lo, f32x2 hi) {
+  f32x2 out;
+  out[0] = __builtin_amdgcn_fmed3f(x[0], lo[0], hi[0]);
+  out[1] = __builtin_amdgcn_fmed3f(x[1], lo[1], hi[1]);
+  return out;
+}
+
+// Frenet errors w.r.t. the (derived) waypoint row(s) g, the stage cost's squares and the bound violations.  The excess
+// over the input box is x - med3(x, lo, hi): the same magnitude as max(lo - x, x - hi, 0), one instruction less.
 template <typename F>
 __device__ __forceinline__ void temporal_cost(StateT_<F>& s, const F (&g)[kCoefT], F v, F k, const Weights& w) {
-  s.ey = fma_(g[2], s.Y - g[1], -(g[3] * (s.X - g[0])));
-  s.ep = wrap_spec<F>(s.phi - g[4]);
-  const F dv = v - g[6];
-  const F dk = k - g[5];
-  // J += 1/2 (q0 ey^2 + q1 ep^2 + r0 dv^2 + r1 dk^2), one fused term at a time with the halved weights
-  s.J = fma_(w.hq0 * s.ey, s.ey, s.J);
-  s.J = fma_(w.hq1 * s.ep, s.ep, s.J);
-  s.J = fma_(w.hr0 * dv, dv, s.J);
-  s.J = fma_(w.hr1 * dk, dk, s.J);
-  const F hv = vmax(vmax(w.ulo0 - v, v - w.uhi0), splat<F>(0.0f));
+  s.ey = fma_(g[2], s.Y, fma_(g[1], s.X, g[0]));
+  s.ep = wrap_spec<F>(s.phi - g[3]);
+  const F dv = v - g[5];
+  const F dk = k - g[4];
+  s.S0 = fma_(s.ey, s.ey, s.S0);
+  s.S1 = fma_(s.ep, s.ep, s.S1);
+  s.S2 = fma_(dv, dv, s.S2);
+  s.S3 = fma_(dk, dk, s.S3);
+  const F hv = v - med3_(v, splat<F>(w.ulo0), splat<F>(w.uhi0));
   s.V = fma_(hv, hv, s.V);
-  const F hk = vmax(vmax(w.ulo1 - k, k - w.uhi1), splat<F>(0.0f));
+  const F hk = k - med3_(k, splat<F>(w.ulo1), splat<F>(w.uhi1));
   s.V = fma_(hk, hk, s.V);
-  const F hc = vmax(abs_(s.ey) - g[7], splat<F>(0.0f));  // outside the corridor |e_y| <= w/2 - margin
+  const F hc = vmax(abs_(s.ey) - g[6], splat<F>(0.0f));  // outside the corridor |e_y| <= w/2 - margin
   s.V = fma_(hc, hc, s.V);
 }
 
@@ -462,63 +508,63 @@ __device__ __forceinline__ void temporal_settle(StateT_<f32x2>& s, const float* 
 
 // The verified search in two phases, so that a kernel can run the window phase of ALL the candidates a lane owns
 // before the (rare, wave-wide) fallback phase and keep the window searches free of control flow.
-__device__ __forceinline__ int verified_window(const StateT& s, const float* xy, const float* thr, int n, int j_prev,
+__device__ __forceinline__ int verified_window(const StateT& s, const float* abc, const float* thr, int n, int j_prev,
                                                int& uncertified) {
   bool ok;
-  const int j = nearest_verified_window(s.X, s.Y, xy, thr, n, j_prev, ok);
+  const int j = nearest_verified_window(s.X, s.Y, abc, thr, n, j_prev, ok);
   uncertified = ok ? 0 : 1;
   return j;
 }
-__device__ __forceinline__ i32x2 verified_window(const StateT_<f32x2>& s, const float* xy, const float* thr, int n,
+__device__ __forceinline__ i32x2 verified_window(const StateT_<f32x2>& s, const float* abc, const float* thr, int n,
                                                  i32x2 j_prev, int& uncertified) {
   bool ok0, ok1;
   i32x2 j;
-  j[0] = nearest_verified_window(s.X[0], s.Y[0], xy, thr, n, j_prev[0], ok0);
-  j[1] = nearest_verified_window(s.X[1], s.Y[1], xy, thr, n, j_prev[1], ok1);
+  j[0] = nearest_verified_window(s.X[0], s.Y[0], abc, thr, n, j_prev[0], ok0);
+  j[1] = nearest_verified_window(s.X[1], s.Y[1], abc, thr, n, j_prev[1], ok1);
   uncertified = (ok0 ? 0 : 1) | (ok1 ? 0 : 2);
   return j;
 }
-__device__ __forceinline__ int verified_fix(const StateT& s, const float* xy, int n, int j, int uncertified) {
-  return nearest_cooperative_fix(s.X, s.Y, uncertified == 0, j, xy, n);
+__device__ __forceinline__ int verified_fix(const StateT& s, const float* abc, int n, int j, int uncertified) {
+  return nearest_cooperative_fix(s.X, s.Y, uncertified == 0, j, abc, n);
 }
-__device__ __forceinline__ i32x2 verified_fix(const StateT_<f32x2>& s, const float* xy, int n, i32x2 j, int uncertified) {
-  j[0] = nearest_cooperative_fix(s.X[0], s.Y[0], (uncertified & 1) == 0, j[0], xy, n);
-  j[1] = nearest_cooperative_fix(s.X[1], s.Y[1], (uncertified & 2) == 0, j[1], xy, n);
+__device__ __forceinline__ i32x2 verified_fix(const StateT_<f32x2>& s, const float* abc, int n, i32x2 j, int uncertified) {
+  j[0] = nearest_cooperative_fix(s.X[0], s.Y[0], (uncertified & 1) == 0, j[0], abc, n);
+  j[1] = nearest_cooperative_fix(s.X[1], s.Y[1], (uncertified & 2) == 0, j[1], abc, n);
   return j;
 }
 
-// `wp` is the waypoint table (kCoefT floats per waypoint) and `xy` the planar copy of its positions (all x, then
-// all y); in the rollout kernels both live in LDS.  Returns the nearest index (per element) for the next step's
+// `wp` holds the derived waypoint rows and `abc` the search keys' entries (stage_temporal_tables); in the rollout
+// kernels both live in LDS.  Returns the nearest index (per element) for the next step's
 // search window.
 template <int SEARCH>
-__device__ __forceinline__ int step_temporal_as(StateT& s, const float* wp, const float* xy, int n, float v, float k,
+__device__ __forceinline__ int step_temporal_as(StateT& s, const float* wp, const float* abc, int n, float v, float k,
                                                 const Weights& w, int j_prev, const float* thr = nullptr) {
   temporal_advance<float>(s, v, k, w);
   int j;
   if constexpr (SEARCH == kSearchExhaustive) {
-    j = temporal_nearest<float>(s, wp, n);
+    j = temporal_nearest<float>(s, abc, n);
   } else if constexpr (SEARCH == kSearchVerified) {
-    j = nearest_verified(s.X, s.Y, xy, thr, n, j_prev);
+    j = nearest_verified(s.X, s.Y, abc, thr, n, j_prev);
   } else {
-    j = temporal_nearest_window<SEARCH>(s.X, s.Y, xy, n, j_prev, w.nn_back, w.nn_ahead);
+    j = temporal_nearest_window<SEARCH>(s.X, s.Y, abc, n, j_prev, w.nn_back, w.nn_ahead);
   }
   temporal_cost(s, wp + j * kCoefT, v, k, w);
   return j;
 }
 
 template <int SEARCH>
-__device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float* wp, const float* xy, int n, f32x2 v,
+__device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float* wp, const float* abc, int n, f32x2 v,
                                                   f32x2 k, const Weights& w, i32x2 j_prev, const float* thr = nullptr) {
   temporal_advance<f32x2>(s, v, k, w);
   i32x2 j;
   if constexpr (SEARCH == kSearchExhaustive) {
-    j = temporal_nearest<f32x2>(s, wp, n);
+    j = temporal_nearest<f32x2>(s, abc, n);
   } else if constexpr (SEARCH == kSearchVerified) {
-    j[0] = nearest_verified(s.X[0], s.Y[0], xy, thr, n, j_prev[0]);
-    j[1] = nearest_verified(s.X[1], s.Y[1], xy, thr, n, j_prev[1]);
+    j[0] = nearest_verified(s.X[0], s.Y[0], abc, thr, n, j_prev[0]);
+    j[1] = nearest_verified(s.X[1], s.Y[1], abc, thr, n, j_prev[1]);
   } else {
-    j[0] = temporal_nearest_window<SEARCH>(s.X[0], s.Y[0], xy, n, j_prev[0], w.nn_back, w.nn_ahead);
-    j[1] = temporal_nearest_window<SEARCH>(s.X[1], s.Y[1], xy, n, j_prev[1], w.nn_back, w.nn_ahead);
+    j[0] = temporal_nearest_window<SEARCH>(s.X[0], s.Y[0], abc, n, j_prev[0], w.nn_back, w.nn_ahead);
+    j[1] = temporal_nearest_window<SEARCH>(s.X[1], s.Y[1], abc, n, j_prev[1], w.nn_back, w.nn_ahead);
   }
   f32x2 g[kCoefT];
   const float* g0 = wp + j[0] * kCoefT;
@@ -545,11 +591,11 @@ __device__ __forceinline__ void with_search_kind(const Weights& w, int n, Body&&
 }
 
 // per-step dispatch, for the kernels that roll out one trajectory per wave or tile (finalize, sampled, tile)
-__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, const float* xy, int n, float v, float k,
+__device__ __forceinline__ int step_temporal(StateT& s, const float* wp, const float* abc, int n, float v, float k,
                                              const Weights& w, int j_prev) {
   int j = 0;
   with_search_kind(w, n, [&](auto kind) {
-    j = step_temporal_as<decltype(kind)::value>(s, wp, xy, n, v, k, w, j_prev);
+    j = step_temporal_as<decltype(kind)::value>(s, wp, abc, n, v, k, w, j_prev);
   });
   return j;
 }
@@ -557,10 +603,15 @@ __device__ __forceinline__ int step_temporal(StateT& s, const float* wp, const f
 template <typename F>
 __device__ __forceinline__ F finish_temporal(const StateT_<F>& s, int n, const Weights& w) {
   const float tN = static_cast<float>(n) * w.dt;
+  // J = 1/2 (q0 sum e_y^2 + q1 sum e_psi^2 + r0 sum dv^2 + r1 sum dkappa^2) with the halved weights, then the terminal terms
+  F stage = splat<F>(w.hq0) * s.S0;
+  stage = fma_(splat<F>(w.hq1), s.S1, stage);
+  stage = fma_(splat<F>(w.hr0), s.S2, stage);
+  stage = fma_(splat<F>(w.hr1), s.S3, stage);
   F a = (w.hqn0 * s.ey) * s.ey;
   a = fma_(w.hqn1 * s.ep, s.ep, a);
   a = fma_(splat<F>(w.hqn2 * tN), splat<F>(tN), a);
-  const F J = s.J + a;
+  const F J = stage + a;
   return fma_(splat<F>(w.wbound), s.V, J);
 }
 

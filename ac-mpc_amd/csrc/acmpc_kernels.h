@@ -132,7 +132,8 @@ struct FusedFinalize {
 // sample + rollout + cost (+ finalize) fused: candidates are drawn inside the rollout kernel and never touch memory
 // (the closed-loop solve, where every launch is ~10 us of latency-bound work)
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
-                                  const FusedFinalize& fused, hipStream_t s);
+                                  const FusedFinalize& fused, hipStream_t s, hipEvent_t start = nullptr,
+                                  hipEvent_t stop = nullptr);
 // acmpc_solve_device in ONE launch (mode S, at most kSoloBlocks workgroups of 64 candidates): rollout, argmin and the
 // winner's record assembled from the winning workgroup's state trace - `fused.trace` [P][workgroups][trace_pitch >=
 // solo_trace_floats(n)], `fused.tickets` [P][ticket_groups + 1] counters (kTicketStride ints apart) zero before and after.  `fused.records` may be

@@ -126,14 +126,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
   const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
 
-  float* s_xy = s_wp + n * kCoefT;  // planar x | y copy for the windowed nearest-waypoint search
-  float* s_thr = s_xy + 2 * n;      // thresholds of the verified search (exhaustive semantics), when given
+  float* s_xy = s_wp + n * kCoefT;  // the nearest-waypoint search's key table: (a, b, c) per waypoint (search_entry)
+  float* s_thr = s_xy + 3 * n;      // thresholds of the verified search (exhaustive semantics), when given
   if constexpr (MODE == 1) {
-    for (int e = tid; e < n * kCoefT; e += BLOCK) s_wp[e] = coef[e];
-    for (int e = tid; e < n; e += BLOCK) {
-      s_xy[e] = coef[e * kCoefT];
-      s_xy[n + e] = coef[e * kCoefT + 1];
-    }
+    stage_temporal_tables(coef, n, tid, BLOCK, s_wp, s_xy);
     if (a.nn_thr != nullptr) {
       const float* __restrict__ thr = a.nn_thr + static_cast<size_t>(p) * n * kVerifiedWindow;
       for (int e = tid; e < n * kVerifiedWindow; e += BLOCK) s_thr[e] = thr[e];
@@ -201,8 +197,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
       I nearest[kGroups];
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
-        st[g] = StateT_<F>{splat<F>(x0[0]), splat<F>(x0[1]), splat<F>(x0[2]), splat<F>(0.0f), splat<F>(0.0f),
-                           splat<F>(0.0f), splat<F>(0.0f)};
+        st[g] = start_temporal<F>(x0);
         nearest[g] = I(0);
       }
       with_search_kind(w, n, [&](auto kind) {
@@ -335,11 +330,7 @@ __global__ void __launch_bounds__(kWave) rollout_tile_kernel(const RolloutArgs a
   }
   float* s_xy = s_wp + n * kCoefT;
   if constexpr (MODE == 1) {
-    for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
-    for (int e = lane; e < n; e += kWave) {
-      s_xy[e] = coef[e * kCoefT];
-      s_xy[n + e] = coef[e * kCoefT + 1];
-    }
+    stage_temporal_tables(coef, n, lane, kWave, s_wp, s_xy);
   }
   __syncthreads();
 
@@ -358,7 +349,7 @@ __global__ void __launch_bounds__(kWave) rollout_tile_kernel(const RolloutArgs a
       cost = finish_spatial(st, w);
       feas = st.V == 0.0f;
     } else {
-      StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+      StateT st = start_temporal<float>(x0);
       int nearest = 0;
       for (int i = 0; i < n; ++i) {
         const f32x2 vk = row[i];
@@ -466,11 +457,7 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   float* s_wp = s_fused;
   float* s_xy = s_wp + n * kCoefT;
   if constexpr (MODE == 1) {
-    for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
-    for (int e = lane; e < n; e += kWave) {
-      s_xy[e] = coef[e * kCoefT];
-      s_xy[n + e] = coef[e * kCoefT + 1];
-    }
+    stage_temporal_tables(coef, n, lane, kWave, s_wp, s_xy);
     __syncthreads();
   }
 
@@ -567,7 +554,7 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     StateS ss{x0[0], x0[1], x0[2], 0.0f, 0.0f};
-    StateT ts{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+    StateT ts = start_temporal<float>(x0);
     int nearest = 0;
     struct StepOperands {
       f32x2 centre, ref;
@@ -848,18 +835,19 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
       s_rec[1] = V;
     }
   } else {
-    StateT st{x0[0], x0[1], x0[2], 0.0f, 0.0f, 0.0f, 0.0f};
+    StateT st = start_temporal<float>(x0);
     // waypoint table -> LDS (behind the record image); each lane also keeps "its" waypoint's (x, y) in registers
     float* s_wp = s_rec + ((rec_floats + 3) & ~3);
-    for (int e = lane; e < n * kCoefT; e += kWave) s_wp[e] = coef[e];
+    float* s_abc = s_wp + n * kCoefT;
+    stage_temporal_tables(coef, n, lane, kWave, s_wp, s_abc);
     if (lane == 0) {
       sx[0] = st.X;
       sx[1] = st.Y;
       sx[2] = st.phi;
     }
     __syncthreads();
-    const float my_x = (lane < n) ? s_wp[lane * kCoefT + 0] : 0.0f;
-    const float my_y = (lane < n) ? s_wp[lane * kCoefT + 1] : 0.0f;
+    const int mine_at = 3 * min(lane, n - 1);   // the search key's entries of "this lane's" waypoint
+    const float my_a = s_abc[mine_at], my_b = s_abc[mine_at + 1], my_c = s_abc[mine_at + 2];
     int j_prev = 0;
     for (int base = 0; base < n; base += kWave) {
       const int mine = base + lane;
@@ -879,10 +867,10 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
         const int win_w = w.nn_back + w.nn_ahead + 1;
         const int win_lo = (w.nn_ahead < 0) ? 0 : max(min(j_prev - w.nn_back, n - win_w), 0);
         const int win_hi = (w.nn_ahead < 0) ? n - 1 : min(win_lo + win_w, n) - 1;
-        float best = (lane >= win_lo && lane <= win_hi) ? dist2(st.X, st.Y, my_x, my_y) : __builtin_inff();
+        float best = (lane >= win_lo && lane <= win_hi) ? search_key<float>(st.X, st.Y, my_a, my_b, my_c) : __builtin_inff();
         int j = lane;
         for (int m = lane + kWave; m <= win_hi; m += kWave) {
-          const float d = (m >= win_lo) ? dist2(st.X, st.Y, s_wp[m * kCoefT + 0], s_wp[m * kCoefT + 1])
+          const float d = (m >= win_lo) ? search_key<float>(st.X, st.Y, s_abc[3 * m], s_abc[3 * m + 1], s_abc[3 * m + 2])
                                         : __builtin_inff();
           const bool better = d < best;
           best = better ? d : best;
@@ -1653,7 +1641,7 @@ template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1
 hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                             hipEvent_t e1) {
   const dim3 grid(shape.blocks_per_problem, args.P);
-  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * (kCoefT + 2 + (args.nn_thr != nullptr ? kVerifiedWindow : 0)) *
+  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * (kCoefT + 3 + (args.nn_thr != nullptr ? kVerifiedWindow : 0)) *
                                            sizeof(float)
                                      : 0);
   if (e0 != nullptr && e1 != nullptr) {
@@ -1888,7 +1876,7 @@ int max_blocks_per_problem(int N) { return (N + kWave - 1) / kWave; }
 
 size_t tile_lds_bytes(int mode, int n) {
   const size_t tile = (static_cast<size_t>(kWave) * 2 * n + 3) & ~static_cast<size_t>(3);
-  return (tile + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 2) : 0)) * sizeof(float);
+  return (tile + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 3) : 0)) * sizeof(float);
 }
 
 LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
@@ -1963,7 +1951,7 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
   const dim3 grid(args.P), block(kWave);
   // record image, then (mode T) the waypoint table
   const size_t rec_floats = static_cast<size_t>(4 + 2 * args.n + 3 * (args.n + 1));
-  const size_t lds = (((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? args.n * kCoefT : 0)) * sizeof(float);
+  const size_t lds = (((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? args.n * (kCoefT + 3) : 0)) * sizeof(float);
   if (mode == 0 && layout == 0) {
     hipLaunchKernelGGL((finalize_kernel<0, 0>), grid, block, lds, s, args);
   } else if (mode == 0 && layout == 1) {
@@ -1994,7 +1982,7 @@ hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
 
 namespace {
 size_t sampled_rollout_floats(int mode, int n) {
-  return (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + 2) + 3) & ~static_cast<size_t>(3)) : 0;
+  return (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + 3) + 3) & ~static_cast<size_t>(3)) : 0;
 }
 // uniform operands of the steps staged in LDS: [n][12] table rows (mode S), centre, reference, knot weights (+ padding
 // for the read one step past the end)
@@ -2003,7 +1991,7 @@ size_t sampled_uniform_floats(int mode, int n) {
 }
 size_t sampled_finalize_floats(int mode, int n) {
   const size_t rec_floats = static_cast<size_t>(4 + 2 * n + 3 * (n + 1));
-  return ((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? static_cast<size_t>(n) * kCoefT : 0);
+  return ((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 3) : 0);
 }
 }  // namespace
 
@@ -2037,7 +2025,7 @@ static hipError_t raise_lds_limit(const void* kernel, int which, size_t lds) {
 }
 
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
-                                  const FusedFinalize& fused, hipStream_t s) {
+                                  const FusedFinalize& fused, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   clear_stale_error();
   const int n = rollout.n;
   const dim3 grid((rollout.N + kWave - 1) / kWave, rollout.P);
@@ -2067,13 +2055,25 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
     if (pair_lds <= 160u * 1024u) {
       hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&rollout_sampled_pair_kernel), 2, pair_lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(rollout_sampled_pair_kernel, grid, dim3(2 * kWave), pair_lds, s, rollout, sample, fused,
-                         static_cast<int>(trace), static_cast<int>(trace + uniform_floats));
+      if (e0 != nullptr && e1 != nullptr) {
+        hipExtLaunchKernelGGL(rollout_sampled_pair_kernel, grid, dim3(2 * kWave), static_cast<std::uint32_t>(pair_lds), s,
+                              e0, e1, 0, rollout, sample, fused, static_cast<int>(trace),
+                              static_cast<int>(trace + uniform_floats));
+      } else {
+        hipLaunchKernelGGL(rollout_sampled_pair_kernel, grid, dim3(2 * kWave), pair_lds, s, rollout, sample, fused,
+                           static_cast<int>(trace), static_cast<int>(trace + uniform_floats));
+      }
       return hipGetLastError();
     }
   }
-  if (mode == 0) {
+  const bool timed = e0 != nullptr && e1 != nullptr;
+  const std::uint32_t lds32 = static_cast<std::uint32_t>(lds);
+  if (mode == 0 && timed) {
+    hipExtLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds32, s, e0, e1, 0, rollout, sample, fused, offset, uniform_offset);
+  } else if (mode == 0) {
     hipLaunchKernelGGL((rollout_sampled_kernel<0>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, uniform_offset);
+  } else if (timed) {
+    hipExtLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds32, s, e0, e1, 0, rollout, sample, fused, offset, uniform_offset);
   } else {
     hipLaunchKernelGGL((rollout_sampled_kernel<1>), grid, dim3(kWave), lds, s, rollout, sample, fused, offset, uniform_offset);
   }

@@ -206,10 +206,10 @@ static inline void sincos_spec(float phi, float* sn, float* cs) {
   *cs = odd ? -c : c;
 }
 
+/* a - 2 pi rint(a / 2 pi), the integer read off the magic-number sum (csrc/acmpc_device.h: wrap_spec) */
 static inline float wrap_spec(float a) {
-  const float b = a + 3.14159265358979f;
-  const float q = floorf(b * 0.159154943091895f);
-  return fmaf(-q, 6.28318530717959f, b) - 3.14159265358979f;
+  const float q = fmaf(a, 0.159154943091895f, 12582912.0f) - 12582912.0f;
+  return fmaf(-q, 6.28318530717959f, a);
 }
 
 void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const float* U, int layout, int64_t N, int n,
@@ -219,7 +219,8 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
   const float hqn0 = 0.5f * w->qn[0], hqn1 = 0.5f * w->qn[1], hqn2 = 0.5f * w->qn[2];
 #pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < N; ++c) {
-    float X = pose0[0], Y = pose0[1], phi = pose0[2], ey = 0.0f, ep = 0.0f, J = 0.0f, V = 0.0f;
+    float X = pose0[0], Y = pose0[1], phi = pose0[2], ey = 0.0f, ep = 0.0f, V = 0.0f;
+    float S0 = 0.0f, S1 = 0.0f, S2 = 0.0f, S3 = 0.0f; /* sums of e_y^2, e_psi^2, dv^2, dkappa^2: weights applied at the end */
     int j_prev = 0;
     if (states) {
       float* s = states + c * (n + 1) * 3;
@@ -245,9 +246,9 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
         j = lo;
       }
       for (int m = lo; m <= hi; ++m) {
-        const float dx = X - wp[m * CT + 0];
-        const float dy = Y - wp[m * CT + 1];
-        const float d = fmaf(dy, dy, dx * dx);
+        /* search key (csrc/acmpc_device.h: search_key): |p - w_m|^2 less |p|^2, two fused multiply-adds */
+        const float wx = wp[m * CT + 0], wy = wp[m * CT + 1];
+        const float d = fmaf(Y, -2.0f * wy, fmaf(X, -2.0f * wx, fmaf(wy, wy, wx * wx)));
         if (d < best) {
           best = d;
           j = m;
@@ -255,17 +256,19 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       }
       j_prev = j;
       const float* g = wp + j * CT;
-      ey = fmaf(g[2], Y - g[1], -(g[3] * (X - g[0])));
+      /* e_y = c (Y - y) - s (X - x) as the kernels' derived rows evaluate it: fma(c, Y, fma(-s, X, s x - c y)) */
+      ey = fmaf(g[2], Y, fmaf(-g[3], X, fmaf(g[3], g[0], -(g[2] * g[1]))));
       ep = wrap_spec(phi - g[4]);
       const float dv = v - g[6];
       const float dk = k - g[5];
-      J = fmaf(hq0 * ey, ey, J);
-      J = fmaf(hq1 * ep, ep, J);
-      J = fmaf(hr0 * dv, dv, J);
-      J = fmaf(hr1 * dk, dk, J);
-      const float hv = fmaxf(fmaxf(w->ulo[0] - v, v - w->uhi[0]), 0.0f);
+      S0 = fmaf(ey, ey, S0);
+      S1 = fmaf(ep, ep, S1);
+      S2 = fmaf(dv, dv, S2);
+      S3 = fmaf(dk, dk, S3);
+      /* excess over the input box: x - med3(x, lo, hi) */
+      const float hv = v - fminf(fmaxf(v, w->ulo[0]), w->uhi[0]);
       V = fmaf(hv, hv, V);
-      const float hk = fmaxf(fmaxf(w->ulo[1] - k, k - w->uhi[1]), 0.0f);
+      const float hk = k - fminf(fmaxf(k, w->ulo[1]), w->uhi[1]);
       V = fmaf(hk, hk, V);
       const float hc = fmaxf(fabsf(ey) - g[7], 0.0f);
       V = fmaf(hc, hc, V);
@@ -278,6 +281,10 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
     float a = (hqn0 * ey) * ey;
     a = fmaf(hqn1 * ep, ep, a);
     a = fmaf(hqn2 * tN, tN, a);
+    float J = hq0 * S0;
+    J = fmaf(hq1, S1, J);
+    J = fmaf(hr0, S2, J);
+    J = fmaf(hr1, S3, J);
     J = J + a;
     costs[c] = fmaf(w->wbound, V, J);
     viol[c] = V;

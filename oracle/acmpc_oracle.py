@@ -523,18 +523,21 @@ def sincos_spec(phi, dtype=np.float32):
 
 
 def wrap_spec(angle, dtype=np.float32):
-    """(-pi, pi] wrap as fma(-floor(b / 2pi), 2pi, b) - pi, b = a + pi, with a reciprocal multiply (no division)."""
+    """Angle difference into [-pi, pi]: a - 2 pi rint(a / 2 pi), the integer read off the magic-number sum
+    fma(a, 1 / 2 pi, 1.5 * 2^23) (csrc/acmpc_device.h: wrap_spec; no float -> int conversion, no division)."""
     T = dtype
     fma = _fma_for(T)
-    a = angle + T(PI_F)
-    q = np.floor(a * T(INV_TWO_PI_F))
-    return fma(-q, T(TWO_PI_F), a) - T(PI_F)
+    magic = T(12582912.0) if T == np.float32 else T(6755399441055744.0)   # 1.5 * 2^23 / 1.5 * 2^52
+    a = np.asarray(angle, dtype=T)
+    q = fma(a, T(INV_TWO_PI_F), magic) - magic
+    return fma(-q, T(TWO_PI_F), a)
 
 
 def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.float32,
                      return_states=False, libm_trig=False, nn_window=None):
     """Mode T: Cartesian kinematic Euler rollout (localiser.py:66-95 with phi_dot = v*kappa, kappa =
-    tan(delta)/L), nearest-waypoint projection (first minimum of squared distance, localiser.py:282-289),
+    tan(delta)/L), nearest-waypoint projection (first minimum of the squared distance, localiser.py:282-289 - compared
+    through the search key e_m = |p - w_m|^2 - |p|^2 evaluated as two fused multiply-adds, see below),
     Frenet errors (dynamics.py:23-40), a9 cost weights and bounds.
 
     pose0 = (X, Y, phi), wp[n,8] (coefficients_temporal), U[N,n,2] = (v, kappa).
@@ -564,6 +567,15 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
     j_prev = np.zeros(N, dtype=np.int64)
     if return_states:
         S[:, 0, 0], S[:, 0, 1], S[:, 0, 2] = X, Y, phi
+    # the nearest-waypoint search key (csrc/acmpc_device.h: search_key): e_m = fma(Y, b_m, fma(X, a_m, c_m)) with
+    # a = -2 x, b = -2 y, c = fma(y, y, x x) - the squared distance less |p|^2, which no waypoint's share of changes
+    key_a, key_b = T(-2.0) * wp[:, CT_X], T(-2.0) * wp[:, CT_Y]
+    key_c = fma(wp[:, CT_Y], wp[:, CT_Y], wp[:, CT_X] * wp[:, CT_X])
+    # the waypoint rows as the kernels derive them once per workgroup (stage_temporal_tables): e_y = c (Y - y) - s (X - x)
+    # becomes fma(c, Y, fma(-s, X, s x - c y))
+    row_k = fma(wp[:, CT_SIN], wp[:, CT_X], -(wp[:, CT_COS] * wp[:, CT_Y]))
+    row_ns = -wp[:, CT_SIN]
+    S0, S1, S2, S3 = (np.zeros(N, dtype=T) for _ in range(4))   # sums of e_y^2, e_psi^2, dv^2, dkappa^2
     for i in range(n):
         v, k = U[:, i, 0], U[:, i, 1]
         if libm_trig:
@@ -578,9 +590,7 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
         if nn_window is None:
             j = np.zeros(N, dtype=np.int64)
             for w in range(n):
-                dx = X - wp[w, CT_X]
-                dy = Y - wp[w, CT_Y]
-                d = fma(dy, dy, dx * dx)
+                d = fma(Y, key_b[w], fma(X, key_a[w], key_c[w]))
                 better = d < best
                 best = np.where(better, d, best)
                 j = np.where(better, w, j)
@@ -592,29 +602,28 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
             j = lo.copy()
             for m in range(width):
                 w = np.minimum(lo + m, hi)
-                dx = X - wp[w, CT_X]
-                dy = Y - wp[w, CT_Y]
-                d = fma(dy, dy, dx * dx)
+                d = fma(Y, key_b[w], fma(X, key_a[w], key_c[w]))
                 better = d < best
                 best = np.where(better, d, best)
                 j = np.where(better, w, j)
         j_prev = j
         g = wp[j]
-        ey = fma(g[:, CT_COS], Y - g[:, CT_Y], -(g[:, CT_SIN] * (X - g[:, CT_X])))
+        ey = fma(g[:, CT_COS], Y, fma(row_ns[j], X, row_k[j]))
         if libm_trig:
             ep = wrap_to_pi(phi - g[:, CT_PSI]).astype(T)
         else:
             ep = wrap_spec(phi - g[:, CT_PSI], T)
         dv = v - g[:, CT_VREF]
         dk = k - g[:, CT_KREF]
-        # J += 1/2 (q0 ey^2 + q1 ep^2 + r0 dv^2 + r1 dk^2), one fused term at a time with the halved weights
-        J = fma(hQ[0] * ey, ey, J)
-        J = fma(hQ[1] * ep, ep, J)
-        J = fma(hR[0] * dv, dv, J)
-        J = fma(hR[1] * dk, dk, J)
-        hv = np.fmax(np.fmax(u_lo[0] - v, v - u_hi[0]), zero)   # IEEE maxNum: a NaN operand is dropped
+        # the stage cost's squares; its weights are applied once, after the horizon
+        S0 = fma(ey, ey, S0)
+        S1 = fma(ep, ep, S1)
+        S2 = fma(dv, dv, S2)
+        S3 = fma(dk, dk, S3)
+        # excess over the input box: x - med3(x, lo, hi) (v_med3_f32: a NaN x gives min(lo, hi))
+        hv = v - np.fmin(np.fmax(v, u_lo[0]), u_hi[0])
         V = fma(hv, hv, V)
-        hk = np.fmax(np.fmax(u_lo[1] - k, k - u_hi[1]), zero)
+        hk = k - np.fmin(np.fmax(k, u_lo[1]), u_hi[1])
         V = fma(hk, hk, V)
         hc = np.fmax(np.abs(ey) - g[:, CT_HALF], zero)           # outside the corridor |e_y| <= w/2 - margin
         V = fma(hc, hc, V)
@@ -622,6 +631,10 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
             S[:, i + 1, 0], S[:, i + 1, 1], S[:, i + 1, 2] = X, Y, phi
             J_idx[:, i] = j
     tN = T(n) * dtT
+    J = hQ[0] * S0
+    J = fma(hQ[1], S1, J)
+    J = fma(hR[0], S2, J)
+    J = fma(hR[1], S3, J)
     s = (hQN[0] * ey) * ey
     s = fma(hQN[1] * ep, ep, s)
     s = fma(hQN[2] * tN, tN, s)
