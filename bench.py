@@ -322,6 +322,40 @@ def latest_traffic(algorithmic_bytes, kernel_name):
     return best
 
 
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles, 2.4 GHz
+
+
+def counted_valu(profile, entry):
+    """VALU instructions per candidate-step of a kernel from the newest committed SQ-counter summary
+    (profiles/*_<profile>_sq_counters.json: SQ_INSTS_VALU / waves / steps / candidates per lane, collected with
+    rocprofv3 --pmc in its own run).  None when no such profile is committed."""
+    import glob
+    found = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_sq_counters.json" % profile))):
+        try:
+            derived = json.load(open(path))[entry]["derived"]
+        except (OSError, ValueError, KeyError):
+            continue
+        if derived.get("valu_instructions_per_candidate_step"):
+            found = (float(derived["valu_instructions_per_candidate_step"]), os.path.relpath(path, ROOT))
+    return found
+
+
+def valu_roofline(counted, candidates, steps, kernel_s):
+    """The roof an instruction-bound kernel is under: wave64 VALU instructions it has to issue (counted per
+    candidate-step, one instruction serving the 64 candidates of a wave) against what 1 024 SIMDs can issue."""
+    if counted is None:
+        return None
+    per_step, source = counted
+    needed = per_step * candidates * steps / 64.0
+    return {"bound": "valu", "valu_instructions_per_candidate_step": per_step, "achieved": needed / kernel_s,
+            "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave-instructions/s", "frac": needed / kernel_s / VALU_PEAK_WAVE_INSTR_PER_S,
+            "peak_is": "1 024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; two-operand float32 instructions (add, mul, "
+                       "fmac, xor, mov) issue in about two cycles on this part (tools/valu_probe.hip), so a kernel made of them "
+                       "can exceed 1.0 on this scale",
+            "instruction_count_source": source, "instruction_count_measured_in_this_run": False}
+
+
 def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300, host_pointer=True):
     """BASELINE.json configs[1] as ONE problem per call (the closed-loop shape): device-resident solve latency
     (rollout + argmin + winner record, HIP events) and the host-pointer acmpc_solve (H2D + kernels + D2H)."""
@@ -360,7 +394,8 @@ def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300
                 "device_resident_us_p50": p50, "device_resident_us_p99": float(np.percentile(dev_us, 99)),
                 "device_resident_traj_per_s": N / (p50 * 1e-6),
                 "frac_of_hbm_roofline": byts / (p50 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                "note": "one problem per launch: rollout + argmin + winner record (two launches), latency-bound"}
+                "note": "one problem per call: rollout + argmin + winner record in ONE launch (rollout_solo_kernel) up to "
+                        "1 024 workgroups of 64 candidates, two launches beyond; latency-bound"}
     U_host, x0_host = U.cpu().numpy(), x0.cpu().numpy()
     wall = []
     for _ in range(20):
@@ -382,7 +417,7 @@ def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300
     return out
 
 
-def closed_loop_replay(workloads, track_name="silverstone", poses=2000):
+def closed_loop_replay(workloads, track_name="silverstone", poses=2000, rollout_mode="S"):
     """BASELINE.json configs[4]: the drop-in controller against consecutive poses along the synthetic Silverstone
     circuit - one full MPC solve per pose, each ONE call into the library: the reference path is cut out of the map on
     the device (150 m window in the vehicle frame, 500 -> H downsample), then waypoints, speed-profile QP, Frenet start
@@ -394,6 +429,7 @@ def closed_loop_replay(workloads, track_name="silverstone", poses=2000):
 
     cfg = copy.deepcopy(workloads.RACING_CONTROL[track_name])
     cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])  # controller.py:241-243
+    cfg["rollout_mode"] = rollout_mode
     track = workloads.synthetic_track(track_name)
     H = cfg["horizon"]
     stride = 2  # 1 m between consecutive poses at 0.5 m map spacing (~30 m/s at 30 Hz perception)
@@ -422,8 +458,8 @@ def closed_loop_replay(workloads, track_name="silverstone", poses=2000):
         host_wall[i] = time.perf_counter() - t0
     return {
         "workload": "%s (synthetic circuit): %d consecutive poses, one SpatialMPC solve per pose (path from the map, "
-                    "prologue and rounds on the device), horizon %d, %d candidates x %d rounds"
-                    % (track_name, poses, H, mpc._control_solver._n_candidates, mpc._control_solver._rounds),
+                    "prologue and rounds on the device), horizon %d, %d candidates x %d rounds, rollout mode %s"
+                    % (track_name, poses, H, mpc._control_solver._n_candidates, mpc._control_solver._rounds, rollout_mode),
         "solve_ms_p50": float(np.percentile(wall, 50) * 1e3), "solve_ms_p99": float(np.percentile(wall, 99) * 1e3),
         "solve_ms_max": float(wall.max() * 1e3), "sustainable_hz": float(1.0 / np.percentile(wall, 99)),
         "infeasible_solves": int(mpc.infeasibility_counter),
@@ -472,9 +508,50 @@ def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
         byts = P * N * (8 * n + 4)
         out[name] = {"kernel_us": ms * 1e3, "candidate_trajectories_per_s": P * N / (ms * 1e-3),
                      "algorithmic_GBps": byts / (ms * 1e-3) / 1e9, "frac_of_hbm_roofline": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        if mode == 1:   # instruction-bound: the roof it is under is the vector pipes', not HBM's
+            entry = "exhaustive" if window is None else "window_%d_%d" % window
+            roof = valu_roofline(counted_valu("mode_T", entry), P * N, n, ms * 1e-3)
+            if roof is not None:
+                out[name]["roofline_valu"] = roof
         eng.close()
         del U, costs
     return out
+
+
+def sampled_fused_at_scale(workloads, Engine, track, H, device, P=1024, N=16384, iters=8):
+    """SURVEY.md 8f #3 at the scale a many-agent deployment would see: P independent problems x N candidates drawn ON THE
+    DEVICE (Philox, smooth noise) and rolled out in the same launch - one fused round of `acmpc_optimize` - so the
+    control-sample matrix never exists and the 8n bytes per candidate of the headline's byte model are not moved at
+    all: reported separately, against the vector pipes' roof.  Kernel time from the event pair attached to the
+    round's dispatch; the winners' records (argmin + re-roll inside the launch) are part of it."""
+    n = H - 1
+    base = workloads.problem_batch(track, 256, H, seed=0)
+    batch = copy.copy(base)
+    reps = P // 256
+    batch.tables, batch.x0, batch.pose0 = (np.tile(base.tables, (reps, 1, 1)), np.tile(base.x0, (reps, 1)),
+                                           np.tile(base.pose0, (reps, 1)))
+    eng = Engine(**workloads.engine_kwargs(batch, 0, N, device=device.index))
+    eng.set_paths(batch.tables)
+    u_ref = np.ascontiguousarray(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=np.float32)
+    x0 = np.ascontiguousarray(batch.x0, dtype=np.float32)
+    eng.optimize(x0, u_ref, u_ref, N, 1, SAMPLE_SIGMA, shrink=0.5, seed=1)        # warm-up (buffers, sampler tables)
+    eng.profile_enable(iters)
+    for i in range(iters):
+        out = eng.optimize(x0, u_ref, u_ref, N, 1, SAMPLE_SIGMA, shrink=0.5, seed=2 + i)
+    ms = float(np.median(eng.profile_collect()))
+    eng.profile_enable(0)
+    eng.close()
+    block = {"workload": "%s (synthetic circuit): %d problems x %d candidates x horizon %d per launch, candidates sampled "
+                         "in the rollout kernel (one fused round: sample + rollout + cost + argmin + winner record)"
+                         % (track, P, N, H),
+             "kernel_us": ms * 1e3, "candidate_trajectories_per_s": P * N / (ms * 1e-3),
+             "winners_finite": bool(np.isfinite(out["cost"]).all()),
+             "note": "no control matrix is read: the HBM byte model of `value` does not apply (a matrix of this batch "
+                     "would be %.1f GB)" % (P * N * 8 * n / 1e9)}
+    roof = valu_roofline(counted_valu("sampled", "fused_round"), P * N, n, ms * 1e-3)
+    if roof is not None:
+        block["roofline_valu"] = roof
+    return block
 
 
 def sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_rank, device, backend, solves=200):
@@ -760,6 +837,8 @@ def main():
         traffic = latest_traffic(algorithmic_bytes, "rollout_kernel<%d, %d" % (mode, args.layout))
         if traffic is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic
+        # (PMC counters need rocprofv3 round the process: the bytes come from the committed profile of this same command)
+        out["roofline"]["traffic_measured_in_this_run"] = False
         if step_latency is not None:
             out["step_latency"] = step_latency
         if collective is not None:
@@ -774,11 +853,14 @@ def main():
         if world == 1 and not args.no_single_solve and args.scaling == "weak":
             out["single_solve"] = single_solve(workloads, Engine, args.track, H, N, mode, args.layout, device)
             out["closed_loop_replay"] = closed_loop_replay(workloads)
+            # the same loop with north_star's literal rollout (Cartesian bicycle + nearest waypoint) behind get_control
+            out["closed_loop_replay_mode_T"] = closed_loop_replay(workloads, poses=1000, rollout_mode="T")
             # the second half of BASELINE.json's metric ("+ MPC solve p50 latency"): the drop-in get_control
             out["mpc_solve_latency_ms"] = {"p50": out["closed_loop_replay"]["solve_ms_p50"],
                                            "p99": out["closed_loop_replay"]["solve_ms_p99"],
                                            "of": "one SpatialMPC solve per pose (get_control_at), closed_loop_replay workload"}
             out["secondary_kernels"] = secondary_kernels(workloads, Engine, args.track, H, N, device)
+            out["secondary_kernels"]["sampled_fused_16M"] = sampled_fused_at_scale(workloads, Engine, args.track, H, device)
             # the other BASELINE configurations as ONE problem per call (what DESIGN.md quotes for them)
             out["config3_single"] = single_solve(workloads, Engine, "spa", 50, 65536, 0, 1, device, host_pointer=False)
             out["config4_share"] = single_solve(workloads, Engine, "nordschleife", 80, 32768, 0, 1, device,

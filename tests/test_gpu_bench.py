@@ -42,6 +42,18 @@ def test_single_gpu_line_has_the_contract_fields():
                  "mode_S_step_major_1M", "mode_T_window_2_5_16M", "mode_S_candidate_major_16M"):
         assert 0 < second[name]["frac_of_hbm_roofline"] < 1 and second[name]["kernel_us"] > 0, name
     assert second["mode_S_candidate_major_16M"]["kernel_us"] > 4 * second["mode_S_candidate_major"]["kernel_us"]
+    # instruction-bound kernels carry the roof they are under (VALU issue), the fused sampled round at scale too
+    for name in ("mode_T_exhaustive_search", "mode_T_window_2_5", "mode_T_window_1_2", "mode_T_window_2_5_16M"):
+        valu = second[name]["roofline_valu"]
+        assert valu["bound"] == "valu" and valu["frac"] > 0 and valu["valu_instructions_per_candidate_step"] > 20
+        assert valu["instruction_count_source"].startswith("profiles/")
+    fused = second["sampled_fused_16M"]
+    assert fused["kernel_us"] > 0 and fused["candidate_trajectories_per_s"] > 1e9 and fused["winners_finite"]
+    assert fused["roofline_valu"]["frac"] > 0
+    assert out["roofline"]["traffic_measured_in_this_run"] is False
+    loop_t = out["closed_loop_replay_mode_T"]
+    assert "rollout mode T" in loop_t["workload"] and loop_t["infeasible_solves"] == 0 and loop_t["solve_ms_p50"] > 0
+    assert out["single_solve"]["device_resident_us_p50"] < 16.0      # one launch (round 2: two launches, 19 us)
     assert out["config3_single"]["device_resident_us_p50"] > 0 and out["config4_share"]["device_resident_us_p50"] > 0
     five = out["config5_host_pointer"]
     assert "10000 consecutive poses" in five["workload"] and 0 < five["solve_us_p50"] <= five["solve_us_p99"]

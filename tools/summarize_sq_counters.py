@@ -1,8 +1,8 @@
-#!/usr/bin/env python3
 """Development tool: mean SQ counters per launch of the mode-T rollout kernel out of the raw rocprofv3 --pmc passes that
-tools/pmc_modeT.sh leaves under gpurun_out/, written as profiles/<tag>_mode_T_sq_counters.json.
+tools/pmc_modeT.sh leaves under gpurun_out/, written as profiles/<tag>_mode_T_sq_counters.json; with a second argument
+`sampled`, of the fused sample + rollout kernel (tools/pmc_sampled.sh) -> profiles/<tag>_sampled_sq_counters.json.
 
-usage: tools/summarize_sq_counters.py r02"""
+usage: python3 tools/summarize_sq_counters.py r03 [sampled]"""
 import csv
 import glob
 import json
@@ -16,19 +16,19 @@ STEPS = 49
 SIMDS = 1024
 
 
-def counters(directory):
+def counters(directory, kernel="::rollout_kernel<1"):
     sums, counts, micros = defaultdict(float), defaultdict(int), []
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as handle:
             for row in csv.DictReader(handle):
-                if not "::rollout_kernel<1" in row["Kernel_Name"]:
+                if kernel not in row["Kernel_Name"]:
                     continue
                 sums[row["Counter_Name"]] += float(row["Counter_Value"])
                 counts[row["Counter_Name"]] += 1
     for path in glob.glob(os.path.join(directory, "**", "*kernel_trace.csv"), recursive=True):
         with open(path, newline="") as handle:
             for row in csv.DictReader(handle):
-                if "::rollout_kernel<1" in row["Kernel_Name"]:
+                if kernel in row["Kernel_Name"]:
                     micros.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
     means = {name: sums[name] / counts[name] for name in sorted(sums)}
     launches = max(counts.values()) if counts else 0
@@ -46,8 +46,54 @@ def unprofiled(tag):
     return out
 
 
+def sampled(tag, problems=1024, candidates=16384):
+    """The fused sample + rollout round at bench.py's `sampled_fused_16M` scale: one wave = 64 candidates."""
+    merged, launches, profiled_us = {}, 0, None
+    for suffix in ("a", "b"):
+        means, count, micros = counters(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_sampled_{suffix}"), "rollout_sampled_kernel<0")
+        merged.update(means)
+        launches = max(launches, count)
+        profiled_us = profiled_us or micros
+    if not merged:
+        raise SystemExit("no counters under gpurun_out/pmc_%s_sampled_*" % tag)
+    waves, valu = merged.get("SQ_WAVES", 0.0), merged.get("SQ_INSTS_VALU", 0.0)
+    unprofiled_line = None
+    path = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_sampled_unprofiled.log")
+    if os.path.exists(path):
+        lines = [line.strip() for line in open(path) if "kernel_us" in line]
+        unprofiled_line = lines[-1] if lines else None
+    derived = {
+        "launches_averaged": launches,
+        "candidates_per_wave": problems * candidates / waves if waves else None,
+        # the horizon's steps are not the whole kernel: the Philox draws, the staging and the winner's re-roll are in the count
+        "valu_instructions_per_candidate_step": valu / waves / STEPS if waves else None,
+        "salu_instructions_per_wave_step": merged.get("SQ_INSTS_SALU", 0.0) / waves / STEPS if waves else None,
+        "lds_instructions_per_wave_step": merged.get("SQ_INSTS_LDS", 0.0) / waves / STEPS if waves else None,
+        "lds_bank_conflict_cycles": merged.get("SQ_LDS_BANK_CONFLICT"),
+        "valu_issue_cycles_per_simd_at_4_per_instruction": valu * 4 / SIMDS,
+        "gpu_active_cycles_per_xcd": (merged["GRBM_GUI_ACTIVE"] / 8 if "GRBM_GUI_ACTIVE" in merged else None),
+        "share_of_wave_cycles_waiting_on_any_counter": (merged["SQ_WAIT_ANY"] / merged["SQ_WAVE_CYCLES"]
+                                                        if "SQ_WAIT_ANY" in merged and "SQ_WAVE_CYCLES" in merged else None),
+        "kernel_us_under_the_profiler": profiled_us,
+        "unprofiled_same_box": unprofiled_line,
+    }
+    result = {
+        "kernel": "rollout_sampled_kernel<mode S> (one wave per workgroup, 64 candidates drawn and rolled in the launch, "
+                  "winner re-rolled by each problem's last workgroup) on %d problems x %d candidates x horizon 50" % (problems, candidates),
+        "command": "tools/pmc_sampled.sh " + tag + ": two rocprofv3 --pmc passes with --kernel-trace round tools/run_sampled_fused.py, "
+                   "then the same un-profiled",
+        "fused_round": {"counters_mean_per_launch": merged, "derived": derived},
+    }
+    path = os.path.join(ROOT, "profiles", f"{tag}_sampled_sq_counters.json")
+    with open(path, "w") as handle:
+        json.dump(result, handle, indent=1)
+    print(json.dumps(derived, indent=1))
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    if len(sys.argv) > 2 and sys.argv[2] == "sampled":
+        return sampled(tag)
     plain = unprofiled(tag)
     result = {
         "kernel": "rollout_kernel<mode T, step-major, 2 candidates per lane, 256 threads, plain float32> on 256 poses x "
@@ -88,10 +134,9 @@ def main():
         }
         result[name] = {"counters_mean_per_launch": merged, "derived": derived}
     result["note"] = ("SQ_INSTS_VALU x 4 cycles / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 XCDs (the counter is summed over the "
-                      "dies): the vector pipe is issuing for (almost) the "
-                      "whole kernel - the kernel is bound by its vector instruction count.  Round 1's form of the kernel "
-                      "(4 candidates per lane, packed pairs, v_cndmask window search) counted 105.3 VALU instructions per "
-                      "candidate-step with window (2,5) and 85.3 with (1,2); see r01_mode_T_sq_counters.json.")
+                      "dies): how much of the kernel the vector pipe is issuing for.  Round 2's form of the kernel (squared "
+                      "distances in packed pairs, weighted stage cost per step) counted 96.8 VALU instructions per "
+                      "candidate-step with window (2,5); see r02_mode_T_sq_counters.json.")
     path = os.path.join(ROOT, "profiles", f"{tag}_mode_T_sq_counters.json")
     with open(path, "w") as handle:
         json.dump(result, handle, indent=1)
