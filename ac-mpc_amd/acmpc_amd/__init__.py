@@ -6,10 +6,10 @@ spatial_mpc.py:20-217); `Engine` is the thin object over the C ABI (include/acmp
 from ._capi import (Engine, EngineError, LAYOUT_CANDIDATE_MAJOR, LAYOUT_STEP_MAJOR, MODE_SPATIAL,  # noqa: F401
                     MODE_TEMPORAL, load_library)
 from .bicycle_model import SpatialBicycleModel  # noqa: F401
-from .command_selection import TemporalCommandInterpolator, TemporalCommandSelector  # noqa: F401
+from .command_selection import TemporalCommandInterpolator, TemporalCommandSelector, steer_target  # noqa: F401
 from .mpc import SpatialMPC, build_mpc  # noqa: F401
 from .reference_path import ReferencePath  # noqa: F401
 
 __all__ = ["Engine", "EngineError", "load_library", "MODE_SPATIAL", "MODE_TEMPORAL", "LAYOUT_CANDIDATE_MAJOR",
            "LAYOUT_STEP_MAJOR", "build_mpc", "SpatialMPC", "SpatialBicycleModel", "ReferencePath",
-           "TemporalCommandSelector", "TemporalCommandInterpolator"]
+           "TemporalCommandSelector", "TemporalCommandInterpolator", "steer_target"]

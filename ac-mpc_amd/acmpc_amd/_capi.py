@@ -165,6 +165,8 @@ SIGNATURES = {
     "acmpc_waypoint_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "acmpc_velocity_ceiling": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                          C.c_int32, C.c_double, C.c_void_p]),
+    "acmpc_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint64]),
+    "acmpc_host_free": (C.c_int, [C.c_void_p]),
     "acmpc_unpack_decision": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_double] + [C.c_void_p] * 6),
     "acmpc_unpack_decision_temporal": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double] + [C.c_void_p] * 6),
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -588,6 +590,23 @@ def unpack_decision(z: np.ndarray, n: int, table: np.ndarray, wheelbase: float):
     if rc != OK:
         raise EngineError(rc, "acmpc_unpack_decision: bad arguments")
     return tuple(a.copy() for a in arrays)
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """A NumPy array in page-locked host memory (`acmpc_host_alloc`): a control matrix built in it goes up to the device
+    in one DMA when handed to `Engine.solve`.  Initialises the HIP runtime - call in the process that solves.  The
+    memory is returned to the runtime when the array (and every view of it) has been collected."""
+    import weakref
+    lib = load_library()
+    count = int(np.prod(shape))
+    nbytes = max(count * np.dtype(dtype).itemsize, 1)
+    pointer = C.c_void_p()
+    rc = lib.acmpc_host_alloc(C.byref(pointer), nbytes)
+    if rc != OK:
+        raise EngineError(rc, (lib.acmpc_last_error(None) or b"").decode())
+    buffer = (C.c_char * nbytes).from_address(pointer.value)
+    weakref.finalize(buffer, lib.acmpc_host_free, pointer.value)
+    return np.frombuffer(buffer, dtype=dtype, count=count).reshape(shape)
 
 
 def unpack_decision_temporal(z: np.ndarray, n: int, dt: float, wheelbase: float):

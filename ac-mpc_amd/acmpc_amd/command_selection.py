@@ -60,3 +60,10 @@ class TemporalCommandInterpolator(_CommandSource):
         span = times[second] - times[first]
         return (commands[first] * ((times[second] - elapsed_time) / span)
                 + commands[second] * ((elapsed_time - times[first]) / span))
+
+
+def steer_target(desired_steering_angle: float, max_steering_angle: float) -> float:
+    """What the agent's steering PID is asked to reach for the selected command's steering angle: the angle as a
+    fraction of full lock, clipped to [-1, 1], with the simulator's sign convention (positive = left there, right in
+    the MPC's frame) - `ElTuarMPC._process_yaw` up to its PID (/root/reference/src/acmpc/agent.py:106-115)."""
+    return -1.0 * float(np.clip(desired_steering_angle / max_steering_angle, -1, 1))

@@ -785,6 +785,21 @@ int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_
   return ACMPC_OK;
 }
 
+int acmpc_host_alloc(void** out, uint64_t bytes) {
+  if (out == nullptr || bytes == 0) return fail(nullptr, ACMPC_EINVAL, "acmpc_host_alloc: null output or zero size");
+  *out = nullptr;
+  const hipError_t e = hipHostMalloc(out, static_cast<size_t>(bytes), hipHostMallocDefault);
+  if (e != hipSuccess) return fail_hip(nullptr, e, "hipHostMalloc");
+  return ACMPC_OK;
+}
+
+int acmpc_host_free(void* memory) {
+  if (memory == nullptr) return ACMPC_OK;
+  const hipError_t e = hipHostFree(memory);
+  if (e != hipSuccess) return fail_hip(nullptr, e, "hipHostFree");
+  return ACMPC_OK;
+}
+
 void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
   acmpc::philox4x32_10(counter, key, out);
 }

@@ -217,7 +217,7 @@ def numpy_all_cores_baseline(batch, U_dev, layout, N, n, seconds=3.0):
                       "the parent (winner %d)" % (N, n + 1, cores, seconds, winner[1])}
 
 
-def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50):
+def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50, pinned=False):
     """BASELINE.json configs[4] exactly as SURVEY.md 8(d) defines it: 10 000 consecutive poses along the synthetic
     Silverstone circuit, one solve each of N = 4 096 candidates through the host-pointer `acmpc_solve` (H2D of the
     1.6 MB control matrix + rollout + argmin + record + D2H), wall-clock p50 / p99 per solve.  Candidates are
@@ -239,6 +239,8 @@ def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50):
     noise = (np.random.default_rng(5).standard_normal((N, n, 2)) * np.array(SAMPLE_SIGMA)).astype(np.float32)
     noise[0] = 0.0
     U = np.empty((1, N, n, 2), dtype=np.float32)
+    if pinned:   # the matrix built in page-locked memory (acmpc_host_alloc): one DMA up instead of the runtime's staging
+        U = _capi.pinned_empty((1, N, n, 2), np.float32)
     warm, wall, infeasible = None, np.empty(poses), 0
     for i in range(poses + 20):
         coords = workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % len(track["centre"])), H)
@@ -263,6 +265,7 @@ def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50):
                         "candidates x horizon %d" % (name, poses, N, H),
             "solve_us_p50": float(np.percentile(wall, 50) * 1e6), "solve_us_p99": float(np.percentile(wall, 99) * 1e6),
             "traj_per_s_at_p50": N / float(np.percentile(wall, 50)), "winners_with_a_bound_violation": infeasible,
+            "controls_in": "page-locked host memory (acmpc_host_alloc)" if pinned else "pageable host memory",
             "note": "PCIe-inclusive (1.6 MB of controls up per solve): never `value`"}
 
 
@@ -866,6 +869,7 @@ def main():
             out["config4_share"] = single_solve(workloads, Engine, "nordschleife", 80, 32768, 0, 1, device,
                                                 host_pointer=False)
             out["config5_host_pointer"] = config5_host_pointer(workloads, Engine, device)
+            out["config5_host_pointer"]["pinned"] = config5_host_pointer(workloads, Engine, device, poses=3000, pinned=True)
             out["particle_filter"] = particle_filter_block(workloads)
         if world == 1 and not args.no_cpu_baseline:
             gpu_costs = last.costs[:32].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]

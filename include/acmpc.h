@@ -136,6 +136,14 @@ int32_t acmpc_record_floats(int32_t n);
 int acmpc_solve(acmpc_ctx* ctx, const float* x0, const float* U, int32_t P, int32_t N, int32_t n,
                 int32_t layout, float* costs, int32_t* best_idx, float* records);
 
+/* Page-locked host memory for acmpc_solve's inputs and outputs.  A control matrix in ordinary (pageable) memory goes
+ * up through the runtime's staging buffers - ~100 us for the 1.6 MB of 4 096 candidates x horizon 50, most of a
+ * host-pointer solve; from memory these calls return it is one DMA (~35 us).  acmpc_host_alloc initialises the HIP
+ * runtime: call it in the process that solves (after the fork of controller.py:94-100), never before.  The closed
+ * loop does not need it: acmpc_control_tick samples on the device and moves 2 kB per tick. */
+int acmpc_host_alloc(void** out, uint64_t bytes);
+int acmpc_host_free(void* memory);
+
 /* Same work with every buffer already resident in device memory, asynchronous on `stream`
  * (a hipStream_t, NULL = the null stream).  `d_keys` [P] receives the packed (cost, index) keys - see
  * acmpc_rollout_device - and `d_records` [P][acmpc_record_floats(n)] the winner records.
@@ -153,7 +161,8 @@ int acmpc_solve_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, int3
  * record on the rank that owns it and zeros elsewhere (owner flag 0), plus every rank's feasible count, so an
  * all-reduce(SUM) of the records gives every rank the selected controls.
  * `d_keys` may be NULL in both calls on a single GPU: the rollout then leaves its per-workgroup partial keys in
- * the handle and the finalize step reduces those itself (two launches in total - what acmpc_solve_device does). */
+ * the handle and the finalize step reduces those itself (two launches in total; acmpc_solve_device does the same
+ * work in ONE launch for mode S problems of up to 65 536 candidates in all, and in these two launches otherwise). */
 int acmpc_rollout_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, int32_t P, int32_t N, int32_t n,
                          int32_t layout, int64_t index_offset, float* d_costs, int64_t* d_keys, void* stream);
 int acmpc_finalize_device(acmpc_ctx* ctx, const int64_t* d_keys, const float* d_x0, const float* d_U, int32_t P,

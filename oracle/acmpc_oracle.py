@@ -219,22 +219,29 @@ def speed_profile_qp(table: np.ndarray, constraints: Dict, end_velocity: Optiona
 
 
 def osqp_restated(P_diag, q, A, l, u, max_iter=4000, rho=0.1, sigma=1e-6, alpha=1.6,
-                  eps_abs=1e-3, eps_rel=1e-3, check_every=25) -> SimpleNamespace:
+                  eps_abs=1e-3, eps_rel=1e-3, check_every=25, adaptive_rho=False) -> SimpleNamespace:
     """ADMM of Stellato et al., "OSQP: an operator splitting solver for quadratic programs"
     (Math. Prog. Comp. 2020), Algorithm 1 - dense, no scaling, no rho adaptation, equality rows
     get 1e3*rho as in the paper's section 5.2.  `osqp` is a third-party dependency of the reference
     with no pinned version (requirements.txt:2) and is absent here, so this restates the published
     algorithm; solutions are parity-UNPINNED and only used as a sanity oracle (is the sampled
     optimum close to the QP optimum?).  Termination tolerances are OSQP's documented defaults.
+    `adaptive_rho`: the paper's section 5.2 step-size update (rho scaled by the square root of the ratio of the
+    normalised primal and dual residuals when it is off by more than a factor 5, the KKT matrix refactored) at the
+    residual checks - what lets the tight-tolerance sanity solves converge on the nearly straight scenarios.
     """
     P_diag = np.asarray(P_diag, dtype=np.float64)
     m, nvar = A.shape
-    rho_vec = np.where(l == u, 1e3 * rho, rho)
-    K = np.diag(P_diag + sigma) + A.T @ (rho_vec[:, None] * A)
-    chol = np.linalg.cholesky(K)
+    from scipy.linalg import cho_factor, cho_solve
 
-    def kkt_solve(rhs):
-        return np.linalg.solve(chol.T, np.linalg.solve(chol, rhs))
+    def factor(rho_now):
+        vec = np.where(l == u, 1e3 * rho_now, rho_now)
+        return vec, cho_factor(np.diag(P_diag + sigma) + A.T @ (vec[:, None] * A), lower=True)
+
+    rho_vec, chol = factor(rho)
+
+    def kkt_solve(rhs):   # two triangular solves (a general solve of the factor would refactor it every iteration)
+        return cho_solve(chol, rhs)
 
     x = np.zeros(nvar)
     z = np.zeros(m)
@@ -258,6 +265,13 @@ def osqp_restated(P_diag, q, A, l, u, max_iter=4000, rho=0.1, sigma=1e-6, alpha=
             if r_prim <= e_prim and r_dual <= e_dual:
                 status = "solved"
                 break
+            if adaptive_rho and it % (4 * check_every) == 0:
+                n_prim = r_prim / max(np.max(np.abs(Ax)), np.max(np.abs(z)), 1e-12)
+                n_dual = r_dual / max(np.max(np.abs(P_diag * x)), np.max(np.abs(A.T @ y)), np.max(np.abs(q)), 1e-12)
+                scale = np.sqrt(n_prim / max(n_dual, 1e-300))
+                if scale > 5.0 or scale < 0.2:
+                    rho = float(np.clip(rho * scale, 1e-6, 1e6))
+                    rho_vec, chol = factor(rho)
     return SimpleNamespace(x=x, y=y, info=SimpleNamespace(status=status, iter=it))
 
 

@@ -339,3 +339,18 @@ def test_native_waypoint_table_equals_numpy_on_arbitrary_paths():
         assert got[3, 0] == got[3, 1]
 
     check()
+
+
+def test_steer_target_against_the_reference_vector():
+    """the steering target of ElTuarMPC._process_yaw (agent.py:106-115), recorded from the reference's
+    own method by tests/golden/gen_agent_golden.py."""
+    import os
+    from acmpc_amd.command_selection import steer_target
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "agent_steer_target.npz"))
+    delta_max = float(g["delta_max"])
+    for yaw, current, want in zip(g["yaw"], g["current"], g["steering"]):
+        # the reference returns current + PID(current, target); the recorded stand-in PID returns target - current
+        assert current + (steer_target(float(yaw), delta_max) - current) == want
+        assert -1.0 <= steer_target(float(yaw), delta_max) <= 1.0
+    assert steer_target(delta_max, delta_max) == -1.0 and steer_target(-2 * delta_max, delta_max) == 1.0
+    assert steer_target(0.0, delta_max) == 0.0
