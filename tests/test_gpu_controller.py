@@ -79,7 +79,9 @@ def test_sampled_optimum_approaches_the_qp_optimum(update):
     spread = abs(j_qp) + 1.0
     print("update=%s  J_sampled=%.6g  J_qp=%.6g  gap=%.3g" % (update, j_sampled, j_qp, (j_sampled - j_qp) / spread))
     assert j_sampled >= j_qp - 1e-2 * spread, "a feasible rollout cannot beat the QP optimum"
-    assert j_sampled <= j_qp + 0.25 * spread, "sampled plan too far from the QP optimum: %g vs %g" % (j_sampled, j_qp)
+    # measured round 3: 8.5e-5 (argmin) and 2.4e-4 (softmin) of |J_qp| + 1; the shipped schedule on the reference's 28
+    # script scenarios is held against the optimum in tests/test_gpu_qp_gap.py
+    assert j_sampled <= j_qp + 0.01 * spread, "sampled plan too far from the QP optimum: %g vs %g" % (j_sampled, j_qp)
 
 
 def test_infeasible_problem_keeps_previous_controls():
