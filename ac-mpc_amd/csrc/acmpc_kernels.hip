@@ -108,8 +108,15 @@ __device__ __forceinline__ void published() {
 }
 
 // PACK = candidates per arithmetic state: 2 = pairs in v_pk_* instructions, 1 = plain float32 instructions.
-template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1)>
-__global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs a) {
+// Mode T with two candidates per lane needs 67 VGPRs as the compiler allocates it freely: seven waves per SIMD, where a
+// launch of 1 M candidates is eight - the eighth workgroup of every CU then runs alone after the others (a second
+// generation of lone waves: +15 % on the launch).  Asking for eight waves per SIMD caps the allocation at 64.
+// WAVES = 8 asks for that many waves per SIMD, which caps the allocation at 64 VGPRs.  Measured, 1 M candidates (256 poses
+// x 4 096), same box, 67 VGPRs / capped: verified 16-waypoint search 331 / 283 us, 4-waypoint window 102.5 / 92.8 us -
+// but the 8-waypoint window 134.9 / 141.3 us (its waves already queue for the LDS: an eighth wave per SIMD adds to the
+// queue what it saves on the tail), so the launcher caps every search but that one.
+template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1), int WAVES = 1>
+__global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // carve: [0,32) wave keys | [32,48) wave feasible counts | [64, ...) mode-T waypoint table
   int64_t* s_key = reinterpret_cast<int64_t*>(smem);
@@ -1637,7 +1644,7 @@ __global__ void __launch_bounds__(kSoftBlock) softmin_final_kernel(const Softmin
   if (threadIdx.x == 0 && a.weight_sum != nullptr) a.weight_sum[p] = wsum;
 }
 
-template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1)>
+template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1), int WAVES = 1>
 hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                             hipEvent_t e1) {
   const dim3 grid(shape.blocks_per_problem, args.P);
@@ -1645,10 +1652,10 @@ hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, h
                                            sizeof(float)
                                      : 0);
   if (e0 != nullptr && e1 != nullptr) {
-    hipExtLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK, PACK>), grid, dim3(BLOCK),
+    hipExtLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK, PACK, WAVES>), grid, dim3(BLOCK),
                           static_cast<std::uint32_t>(lds), s, e0, e1, 0, args);
   } else {
-    hipLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK, PACK>), grid, dim3(BLOCK), lds, s, args);
+    hipLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK, PACK, WAVES>), grid, dim3(BLOCK), lds, s, args);
   }
   return hipGetLastError();
 }
@@ -1862,7 +1869,12 @@ hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const Rollout
                                          hipEvent_t e0, hipEvent_t e1) {
   if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<1, 1, 1, 64, 1>(shape, args, s, e0, e1);
   if (shape.block == 256 && shape.cpt == 1) return launch_rollout_t<1, 1, 1, 256, 1>(shape, args, s, e0, e1);
-  if (shape.block == 256 && shape.cpt == 2) return launch_rollout_t<1, 1, 2, 256, 1>(shape, args, s, e0, e1);
+  if (shape.block == 256 && shape.cpt == 2) {
+    // two candidates per lane: 67 VGPRs, or 63 when capped at eight waves per SIMD (see rollout_kernel)
+    const bool window_of_eight = args.w.nn_ahead >= 0 && args.w.nn_back + args.w.nn_ahead + 1 == 8;
+    return window_of_eight ? launch_rollout_t<1, 1, 2, 256, 1>(shape, args, s, e0, e1)
+                           : launch_rollout_t<1, 1, 2, 256, 1, 8>(shape, args, s, e0, e1);
+  }
   if (shape.block == 256 && shape.cpt == 4) return launch_rollout_t<1, 1, 4, 256, 1>(shape, args, s, e0, e1);
   return hipErrorInvalidConfiguration;
 }
