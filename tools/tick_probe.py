@@ -1,4 +1,5 @@
-"""Development probe (GPU box): closed-loop get_control latency on consecutive poses (TICK_H = horizon, default 50)."""
+"""Development probe (GPU box): closed-loop get_control latency on consecutive poses (TICK_H = horizon, default 50;
+TICK_MODE = S | T, the controller's rollout_mode)."""
 import copy, os, sys, time
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -10,6 +11,7 @@ track = workloads.synthetic_track("silverstone")
 paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % len(track["centre"])), H) for i in range(1520)]
 cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"])
 cfg["horizon"] = H
+cfg["rollout_mode"] = os.environ.get("TICK_MODE", "S")
 if "TICK_CHECK" in os.environ:
     cfg["speed_profile_check_every"] = int(os.environ["TICK_CHECK"])
 cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
