@@ -72,6 +72,7 @@ struct acmpc_ctx {
   std::vector<float> h_nn_thr;  // [P][n][kVerifiedWindow], empty when not applicable
   float* d_nn_thr = nullptr;
   int64_t* h_keys = nullptr;  // pinned
+  float* h_io = nullptr;      // pinned: x0 [P][3] on the way up, records [P][record_floats] on the way down (acmpc_solve)
 
   // acmpc_optimize as a hipGraph: the whole sample -> rollout -> finalize chain of `rounds` rounds plus the
   // transfers either side of it is captured once per shape and replayed; per-call inputs travel through the pinned
@@ -511,6 +512,7 @@ int ensure_staging(acmpc_ctx* c) {
   const int rc_tail = ensure_tail_buffers(c);
   if (rc_tail != ACMPC_OK) return rc_tail;
   ACMPC_HIP(c, host_alloc_once(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
+  ACMPC_HIP(c, host_alloc_once(&c->h_io, static_cast<size_t>(p.max_problems) * (3 + acmpc_record_floats(p.max_steps)) * sizeof(float)));
   c->staging_ready = true;
   return ACMPC_OK;
 }
@@ -606,6 +608,7 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_trace);
     (void)hipFree(c->d_nn_thr);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
+    if (c->h_io != nullptr) (void)hipHostFree(c->h_io);
     for (hipGraphExec_t g : c->opt_graph)
       if (g != nullptr) (void)hipGraphExecDestroy(g);
     for (hipGraphExec_t g : c->tick_graph)
@@ -763,7 +766,12 @@ int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_
   if (rc != ACMPC_OK) return rc;
   const size_t cand = static_cast<size_t>(P) * N;
   const size_t rec_bytes = static_cast<size_t>(P) * acmpc_record_floats(n) * sizeof(float);
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  // the small transfers go through page-locked staging: a copy from or to pageable memory is a synchronous staged copy of
+  // ~15 us whatever its size (measured: 1 kB down), two of which were a third of a 4 096-candidate solve
+  float* h_x0 = c->h_io;
+  float* h_records = c->h_io + static_cast<size_t>(P) * 3;
+  std::memcpy(h_x0, x0, static_cast<size_t>(P) * 3 * sizeof(float));
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, h_x0, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
   ACMPC_HIP(c, hipMemcpyAsync(c->d_U, U, cand * n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
   if (use_solo(c, P, N, n, layout)) {
     rc = solve_solo(c, c->d_x0, c->d_U, P, N, n, layout, costs != nullptr ? c->d_costs : nullptr, c->d_keys,
@@ -778,8 +786,9 @@ int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_
   if (rc != ACMPC_OK) return rc;
   ACMPC_HIP(c, hipMemcpyAsync(c->h_keys, c->d_keys, static_cast<size_t>(P) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
   if (costs != nullptr) ACMPC_HIP(c, hipMemcpyAsync(costs, c->d_costs, cand * sizeof(float), hipMemcpyDeviceToHost, s));
-  if (records != nullptr) ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
+  if (records != nullptr) ACMPC_HIP(c, hipMemcpyAsync(h_records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
+  if (records != nullptr) std::memcpy(records, h_records, rec_bytes);
   if (best_idx != nullptr)
     for (int p = 0; p < P; ++p) best_idx[p] = static_cast<int32_t>(acmpc_key_index(c->h_keys[p]));
   return ACMPC_OK;

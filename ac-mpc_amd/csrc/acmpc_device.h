@@ -270,6 +270,12 @@ template <typename F, typename G>
 __device__ __forceinline__ F search_key(F X, F Y, G a, G b, G c) {
   return fma_(Y, F(b), fma_(X, F(a), F(c)));
 }
+// floats per waypoint in the key table: a, b, c side by side, read with ds_read2_b32 from one address.  (Padded to 16 bytes
+// and read with ds_read_b128 - 8 LDS instructions per search instead of 12, a third more bytes - the 8-waypoint kernel took
+// 161 us against 138-152; accumulating the key with two v_fmac_f32 in the register its c arrived in, by inline asm,
+// instead of the compiler's v_fma_f32 + v_fmac_f32: no gain either.  Measured round 3, not kept.)
+constexpr int kKeyStride = 3;
+
 // the key's table entries for one waypoint (x, y): a, b, c
 __device__ __forceinline__ void search_entry(float x, float y, float& a, float& b, float& c) {
   a = -2.0f * x;
@@ -294,7 +300,7 @@ __device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const Stat
   F best = splat<F>(__builtin_inff());
   I j = I(0);
   for (int i = 0; i < n; ++i) {
-    const F d = search_key<F>(s.X, s.Y, abc[3 * i], abc[3 * i + 1], abc[3 * i + 2]);
+    const F d = search_key<F>(s.X, s.Y, abc[kKeyStride * i], abc[kKeyStride * i + 1], abc[kKeyStride * i + 2]);
     const auto better = d < best;
     best = better ? d : best;
     j = better ? I(i) : j;
@@ -310,9 +316,11 @@ __device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const Stat
 template <int W>
 __device__ __forceinline__ int nearest_in_window(float X, float Y, const float* abc, int lo, float* best_out = nullptr) {
   float d[W];
-  const float* first = abc + 3 * lo;   // one address; the W entries at constant offsets
+  const float* first = abc + kKeyStride * lo;   // one address; the W entries at constant offsets
 #pragma unroll
-  for (int m = 0; m < W; ++m) d[m] = search_key<float>(X, Y, first[3 * m], first[3 * m + 1], first[3 * m + 2]);
+  for (int m = 0; m < W; ++m) {
+    d[m] = search_key<float>(X, Y, first[kKeyStride * m], first[kKeyStride * m + 1], first[kKeyStride * m + 2]);
+  }
   float best = d[0];
 #pragma unroll
   for (int m = 1; m < W; ++m) best = __builtin_fminf(best, d[m]);  // NaN keys are skipped, like `d < best`
@@ -381,7 +389,7 @@ __device__ __forceinline__ int nearest_cooperative_fix(float X, float Y, bool ce
     float best = __builtin_inff();
     int jj = 0x7fffffff;
     for (int m = lane; m < n; m += kWave) {
-      const float d = search_key<float>(px, py, abc[3 * m], abc[3 * m + 1], abc[3 * m + 2]);
+      const float d = search_key<float>(px, py, abc[kKeyStride * m], abc[kKeyStride * m + 1], abc[kKeyStride * m + 2]);
       const bool better = d < best;
       best = better ? d : best;
       jj = better ? m : jj;
@@ -427,7 +435,7 @@ __device__ __forceinline__ int temporal_nearest_window(float X, float Y, const f
     float best = __builtin_inff();
     int j = lo;
     for (int i = lo; i < hi; ++i) {
-      const float d = search_key<float>(X, Y, abc[3 * i], abc[3 * i + 1], abc[3 * i + 2]);
+      const float d = search_key<float>(X, Y, abc[kKeyStride * i], abc[kKeyStride * i + 1], abc[kKeyStride * i + 2]);
       const bool better = d < best;
       best = better ? d : best;
       j = better ? i : j;
@@ -454,7 +462,7 @@ __device__ __forceinline__ void stage_temporal_tables(const float* __restrict__ 
     r[5] = g[6];
     r[6] = g[7];
     r[7] = 0.0f;
-    search_entry(x, y, abc[3 * m], abc[3 * m + 1], abc[3 * m + 2]);
+    search_entry(x, y, abc[kKeyStride * m], abc[kKeyStride * m + 1], abc[kKeyStride * m + 2]);
   }
 }
 

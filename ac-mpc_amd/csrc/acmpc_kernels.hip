@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs
   const float* __restrict__ x0 = a.x0 + p * 3;
 
   float* s_xy = s_wp + n * kCoefT;  // the nearest-waypoint search's key table: (a, b, c) per waypoint (search_entry)
-  float* s_thr = s_xy + 3 * n;      // thresholds of the verified search (exhaustive semantics), when given
+  float* s_thr = s_xy + kKeyStride * n;      // thresholds of the verified search (exhaustive semantics), when given
   if constexpr (MODE == 1) {
     stage_temporal_tables(coef, n, tid, BLOCK, s_wp, s_xy);
     if (a.nn_thr != nullptr) {
@@ -853,7 +853,7 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
       sx[2] = st.phi;
     }
     __syncthreads();
-    const int mine_at = 3 * min(lane, n - 1);   // the search key's entries of "this lane's" waypoint
+    const int mine_at = kKeyStride * min(lane, n - 1);   // the search key's entries of "this lane's" waypoint
     const float my_a = s_abc[mine_at], my_b = s_abc[mine_at + 1], my_c = s_abc[mine_at + 2];
     int j_prev = 0;
     for (int base = 0; base < n; base += kWave) {
@@ -877,7 +877,7 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
         float best = (lane >= win_lo && lane <= win_hi) ? search_key<float>(st.X, st.Y, my_a, my_b, my_c) : __builtin_inff();
         int j = lane;
         for (int m = lane + kWave; m <= win_hi; m += kWave) {
-          const float d = (m >= win_lo) ? search_key<float>(st.X, st.Y, s_abc[3 * m], s_abc[3 * m + 1], s_abc[3 * m + 2])
+          const float d = (m >= win_lo) ? search_key<float>(st.X, st.Y, s_abc[kKeyStride * m], s_abc[kKeyStride * m + 1], s_abc[kKeyStride * m + 2])
                                         : __builtin_inff();
           const bool better = d < best;
           best = better ? d : best;
@@ -1648,7 +1648,7 @@ template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1
 hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                             hipEvent_t e1) {
   const dim3 grid(shape.blocks_per_problem, args.P);
-  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * (kCoefT + 3 + (args.nn_thr != nullptr ? kVerifiedWindow : 0)) *
+  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * (kCoefT + kKeyStride + (args.nn_thr != nullptr ? kVerifiedWindow : 0)) *
                                            sizeof(float)
                                      : 0);
   if (e0 != nullptr && e1 != nullptr) {
@@ -1888,7 +1888,7 @@ int max_blocks_per_problem(int N) { return (N + kWave - 1) / kWave; }
 
 size_t tile_lds_bytes(int mode, int n) {
   const size_t tile = (static_cast<size_t>(kWave) * 2 * n + 3) & ~static_cast<size_t>(3);
-  return (tile + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 3) : 0)) * sizeof(float);
+  return (tile + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + kKeyStride) : 0)) * sizeof(float);
 }
 
 LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
@@ -1963,7 +1963,7 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
   const dim3 grid(args.P), block(kWave);
   // record image, then (mode T) the waypoint table
   const size_t rec_floats = static_cast<size_t>(4 + 2 * args.n + 3 * (args.n + 1));
-  const size_t lds = (((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? args.n * (kCoefT + 3) : 0)) * sizeof(float);
+  const size_t lds = (((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? args.n * (kCoefT + kKeyStride) : 0)) * sizeof(float);
   if (mode == 0 && layout == 0) {
     hipLaunchKernelGGL((finalize_kernel<0, 0>), grid, block, lds, s, args);
   } else if (mode == 0 && layout == 1) {
@@ -1994,7 +1994,7 @@ hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s) {
 
 namespace {
 size_t sampled_rollout_floats(int mode, int n) {
-  return (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + 3) + 3) & ~static_cast<size_t>(3)) : 0;
+  return (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3)) : 0;
 }
 // uniform operands of the steps staged in LDS: [n][12] table rows (mode S), centre, reference, knot weights (+ padding
 // for the read one step past the end)
@@ -2003,7 +2003,7 @@ size_t sampled_uniform_floats(int mode, int n) {
 }
 size_t sampled_finalize_floats(int mode, int n) {
   const size_t rec_floats = static_cast<size_t>(4 + 2 * n + 3 * (n + 1));
-  return ((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + 3) : 0);
+  return ((rec_floats + 3) & ~static_cast<size_t>(3)) + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + kKeyStride) : 0);
 }
 }  // namespace
 
