@@ -589,6 +589,19 @@ __device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float
   return j;
 }
 
+// the search of one step alone (the three-wave round splits a step into pose / search / cost)
+template <int SEARCH>
+__device__ __forceinline__ int search_temporal_as(float X, float Y, const float* abc, int n, const Weights& w, int j_prev) {
+  if constexpr (SEARCH == kSearchExhaustive || SEARCH == kSearchVerified) {
+    StateT probe{};
+    probe.X = X;
+    probe.Y = Y;
+    return temporal_nearest<float>(probe, abc, n);
+  } else {
+    return temporal_nearest_window<SEARCH>(X, Y, abc, n, j_prev, w.nn_back, w.nn_ahead);
+  }
+}
+
 // run `body(tag)` with tag::value = the launch's search kind (one wave-uniform branch for the whole rollout)
 template <typename Body>
 __device__ __forceinline__ void with_search_kind(const Weights& w, int n, Body&& body, bool has_thresholds = false) {

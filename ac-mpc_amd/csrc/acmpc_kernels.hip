@@ -1278,6 +1278,189 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
   fused_tail<0>(a, smp, fused, true, nullptr);
 }
 
+// The traced mode-T round on THREE waves per workgroup.  On one wave a mode T step is a serial stream of ~110 instructions
+// with two dependent LDS gathers in it (the window's keys, then the nearest waypoint's row): 0.6 us per step, 29 us per
+// round.  But the pose does not depend on the search - only the cost does - so the step falls into three stages that
+// meet in LDS, in the trace the round keeps anyway:
+//   wave 2 (poses):  draws and blends the controls, integrates the pose (temporal_advance), leaves (v, kappa) and
+//                    (X, Y, phi) of every step in the lane's trace column;
+//   wave 1 (search): reads (X, Y), finds the nearest waypoint from the previous step's (the one sequential chain left),
+//                    leaves the index;
+//   wave 0 (costs):  reads pose, controls and index, gathers the waypoint's row, accumulates the cost terms
+//                    (temporal_cost) - independent from step to step, so its gathers overlap - then reduces, publishes
+//                    and runs the tail as the single-wave kernel does.
+// A software pipeline over chunks of kTrioChunk steps, one workgroup barrier per chunk: at chunk time t wave 2 works on
+// chunk t, wave 1 on chunk t - 1, wave 0 on chunk t - 2.  Same operations on the same operands: same bits
+// (test_tick_forms_agree with ACMPC_NO_TRIO_ROUNDS).
+// LDS: [waypoint rows n x 8 | key table n x 3] [trace [5n + 2][64]] [uniform operands: centre, reference, knot weights]
+//      [nearest indices [n][64]].
+constexpr int kTrioChunk = 7;
+
+__global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const RolloutArgs a, const SampleArgs smp,
+                                                                         const FusedFinalize fused, const int trace_lds_floats,
+                                                                         const int uniform_lds_floats,
+                                                                         const int index_lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float s_fused[];
+  const int p = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave);
+  const int n = a.n;
+  const Weights w = a.w;
+  float* s_wp = s_fused;
+  float* s_abc = s_wp + n * kCoefT;
+  float* s_trace = s_fused + trace_lds_floats;
+  float* s_centre = s_fused + uniform_lds_floats;
+  float* s_ref = s_centre + 2 * n;
+  float* s_weight = s_ref + 2 * n;
+  int* s_index = reinterpret_cast<int*>(s_fused + index_lds_floats);
+  const int c = blockIdx.x * kWave + lane;
+  const bool active = c < a.N;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kCoefT;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+  const int chunks = (n + kTrioChunk - 1) / kTrioChunk;
+  float* col = s_trace + lane;   // this lane's trace column: rows 2i, 2i + 1 = (v, kappa); 2n + 3i .. + 2 = pose after step i
+
+  if (wave == 2) {
+    // ---- poses: requests, draws, uniform operands into LDS, then controls and poses chunk by chunk ----
+    const SampleSpec sp = smp.spec;
+    const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
+    const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ knot_weight = sp.segments;
+    const bool chained = smp.prev_keys != nullptr;
+    constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
+    f32x2 g_centre[kPairs], g_ref[kPairs], g_weight[kPairs];
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q) {
+      const int j = min(lane + q * kWave, n - 1);
+      if (!chained) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[j];
+      if (ref != nullptr) g_ref[q] = reinterpret_cast<const f32x2*>(ref)[j];
+      g_weight[q] = reinterpret_cast<const f32x2*>(knot_weight)[j];
+    }
+    int64_t prev_key[kChainBlocks / kWave];
+    if (chained) {
+#pragma unroll
+      for (int q = 0; q < kChainBlocks / kWave; ++q)
+        prev_key[q] = smp.prev_keys[static_cast<size_t>(p) * smp.prev_blocks + min(lane + q * kWave, smp.prev_blocks - 1)];
+    }
+    float z[kKnots][2] = {};
+    const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
+    draw_normals<0, kKnots / 4>(sp, gidx, static_cast<uint32_t>(p), z);
+    if (chained) {
+      int64_t best = kKeyMax;
+#pragma unroll
+      for (int q = 0; q < kChainBlocks / kWave; ++q) {
+        const int64_t kb = (lane + q * kWave < smp.prev_blocks) ? prev_key[q] : kKeyMax;
+        best = (kb < best) ? kb : best;
+      }
+      const int64_t winner = wave_min_key(best);
+      const int block = static_cast<int>(static_cast<int64_t>(static_cast<uint32_t>(winner & 0xffffffffLL)) - a.index_offset) / kWave;
+      centre = smp.prev_trace + (static_cast<size_t>(p) * smp.prev_blocks + block) * smp.prev_pitch;
+#pragma unroll
+      for (int q = 0; q < kPairs; ++q) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[min(lane + q * kWave, n - 1)];
+    }
+    draw_normals<kKnots / 4, kKnots / 2>(sp, gidx, static_cast<uint32_t>(p), z);
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q) {
+      const int j = lane + q * kWave;
+      if (j < n) {
+        reinterpret_cast<f32x2*>(s_centre)[j] = g_centre[q];
+        reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? g_ref[q] : g_centre[q];
+        s_weight[j] = g_weight[q][1];
+      }
+    }
+    for (int j = lane + kPairs * kWave; j < n; j += kWave) {   // horizons beyond the registers' share
+      const f32x2 cj = reinterpret_cast<const f32x2*>(centre)[j];
+      reinterpret_cast<f32x2*>(s_centre)[j] = cj;
+      reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? reinterpret_cast<const f32x2*>(ref)[j] : cj;
+      s_weight[j] = knot_weight[2 * j + 1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave reads what its own lanes staged
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
+    const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
+    StateT pose = start_temporal<float>(x0);
+    int in_chunk = 0;
+#pragma unroll
+    for (int knot = 0; knot < kKnots - 1; ++knot) {
+      for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
+        const f32x2 cc = reinterpret_cast<const f32x2*>(s_centre)[i];
+        const f32x2 rr = reinterpret_cast<const f32x2*>(s_ref)[i];
+        float v, k;
+        blend_control(sp, amp, s_weight[i], use_ref ? rr[0] : cc[0], use_ref ? rr[1] : cc[1], z[knot][0], z[knot][1],
+                      z[knot + 1][0], z[knot + 1][1], v, k);
+        temporal_advance<float>(pose, v, k, w);
+        col[(2 * i) * kWave] = v;
+        col[(2 * i + 1) * kWave] = k;
+        col[(2 * n + 3 * i) * kWave] = pose.X;
+        col[(2 * n + 3 * i + 1) * kWave] = pose.Y;
+        col[(2 * n + 3 * i + 2) * kWave] = pose.phi;
+        if (++in_chunk == kTrioChunk || i == n - 1) {   // chunk handed on (wave-uniform)
+          __syncthreads();
+          in_chunk = 0;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- the other two waves put the waypoint tables into LDS (the pose wave does not read them) ----
+  stage_temporal_tables(coef, n, static_cast<int>(threadIdx.x), 2 * kWave, s_wp, s_abc);
+  if (wave == 1) {
+    // ---- search: one chunk behind the poses ----
+    int j_prev = 0;
+    __syncthreads();   // chunk 0 of the poses is in (and - a barrier orders all LDS writes before it - the tables)
+    with_search_kind(w, n, [&](auto kind) {
+      for (int t = 1; t <= chunks; ++t) {
+        const int last = min(t * kTrioChunk, n);
+        for (int i = (t - 1) * kTrioChunk; i < last; ++i) {
+          const float X = col[(2 * n + 3 * i) * kWave], Y = col[(2 * n + 3 * i + 1) * kWave];
+          j_prev = search_temporal_as<decltype(kind)::value>(X, Y, s_abc, n, w, j_prev);
+          s_index[i * kWave + lane] = j_prev;
+        }
+        __syncthreads();   // chunk t - 1 searched (and, while t < chunks, chunk t of the poses is in)
+      }
+    });
+    return;
+  }
+
+  // ---- costs: two chunks behind the poses ----
+  StateT st = start_temporal<float>(x0);
+  __syncthreads();   // chunk time 0
+  __syncthreads();   // chunk time 1: chunk 0 searched
+  for (int t = 2; t <= chunks + 1; ++t) {
+    const int last = min((t - 1) * kTrioChunk, n);
+#pragma unroll 7
+    for (int i = (t - 2) * kTrioChunk; i < last; ++i) {
+      st.X = col[(2 * n + 3 * i) * kWave];
+      st.Y = col[(2 * n + 3 * i + 1) * kWave];
+      st.phi = col[(2 * n + 3 * i + 2) * kWave];
+      const int j = s_index[i * kWave + lane];
+      temporal_cost(st, s_wp + j * kCoefT, col[(2 * i) * kWave], col[(2 * i + 1) * kWave], w);
+    }
+    if (t <= chunks) __syncthreads();   // (the last chunk times have no partner left to wait for)
+  }
+  const float cost = finish_temporal<float>(st, n, w);
+  s_trace[(5 * n) * kWave + lane] = st.V;
+  s_trace[(5 * n + 1) * kWave + lane] = cost;
+  if (active && a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c] = cost;
+  const int64_t own_key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
+  int best_lane;
+  const int64_t key = wave_min_key_by_lane(own_key, best_lane);   // (the index rises with the lane)
+  const int nfeas = wave_sum_int((active && st.V == 0.0f) ? 1 : 0);
+  {
+    __syncthreads();   // this wave alone by now: orders its column writes before the row reads
+    float* trace_out = fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch;
+    for (int e = lane; e < 5 * n + 2; e += kWave) publish(&trace_out[e], s_trace[e * kWave + best_lane]);
+  }
+  if (lane == 0) {
+    const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;
+    publish(&a.partial_keys[slot], key);
+    publish(&a.partial_feas[slot], nfeas);
+  }
+  fused_tail<1>(a, smp, fused, true, nullptr);
+}
+
 // ---- one problem (or a few) of a few thousand candidates per call: ONE launch, the winner never rolled twice ------
 // acmpc_solve_device on a caller's control matrix, mode S.  What rollout_kernel + finalize_kernel do in two launches -
 // the second re-rolling the winner on one wave, which takes as long as the rollout itself at this size - is one launch
@@ -2023,7 +2206,7 @@ bool traced_finalize_fits(int mode, int n) {
 // More dynamic LDS than a kernel gets by default (64 kB): raise the kernel's limit, once per kernel and device.
 static hipError_t raise_lds_limit(const void* kernel, int which, size_t lds) {
   if (lds <= 64 * 1024) return hipSuccess;
-  static bool raised[11][64] = {};
+  static bool raised[12][64] = {};
   int device = 0;
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
@@ -2058,6 +2241,28 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
                                                    : reinterpret_cast<const void*>(&rollout_sampled_kernel<1>),
                                          mode, lds);
     if (e != hipSuccess) return e;
+  }
+  if (mode == 1 && traced && std::getenv("ACMPC_NO_TRIO_ROUNDS") == nullptr) {
+    // three waves per workgroup: tables | trace | uniform operands (centre, reference, weights) | nearest indices
+    const size_t tables = (static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3);
+    const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
+    const size_t uniform = (static_cast<size_t>(n) * 5 + 4 + 3) & ~static_cast<size_t>(3);
+    const size_t index = static_cast<size_t>(n) * kWave;
+    const size_t trio_lds = (tables + trace + uniform + index) * sizeof(float);
+    if (trio_lds <= 160u * 1024u) {
+      hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&rollout_sampled_trio_kernel), 11, trio_lds);
+      if (e != hipSuccess) return e;
+      if (e0 != nullptr && e1 != nullptr) {
+        hipExtLaunchKernelGGL(rollout_sampled_trio_kernel, grid, dim3(3 * kWave), static_cast<std::uint32_t>(trio_lds), s, e0,
+                              e1, 0, rollout, sample, fused, static_cast<int>(tables), static_cast<int>(tables + trace),
+                              static_cast<int>(tables + trace + uniform));
+      } else {
+        hipLaunchKernelGGL(rollout_sampled_trio_kernel, grid, dim3(3 * kWave), trio_lds, s, rollout, sample, fused,
+                           static_cast<int>(tables), static_cast<int>(tables + trace),
+                           static_cast<int>(tables + trace + uniform));
+      }
+      return hipGetLastError();
+    }
   }
   if (mode == 0 && traced && std::getenv("ACMPC_NO_PAIR_ROUNDS") == nullptr) {
     // two waves per workgroup: trace | uniform operands | exchange buffers (no mode T tables, no record image)

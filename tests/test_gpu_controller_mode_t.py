@@ -135,3 +135,37 @@ def test_mode_t_controller_keeps_the_car_on_the_track():
     assert lateral[100:].mean() < 0.8, "does not converge to the centreline: %.2f m" % lateral[100:].mean()
     assert 8.0 <= min(speeds[50:]) and max(speeds) <= 30.1
     assert (progress[-1] - progress[0]) % len(centre) > 400
+
+
+def test_mode_t_tick_forms_agree(monkeypatch):
+    """However the mode T rounds are run - three waves per workgroup (poses / search / costs, the default), one wave,
+    chained or each finalized, the winner copied from its trace or re-drawn and rolled again - a sequence of warm-started
+    ticks returns the same numbers, bit for bit."""
+    cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=28.0)
+    n = 49
+    paths = [np.stack([0.004 * (1 + 0.1 * j) * np.linspace(0, 120, 50) ** 2, np.linspace(0, 120, 50),
+                       np.linspace(10, 6, 50)], axis=1) for j in range(4)]
+
+    def run(nn_window):
+        eng = _engine(n, 16384, nn_window)
+        outs, centre = [], None
+        for j, coords in enumerate(paths):
+            t = _tick(50, cons, 16384, 2, 0.1 * j, 5 + j)
+            t.centre_is_reference = 1 if centre is None else 0
+            out = eng.control_tick(t, coords, centre)
+            centre = out["decision"][3 * (n + 1):].reshape(n, 2).astype(np.float32)
+            outs.append(out)
+        eng.close()
+        return outs
+
+    for nn_window in ((2, 5), None, (3, 6)):      # the unrolled 8-waypoint window, every waypoint, a generic width
+        reference = run(nn_window)
+        for switches in (("ACMPC_NO_TRIO_ROUNDS",), ("ACMPC_NO_TRIO_ROUNDS", "ACMPC_NO_CHAINED_ROUNDS"),
+                         ("ACMPC_NO_CHAINED_ROUNDS",), ("ACMPC_NO_TRACED_FINALIZE",)):
+            for name in switches:
+                monkeypatch.setenv(name, "1")
+            for want, got in zip(reference, run(nn_window)):
+                for key in ("record", "table", "decision", "projected_control", "prediction", "cum_time"):
+                    np.testing.assert_array_equal(want[key], got[key], err_msg="%s with %s, window %s" % (key, switches, nn_window))
+            for name in switches:
+                monkeypatch.delenv(name)
