@@ -589,7 +589,10 @@ __device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float
   return j;
 }
 
-// the search of one step alone (the three-wave round splits a step into pose / search / cost)
+// the search of one step alone (the three-wave round splits a step into pose / search / cost).  Run by a LONE wave: there
+// every instruction costs the same ~2 ns, scalar ones included, so the unrolled windows use the plain `d < best` chain
+// (three vector instructions per waypoint) instead of nearest_in_window's min chain + equality masks, whose ~30 scalar
+// mask operations are free only where other waves fill the gaps.  The same first minimum either way.
 template <int SEARCH>
 __device__ __forceinline__ int search_temporal_as(float X, float Y, const float* abc, int n, const Weights& w, int j_prev) {
   if constexpr (SEARCH == kSearchExhaustive || SEARCH == kSearchVerified) {
@@ -597,6 +600,22 @@ __device__ __forceinline__ int search_temporal_as(float X, float Y, const float*
     probe.X = X;
     probe.Y = Y;
     return temporal_nearest<float>(probe, abc, n);
+  } else if constexpr (SEARCH > 0) {
+    const int lo = max(min(j_prev - w.nn_back, n - SEARCH), 0);
+    const float* first = abc + kKeyStride * lo;
+    float d[SEARCH];
+#pragma unroll
+    for (int m = 0; m < SEARCH; ++m)
+      d[m] = search_key<float>(X, Y, first[kKeyStride * m], first[kKeyStride * m + 1], first[kKeyStride * m + 2]);
+    float best = __builtin_inff();
+    int j = lo;
+#pragma unroll
+    for (int m = 0; m < SEARCH; ++m) {
+      const bool better = d[m] < best;
+      best = better ? d[m] : best;
+      j = better ? lo + m : j;
+    }
+    return j;
   } else {
     return temporal_nearest_window<SEARCH>(X, Y, abc, n, j_prev, w.nn_back, w.nn_ahead);
   }

@@ -1290,11 +1290,16 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
 //                    (temporal_cost) - independent from step to step, so its gathers overlap - then reduces, publishes
 //                    and runs the tail as the single-wave kernel does.
 // A software pipeline over chunks of kTrioChunk steps, one workgroup barrier per chunk: at chunk time t wave 2 works on
-// chunk t, wave 1 on chunk t - 1, wave 0 on chunk t - 2.  Same operations on the same operands: same bits
+// chunk t, wave 1 on chunk t - 1, wave 0 on chunk t - 2.  The search wave sets the pace (~0.2 us per step: its keys are a
+// dependent LDS gather per step), so the chunk only decides how long the pipeline takes to fill and drain: measured tick
+// p50 at chunks of 10 / 7 / 4 / 3 / 2 steps: 67.1 / 65.5 / 63.0 / 61.8 / 62.7 us (one wave per workgroup: 86.3).  Same operations on the same operands: same bits
 // (test_tick_forms_agree with ACMPC_NO_TRIO_ROUNDS).
 // LDS: [waypoint rows n x 8 | key table n x 3] [trace [5n + 2][64]] [uniform operands: centre, reference, knot weights]
 //      [nearest indices [n][64]].
-constexpr int kTrioChunk = 7;
+#ifndef ACMPC_TRIO_CHUNK
+#define ACMPC_TRIO_CHUNK 3
+#endif
+constexpr int kTrioChunk = ACMPC_TRIO_CHUNK;
 
 __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const RolloutArgs a, const SampleArgs smp,
                                                                          const FusedFinalize fused, const int trace_lds_floats,
@@ -1412,11 +1417,21 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
     __syncthreads();   // chunk 0 of the poses is in (and - a barrier orders all LDS writes before it - the tables)
     with_search_kind(w, n, [&](auto kind) {
       for (int t = 1; t <= chunks; ++t) {
-        const int last = min(t * kTrioChunk, n);
-        for (int i = (t - 1) * kTrioChunk; i < last; ++i) {
-          const float X = col[(2 * n + 3 * i) * kWave], Y = col[(2 * n + 3 * i + 1) * kWave];
-          j_prev = search_temporal_as<decltype(kind)::value>(X, Y, s_abc, n, w, j_prev);
-          s_index[i * kWave + lane] = j_prev;
+        const int first = (t - 1) * kTrioChunk;
+        // the chunk's positions first (they do not depend on the search): one round trip, not one per step
+        float X[kTrioChunk], Y[kTrioChunk];
+#pragma unroll
+        for (int q = 0; q < kTrioChunk; ++q) {
+          const int i = min(first + q, n - 1);
+          X[q] = col[(2 * n + 3 * i) * kWave];
+          Y[q] = col[(2 * n + 3 * i + 1) * kWave];
+        }
+#pragma unroll
+        for (int q = 0; q < kTrioChunk; ++q) {
+          if (first + q < n) {   // (wave-uniform)
+            j_prev = search_temporal_as<decltype(kind)::value>(X[q], Y[q], s_abc, n, w, j_prev);
+            s_index[(first + q) * kWave + lane] = j_prev;
+          }
         }
         __syncthreads();   // chunk t - 1 searched (and, while t < chunks, chunk t of the poses is in)
       }
@@ -1430,13 +1445,16 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
   __syncthreads();   // chunk time 1: chunk 0 searched
   for (int t = 2; t <= chunks + 1; ++t) {
     const int last = min((t - 1) * kTrioChunk, n);
-#pragma unroll 7
-    for (int i = (t - 2) * kTrioChunk; i < last; ++i) {
-      st.X = col[(2 * n + 3 * i) * kWave];
-      st.Y = col[(2 * n + 3 * i + 1) * kWave];
-      st.phi = col[(2 * n + 3 * i + 2) * kWave];
-      const int j = s_index[i * kWave + lane];
-      temporal_cost(st, s_wp + j * kCoefT, col[(2 * i) * kWave], col[(2 * i + 1) * kWave], w);
+#pragma unroll
+    for (int q = 0; q < kTrioChunk; ++q) {
+      const int i = (t - 2) * kTrioChunk + q;
+      if (i < last) {   // (wave-uniform)
+        st.X = col[(2 * n + 3 * i) * kWave];
+        st.Y = col[(2 * n + 3 * i + 1) * kWave];
+        st.phi = col[(2 * n + 3 * i + 2) * kWave];
+        const int j = s_index[i * kWave + lane];
+        temporal_cost(st, s_wp + j * kCoefT, col[(2 * i) * kWave], col[(2 * i + 1) * kWave], w);
+      }
     }
     if (t <= chunks) __syncthreads();   // (the last chunk times have no partner left to wait for)
   }
