@@ -1278,6 +1278,288 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
   fused_tail<0>(a, smp, fused, true, nullptr);
 }
 
+// The traced mode-S round on FOUR waves per workgroup.  The two-wave form above splits drawing from rolling.  Measured with
+// either side stubbed out, its pace (0.144 us per step) was the DRAWING wave's blend - 124 ns per step - not the rolling
+// wave's.  Of a mode S step only the 9-operation recurrence is sequential: the blend of step i needs nothing of step
+// i - 1, and the bound violations read the state AFTER the step and the controls and feed nothing back (J never reads V,
+// V never reads J: the split of rollout_solo_kernel).  So, one wave per SIMD of the CU:
+//   waves 2, 3 (controls):       blend and leave (v, kappa) of every step in the lane's trace column - the even steps one
+//                                wave, the odd steps the other;
+//   wave 1 (recurrence + cost):  step_spatial_cost on those controls, one chunk behind: J, and the states into the trace;
+//   wave 0 (bounds):             V += the four hinges from the trace, two chunks behind; takes J over at the end,
+//                                finishes the cost, reduces, publishes and runs the tail.
+// Every accumulation sees the operands of step_spatial() in its order: same bits (test_tick_forms_agree).  The Philox
+// draws - a quarter of the normals each - are shared out over the four waves and exchanged through LDS, so the round's
+// fixed part shrinks too.  A software pipeline over chunks of kQuadChunk steps, one workgroup barrier per chunk; every
+// wave's chunk is straight-line code with all its LDS reads in front of the arithmetic.  (A fifth wave - cost and
+// recurrence apart - shares a SIMD with another and set the pace there: 10.2 us per round against this form's.)
+// LDS: [trace [5n + 2][64]] [table rows n x 12 | centre | reference | knot weights] [normals 16 x 64] [J 64].
+#ifndef ACMPC_QUAD_CHUNK
+#define ACMPC_QUAD_CHUNK 7
+#endif
+constexpr int kQuadChunk = ACMPC_QUAD_CHUNK;
+
+constexpr int kQuadWaves = 4;   // bounds; recurrence + cost; two control waves
+
+__global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kernel(const RolloutArgs a, const SampleArgs smp,
+                                                                         const FusedFinalize fused, const int uniform_lds_floats,
+                                                                         const int normals_lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float s_fused[];
+  float* s_trace = s_fused;
+  float* s_row = s_fused + uniform_lds_floats;
+  const int p = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave);
+  const int n = a.n;
+  float* s_centre = s_row + n * kCoefS;
+  float* s_ref = s_centre + 2 * n;
+  float* s_weight = s_ref + 2 * n;
+  float* s_z = s_fused + normals_lds_floats;          // [knot][component][lane]
+  float* s_j = s_z + 2 * kKnots * kWave;
+  const int c = blockIdx.x * kWave + lane;
+  const bool active = c < a.N;
+  const Weights w = a.w;
+  const SampleSpec sp = smp.spec;
+  const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
+  const int chunks = (n + kQuadChunk - 1) / kQuadChunk;
+  float* col = s_trace + lane;   // rows 2i, 2i + 1 = (v, kappa) of step i; 2n + 3i .. + 2 = state after step i
+  const float* __restrict__ x0 = a.x0 + p * 3;
+
+  // this wave's quarter of the candidate's normals (Philox call `wave`: knots 2 wave, 2 wave + 1) -> LDS
+  auto draw_quarter = [&](auto quarter) {
+    constexpr int Q = decltype(quarter)::value;
+    float z[kKnots][2] = {};
+    draw_normals<Q, Q + 1>(sp, gidx, static_cast<uint32_t>(p), z);
+#pragma unroll
+    for (int knot = 2 * Q; knot < 2 * Q + 2; ++knot) {
+      s_z[(2 * knot) * kWave + lane] = z[knot][0];
+      s_z[(2 * knot + 1) * kWave + lane] = z[knot][1];
+    }
+  };
+  static_assert(kKnots == 8, "four Philox calls per candidate, one per wave");
+
+  // the controls of the steps i = parity, parity + 2, ... (every step with one control wave's worth of work halved): blend,
+  // leave (v, kappa) in the trace; one barrier per chunk, taken by both control waves
+  auto produce_controls = [&](const float (&z)[kKnots][2], const int parity) {
+    const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
+    const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
+    struct Operands {
+      f32x2 centre, ref;
+      float weight;
+    };
+    auto request = [&](int i) {   // (up to two steps past the end are read - inside the block's padding - and never used)
+      Operands o;
+      o.centre = reinterpret_cast<const f32x2*>(s_centre)[i];
+      o.ref = reinterpret_cast<const f32x2*>(s_ref)[i];
+      o.weight = s_weight[i];
+      return o;
+    };
+    // (Broadcasting the operands out of the registers they were fetched into with v_readlane, instead of reading them
+    // back from LDS one step ahead: 187 ns per step against 144 - measured, not kept.)
+    Operands now = request(parity);
+    int in_chunk = 0;
+#pragma unroll
+    for (int knot = 0; knot < kKnots - 1; ++knot) {
+      for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
+        if ((i & 1) == parity) {   // (wave-uniform)
+          const Operands next = request(i + 2);   // one own step ahead of the arithmetic
+          float v, k;
+          blend_control(sp, amp, now.weight, use_ref ? now.ref[0] : now.centre[0], use_ref ? now.ref[1] : now.centre[1],
+                        z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1], v, k);
+          col[(2 * i) * kWave] = v;
+          col[(2 * i + 1) * kWave] = k;
+          now = next;
+        }
+        if (++in_chunk == kQuadChunk || i == n - 1) {   // chunk handed on (wave-uniform)
+          __syncthreads();
+          in_chunk = 0;
+        }
+      }
+    }
+  };
+
+  if (wave == 3) {
+    // ---- the second control wave: its quarter of the draws, nothing to stage; the odd steps of every chunk ----
+    draw_quarter(std::integral_constant<int, 3>{});
+    __syncthreads();   // (S)
+    float z[kKnots][2];
+#pragma unroll
+    for (int knot = 0; knot < kKnots; ++knot) {
+      z[knot][0] = s_z[(2 * knot) * kWave + lane];
+      z[knot][1] = s_z[(2 * knot + 1) * kWave + lane];
+    }
+    produce_controls(z, 1);
+    return;
+  }
+  if (wave == 2) {
+    // ---- controls: requests, its quarter of the draws, the uniform operands of the control waves into LDS, then chunk by chunk ----
+    const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
+    const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ knot_weight = sp.segments;
+    const bool chained = smp.prev_keys != nullptr;
+    constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
+    f32x2 g_centre[kPairs], g_ref[kPairs], g_weight[kPairs];
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q) {
+      const int j = min(lane + q * kWave, n - 1);
+      if (!chained) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[j];
+      if (ref != nullptr) g_ref[q] = reinterpret_cast<const f32x2*>(ref)[j];
+      g_weight[q] = reinterpret_cast<const f32x2*>(knot_weight)[j];
+    }
+    int64_t prev_key[kChainBlocks / kWave];
+    if (chained) {
+#pragma unroll
+      for (int q = 0; q < kChainBlocks / kWave; ++q)
+        prev_key[q] = smp.prev_keys[static_cast<size_t>(p) * smp.prev_blocks + min(lane + q * kWave, smp.prev_blocks - 1)];
+    }
+    draw_quarter(std::integral_constant<int, 2>{});
+    if (chained) {
+      int64_t best = kKeyMax;
+#pragma unroll
+      for (int q = 0; q < kChainBlocks / kWave; ++q) {
+        const int64_t kb = (lane + q * kWave < smp.prev_blocks) ? prev_key[q] : kKeyMax;
+        best = (kb < best) ? kb : best;
+      }
+      const int64_t winner = wave_min_key(best);
+      const int block = static_cast<int>(static_cast<int64_t>(static_cast<uint32_t>(winner & 0xffffffffLL)) - a.index_offset) / kWave;
+      centre = smp.prev_trace + (static_cast<size_t>(p) * smp.prev_blocks + block) * smp.prev_pitch;
+#pragma unroll
+      for (int q = 0; q < kPairs; ++q) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[min(lane + q * kWave, n - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q) {
+      const int j = lane + q * kWave;
+      if (j < n) {
+        reinterpret_cast<f32x2*>(s_centre)[j] = g_centre[q];
+        reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? g_ref[q] : g_centre[q];
+        s_weight[j] = g_weight[q][1];
+      }
+    }
+    for (int j = lane + kPairs * kWave; j < n; j += kWave) {   // horizons beyond the registers' share
+      const f32x2 cj = reinterpret_cast<const f32x2*>(centre)[j];
+      reinterpret_cast<f32x2*>(s_centre)[j] = cj;
+      reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? reinterpret_cast<const f32x2*>(ref)[j] : cj;
+      s_weight[j] = knot_weight[2 * j + 1];
+    }
+    __syncthreads();   // (S) every wave's normals and the table rows are in
+    float z[kKnots][2];
+#pragma unroll
+    for (int knot = 0; knot < kKnots; ++knot) {
+      z[knot][0] = s_z[(2 * knot) * kWave + lane];
+      z[knot][1] = s_z[(2 * knot + 1) * kWave + lane];
+    }
+    produce_controls(z, 0);
+    return;
+  }
+
+  // ---- the other two waves: table rows into LDS, their quarters of the draws ----
+  {
+    const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kCoefS;
+    for (int q = threadIdx.x; q < n * (kCoefS / 4); q += 2 * kWave)
+      reinterpret_cast<f32x4*>(s_row)[q] = reinterpret_cast<const f32x4*>(coef)[q];
+  }
+  if (wave == 0) draw_quarter(std::integral_constant<int, 0>{});
+  if (wave == 1) draw_quarter(std::integral_constant<int, 1>{});
+  __syncthreads();   // (S)
+
+  if (wave == 1) {
+    // ---- recurrence + cost: one chunk behind the controls ----
+    StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+    auto roll = [&](int i, float v, float k, const f32x4& lo, const f32x4& hi) {
+      const float cr[7] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2]};
+      step_spatial_cost(st, cr, v, k, w);
+      col[(2 * n + 3 * i) * kWave] = st.ey;
+      col[(2 * n + 3 * i + 1) * kWave] = st.ep;
+      col[(2 * n + 3 * i + 2) * kWave] = st.t;
+    };
+    __syncthreads();   // chunk 0 of the controls is in
+    for (int t = 1; t <= chunks; ++t) {
+      const int first = (t - 1) * kQuadChunk;
+      if (first + kQuadChunk <= n) {   // a full chunk, straight-line: every step's reads move ahead of the arithmetic
+        float v[kQuadChunk], k[kQuadChunk];
+        f32x4 lo[kQuadChunk], hi[kQuadChunk];
+#pragma unroll
+        for (int q = 0; q < kQuadChunk; ++q) {
+          v[q] = col[(2 * (first + q)) * kWave];
+          k[q] = col[(2 * (first + q) + 1) * kWave];
+          lo[q] = *reinterpret_cast<const f32x4*>(s_row + (first + q) * kCoefS);
+          hi[q] = *reinterpret_cast<const f32x4*>(s_row + (first + q) * kCoefS + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < kQuadChunk; ++q) roll(first + q, v[q], k[q], lo[q], hi[q]);
+      } else {
+        for (int i = first; i < n; ++i)
+          roll(i, col[(2 * i) * kWave], col[(2 * i + 1) * kWave], *reinterpret_cast<const f32x4*>(s_row + i * kCoefS),
+               *reinterpret_cast<const f32x4*>(s_row + i * kCoefS + 4));
+      }
+      if (t == chunks) s_j[lane] = st.J;   // (ordered before the bounds wave's read by the two barriers that follow there)
+      __syncthreads();   // chunk t - 1 rolled (and, while t < chunks, chunk t of the controls is in)
+    }
+    return;
+  }
+
+  // ---- bounds (wave 0): two chunks behind the controls ----
+  StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+  __syncthreads();   // chunk time 0
+  __syncthreads();   // chunk time 1: chunk 0 rolled
+  {
+    auto account = [&](float v, float k, float ey_lo, float ey_hi, float ey_after, float t_after) {
+      st.V = st.V + hinge2<float>(w.ulo0 - v, v - w.uhi0);
+      st.V = st.V + hinge2<float>(w.ulo1 - k, k - w.uhi1);
+      st.V = st.V + hinge2<float>(ey_lo - ey_after, ey_after - ey_hi);
+      const float tv = vmax(w.tmin - t_after, 0.0f);
+      st.V = st.V + tv * tv;
+    };
+    for (int t = 2; t <= chunks + 1; ++t) {
+      const int first = (t - 2) * kQuadChunk;
+      if (first + kQuadChunk <= n) {
+        float v[kQuadChunk], k[kQuadChunk], ey[kQuadChunk], tt[kQuadChunk], lo[kQuadChunk], hi[kQuadChunk];
+#pragma unroll
+        for (int q = 0; q < kQuadChunk; ++q) {
+          const int i = first + q;
+          v[q] = col[(2 * i) * kWave];
+          k[q] = col[(2 * i + 1) * kWave];
+          ey[q] = col[(2 * n + 3 * i) * kWave];
+          tt[q] = col[(2 * n + 3 * i + 2) * kWave];
+          lo[q] = s_row[i * kCoefS + 7];
+          hi[q] = s_row[i * kCoefS + 8];
+        }
+#pragma unroll
+        for (int q = 0; q < kQuadChunk; ++q) account(v[q], k[q], lo[q], hi[q], ey[q], tt[q]);
+      } else {
+        for (int i = first; i < n; ++i)
+          account(col[(2 * i) * kWave], col[(2 * i + 1) * kWave], s_row[i * kCoefS + 7], s_row[i * kCoefS + 8],
+                  col[(2 * n + 3 * i) * kWave], col[(2 * n + 3 * i + 2) * kWave]);
+      }
+      __syncthreads();   // (the last one: J handed over)
+    }
+    // the state after the last step, for the terminal cost
+    st.ey = col[(2 * n + 3 * (n - 1)) * kWave];
+    st.ep = col[(2 * n + 3 * (n - 1) + 1) * kWave];
+    st.t = col[(2 * n + 3 * (n - 1) + 2) * kWave];
+  }
+  st.J = s_j[lane];
+  const float cost = finish_spatial<float>(st, w);   // (st.ey / ep / t: the state after the last step)
+  s_trace[(5 * n) * kWave + lane] = st.V;
+  s_trace[(5 * n + 1) * kWave + lane] = cost;
+  if (active && a.costs != nullptr) a.costs[static_cast<size_t>(p) * a.N + c] = cost;
+  const int64_t own_key = active ? pack_key(cost, static_cast<uint32_t>(a.index_offset + c)) : kKeyMax;
+  int best_lane;
+  const int64_t key = wave_min_key_by_lane(own_key, best_lane);   // (the index rises with the lane)
+  const int nfeas = wave_sum_int((active && st.V == 0.0f) ? 1 : 0);
+  {
+    __syncthreads();   // this wave alone by now: orders its column writes before the row reads
+    float* trace_out = fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch;
+    for (int e = lane; e < 5 * n + 2; e += kWave) publish(&trace_out[e], s_trace[e * kWave + best_lane]);
+  }
+  if (lane == 0) {
+    const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;
+    publish(&a.partial_keys[slot], key);
+    publish(&a.partial_feas[slot], nfeas);
+  }
+  fused_tail<0>(a, smp, fused, true, nullptr);
+}
+
 // The traced mode-T round on THREE waves per workgroup.  On one wave a mode T step is a serial stream of ~110 instructions
 // with two dependent LDS gathers in it (the window's keys, then the nearest waypoint's row): 0.6 us per step, 29 us per
 // round.  But the pose does not depend on the search - only the cost does - so the step falls into three stages that
@@ -1385,15 +1667,27 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
     const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     StateT pose = start_temporal<float>(x0);
+    struct Operands {
+      f32x2 centre, ref;
+      float weight;
+    };
+    auto request = [&](int i) {   // (one step past the end is read - inside the block - and never used)
+      Operands o;
+      o.centre = reinterpret_cast<const f32x2*>(s_centre)[i];
+      o.ref = reinterpret_cast<const f32x2*>(s_ref)[i];
+      o.weight = s_weight[i];
+      return o;
+    };
+    Operands now = request(sp.knot_begin[0]);
     int in_chunk = 0;
 #pragma unroll
     for (int knot = 0; knot < kKnots - 1; ++knot) {
       for (int i = sp.knot_begin[knot]; i < sp.knot_begin[knot + 1]; ++i) {
-        const f32x2 cc = reinterpret_cast<const f32x2*>(s_centre)[i];
-        const f32x2 rr = reinterpret_cast<const f32x2*>(s_ref)[i];
+        const Operands next = request(i + 1);
         float v, k;
-        blend_control(sp, amp, s_weight[i], use_ref ? rr[0] : cc[0], use_ref ? rr[1] : cc[1], z[knot][0], z[knot][1],
-                      z[knot + 1][0], z[knot + 1][1], v, k);
+        blend_control(sp, amp, now.weight, use_ref ? now.ref[0] : now.centre[0], use_ref ? now.ref[1] : now.centre[1],
+                      z[knot][0], z[knot][1], z[knot + 1][0], z[knot + 1][1], v, k);
+        now = next;
         temporal_advance<float>(pose, v, k, w);
         col[(2 * i) * kWave] = v;
         col[(2 * i + 1) * kWave] = k;
@@ -2224,7 +2518,7 @@ bool traced_finalize_fits(int mode, int n) {
 // More dynamic LDS than a kernel gets by default (64 kB): raise the kernel's limit, once per kernel and device.
 static hipError_t raise_lds_limit(const void* kernel, int which, size_t lds) {
   if (lds <= 64 * 1024) return hipSuccess;
-  static bool raised[12][64] = {};
+  static bool raised[13][64] = {};
   int device = 0;
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
@@ -2278,6 +2572,24 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
         hipLaunchKernelGGL(rollout_sampled_trio_kernel, grid, dim3(3 * kWave), trio_lds, s, rollout, sample, fused,
                            static_cast<int>(tables), static_cast<int>(tables + trace),
                            static_cast<int>(tables + trace + uniform));
+      }
+      return hipGetLastError();
+    }
+  }
+  if (mode == 0 && traced && std::getenv("ACMPC_NO_QUAD_ROUNDS") == nullptr && std::getenv("ACMPC_NO_PAIR_ROUNDS") == nullptr) {
+    // four waves per workgroup: trace | uniform operands (table rows, centre, reference, weights) | normals | J
+    const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
+    const size_t uniform = (uniform_floats + 3) & ~static_cast<size_t>(3);
+    const size_t quad_lds = (trace + uniform + static_cast<size_t>(2 * kKnots + 1) * kWave) * sizeof(float);
+    if (quad_lds <= 160u * 1024u) {
+      hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&rollout_sampled_quad_kernel), 12, quad_lds);
+      if (e != hipSuccess) return e;
+      if (e0 != nullptr && e1 != nullptr) {
+        hipExtLaunchKernelGGL(rollout_sampled_quad_kernel, grid, dim3(kQuadWaves * kWave), static_cast<std::uint32_t>(quad_lds), s, e0,
+                              e1, 0, rollout, sample, fused, static_cast<int>(trace), static_cast<int>(trace + uniform));
+      } else {
+        hipLaunchKernelGGL(rollout_sampled_quad_kernel, grid, dim3(kQuadWaves * kWave), quad_lds, s, rollout, sample, fused,
+                           static_cast<int>(trace), static_cast<int>(trace + uniform));
       }
       return hipGetLastError();
     }

@@ -174,8 +174,8 @@ def test_tick_at_the_horizon_limits(H, N, rounds):
 
 def test_tick_forms_agree(monkeypatch):
     """However the tick is run - completion flag polled in pinned memory (default) or the stream synchronised, rounds on
-    two waves per workgroup or one, chained or each finalized, the winner copied from its trace or rolled again - a
-    sequence of warm-started ticks returns the same numbers."""
+    four waves per workgroup (default), two or one, chained or each finalized, the winner copied from its trace or rolled
+    again - a sequence of warm-started ticks returns the same numbers."""
     cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=28.0)
     n = 49
     paths = [np.stack([0.004 * (1 + 0.1 * j) * np.linspace(0, 120, 50) ** 2, np.linspace(0, 120, 50),
@@ -194,8 +194,9 @@ def test_tick_forms_agree(monkeypatch):
         return outs
 
     reference = run()
-    for switches in (("ACMPC_TICK_NO_FLAG",), ("ACMPC_NO_PAIR_ROUNDS",), ("ACMPC_NO_PAIR_ROUNDS", "ACMPC_NO_CHAINED_ROUNDS"),
-                     ("ACMPC_NO_TRACED_FINALIZE",)):
+    for switches in (("ACMPC_TICK_NO_FLAG",), ("ACMPC_NO_QUAD_ROUNDS",), ("ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_CHAINED_ROUNDS"),
+                     ("ACMPC_NO_PAIR_ROUNDS",), ("ACMPC_NO_PAIR_ROUNDS", "ACMPC_NO_CHAINED_ROUNDS"),
+                     ("ACMPC_NO_CHAINED_ROUNDS",), ("ACMPC_NO_TRACED_FINALIZE",)):
         for name in switches:
             monkeypatch.setenv(name, "1")
         for want, got in zip(reference, run()):
