@@ -25,6 +25,19 @@
 
 namespace acmpc {
 
+// Phase stamps of the prologue for tools/prologue_probe.py (an A/B build with -DACMPC_STAMPS); nothing in the library.
+#ifdef ACMPC_STAMPS
+__device__ unsigned long long g_prologue_stamps[16];
+#define ACMPC_PSTAMP(slot)                                                    \
+  do {                                                                        \
+    if (threadIdx.x == 0) g_prologue_stamps[(slot)] = wall_clock64();         \
+  } while (0)
+#else
+#define ACMPC_PSTAMP(slot) \
+  do {                     \
+  } while (0)
+#endif
+
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;
@@ -92,6 +105,7 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   // ONE read of the head (kernel arguments, or the pinned block over the host link); everything below uses the copy
   const TickHeader h = (a.header_by_value != 0) ? a.header_value : *a.header;
+  ACMPC_PSTAMP(0);
   const int lane = static_cast<int>(threadIdx.x);
   const int H = h.horizon;
   const int n = H - 1;
@@ -146,6 +160,7 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     coords = s_coords;
   }
 
+  ACMPC_PSTAMP(1);
   // ---- construct_waypoints (spatial_mpc.py:125-154) ------------------------------------------------------------
   // headings of the n forward segments and of the segment that closes the loop from the last point to point 0
   for (int i = lane; i <= n; i += 64) {
@@ -172,6 +187,7 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   if (lane == 0) tkappa[0] = tkappa[1];
   team.sync();
 
+  ACMPC_PSTAMP(2);
   // ---- velocity ceiling (speed_profile.py:26-43, localised: 131-150) ----------------------------------------------
   for (int i = lane; i < n; i += 64) {
     double c;
@@ -200,10 +216,12 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
       if (lane + 64 * q < 2 * n - 1) qy[lane + 64 * q] = warm_y[q];
   }
   team.sync();
+  ACMPC_PSTAMP(3);
   const admm::Settings settings{h.a_min, h.a_max, h.v_min, h.qp_max_iter, h.qp_check_every > 0 ? h.qp_check_every : 10,
                                 h.qp_eps_abs, h.qp_eps_rel};
   int iterations = 0;
   const int status = admm::solve(team, ws, v_hi, tds, n, settings, qv, qy, warm ? 1 : 0, &iterations);
+  ACMPC_PSTAMP(4);
   if (status == 0 && a.warm_capacity >= n) {  // keep the iterate only when solved, as the host solver object does
     for (int i = lane; i < n; i += 64) state[2 + i] = qv[i];
     for (int i = lane; i < 2 * n - 1; i += 64) state[2 + n + i] = qy[i];
@@ -216,6 +234,7 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   for (int i = lane; i < n; i += 64) tv[i] = (status == 0) ? qv[i] : 0.0;
   team.sync();
 
+  ACMPC_PSTAMP(5);
   // ---- t2s of the pose (offset, 0, pi/2) w.r.t. waypoint 0 (dynamics.py:23-40, spatial_mpc.py:187) -------------------
   if (lane == 0) {
     const double wx = tx[0], wy = ty[0], wpsi = tpsi[0];
@@ -275,8 +294,10 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     a.centre[2 * i] = (h.centre_is_reference != 0) ? static_cast<float>(uv) : centre_in_v[q];
     a.centre[2 * i + 1] = (h.centre_is_reference != 0) ? static_cast<float>(uk) : centre_in_k[q];
   }
+  ACMPC_PSTAMP(6);
   // the 7 x n table for the caller (pinned host memory: posted writes, visible once the stream has drained)
   for (int e = lane; e < 7 * n; e += 64) a.table_out[e] = table[e];
+  ACMPC_PSTAMP(7);
   (void)m;
 }
 
@@ -344,6 +365,12 @@ __global__ void __launch_bounds__(256) map_window_kernel(const MapWindowArgs a) 
   }
   if (tid == 0 && a.first_out != nullptr) a.first_out[0] = first;
 }
+
+#ifdef ACMPC_STAMPS
+extern "C" int acmpc_debug_prologue_stamps(unsigned long long* out) {
+  return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prologue_stamps), sizeof(unsigned long long) * 16));
+}
+#endif
 
 hipError_t launch_map_window(const MapWindowArgs& args, hipStream_t s) {
   (void)hipGetLastError();
