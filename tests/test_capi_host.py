@@ -150,3 +150,24 @@ def test_key_minimum_is_the_oracles_argmin_on_arbitrary_bit_patterns():
 
     check()
 
+
+
+def test_unpack_decision_temporal_on_the_host():
+    """acmpc_unpack_decision_temporal (no GPU): a mode T plan's dec.x -> poses as the prediction, time = i dt, the
+    derivatives of the plan's own controls."""
+    from acmpc_amd import _capi
+    n, dt, wheelbase = 19, 0.05, 2.65
+    rng = np.random.default_rng(3)
+    poses = rng.normal(size=(n + 1, 3))
+    controls = np.stack([rng.uniform(8, 28, n), rng.uniform(-0.05, 0.05, n)], axis=1)
+    z = np.concatenate([poses.ravel(), controls.ravel()])
+    projected, prediction, cum_time, times, accelerations, steer_rates = _capi.unpack_decision_temporal(z, n, dt, wheelbase)
+    np.testing.assert_array_equal(projected[0], controls[:, 0])
+    np.testing.assert_allclose(projected[1], np.arctan(controls[:, 1] * wheelbase), rtol=4e-16, atol=0)   # libm vs NumPy atan
+    np.testing.assert_array_equal(prediction, poses[:n, :2])
+    np.testing.assert_array_equal(cum_time, np.arange(n) * dt)
+    np.testing.assert_array_equal(times, np.full(n - 1, dt))
+    np.testing.assert_array_equal(accelerations, (projected[0, 1:] - projected[0, :-1]) / dt)
+    np.testing.assert_array_equal(steer_rates, (projected[1, 1:] - projected[1, :-1]) / dt)
+    with pytest.raises(ValueError):
+        _capi.unpack_decision_temporal(z[:-1], n, dt, wheelbase)
