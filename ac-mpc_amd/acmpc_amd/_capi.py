@@ -169,6 +169,9 @@ SIGNATURES = {
     "acmpc_host_free": (C.c_int, [C.c_void_p]),
     "acmpc_unpack_decision": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_double] + [C.c_void_p] * 6),
     "acmpc_unpack_decision_temporal": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double] + [C.c_void_p] * 6),
+    "acmpc_search_window": (C.c_int32, [_I32P]),
+    "acmpc_search_frame_floats": (C.c_int32, [C.c_int32]),
+    "acmpc_search_frames": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "acmpc_speed_profile_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
                                          C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, _I32P]),
@@ -621,6 +624,27 @@ def unpack_decision_temporal(z: np.ndarray, n: int, dt: float, wheelbase: float)
     if rc != OK:
         raise EngineError(rc, "acmpc_unpack_decision_temporal: bad arguments")
     return arrays
+
+
+def search_window():
+    """(waypoints per window, how many of them behind the previous nearest one) of mode T's verified search."""
+    back = C.c_int32(0)
+    width = load_library().acmpc_search_window(C.byref(back))
+    return int(width), int(back.value)
+
+
+def search_frames(coef: np.ndarray) -> np.ndarray:
+    """coef [P][n][8] packed waypoint rows -> [P][acmpc_search_frame_floats(n)] frames of the verified search, as
+    acmpc_set_paths hands them to the kernels (host computation)."""
+    coef = np.ascontiguousarray(coef, dtype=np.float32)
+    P, n = coef.shape[0], coef.shape[1]
+    lib = load_library()
+    floats = lib.acmpc_search_frame_floats(n)
+    out = np.empty((P, floats), dtype=np.float32)
+    rc = lib.acmpc_search_frames(coef.ctypes.data, P, n, out.ctypes.data, out.size)
+    if rc != OK:
+        raise EngineError(rc, "acmpc_search_frames: bad arguments")
+    return out
 
 
 def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: float, v_min: float, max_iter: int = 4000,

@@ -38,7 +38,7 @@ struct acmpc_ctx {
   std::vector<float> h_coef;
   int P_set = 0, n_set = 0;
   bool tables_dirty = false;
-  bool thr_dirty = false;  // the verified-search thresholds of the current paths are not on the device yet
+  bool frames_dirty = false;  // the verified search's frames of the current paths are not on the device yet
 
   // device state (created lazily)
   bool device_ready = false;
@@ -68,9 +68,9 @@ struct acmpc_ctx {
   int* d_tickets = nullptr;  // last-workgroup counters of the in-launch finalizes (ensure_tail_buffers); zero between launches
   unsigned tick_sequence = 0;   // completion flag values of acmpc_control_tick
   float* d_trace = nullptr;  // [2][kTraceBlocks][trace_floats(max_steps)] best-candidate traces of the fused rounds' workgroups
-  // mode T with exhaustive search: thresholds of the verified window search (acmpc_device.h: nearest_verified)
-  std::vector<float> h_nn_thr;  // [P][n][kVerifiedWindow], empty when not applicable
-  float* d_nn_thr = nullptr;
+  // mode T with exhaustive search: frames of the verified window search (acmpc_device.h: nearest_verified)
+  std::vector<float> h_nn_frames;  // [P][verified_frame_floats(n)], empty when not applicable
+  float* d_nn_frames = nullptr;
   int64_t* h_keys = nullptr;  // pinned
   float* h_io = nullptr;      // pinned: x0 [P][3] on the way up, records [P][record_floats] on the way down (acmpc_solve)
 
@@ -158,64 +158,160 @@ int fail_hip(const acmpc_ctx* ctx, hipError_t e, const char* what) {
     if (e_ != hipSuccess) return fail_hip((ctx), e_, #call);   \
   } while (0)
 
-// Thresholds of the verified nearest-waypoint search (acmpc_device.h: nearest_verified), from the float32 waypoint
-// positions the kernels use.  thr[p][j][o] bounds the squared distance to waypoint j - as the kernel estimates it from
-// the winning key - below which no waypoint OUTSIDE the kVerifiedWindow-wide window that starts at j - o can have a
-// smaller key.  With R = distance from waypoint j to the nearest outside waypoint and r = |p - w_j| < R / 2, every
-// outside waypoint m has |p - w_m|^2 - r^2 >= R (R - 2 r).  The keys carry that difference to within 2 E_key, the
-// estimate of r^2 is good to E_est (bounds below, from the largest coordinate of the path and R), so
-//     thr = ((R - 2 E_key / R) / (2 (1 + 1e-3)))^2 - E_est,
-// rounded down; -inf = "always scan" (nothing to certify with, or window positions that cannot occur).  O(n^2) per path
-// through prefix / suffix minima, hence the cap.
+// Frames of the verified nearest-waypoint search (acmpc_device.h: nearest_verified_window), from the float32 waypoint
+// positions the kernels use.  For every window position lo (window = waypoints lo .. lo + W - 1) eight floats
+// [t_x, t_y, k_along, k_across, slab, tube, far, -slack] with which the kernel evaluates, at a pose p,
+//     alpha = t . p + k_along     (distance past the plane BEHIND which every near waypoint m < lo lies)
+//     beta  = n . p + k_across    (n = (-t_y, t_x); offset from the middle of the tube that holds every near outside waypoint)
+//     along = med3(alpha, slab - alpha, 0),   across = med3(|beta| - tube, 0, kFrameAcrossMax)
+// and certifies the window's winner j when  |r_j^2 recovered from its key|  <  min(along^2 + across^2 - slack, far).
+//
+// The outside waypoints are split by index: NEAR = within `near` waypoints of the window's ends, FAR = the rest; `near`
+// is the smallest of 16, 24, 32, ... for which the far ones are at least kFarReach from the window (all of them near when
+// none is: a path that comes back to the window).
+//
+// Near waypoints: why the slab-and-tube bound is sound.  t is the float32 direction of the window's chord scaled so that
+// |t| <= 1, and n has the same norm, so for any waypoint w: (t.(w - p))^2 + (n.(w - p))^2 <= |w - p|^2.  Every near
+// waypoint m < lo has t.w <= a_B, every near m >= lo + W has t.w >= a_A (a_B, a_A = the extreme projections, taken here
+// over the same float32 vectors), and every near outside waypoint has |n.w - mid| <= tube; hence |w - p|^2 >= along^2 +
+// across^2 in exact arithmetic.  A side without waypoints (window at an end of the path) gets a virtual plane
+// kFrameVirtualPlane beyond the window: any plane is valid there, a finite one keeps `slab` - and with it the distance of
+// a certified pose from the path - bounded.  Rounding: alpha and beta are two fused multiply-adds each; their error at a
+// certified pose is below `delta` (computed per window from the magnitudes involved); k_along is lowered by delta, slab by
+// 4 delta, tube raised by 3 delta, each rounded outward, so that the kernel's along / across never exceed the exact ones.
+// What remains - the rounding of the two squares, twice the error E_key of a key and the error E_est of the recovered
+// r_j^2 - is `slack`: a certified pose satisfies r_est < D := slab_max^2 + kFrameAcrossMax^2, so |p| <= Lc with Lc found
+// below such that any pose further out has r_est >= D whatever its rounding; every intermediate of a key is then below
+// B = 6 Lc^2 in magnitude, a key off by at most 3 B ulp (two roundings in c, two fused multiply-adds), the recovered r^2
+// by at most 7 B ulp.  (Where keys overflow - poses beyond 1e17 m - the winning key is -inf and so is the recovered
+// r^2: hence its magnitude in the test.)
+//
+// Far waypoints: with R = the smallest distance between a waypoint of the window and a far one, a pose within r of the
+// winner is at least R - r from every far waypoint, whose squared distance therefore exceeds r^2 by R (R - 2 r);
+//     far = ((R - 2 E_key / R) / (2 (1 + 1e-3)))^2 - E_est,   rounded down
+// keeps that gap above twice a key's error (+inf when there is no far waypoint).
+//
+// A window whose chord has no length, or a path with a non-finite waypoint: slab = -1, tube = +inf, far = 0 - never
+// certified.  O(n W) per window and choice of `near`, O(n^2) per path, hence the cap.
 constexpr int kMaxVerifiedSteps = 256;
+constexpr double kFarReach = 50.0;   // [m]: poses up to half of this from the winner are not cut off by the far bound
 
-void verified_thresholds(const float* coef, int P, int n, std::vector<float>* out) {
+void verified_frames(const float* coef, int P, int n, std::vector<float>* out) {
   constexpr int W = acmpc::kVerifiedWindow;
+  const int windows = n - W + 1;
+  const int floats = acmpc::verified_frame_floats(n);
   const double inf = std::numeric_limits<double>::infinity();
-  const float never = -std::numeric_limits<float>::infinity();
-  out->assign(static_cast<size_t>(P) * n * W, never);
-  std::vector<double> left(static_cast<size_t>(n) + 1), right(static_cast<size_t>(n) + 1);
+  const float finf = std::numeric_limits<float>::infinity();
   const double ulp = std::ldexp(1.0, -24);   // half an ulp of a float32 of magnitude 1: one rounding's relative error
+  const double across_max = acmpc::kFrameAcrossMax, virtual_plane = acmpc::kFrameVirtualPlane;
+  out->assign(static_cast<size_t>(P) * floats, 0.0f);
+  struct Frame { double tx, ty, aB, aA, mid, tube, R; bool usable; };
+  std::vector<Frame> frames(static_cast<size_t>(windows));
   for (int p = 0; p < P; ++p) {
     const float* t = coef + static_cast<size_t>(p) * n * acmpc::kCoefT;
-    float* thr = out->data() + static_cast<size_t>(p) * n * W;
-    double wc = 0.0;   // largest |coordinate| of the path
-    for (int m = 0; m < n; ++m)
-      wc = std::max(wc, std::max(std::fabs(static_cast<double>(t[m * acmpc::kCoefT])),
-                                 std::fabs(static_cast<double>(t[m * acmpc::kCoefT + 1]))));
-    for (int j = 0; j < n; ++j) {
-      const double xj = t[j * acmpc::kCoefT], yj = t[j * acmpc::kCoefT + 1];
-      // left[a] = min distance to waypoints m < a; right[b] = min distance to waypoints m >= b
-      left[0] = inf;
-      for (int m = 0; m < n; ++m) {
-        const double dx = t[m * acmpc::kCoefT] - xj, dy = t[m * acmpc::kCoefT + 1] - yj;
-        left[m + 1] = std::min(left[m], std::sqrt(dx * dx + dy * dy));
-      }
-      right[n] = inf;
-      for (int m = n - 1; m >= 0; --m) {
-        const double dx = t[m * acmpc::kCoefT] - xj, dy = t[m * acmpc::kCoefT + 1] - yj;
-        right[m] = std::min(right[m + 1], std::sqrt(dx * dx + dy * dy));
-      }
-      for (int o = 0; o < W; ++o) {
-        const int lo = j - o;
-        if (lo < 0 || lo + W > n) continue;
-        const double R = std::min(left[lo], right[lo + W]);
-        if (std::isinf(R)) {   // the window is the whole path: its minimum is the global one wherever the candidate is
-          thr[j * W + o] = std::numeric_limits<float>::infinity();
-          continue;
+    float* table = out->data() + static_cast<size_t>(p) * floats;
+    auto wx = [&](int m) { return static_cast<double>(t[m * acmpc::kCoefT]); };
+    auto wy = [&](int m) { return static_cast<double>(t[m * acmpc::kCoefT + 1]); };
+    double wn = 0.0;   // largest norm of a waypoint
+    bool finite = true;
+    for (int m = 0; m < n; ++m) {
+      finite = finite && std::isfinite(wx(m)) && std::isfinite(wy(m));
+      wn = std::max(wn, std::hypot(wx(m), wy(m)));
+    }
+    double slab_max = 0.0;
+    for (int lo = 0; lo < windows; ++lo) {
+      Frame& f = frames[lo];
+      f.usable = false;
+      const int hi = lo + W - 1;
+      const double cx = wx(hi) - wx(lo), cy = wy(hi) - wy(lo), chord = std::hypot(cx, cy);
+      if (!finite || !(chord > 0.0) || !std::isfinite(chord)) continue;
+      // the split: distance from the window to the waypoints more than `near` indices beyond its ends
+      auto far_distance = [&](int near) {
+        double R = inf;
+        for (int m = 0; m < n; ++m) {
+          if (m >= lo - near && m <= hi + near) {
+            m = hi + near;   // (skip the window and its near neighbourhood)
+            continue;
+          }
+          for (int q = lo; q <= hi; ++q) R = std::min(R, std::hypot(wx(m) - wx(q), wy(m) - wy(q)));
         }
-        if (!(R > 0.0)) continue;
-        // a certified candidate has |X|, |Y| <= L; every intermediate of a key is below B = 6 L^2 in magnitude:
-        // a key is off by at most 3 B ulp (two roundings in c, two fused multiply-adds), the estimate
-        // fma(Y, Y, fma(X, X, key)) of r^2 by at most 7 B ulp
-        const double L = wc + 0.5 * R, B = 6.0 * L * L;
-        const double e_key = 3.0 * B * ulp, e_est = 7.0 * B * ulp;
-        const double rho = (R - 2.0 * e_key / R) / (2.0 * (1.0 + 1.0e-3));
-        const double bound = rho * rho - e_est;
-        if (!(rho > 0.0) || !(bound > 0.0) || !std::isfinite(bound)) continue;
-        // rounded down: the test `estimate < thr` must never be more permissive than the real-number one
-        thr[j * W + o] = std::nextafter(static_cast<float>(bound), never);
+        return R;
+      };
+      int near = 16;
+      f.R = far_distance(near);
+      while (f.R < kFarReach) {
+        near += 8;
+        f.R = far_distance(near);   // (+inf once nothing is far)
       }
+      // float32 direction with |t| <= 1: shrunk by more than its two roundings can add
+      f.tx = static_cast<double>(static_cast<float>(cx / chord * (1.0 - 4.0e-7)));
+      f.ty = static_cast<double>(static_cast<float>(cy / chord * (1.0 - 4.0e-7)));
+      double aB = -inf, aA = inf, lowest = inf, highest = -inf, first = inf, last = -inf;
+      bool behind = false, ahead = false;
+      for (int m = std::max(lo - near, 0); m <= std::min(hi + near, n - 1); ++m) {
+        const double a = f.tx * wx(m) + f.ty * wy(m), b = -f.ty * wx(m) + f.tx * wy(m);
+        if (m < lo) {
+          aB = std::max(aB, a);
+          behind = true;
+        }
+        if (m > hi) {
+          aA = std::min(aA, a);
+          ahead = true;
+        }
+        if (m < lo || m > hi) {
+          lowest = std::min(lowest, b);
+          highest = std::max(highest, b);
+        } else {
+          first = std::min(first, a);
+          last = std::max(last, a);
+        }
+      }
+      if (!behind) aB = first - virtual_plane;
+      if (!ahead) aA = last + virtual_plane;
+      if (!behind && !ahead) lowest = highest = 0.0;   // no near outside waypoint at all: any tube will do
+      f.aB = aB;
+      f.aA = aA;
+      f.mid = 0.5 * (lowest + highest);
+      f.tube = 0.5 * (highest - lowest);
+      f.usable = aA > aB;
+      if (f.usable) slab_max = std::max(slab_max, aA - aB);
+    }
+    // how far out a certified pose can be: r_est < D, and beyond Lc the recovered r^2 is at least D whatever it rounds to
+    const double D = slab_max * slab_max + across_max * across_max;
+    double Lc = wn + 1.01 * std::sqrt(D) + 1.0;
+    while (!((Lc - wn) * (Lc - wn) - 42.0 * ulp * (Lc + wn) * (Lc + wn) >= 1.01 * D) && Lc < 1.0e12) Lc *= 1.5;
+    const double B = 6.0 * Lc * Lc;
+    const double e_key = 3.0 * B * ulp, e_est = 7.0 * B * ulp;
+    const double slack = 1.01 * (2.0 * e_key + e_est + 8.0 * ulp * D);
+    for (int lo = 0; lo < windows; ++lo) {
+      const Frame& f = frames[lo];
+      float* row = table + acmpc::kFrameStride * lo;
+      row[0] = row[1] = row[2] = row[3] = 0.0f;
+      row[4] = -1.0f;
+      row[5] = finf;
+      row[6] = 0.0f;
+      row[7] = -std::nextafter(static_cast<float>(slack), finf);
+      if (!f.usable || !(Lc < 1.0e12)) continue;
+      // |alpha|, |beta| evaluated at |X|, |Y| <= Lc: each of the two fused multiply-adds rounds a value below
+      // 2 Lc + |k|; the subtraction that follows (slab - alpha, |beta| - tube) one below 2 Lc + |k| + slab + tube
+      const double k_along = -f.aB, k_across = -f.mid;
+      const double delta = ulp * (8.0 * Lc + 4.0 * (std::fabs(k_along) + std::fabs(k_across)) + 2.0 * ((f.aA - f.aB) + f.tube));
+      const double slab = (f.aA - f.aB) - 4.0 * delta;
+      if (!(slab > 0.0)) continue;
+      float far = finf;
+      if (!std::isinf(f.R)) {
+        const double rho = (f.R - 2.0 * e_key / f.R) / (2.0 * (1.0 + 1.0e-3));
+        const double bound = rho * rho - e_est;
+        if (!(f.R > 0.0) || !(rho > 0.0) || !(bound > 0.0) || !std::isfinite(bound)) continue;
+        far = std::nextafter(static_cast<float>(bound), -finf);
+      }
+      row[0] = static_cast<float>(f.tx);
+      row[1] = static_cast<float>(f.ty);
+      row[2] = std::nextafter(static_cast<float>(k_along - delta), -finf);
+      row[3] = static_cast<float>(k_across);
+      row[4] = std::nextafter(static_cast<float>(slab), -finf);
+      row[5] = std::nextafter(static_cast<float>(f.tube + 3.0 * delta), finf);
+      row[6] = far;
     }
   }
 }
@@ -258,8 +354,9 @@ int ensure_device(acmpc_ctx* c) {
   ACMPC_HIP(c, alloc_once(&c->d_soft_partial, c->soft_partial_doubles * sizeof(double)));
   ACMPC_HIP(c, alloc_once(&c->d_segments, static_cast<size_t>(p.max_steps) * 2 * sizeof(float)));
   if (p.mode == ACMPC_MODE_TEMPORAL && p.nn_ahead < 0)
-    ACMPC_HIP(c, alloc_once(&c->d_nn_thr, static_cast<size_t>(p.max_problems) * std::min(p.max_steps, kMaxVerifiedSteps) *
-                                              acmpc::kVerifiedWindow * sizeof(float)));
+    ACMPC_HIP(c, alloc_once(&c->d_nn_frames, static_cast<size_t>(p.max_problems) * sizeof(float) *
+                                                 acmpc::verified_frame_floats(std::max(std::min(p.max_steps, kMaxVerifiedSteps),
+                                                                                       acmpc::kVerifiedWindow))));
   c->device_ready = true;
   return ACMPC_OK;
 }
@@ -267,10 +364,10 @@ int ensure_device(acmpc_ctx* c) {
 int upload_tables(acmpc_ctx* c, hipStream_t s) {
   if (c->P_set == 0) return fail(c, ACMPC_ESTATE, "acmpc_set_paths has not been called");
   // pageable source: hipMemcpyAsync stages it before returning, so the host vectors may change afterwards
-  if (c->thr_dirty && !c->h_nn_thr.empty() && c->d_nn_thr != nullptr) {
-    ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_thr, c->h_nn_thr.data(), c->h_nn_thr.size() * sizeof(float),
+  if (c->frames_dirty && !c->h_nn_frames.empty() && c->d_nn_frames != nullptr) {
+    ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_frames, c->h_nn_frames.data(), c->h_nn_frames.size() * sizeof(float),
                                 hipMemcpyHostToDevice, s));
-    c->thr_dirty = false;
+    c->frames_dirty = false;
   }
   if (!c->tables_dirty) return ACMPC_OK;
   const size_t bytes = static_cast<size_t>(c->P_set) * c->n_set * c->coef_stride * sizeof(float);
@@ -279,14 +376,14 @@ int upload_tables(acmpc_ctx* c, hipStream_t s) {
   return ACMPC_OK;
 }
 
-// The captured optimisation carries the coefficient table in its staging block but not the thresholds of mode T's
-// verified nearest-waypoint search, which the three-kernel form of a round reads (rollout(): a.nn_thr): bring them
+// The captured optimisation carries the coefficient table in its staging block but not the frames of mode T's
+// verified nearest-waypoint search, which the three-kernel form of a round reads (rollout(): a.nn_frames): bring them
 // up to date on the launch stream before the graph runs.
-int upload_thresholds(acmpc_ctx* c, hipStream_t s) {
-  if (!c->thr_dirty || c->h_nn_thr.empty() || c->d_nn_thr == nullptr) return ACMPC_OK;
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_thr, c->h_nn_thr.data(), c->h_nn_thr.size() * sizeof(float),
+int upload_frames(acmpc_ctx* c, hipStream_t s) {
+  if (!c->frames_dirty || c->h_nn_frames.empty() || c->d_nn_frames == nullptr) return ACMPC_OK;
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_frames, c->h_nn_frames.data(), c->h_nn_frames.size() * sizeof(float),
                               hipMemcpyHostToDevice, s));
-  c->thr_dirty = false;
+  c->frames_dirty = false;
   return ACMPC_OK;
 }
 
@@ -317,7 +414,7 @@ int rollout(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int
   a.U = d_U;
   a.x0 = d_x0;
   a.coef = c->d_coef;
-  a.nn_thr = (!c->h_nn_thr.empty() && std::getenv("ACMPC_NO_VERIFIED_SEARCH") == nullptr) ? c->d_nn_thr : nullptr;
+  a.nn_frames = (!c->h_nn_frames.empty() && std::getenv("ACMPC_NO_VERIFIED_SEARCH") == nullptr) ? c->d_nn_frames : nullptr;
   a.costs = d_costs;
   a.partial_keys = c->d_partial_keys;
   a.partial_feas = c->d_partial_feas;
@@ -606,7 +703,7 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_keys);
     (void)hipFree(c->d_tickets);
     (void)hipFree(c->d_trace);
-    (void)hipFree(c->d_nn_thr);
+    (void)hipFree(c->d_nn_frames);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
     if (c->h_io != nullptr) (void)hipHostFree(c->h_io);
     for (hipGraphExec_t g : c->opt_graph)
@@ -668,13 +765,31 @@ int acmpc_set_paths(acmpc_ctx* c, const double* tables, int32_t P, int32_t n) {
       }
     }
   }
-  c->h_nn_thr.clear();
+  c->h_nn_frames.clear();
   if (c->prm.mode == ACMPC_MODE_TEMPORAL && c->prm.nn_ahead < 0 && n >= acmpc::kVerifiedWindow && n <= kMaxVerifiedSteps)
-    verified_thresholds(c->h_coef.data(), P, n, &c->h_nn_thr);
+    verified_frames(c->h_coef.data(), P, n, &c->h_nn_frames);
   c->P_set = P;
   c->n_set = n;
   c->tables_dirty = true;
-  c->thr_dirty = !c->h_nn_thr.empty();
+  c->frames_dirty = !c->h_nn_frames.empty();
+  return ACMPC_OK;
+}
+
+int32_t acmpc_search_window(int32_t* back) {
+  if (back != nullptr) *back = acmpc::kVerifiedBack;
+  return acmpc::kVerifiedWindow;
+}
+
+int32_t acmpc_search_frame_floats(int32_t n) {
+  return n >= acmpc::kVerifiedWindow ? acmpc::verified_frame_floats(n) : 0;
+}
+
+int acmpc_search_frames(const float* coef, int32_t P, int32_t n, float* out, int64_t capacity_floats) {
+  if (coef == nullptr || out == nullptr || P < 1 || n < acmpc::kVerifiedWindow) return ACMPC_EINVAL;
+  std::vector<float> frames;
+  verified_frames(coef, P, n, &frames);
+  if (capacity_floats < static_cast<int64_t>(frames.size())) return ACMPC_ECAPACITY;
+  std::memcpy(out, frames.data(), frames.size() * sizeof(float));
   return ACMPC_OK;
 }
 
@@ -1120,7 +1235,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   std::memcpy(c->h_opt + off_table, c->h_coef.data(), table_bytes);
   const uint32_t seed_words[2] = {static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
   std::memcpy(c->h_opt + off_seed, seed_words, sizeof seed_words);
-  rc = upload_thresholds(c, s);
+  rc = upload_frames(c, s);
   if (rc != ACMPC_OK) return rc;
   ACMPC_HIP(c, hipGraphLaunch(c->opt_graph[slot], s));
   ACMPC_HIP(c, hipStreamSynchronize(s));

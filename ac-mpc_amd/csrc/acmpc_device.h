@@ -18,10 +18,10 @@ namespace acmpc {
 constexpr int kWave = 64;
 
 // window of mode T's verified nearest-waypoint search (exhaustive semantics): waypoints searched per step and how many
-// of them lie behind the previous step's nearest one (A/B builds: ACMPC_HIPCC_EXTRA="-DACMPC_VERIFIED_WINDOW=8 ...")
+// of them lie behind the previous step's nearest one (A/B builds: ACMPC_HIPCC_EXTRA="-DACMPC_VERIFIED_WINDOW=16 ...")
 #ifndef ACMPC_VERIFIED_WINDOW
-#define ACMPC_VERIFIED_WINDOW 16
-#define ACMPC_VERIFIED_BACK 7
+#define ACMPC_VERIFIED_WINDOW 8
+#define ACMPC_VERIFIED_BACK 3
 #endif
 
 __device__ __forceinline__ int wave_min_int(int v);
@@ -49,6 +49,7 @@ struct Weights {
 // halves the issue slots of everything that has a packed form.  Per element the operations and their order are
 // identical, so results do not depend on F.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
@@ -282,7 +283,7 @@ __device__ __forceinline__ void search_entry(float x, float y, float& a, float& 
   b = -2.0f * y;
   c = fma_(y, y, x * x);
 }
-// |p - w_m|^2 back from the key (to ~0.01 m^2): what the verified search tests against its thresholds
+// |p - w_m|^2 back from the key (to ~0.01 m^2): what the verified search tests against its frame's bound
 __device__ __forceinline__ float distance2_of_key(float X, float Y, float e) { return fma_(Y, Y, fma_(X, X, e)); }
 
 template <typename F, typename G>
@@ -349,24 +350,48 @@ __device__ __forceinline__ int nearest_in_window(float X, float Y, const float* 
 }
 
 // EXHAUSTIVE semantics at windowed cost.  The kVerifiedWindow waypoints from lo = clamp(j_prev - kVerifiedBack, 0,
-// n - kVerifiedWindow) are searched as above; the host has tabulated, for every waypoint j and every window position
-// o = j - lo, a threshold thr[j][o] on the squared distance to waypoint j below which no waypoint OUTSIDE that window
-// can have a smaller key: with R = distance from waypoint j to the nearest outside waypoint and r = |p - w_j|, every
-// outside waypoint is at least R - r away, i.e. its squared distance exceeds r^2 by R (R - 2 r); the threshold keeps
-// that gap above twice the rounding error of a key (acmpc_capi.hip: verified_thresholds), so the window's first minimum
-// IS the global first minimum and the scan of all n waypoints is skipped.  Otherwise (a candidate far off the path, a
-// non-finite position) all waypoints are scanned - by the whole wave, see nearest_cooperative_fix().  Either way the
-// index is exactly the exhaustive one, bit for bit.
+// n - kVerifiedWindow) are searched as above, and a certificate decides whether the window's first minimum IS the global
+// first minimum.  For every window position lo the host tabulates a frame (acmpc_capi.hip: verified_frames) that splits
+// the waypoints OUTSIDE the window in two:
+//   - the NEAR ones (the next few dozen metres of path either side) lie behind the window or ahead of it and, seen from
+//     the window, inside a tube round the path.  The frame holds a direction t along the window's chord (|t| <= 1) and
+//     its normal, the plane behind which every near earlier waypoint lies, the plane beyond which every near later one
+//     lies, and the tube's half-width across.  With
+//         along  = distance of the pose to the nearer of the two planes (0 outside the slab between them),
+//         across = what the pose's lateral offset exceeds the tube by (0 inside it, capped at kFrameAcrossMax),
+//     every near outside waypoint is at least sqrt(along^2 + across^2) away - a bound that does not decay when a
+//     candidate runs wide of the path, which is where the candidates of a sampling round are (a ball round the winning
+//     waypoint, round 2's certificate, needs twice the window for the same yield);
+//   - the FAR ones are at least D from every waypoint of the window, so further than r from a pose within r < D / 2 of
+//     the window's winner.
+// The winner j is certified when the squared distance recovered from its key is below min(along^2 + across^2 - slack,
+// far) - slack and the margin inside `far` keep the gap above twice a key's rounding error plus the error of the
+// recovered distance and of the frame arithmetic.  Otherwise (a path that folds back on itself, a non-finite position)
+// all waypoints are scanned - by the whole wave, see nearest_cooperative_fix().  Either way the index is exactly the
+// exhaustive one, bit for bit.
 constexpr int kVerifiedWindow = ACMPC_VERIFIED_WINDOW;
 constexpr int kVerifiedBack = ACMPC_VERIFIED_BACK;
+// the table of one problem, per window position: [t_x, t_y, k_along, k_across | slab, tube, far, -slack] (two 16-byte reads)
+constexpr int kFrameStride = 8;
+constexpr float kFrameAcrossMax = 32.0f;     // [m] cap of `across`: bounds how far from the path a certified pose can be
+constexpr float kFrameVirtualPlane = 32.0f;  // [m] where the plane of an EMPTY side (window at the path's end) is put
+__host__ __device__ constexpr int verified_frame_floats(int n) { return kFrameStride * (n - kVerifiedWindow + 1); }
 
-// The window part: index of the window's first minimum and whether the threshold test certifies it as global.
-__device__ __forceinline__ int nearest_verified_window(float X, float Y, const float* abc, const float* thr, int n,
+// The window part: index of the window's first minimum and whether the frame test certifies it as global.
+__device__ __forceinline__ int nearest_verified_window(float X, float Y, const float* abc, const float* frames, int n,
                                                        int j_prev, bool& certified) {
   const int lo = max(min(j_prev - kVerifiedBack, n - kVerifiedWindow), 0);
   float best;
   const int j = nearest_in_window<kVerifiedWindow>(X, Y, abc, lo, &best);
-  certified = distance2_of_key(X, Y, best) < thr[j * kVerifiedWindow + (j - lo)];
+  const f32x4* f = reinterpret_cast<const f32x4*>(frames) + (kFrameStride / 4) * lo;   // (16-byte aligned)
+  const f32x4 t = f[0], ext = f[1];
+  const float alpha = fma_(t[0], X, fma_(t[1], Y, t[2]));    // along the chord, from the plane behind the window
+  const float beta = fma_(t[0], Y, fma_(-t[1], X, t[3]));    // across, from the tube's middle
+  const float along = __builtin_amdgcn_fmed3f(alpha, ext[0] - alpha, 0.0f);
+  const float across = __builtin_amdgcn_fmed3f(__builtin_fabsf(beta) - ext[1], 0.0f, kFrameAcrossMax);
+  const float bound = __builtin_fminf(fma_(across, across, fma_(along, along, ext[3])), ext[2]);
+  // (the magnitude: a pose so far out that its keys overflow to -inf must not pass - and costs nothing, a source modifier)
+  certified = __builtin_fabsf(distance2_of_key(X, Y, best)) < bound;
 #ifdef ACMPC_DEBUG_ALWAYS_CERTIFIED   // (timing experiment only: what the kernel costs without its fallback; WRONG results)
   certified = true;
 #endif
@@ -381,33 +406,48 @@ __device__ __forceinline__ int nearest_verified_window(float X, float Y, const f
 __device__ __forceinline__ int nearest_cooperative_fix(float X, float Y, bool certified, int j, const float* abc, int n) {
   unsigned long long pending = __ballot(!certified);
   const int lane = static_cast<int>(__lane_id());
+  constexpr int kNothing = 0x7f800000;   // the ordered pattern of +inf: what a lane without a finite key holds
   while (pending != 0ull) {
     const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(pending)) - 1);
     pending &= pending - 1ull;
     const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(X), src));
     const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Y), src));
-    float best = __builtin_inff();
-    int jj = 0x7fffffff;
-    for (int m = lane; m < n; m += kWave) {
+    int found;
+    if (n <= kWave) {
+      // one waypoint per lane: the smallest key (keys order as their sign-flipped bit patterns), then the first lane
+      // that holds it - a ballot instead of a second reduction
+      const int m = min(lane, n - 1);
       const float d = search_key<float>(px, py, abc[kKeyStride * m], abc[kKeyStride * m + 1], abc[kKeyStride * m + 2]);
-      const bool better = d < best;
-      best = better ? d : best;
-      jj = better ? m : jj;
+      const int bits = __float_as_int(d);
+      const int ordered = (lane < n && d < __builtin_inff()) ? ((bits >= 0) ? bits : (bits ^ 0x7fffffff)) : kNothing;
+      const int least = wave_min_int(ordered);
+      const unsigned long long holders = __ballot(ordered == least);
+      found = (least == kNothing) ? 0 : __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holders)) - 1);
+    } else {
+      float best = __builtin_inff();
+      int jj = 0x7fffffff;
+      for (int m = lane; m < n; m += kWave) {
+        const float d = search_key<float>(px, py, abc[kKeyStride * m], abc[kKeyStride * m + 1], abc[kKeyStride * m + 2]);
+        const bool better = d < best;
+        best = better ? d : best;
+        jj = better ? m : jj;
+      }
+      // first minimum over the lanes: the smallest key (+inf where a lane found nothing), then the lowest index among
+      // the lanes that hold it
+      const int bits = __float_as_int(best);
+      const int ordered = (bits >= 0) ? bits : (bits ^ 0x7fffffff);
+      const int least = wave_min_int(ordered);
+      found = wave_min_int((ordered == least) ? jj : 0x7fffffff);
+      found = (found == 0x7fffffff) ? 0 : found;
     }
-    // first minimum over the lanes: the smallest key (keys order as their sign-flipped bit patterns; +inf where a lane
-    // found nothing), then the lowest index among the lanes that hold it
-    const int bits = __float_as_int(best);
-    const int ordered = (bits >= 0) ? bits : (bits ^ 0x7fffffff);
-    const int least = wave_min_int(ordered);
-    const int found = wave_min_int((ordered == least) ? jj : 0x7fffffff);
-    j = (lane == src) ? ((found == 0x7fffffff) ? 0 : found) : j;
+    j = (lane == src) ? found : j;
   }
   return j;
 }
 
-__device__ __forceinline__ int nearest_verified(float X, float Y, const float* abc, const float* thr, int n, int j_prev) {
+__device__ __forceinline__ int nearest_verified(float X, float Y, const float* abc, const float* frames, int n, int j_prev) {
   bool certified;
-  const int j = nearest_verified_window(X, Y, abc, thr, n, j_prev, certified);
+  const int j = nearest_verified_window(X, Y, abc, frames, n, j_prev, certified);
   return nearest_cooperative_fix(X, Y, certified, j, abc, n);
 }
 
@@ -415,10 +455,10 @@ __device__ __forceinline__ int nearest_verified(float X, float Y, const float* a
 // branch-free and the scheduler can interleave the searches of the candidates a lane owns.
 constexpr int kSearchExhaustive = 0;
 constexpr int kSearchGeneric = -1;   // any window width, rolled loop; 8 and 4 name the unrolled widths
-constexpr int kSearchVerified = -2;  // exhaustive semantics through nearest_verified() (needs the threshold table)
+constexpr int kSearchVerified = -2;  // exhaustive semantics through nearest_verified() (needs the frame table)
 
-__device__ __forceinline__ int search_kind(const Weights& w, int n, bool has_thresholds = false) {
-  if (w.nn_ahead < 0) return (has_thresholds && n >= kVerifiedWindow) ? kSearchVerified : kSearchExhaustive;
+__device__ __forceinline__ int search_kind(const Weights& w, int n, bool has_frames = false) {
+  if (w.nn_ahead < 0) return (has_frames && n >= kVerifiedWindow) ? kSearchVerified : kSearchExhaustive;
   const int W = w.nn_back + w.nn_ahead + 1;
   return ((W == 8 || W == 4) && n >= W) ? W : kSearchGeneric;
 }
@@ -519,19 +559,19 @@ __device__ __forceinline__ void temporal_settle(StateT_<f32x2>& s, const float* 
 
 // The verified search in two phases, so that a kernel can run the window phase of ALL the candidates a lane owns
 // before the (rare, wave-wide) fallback phase and keep the window searches free of control flow.
-__device__ __forceinline__ int verified_window(const StateT& s, const float* abc, const float* thr, int n, int j_prev,
+__device__ __forceinline__ int verified_window(const StateT& s, const float* abc, const float* frames, int n, int j_prev,
                                                int& uncertified) {
   bool ok;
-  const int j = nearest_verified_window(s.X, s.Y, abc, thr, n, j_prev, ok);
+  const int j = nearest_verified_window(s.X, s.Y, abc, frames, n, j_prev, ok);
   uncertified = ok ? 0 : 1;
   return j;
 }
-__device__ __forceinline__ i32x2 verified_window(const StateT_<f32x2>& s, const float* abc, const float* thr, int n,
+__device__ __forceinline__ i32x2 verified_window(const StateT_<f32x2>& s, const float* abc, const float* frames, int n,
                                                  i32x2 j_prev, int& uncertified) {
   bool ok0, ok1;
   i32x2 j;
-  j[0] = nearest_verified_window(s.X[0], s.Y[0], abc, thr, n, j_prev[0], ok0);
-  j[1] = nearest_verified_window(s.X[1], s.Y[1], abc, thr, n, j_prev[1], ok1);
+  j[0] = nearest_verified_window(s.X[0], s.Y[0], abc, frames, n, j_prev[0], ok0);
+  j[1] = nearest_verified_window(s.X[1], s.Y[1], abc, frames, n, j_prev[1], ok1);
   uncertified = (ok0 ? 0 : 1) | (ok1 ? 0 : 2);
   return j;
 }
@@ -549,13 +589,13 @@ __device__ __forceinline__ i32x2 verified_fix(const StateT_<f32x2>& s, const flo
 // search window.
 template <int SEARCH>
 __device__ __forceinline__ int step_temporal_as(StateT& s, const float* wp, const float* abc, int n, float v, float k,
-                                                const Weights& w, int j_prev, const float* thr = nullptr) {
+                                                const Weights& w, int j_prev, const float* frames = nullptr) {
   temporal_advance<float>(s, v, k, w);
   int j;
   if constexpr (SEARCH == kSearchExhaustive) {
     j = temporal_nearest<float>(s, abc, n);
   } else if constexpr (SEARCH == kSearchVerified) {
-    j = nearest_verified(s.X, s.Y, abc, thr, n, j_prev);
+    j = nearest_verified(s.X, s.Y, abc, frames, n, j_prev);
   } else {
     j = temporal_nearest_window<SEARCH>(s.X, s.Y, abc, n, j_prev, w.nn_back, w.nn_ahead);
   }
@@ -565,14 +605,14 @@ __device__ __forceinline__ int step_temporal_as(StateT& s, const float* wp, cons
 
 template <int SEARCH>
 __device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float* wp, const float* abc, int n, f32x2 v,
-                                                  f32x2 k, const Weights& w, i32x2 j_prev, const float* thr = nullptr) {
+                                                  f32x2 k, const Weights& w, i32x2 j_prev, const float* frames = nullptr) {
   temporal_advance<f32x2>(s, v, k, w);
   i32x2 j;
   if constexpr (SEARCH == kSearchExhaustive) {
     j = temporal_nearest<f32x2>(s, abc, n);
   } else if constexpr (SEARCH == kSearchVerified) {
-    j[0] = nearest_verified(s.X[0], s.Y[0], abc, thr, n, j_prev[0]);
-    j[1] = nearest_verified(s.X[1], s.Y[1], abc, thr, n, j_prev[1]);
+    j[0] = nearest_verified(s.X[0], s.Y[0], abc, frames, n, j_prev[0]);
+    j[1] = nearest_verified(s.X[1], s.Y[1], abc, frames, n, j_prev[1]);
   } else {
     j[0] = temporal_nearest_window<SEARCH>(s.X[0], s.Y[0], abc, n, j_prev[0], w.nn_back, w.nn_ahead);
     j[1] = temporal_nearest_window<SEARCH>(s.X[1], s.Y[1], abc, n, j_prev[1], w.nn_back, w.nn_ahead);
@@ -623,8 +663,8 @@ __device__ __forceinline__ int search_temporal_as(float X, float Y, const float*
 
 // run `body(tag)` with tag::value = the launch's search kind (one wave-uniform branch for the whole rollout)
 template <typename Body>
-__device__ __forceinline__ void with_search_kind(const Weights& w, int n, Body&& body, bool has_thresholds = false) {
-  switch (search_kind(w, n, has_thresholds)) {
+__device__ __forceinline__ void with_search_kind(const Weights& w, int n, Body&& body, bool has_frames = false) {
+  switch (search_kind(w, n, has_frames)) {
     case kSearchExhaustive: body(std::integral_constant<int, kSearchExhaustive>{}); break;
     case kSearchVerified: body(std::integral_constant<int, kSearchVerified>{}); break;
     case 8: body(std::integral_constant<int, 8>{}); break;
@@ -763,28 +803,26 @@ constexpr int64_t kKeyMax = INT64_MAX;
 // Wave reductions on the DPP path (row shifts inside the rows of 16 lanes, then row_bcast:15 / :31 across them; the
 // result is lane 63's): six vector instructions per 32-bit reduction where the shuffle forms (ds_bpermute) make six round
 // trips through the LDS crossbar - half a microsecond for a key + a count on a lone wave.  Integers: exact either way.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_move(int identity, int v) {
-  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
-}
+// In place: v = op(v shifted within its row, v) - lanes the shift has no source for keep their value (no bound_ctrl), which
+// is what a scan wants.  Inline assembly because the compiler does not fold update_dpp into the consumer here (it emits
+// v_mov + s_nop + v_mov_dpp + op per stage); the two wait states a DPP read needs after a vector write are spelt out, and
+// one more pair after the last stage for whatever reads the result next (the hazard recogniser does not look in here).
+#define ACMPC_DPP_SCAN(op)                                                         \
+  "s_nop 1\n" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"             \
+  "s_nop 1\n" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"             \
+  "s_nop 1\n" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"             \
+  "s_nop 1\n" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"             \
+  "s_nop 1\n" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"          \
+  "s_nop 1\n" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"          \
+  "s_nop 1"
 
 __device__ __forceinline__ int wave_sum_int(int v) {
-  v += dpp_move<0x111, 0xf>(0, v);   // row_shr:1
-  v += dpp_move<0x112, 0xf>(0, v);   // row_shr:2
-  v += dpp_move<0x114, 0xf>(0, v);   // row_shr:4
-  v += dpp_move<0x118, 0xf>(0, v);   // row_shr:8   -> lane 15 of every row holds the row's sum
-  v += dpp_move<0x142, 0xa>(0, v);   // row_bcast:15 into rows 1 and 3
-  v += dpp_move<0x143, 0xc>(0, v);   // row_bcast:31 into rows 2 and 3
+  asm volatile(ACMPC_DPP_SCAN("v_add_u32_dpp") : "+v"(v));   // lane 63 holds the wave's sum
   return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ int wave_min_int(int v) {
-  v = min(v, dpp_move<0x111, 0xf>(v, v));
-  v = min(v, dpp_move<0x112, 0xf>(v, v));
-  v = min(v, dpp_move<0x114, 0xf>(v, v));
-  v = min(v, dpp_move<0x118, 0xf>(v, v));
-  v = min(v, dpp_move<0x142, 0xa>(v, v));
-  v = min(v, dpp_move<0x143, 0xc>(v, v));
+  asm volatile(ACMPC_DPP_SCAN("v_min_i32_dpp") : "+v"(v));
   return __builtin_amdgcn_readlane(v, 63);
 }
 

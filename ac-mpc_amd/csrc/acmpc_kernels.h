@@ -11,7 +11,7 @@ struct RolloutArgs {
   const float* U;         // control-sample matrix, layout per `layout`
   const float* x0;        // [P][3]
   const float* coef;      // [P][n][stride] packed per-step table
-  const float* nn_thr;    // mode T, exhaustive search: [P][n][16] thresholds of the verified window search, or nullptr
+  const float* nn_frames; // mode T, exhaustive search: [P][verified_frame_floats(n)] frames of the verified window search, or nullptr
   float* costs;           // [P][N] or nullptr
   int64_t* partial_keys;  // [P][blocks_per_problem]
   int* partial_feas;      // [P][blocks_per_problem]

@@ -114,7 +114,8 @@ __device__ __forceinline__ void published() {
 // WAVES = 8 asks for that many waves per SIMD, which caps the allocation at 64 VGPRs.  Measured, 1 M candidates (256 poses
 // x 4 096), same box, 67 VGPRs / capped: verified 16-waypoint search 331 / 283 us, 4-waypoint window 102.5 / 92.8 us -
 // but the 8-waypoint window 134.9 / 141.3 us (its waves already queue for the LDS: an eighth wave per SIMD adds to the
-// queue what it saves on the tail), so the launcher caps every search but that one.
+// queue what it saves on the tail), so the launcher caps every search but that one.  (The verified search, since round 3
+// an 8-waypoint window + its certificate: 190 us capped, 225 us uncapped.)
 template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1), int WAVES = 1>
 __global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -134,12 +135,12 @@ __global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs
   const float* __restrict__ x0 = a.x0 + p * 3;
 
   float* s_xy = s_wp + n * kCoefT;  // the nearest-waypoint search's key table: (a, b, c) per waypoint (search_entry)
-  float* s_thr = s_xy + kKeyStride * n;      // thresholds of the verified search (exhaustive semantics), when given
+  float* s_frames = s_xy + ((kKeyStride * n + 3) & ~3);  // frames of the verified search (exhaustive semantics), when given
   if constexpr (MODE == 1) {
     stage_temporal_tables(coef, n, tid, BLOCK, s_wp, s_xy);
-    if (a.nn_thr != nullptr) {
-      const float* __restrict__ thr = a.nn_thr + static_cast<size_t>(p) * n * kVerifiedWindow;
-      for (int e = tid; e < n * kVerifiedWindow; e += BLOCK) s_thr[e] = thr[e];
+    if (a.nn_frames != nullptr) {
+      const float* __restrict__ frames = a.nn_frames + static_cast<size_t>(p) * verified_frame_floats(n);
+      for (int e = tid; e < verified_frame_floats(n); e += BLOCK) s_frames[e] = frames[e];
     }
     __syncthreads();
   }
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs
 
   // Mode T's verified nearest-waypoint search has a wave-cooperative fallback that every lane must reach, so there
   // the tail lanes of the last workgroup roll a valid dummy (the problem's last candidates) instead of idling.
-  const bool run = active || (MODE == 1 && a.nn_thr != nullptr);
+  const bool run = active || (MODE == 1 && a.nn_frames != nullptr);
   const int c_run = active ? c0 : max(a.N - CPT, 0);
   if (run) {
     constexpr int kPack = PACK;
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs
 #pragma unroll
             for (int g = 0; g < kGroups; ++g) {
               temporal_advance<F>(st[g], pack(v, g), pack(k, g), w);
-              nearest[g] = verified_window(st[g], s_xy, s_thr, n, nearest[g], uncertified[g]);
+              nearest[g] = verified_window(st[g], s_xy, s_frames, n, nearest[g], uncertified[g]);
             }
             int any = 0;
 #pragma unroll
@@ -233,10 +234,10 @@ __global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs
 #pragma unroll
             for (int g = 0; g < kGroups; ++g)
               nearest[g] = step_temporal_as<decltype(kind)::value>(st[g], s_wp, s_xy, n, pack(v, g), pack(k, g), w,
-                                                                   nearest[g], s_thr);
+                                                                   nearest[g], s_frames);
           }
         }
-      }, a.nn_thr != nullptr);
+      }, a.nn_frames != nullptr);
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
         unpack_to(finish_temporal<F>(st[g], n, w), cost, g);
@@ -2143,8 +2144,8 @@ template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1
 hipError_t launch_rollout_t(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s, hipEvent_t e0,
                             hipEvent_t e1) {
   const dim3 grid(shape.blocks_per_problem, args.P);
-  const size_t lds = 64 + (MODE == 1 ? static_cast<size_t>(args.n) * (kCoefT + kKeyStride + (args.nn_thr != nullptr ? kVerifiedWindow : 0)) *
-                                           sizeof(float)
+  const size_t lds = 64 + (MODE == 1 ? (static_cast<size_t>(args.n) * (kCoefT + kKeyStride) + 3 +
+                                        (args.nn_frames != nullptr ? verified_frame_floats(args.n) : 0)) * sizeof(float)
                                      : 0);
   if (e0 != nullptr && e1 != nullptr) {
     hipExtLaunchKernelGGL((rollout_kernel<MODE, LAYOUT, CPT, BLOCK, PACK, WAVES>), grid, dim3(BLOCK),

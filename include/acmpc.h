@@ -311,6 +311,19 @@ int acmpc_unpack_decision_temporal(const double* z, int32_t n, double dt, double
                                    double* prediction, double* cum_time, double* times, double* accelerations,
                                    double* steer_rates);
 
+/* Host side of mode T's verified nearest-waypoint search (exhaustive semantics, localiser.py:282-289: the first minimum
+ * over ALL waypoints), as acmpc_set_paths tabulates it for the kernels: coef = P packed [n][8] waypoint rows
+ * (acmpc_get_coefficients) -> per problem acmpc_search_frame_floats(n) floats: for every window of
+ * acmpc_search_window(NULL) consecutive waypoints [t_x, t_y, k_along, k_across, slab, tube, far, -slack].  The kernel
+ * accepts the window's first minimum j as the global one when
+ *     |fma(Y, Y, fma(X, X, key_j))| < min(fma(across, across, fma(along, along, -slack)), far),
+ * alpha = fma(t_x, X, fma(t_y, Y, k_along)), beta = fma(t_x, Y, fma(-t_y, X, k_across)), along = med3(alpha,
+ * slab - alpha, 0), across = med3(|beta| - tube, 0, 32), and scans the whole path otherwise.  No device work: lets
+ * tests check on the CPU that an accepted index is always the exhaustive one.  n < the window: ACMPC_EINVAL. */
+int32_t acmpc_search_window(int32_t* back);
+int32_t acmpc_search_frame_floats(int32_t n);
+int acmpc_search_frames(const float* coef, int32_t P, int32_t n, float* out, int64_t capacity_floats);
+
 /* The generator itself, on the host (same code as the kernels): lets tests pin the integer stream. */
 void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 

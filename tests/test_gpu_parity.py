@@ -336,6 +336,39 @@ def test_verified_window_search_is_the_exhaustive_search(layout, monkeypatch):
         assert np.abs(np.diff(J, axis=1)).max() > 8
 
 
+@pytest.mark.parametrize("name", ["loop", "spiral", "figure_eight", "random_walk", "stall", "far_from_origin", "fold_2"])
+def test_verified_search_on_paths_that_defeat_its_certificate(name, monkeypatch):
+    """The geometries tests/test_search_frames.py checks the certificate on - paths that close on themselves, cross
+    themselves, stall on one spot, lie kilometres from the origin - rolled on the GPU with candidates that wander:
+    exhaustive semantics through the verified window search = the plain scan of all waypoints = the oracle."""
+    from acmpc_amd import Engine
+    from test_search_frames import _paths
+    H, N = 50, 640
+    n = H - 1
+    prob = make_problem(orc, "monza", H, N, seed=77, sigma=(6.0, 0.05))
+    xy = _paths()[name]
+    assert xy.shape[0] == H
+    table = orc.construct_waypoints(np.column_stack([xy, np.full(H, 9.5)]))
+    table[orc.ROW_V] = prob["table"][orc.ROW_V]
+    heading = np.arctan2(xy[1, 1] - xy[0, 1], xy[1, 0] - xy[0, 0])
+    pose0 = np.array([[xy[0, 0], xy[0, 1], heading]], dtype=np.float32)   # on the path's first waypoint, along it
+    outs = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("ACMPC_NO_VERIFIED_SEARCH", "1")
+        eng = Engine(**engine_kwargs(prob, 1, 1, N, n))
+        eng.set_paths(table[None])
+        outs.append((eng.solve(pose0, _as_layout(prob["U"][None], LAYOUT_SM), layout=LAYOUT_SM), eng.coefficients(0)))
+        eng.close()
+    (out, coef), (out_plain, _) = outs
+    np.testing.assert_array_equal(out["costs"], out_plain["costs"])
+    np.testing.assert_array_equal(out["records"], out_plain["records"])
+    cfg = prob["cfg"]
+    cost = orc.rollout_temporal(pose0[0], coef, prob["U"], cfg["step_cost"], cfg["r_term"], cfg["final_cost"],
+                                prob["u_lo"], prob["u_hi"], 1.0e6, 0.05, dtype=np.float32)[0]
+    np.testing.assert_array_equal(out["costs"][0], cost)
+
+
 def test_every_launch_shape_gives_the_same_bits(monkeypatch):
     """ACMPC_SHAPE forces the workgroup size / candidates per lane; results must not depend on it."""
     H, N, P = 50, 2048, 2
