@@ -227,15 +227,18 @@ void verified_frames(const float* coef, int P, int n, std::vector<float>* out) {
       if (!finite || !(chord > 0.0) || !std::isfinite(chord)) continue;
       // the split: distance from the window to the waypoints more than `near` indices beyond its ends
       auto far_distance = [&](int near) {
-        double R = inf;
+        double R2 = inf;
         for (int m = 0; m < n; ++m) {
           if (m >= lo - near && m <= hi + near) {
             m = hi + near;   // (skip the window and its near neighbourhood)
             continue;
           }
-          for (int q = lo; q <= hi; ++q) R = std::min(R, std::hypot(wx(m) - wx(q), wy(m) - wy(q)));
+          for (int q = lo; q <= hi; ++q) {
+            const double dx = wx(m) - wx(q), dy = wy(m) - wy(q);
+            R2 = std::min(R2, dx * dx + dy * dy);
+          }
         }
-        return R;
+        return std::sqrt(R2) * (1.0 - 1.0e-12);   // (rounded towards the window: the squares and the root round)
       };
       int near = 16;
       f.R = far_distance(near);

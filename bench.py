@@ -477,7 +477,7 @@ def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
     mode T (Cartesian rollout + nearest-waypoint projection; exhaustive and windowed search) and the
     candidate-major layout.  256 poses x N candidates each (1 M candidates per launch: one generation of waves, launch
     ramp and tail included), and - `*_16M` - the two that are furthest from the roofline again at the headline's own
-    batch of 4 096 poses (their steady state)."""
+    batch of 4 096 poses (their steady state), mode T with both searches."""
     n = H - 1
     base = workloads.problem_batch(track, 256, H, seed=0)
     stream = torch.cuda.current_stream().cuda_stream
@@ -485,7 +485,8 @@ def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
     cases = [("mode_S_candidate_major", 0, 0, None, 256), ("mode_T_exhaustive_search", 1, 1, None, 256),
              ("mode_T_window_2_5", 1, 1, (2, 5), 256), ("mode_T_window_1_2", 1, 1, (1, 2), 256),
              ("mode_S_step_major_1M", 0, 1, None, 256),
-             ("mode_T_window_2_5_16M", 1, 1, (2, 5), 4096), ("mode_S_candidate_major_16M", 0, 0, None, 4096)]
+             ("mode_T_window_2_5_16M", 1, 1, (2, 5), 4096), ("mode_T_exhaustive_search_16M", 1, 1, None, 4096),
+             ("mode_S_candidate_major_16M", 0, 0, None, 4096)]
     for name, mode, layout, window, P in cases:
         batch = copy.copy(base)
         reps = P // 256

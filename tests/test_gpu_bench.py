@@ -39,11 +39,13 @@ def test_single_gpu_line_has_the_contract_fields():
     assert cpu["numpy_all_cores"]["cores"] >= 1 and cpu["numpy_all_cores"]["value"] > 0      # SURVEY 8d's second figure
     second = out["secondary_kernels"]
     for name in ("mode_S_candidate_major", "mode_T_exhaustive_search", "mode_T_window_2_5", "mode_T_window_1_2",
-                 "mode_S_step_major_1M", "mode_T_window_2_5_16M", "mode_S_candidate_major_16M"):
+                 "mode_S_step_major_1M", "mode_T_window_2_5_16M", "mode_T_exhaustive_search_16M",
+                 "mode_S_candidate_major_16M"):
         assert 0 < second[name]["frac_of_hbm_roofline"] < 1 and second[name]["kernel_us"] > 0, name
     assert second["mode_S_candidate_major_16M"]["kernel_us"] > 4 * second["mode_S_candidate_major"]["kernel_us"]
     # instruction-bound kernels carry the roof they are under (VALU issue), the fused sampled round at scale too
-    for name in ("mode_T_exhaustive_search", "mode_T_window_2_5", "mode_T_window_1_2", "mode_T_window_2_5_16M"):
+    for name in ("mode_T_exhaustive_search", "mode_T_window_2_5", "mode_T_window_1_2", "mode_T_window_2_5_16M",
+                 "mode_T_exhaustive_search_16M"):
         valu = second[name]["roofline_valu"]
         assert valu["bound"] == "valu" and valu["frac"] > 0 and valu["valu_instructions_per_candidate_step"] > 20
         assert valu["instruction_count_source"].startswith("profiles/")
