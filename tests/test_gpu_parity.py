@@ -369,6 +369,42 @@ def test_verified_search_on_paths_that_defeat_its_certificate(name, monkeypatch)
     np.testing.assert_array_equal(out["costs"][0], cost)
 
 
+@pytest.mark.parametrize("H", [9, 10, 13, 65, 66, 101, 140])
+def test_verified_search_at_other_horizons(H, monkeypatch):
+    """Horizons round the verified search's limits: n = 8 (the window is the whole path), just above it, n = 64 / 65
+    (the wave-wide fallback holds one waypoint per lane up to 64, several beyond), the mapping controller's n = 100 and
+    a longer one - on a path that turns back on itself, so that the fallback is taken."""
+    from acmpc_amd import Engine
+    N = 448
+    n = H - 1
+    prob = make_problem(orc, "monza", H, N, seed=300 + H, sigma=(6.0, 0.05))
+    half = H // 2
+    gap = 5.0
+    up = [(0.0, 2.0 * i) for i in range(half)]
+    down = [(gap, 2.0 * (half - 1) - 2.0 * i) for i in range(H - half)]
+    xy = np.array(up + down)
+    table = orc.construct_waypoints(np.column_stack([xy, np.full(H, 9.5)]))
+    table[orc.ROW_V] = prob["table"][orc.ROW_V]
+    pose0 = np.array([[0.3, 0.0, np.pi / 2]], dtype=np.float32)
+    outs = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("ACMPC_NO_VERIFIED_SEARCH", "1")
+        eng = Engine(**engine_kwargs(prob, 1, 1, N, n))
+        eng.set_paths(table[None])
+        outs.append((eng.solve(pose0, _as_layout(prob["U"][None], LAYOUT_SM), layout=LAYOUT_SM), eng.coefficients(0)))
+        eng.close()
+    (out, coef), (out_plain, _) = outs
+    np.testing.assert_array_equal(out["costs"], out_plain["costs"])
+    np.testing.assert_array_equal(out["records"], out_plain["records"])
+    cfg = prob["cfg"]
+    cost, _, _, J = orc.rollout_temporal(pose0[0], coef, prob["U"], cfg["step_cost"], cfg["r_term"], cfg["final_cost"],
+                                         prob["u_lo"], prob["u_hi"], 1.0e6, 0.05, dtype=np.float32, return_states=True)
+    np.testing.assert_array_equal(out["costs"][0], cost)
+    if H >= 65:
+        assert np.abs(np.diff(J, axis=1)).max() > 4   # rollouts do jump to the return leg
+
+
 def test_every_launch_shape_gives_the_same_bits(monkeypatch):
     """ACMPC_SHAPE forces the workgroup size / candidates per lane; results must not depend on it."""
     H, N, P = 50, 2048, 2

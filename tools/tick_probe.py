@@ -1,5 +1,5 @@
 """Development probe (GPU box): closed-loop get_control latency on consecutive poses (TICK_H = horizon, default 50;
-TICK_MODE = S | T, the controller's rollout_mode)."""
+TICK_MODE = S | T, the controller's rollout_mode; TICK_WINDOW = "back,ahead" or "none" = mode T's nn_window)."""
 import copy, os, sys, time
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -12,6 +12,8 @@ paths = [workloads.reference_path_from_centreline(workloads.local_centreline(tra
 cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"])
 cfg["horizon"] = H
 cfg["rollout_mode"] = os.environ.get("TICK_MODE", "S")
+if "TICK_WINDOW" in os.environ:
+    cfg["nn_window"] = None if os.environ["TICK_WINDOW"] == "none" else tuple(int(v) for v in os.environ["TICK_WINDOW"].split(","))
 if "TICK_CHECK" in os.environ:
     cfg["speed_profile_check_every"] = int(os.environ["TICK_CHECK"])
 cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
