@@ -159,6 +159,7 @@ SIGNATURES = {
     "acmpc_map_reference_path": (C.c_int, [_CTX, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                            C.c_void_p, _I32P]),
     "acmpc_tick_read_device_tables": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acmpc_tick_read_device_frames": (C.c_int, [_CTX, C.c_void_p, C.c_int64]),
     "acmpc_speed_profile_qp_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double,
                                                 C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p,
                                                 C.c_void_p, C.c_int32, _I32P]),
@@ -490,6 +491,12 @@ class Engine:
         coef = np.empty((n, COEF_STRIDE[self.mode]), dtype=np.float32)
         self._check(self._lib.acmpc_tick_read_device_tables(self._ctx, x0.ctypes.data, u_ref.ctypes.data, coef.ctypes.data))
         return x0, u_ref, coef
+
+    def tick_device_frames(self, n: int):
+        """The verified search's frames the last tick's prologue tabulated (mode T, exhaustive search; test hook)."""
+        out = np.empty(self._lib.acmpc_search_frame_floats(n), dtype=np.float32)
+        self._check(self._lib.acmpc_tick_read_device_frames(self._ctx, out.ctypes.data, out.size))
+        return out
 
     def speed_profile_qp_device(self, v_hi, ds, a_min, a_max, v_min, max_iter=4000, eps_abs=1e-3, eps_rel=1e-3,
                                 warm=None, check_every=10):

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/acmpc.h"
+#include "acmpc_frames.h"
 #include "acmpc_kernels.h"
 #include "acmpc_prologue.h"
 
@@ -158,164 +159,40 @@ int fail_hip(const acmpc_ctx* ctx, hipError_t e, const char* what) {
     if (e_ != hipSuccess) return fail_hip((ctx), e_, #call);   \
   } while (0)
 
-// Frames of the verified nearest-waypoint search (acmpc_device.h: nearest_verified_window), from the float32 waypoint
-// positions the kernels use.  For every window position lo (window = waypoints lo .. lo + W - 1) eight floats
-// [t_x, t_y, k_along, k_across, slab, tube, far, -slack] with which the kernel evaluates, at a pose p,
-//     alpha = t . p + k_along     (distance past the plane BEHIND which every near waypoint m < lo lies)
-//     beta  = n . p + k_across    (n = (-t_y, t_x); offset from the middle of the tube that holds every near outside waypoint)
-//     along = med3(alpha, slab - alpha, 0),   across = med3(|beta| - tube, 0, kFrameAcrossMax)
-// and certifies the window's winner j when  |r_j^2 recovered from its key|  <  min(along^2 + across^2 - slack, far).
-//
-// The outside waypoints are split by index: NEAR = within `near` waypoints of the window's ends, FAR = the rest; `near`
-// is the smallest of 16, 24, 32, ... for which the far ones are at least kFarReach from the window (all of them near when
-// none is: a path that comes back to the window).
-//
-// Near waypoints: why the slab-and-tube bound is sound.  t is the float32 direction of the window's chord scaled so that
-// |t| <= 1, and n has the same norm, so for any waypoint w: (t.(w - p))^2 + (n.(w - p))^2 <= |w - p|^2.  Every near
-// waypoint m < lo has t.w <= a_B, every near m >= lo + W has t.w >= a_A (a_B, a_A = the extreme projections, taken here
-// over the same float32 vectors), and every near outside waypoint has |n.w - mid| <= tube; hence |w - p|^2 >= along^2 +
-// across^2 in exact arithmetic.  A side without waypoints (window at an end of the path) gets a virtual plane
-// kFrameVirtualPlane beyond the window: any plane is valid there, a finite one keeps `slab` - and with it the distance of
-// a certified pose from the path - bounded.  Rounding: alpha and beta are two fused multiply-adds each; their error at a
-// certified pose is below `delta` (computed per window from the magnitudes involved); k_along is lowered by delta, slab by
-// 4 delta, tube raised by 3 delta, each rounded outward, so that the kernel's along / across never exceed the exact ones.
-// What remains - the rounding of the two squares, twice the error E_key of a key and the error E_est of the recovered
-// r_j^2 - is `slack`: a certified pose satisfies r_est < D := slab_max^2 + kFrameAcrossMax^2, so |p| <= Lc with Lc found
-// below such that any pose further out has r_est >= D whatever its rounding; every intermediate of a key is then below
-// B = 6 Lc^2 in magnitude, a key off by at most 3 B ulp (two roundings in c, two fused multiply-adds), the recovered r^2
-// by at most 7 B ulp.  (Where keys overflow - poses beyond 1e17 m - the winning key is -inf and so is the recovered
-// r^2: hence its magnitude in the test.)
-//
-// Far waypoints: with R = the smallest distance between a waypoint of the window and a far one, a pose within r of the
-// winner is at least R - r from every far waypoint, whose squared distance therefore exceeds r^2 by R (R - 2 r);
-//     far = ((R - 2 E_key / R) / (2 (1 + 1e-3)))^2 - E_est,   rounded down
-// keeps that gap above twice a key's error (+inf when there is no far waypoint).
-//
-// A window whose chord has no length, or a path with a non-finite waypoint: slab = -1, tube = +inf, far = 0 - never
-// certified.  O(n W) per window and choice of `near`, O(n^2) per path, hence the cap.
+// Frames of mode T's verified nearest-waypoint search for P paths of n packed waypoint rows (acmpc_frames.h has the
+// arithmetic and why it is sound).  O(n^2) per path, hence the cap on n.
 constexpr int kMaxVerifiedSteps = 256;
-constexpr double kFarReach = 50.0;   // [m]: poses up to half of this from the winner are not cut off by the far bound
 
 void verified_frames(const float* coef, int P, int n, std::vector<float>* out) {
   constexpr int W = acmpc::kVerifiedWindow;
   const int windows = n - W + 1;
   const int floats = acmpc::verified_frame_floats(n);
-  const double inf = std::numeric_limits<double>::infinity();
-  const float finf = std::numeric_limits<float>::infinity();
-  const double ulp = std::ldexp(1.0, -24);   // half an ulp of a float32 of magnitude 1: one rounding's relative error
-  const double across_max = acmpc::kFrameAcrossMax, virtual_plane = acmpc::kFrameVirtualPlane;
   out->assign(static_cast<size_t>(P) * floats, 0.0f);
-  struct Frame { double tx, ty, aB, aA, mid, tube, R; bool usable; };
-  std::vector<Frame> frames(static_cast<size_t>(windows));
+  std::vector<acmpc::frames::Geometry> geometry(static_cast<size_t>(windows));
   for (int p = 0; p < P; ++p) {
     const float* t = coef + static_cast<size_t>(p) * n * acmpc::kCoefT;
-    float* table = out->data() + static_cast<size_t>(p) * floats;
-    auto wx = [&](int m) { return static_cast<double>(t[m * acmpc::kCoefT]); };
-    auto wy = [&](int m) { return static_cast<double>(t[m * acmpc::kCoefT + 1]); };
+    auto at = [t](int m, double& x, double& y) {
+      x = static_cast<double>(t[m * acmpc::kCoefT]);
+      y = static_cast<double>(t[m * acmpc::kCoefT + 1]);
+    };
     double wn = 0.0;   // largest norm of a waypoint
     bool finite = true;
     for (int m = 0; m < n; ++m) {
-      finite = finite && std::isfinite(wx(m)) && std::isfinite(wy(m));
-      wn = std::max(wn, std::hypot(wx(m), wy(m)));
+      double x, y;
+      at(m, x, y);
+      finite = finite && std::isfinite(x) && std::isfinite(y);
+      wn = std::max(wn, std::sqrt(x * x + y * y));
     }
     double slab_max = 0.0;
     for (int lo = 0; lo < windows; ++lo) {
-      Frame& f = frames[lo];
-      f.usable = false;
-      const int hi = lo + W - 1;
-      const double cx = wx(hi) - wx(lo), cy = wy(hi) - wy(lo), chord = std::hypot(cx, cy);
-      if (!finite || !(chord > 0.0) || !std::isfinite(chord)) continue;
-      // the split: distance from the window to the waypoints more than `near` indices beyond its ends
-      auto far_distance = [&](int near) {
-        double R2 = inf;
-        for (int m = 0; m < n; ++m) {
-          if (m >= lo - near && m <= hi + near) {
-            m = hi + near;   // (skip the window and its near neighbourhood)
-            continue;
-          }
-          for (int q = lo; q <= hi; ++q) {
-            const double dx = wx(m) - wx(q), dy = wy(m) - wy(q);
-            R2 = std::min(R2, dx * dx + dy * dy);
-          }
-        }
-        return std::sqrt(R2) * (1.0 - 1.0e-12);   // (rounded towards the window: the squares and the root round)
-      };
-      int near = 16;
-      f.R = far_distance(near);
-      while (f.R < kFarReach) {
-        near += 8;
-        f.R = far_distance(near);   // (+inf once nothing is far)
-      }
-      // float32 direction with |t| <= 1: shrunk by more than its two roundings can add
-      f.tx = static_cast<double>(static_cast<float>(cx / chord * (1.0 - 4.0e-7)));
-      f.ty = static_cast<double>(static_cast<float>(cy / chord * (1.0 - 4.0e-7)));
-      double aB = -inf, aA = inf, lowest = inf, highest = -inf, first = inf, last = -inf;
-      bool behind = false, ahead = false;
-      for (int m = std::max(lo - near, 0); m <= std::min(hi + near, n - 1); ++m) {
-        const double a = f.tx * wx(m) + f.ty * wy(m), b = -f.ty * wx(m) + f.tx * wy(m);
-        if (m < lo) {
-          aB = std::max(aB, a);
-          behind = true;
-        }
-        if (m > hi) {
-          aA = std::min(aA, a);
-          ahead = true;
-        }
-        if (m < lo || m > hi) {
-          lowest = std::min(lowest, b);
-          highest = std::max(highest, b);
-        } else {
-          first = std::min(first, a);
-          last = std::max(last, a);
-        }
-      }
-      if (!behind) aB = first - virtual_plane;
-      if (!ahead) aA = last + virtual_plane;
-      if (!behind && !ahead) lowest = highest = 0.0;   // no near outside waypoint at all: any tube will do
-      f.aB = aB;
-      f.aA = aA;
-      f.mid = 0.5 * (lowest + highest);
-      f.tube = 0.5 * (highest - lowest);
-      f.usable = aA > aB;
-      if (f.usable) slab_max = std::max(slab_max, aA - aB);
+      double R = finite ? acmpc::frames::far_distance(at, n, lo, acmpc::frames::kNearFirst) : 0.0;
+      const int near = finite ? acmpc::frames::choose_near(at, n, lo, R) : acmpc::frames::kNearFirst;
+      geometry[lo] = acmpc::frames::window_geometry<0>(at, n, lo, finite, near, R);
+      if (geometry[lo].usable) slab_max = std::max(slab_max, geometry[lo].aA - geometry[lo].aB);
     }
-    // how far out a certified pose can be: r_est < D, and beyond Lc the recovered r^2 is at least D whatever it rounds to
-    const double D = slab_max * slab_max + across_max * across_max;
-    double Lc = wn + 1.01 * std::sqrt(D) + 1.0;
-    while (!((Lc - wn) * (Lc - wn) - 42.0 * ulp * (Lc + wn) * (Lc + wn) >= 1.01 * D) && Lc < 1.0e12) Lc *= 1.5;
-    const double B = 6.0 * Lc * Lc;
-    const double e_key = 3.0 * B * ulp, e_est = 7.0 * B * ulp;
-    const double slack = 1.01 * (2.0 * e_key + e_est + 8.0 * ulp * D);
-    for (int lo = 0; lo < windows; ++lo) {
-      const Frame& f = frames[lo];
-      float* row = table + acmpc::kFrameStride * lo;
-      row[0] = row[1] = row[2] = row[3] = 0.0f;
-      row[4] = -1.0f;
-      row[5] = finf;
-      row[6] = 0.0f;
-      row[7] = -std::nextafter(static_cast<float>(slack), finf);
-      if (!f.usable || !(Lc < 1.0e12)) continue;
-      // |alpha|, |beta| evaluated at |X|, |Y| <= Lc: each of the two fused multiply-adds rounds a value below
-      // 2 Lc + |k|; the subtraction that follows (slab - alpha, |beta| - tube) one below 2 Lc + |k| + slab + tube
-      const double k_along = -f.aB, k_across = -f.mid;
-      const double delta = ulp * (8.0 * Lc + 4.0 * (std::fabs(k_along) + std::fabs(k_across)) + 2.0 * ((f.aA - f.aB) + f.tube));
-      const double slab = (f.aA - f.aB) - 4.0 * delta;
-      if (!(slab > 0.0)) continue;
-      float far = finf;
-      if (!std::isinf(f.R)) {
-        const double rho = (f.R - 2.0 * e_key / f.R) / (2.0 * (1.0 + 1.0e-3));
-        const double bound = rho * rho - e_est;
-        if (!(f.R > 0.0) || !(rho > 0.0) || !(bound > 0.0) || !std::isfinite(bound)) continue;
-        far = std::nextafter(static_cast<float>(bound), -finf);
-      }
-      row[0] = static_cast<float>(f.tx);
-      row[1] = static_cast<float>(f.ty);
-      row[2] = std::nextafter(static_cast<float>(k_along - delta), -finf);
-      row[3] = static_cast<float>(k_across);
-      row[4] = std::nextafter(static_cast<float>(slab), -finf);
-      row[5] = std::nextafter(static_cast<float>(f.tube + 3.0 * delta), finf);
-      row[6] = far;
-    }
+    const acmpc::frames::Scale scale = acmpc::frames::path_scale(wn, slab_max);
+    float* table = out->data() + static_cast<size_t>(p) * floats;
+    for (int lo = 0; lo < windows; ++lo) acmpc::frames::frame_row(geometry[lo], scale, table + acmpc::kFrameStride * lo);
   }
 }
 
@@ -976,7 +853,11 @@ struct OptInputs {
   const float* centre;
   const float* uref;  // or nullptr
   const float* coef;
+  const float* frames = nullptr;  // mode T, exhaustive search: the verified search's frames of these paths, or nullptr
 };
+
+// the handle's own frames (acmpc_set_paths), for the rounds that read the handle's own table
+const float* own_frames(const acmpc_ctx* c) { return c->h_nn_frames.empty() ? nullptr : c->d_nn_frames; }
 
 bool use_fused_finalize(const acmpc_ctx* c, int n) {
   return std::getenv("ACMPC_NO_FUSED_FINALIZE") == nullptr && acmpc::fused_finalize_fits(c->prm.mode, n);
@@ -1056,6 +937,7 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     acmpc::RolloutArgs ra{};
     ra.x0 = in.x0;
     ra.coef = in.coef;
+    ra.nn_frames = (std::getenv("ACMPC_NO_VERIFIED_SEARCH") == nullptr) ? in.frames : nullptr;
     ra.partial_keys = c->d_partial_keys + set * c->partial_slots;
     ra.partial_feas = c->d_partial_feas + set * c->partial_slots;
     ra.P = P;
@@ -1138,7 +1020,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, x0_bytes, hipMemcpyHostToDevice, s));
     ACMPC_HIP(c, hipMemcpyAsync(c->d_centre, centre, path_bytes, hipMemcpyHostToDevice, s));
     if (has_uref) ACMPC_HIP(c, hipMemcpyAsync(c->d_uref, u_ref, path_bytes, hipMemcpyHostToDevice, s));
-    const OptInputs in{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef};
+    const OptInputs in{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef, own_frames(c)};
     rc = enqueue_rounds(c, in, P, N, n, rounds, sigma[0], sigma[1], shrink, seed, nullptr, s,
                         std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr && c->prm.centre_update == 0);
     if (rc != ACMPC_OK) return rc;
@@ -1194,7 +1076,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     const bool fused = std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr && c->prm.centre_update == 0;
     OptInputs in{reinterpret_cast<const float*>(c->d_opt + off_x0), reinterpret_cast<const float*>(c->d_opt + off_centre),
                  has_uref ? reinterpret_cast<const float*>(c->d_opt + off_uref) : nullptr,
-                 reinterpret_cast<const float*>(c->d_opt + off_table)};
+                 reinterpret_cast<const float*>(c->d_opt + off_table), own_frames(c)};
     if (!fused) {  // the three-kernel form runs on the handle's own buffers: copy the block's parts there
       auto spread = [&](void* dst, size_t off, size_t bytes) {
         if (e == hipSuccess) e = hipMemcpyAsync(dst, c->d_opt + off, bytes, hipMemcpyDeviceToDevice, s);
@@ -1203,7 +1085,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
       spread(c->d_centre, off_centre, path_bytes);
       if (has_uref) spread(c->d_uref, off_uref, path_bytes);
       spread(c->d_coef, off_table, table_bytes);
-      in = OptInputs{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef};
+      in = OptInputs{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef, own_frames(c)};
     }
     int rc_rounds = ACMPC_OK;
     // with the fused finalize the last round writes the winners straight into the pinned host buffer (posted
@@ -1256,7 +1138,7 @@ size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 // device block the prologue fills for the rollout kernels (seed | x0 | centre | u_ref | table)
 struct TickLayout {
   size_t coords, centre_in, host_total;            // pinned host block
-  size_t seed, x0, centre, uref, coef, total;      // device block
+  size_t seed, x0, centre, uref, coef, frames, total;   // device block
   explicit TickLayout(int n, int coef_stride = ACMPC_COEF_STRIDE_SPATIAL) {
     coords = align16(sizeof(acmpc::TickHeader));
     centre_in = align16(coords + static_cast<size_t>(n + 1) * 3 * sizeof(double));
@@ -1266,7 +1148,8 @@ struct TickLayout {
     centre = 32;
     uref = align16(centre + static_cast<size_t>(n) * 2 * sizeof(float));
     coef = align16(uref + static_cast<size_t>(n) * 2 * sizeof(float));
-    total = align16(coef + static_cast<size_t>(n) * coef_stride * sizeof(float));
+    frames = align16(coef + static_cast<size_t>(n) * coef_stride * sizeof(float));   // (mode T, exhaustive search)
+    total = align16(frames + static_cast<size_t>(acmpc::verified_frame_floats(std::max(n, acmpc::kVerifiedWindow))) * sizeof(float));
   }
 };
 
@@ -1398,6 +1281,8 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   pa.x0 = reinterpret_cast<float*>(c->d_tick + in.x0);
   pa.u_ref = reinterpret_cast<float*>(c->d_tick + in.uref);
   pa.coef = reinterpret_cast<float*>(c->d_tick + in.coef);
+  pa.frames = (temporal && c->prm.nn_ahead < 0 && n >= acmpc::kVerifiedWindow) ? reinterpret_cast<float*>(c->d_tick + in.frames)
+                                                                              : nullptr;
   pa.centre = reinterpret_cast<float*>(c->d_tick + in.centre);
   pa.seed = reinterpret_cast<uint32_t*>(c->d_tick + in.seed);
   pa.table_out = reinterpret_cast<double*>(c->h_tick_out + out.table);
@@ -1425,7 +1310,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     hipError_t e = (from_map && t->map_index < 0) ? acmpc::launch_map_window(ma, q) : hipSuccess;
     if (e == hipSuccess) e = acmpc::launch_prologue(pa, n, q);
     if (e != hipSuccess) return e;
-    const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef};
+    const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef, pa.frames};
     // (launched directly the rounds take the seed by value: read from the device block, as a replayed graph must, it is
     // a dependent load in front of every round's first Philox draw)
     *rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink,
@@ -1640,6 +1525,20 @@ int acmpc_tick_read_device_tables(acmpc_ctx* c, float* x0, float* u_ref, float* 
   ACMPC_HIP(c, hipMemcpy(u_ref, c->d_tick + in.uref, static_cast<size_t>(n) * 2 * sizeof(float), hipMemcpyDeviceToHost));
   ACMPC_HIP(c, hipMemcpy(coef, c->d_tick + in.coef, static_cast<size_t>(n) * c->coef_stride * sizeof(float),
                          hipMemcpyDeviceToHost));
+  return ACMPC_OK;
+}
+
+int acmpc_tick_read_device_frames(acmpc_ctx* c, float* out, int64_t capacity_floats) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (out == nullptr) return fail(c, ACMPC_EINVAL, "null output");
+  if (!c->tick_ready || c->tick_last_n == 0) return fail(c, ACMPC_ESTATE, "acmpc_control_tick has not run");
+  const int n = c->tick_last_n;
+  if (c->prm.mode != ACMPC_MODE_TEMPORAL || c->prm.nn_ahead >= 0 || n < acmpc::kVerifiedWindow)
+    return fail(c, ACMPC_ESTATE, "the last tick had no verified search (mode T with the exhaustive search, n >= the window)");
+  const int floats = acmpc::verified_frame_floats(n);
+  if (capacity_floats < floats) return fail(c, ACMPC_ECAPACITY, "output buffer too small");
+  const TickLayout in(n, c->coef_stride);
+  ACMPC_HIP(c, hipMemcpy(out, c->d_tick + in.frames, static_cast<size_t>(floats) * sizeof(float), hipMemcpyDeviceToHost));
   return ACMPC_OK;
 }
 

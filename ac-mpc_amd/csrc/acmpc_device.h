@@ -11,18 +11,13 @@
 
 #include <type_traits>
 
+#include "acmpc_frames.h"
+
 #pragma clang fp contract(off)
 
 namespace acmpc {
 
 constexpr int kWave = 64;
-
-// window of mode T's verified nearest-waypoint search (exhaustive semantics): waypoints searched per step and how many
-// of them lie behind the previous step's nearest one (A/B builds: ACMPC_HIPCC_EXTRA="-DACMPC_VERIFIED_WINDOW=16 ...")
-#ifndef ACMPC_VERIFIED_WINDOW
-#define ACMPC_VERIFIED_WINDOW 8
-#define ACMPC_VERIFIED_BACK 3
-#endif
 
 __device__ __forceinline__ int wave_min_int(int v);
 __device__ __forceinline__ int wave_sum_int(int v);
@@ -369,20 +364,10 @@ __device__ __forceinline__ int nearest_in_window(float X, float Y, const float* 
 // recovered distance and of the frame arithmetic.  Otherwise (a path that folds back on itself, a non-finite position)
 // all waypoints are scanned - by the whole wave, see nearest_cooperative_fix().  Either way the index is exactly the
 // exhaustive one, bit for bit.
-constexpr int kVerifiedWindow = ACMPC_VERIFIED_WINDOW;
-constexpr int kVerifiedBack = ACMPC_VERIFIED_BACK;
-// the table of one problem, per window position: [t_x, t_y, k_along, k_across | slab, tube, far, -slack] (two 16-byte reads)
-constexpr int kFrameStride = 8;
-constexpr float kFrameAcrossMax = 32.0f;     // [m] cap of `across`: bounds how far from the path a certified pose can be
-constexpr float kFrameVirtualPlane = 32.0f;  // [m] where the plane of an EMPTY side (window at the path's end) is put
-__host__ __device__ constexpr int verified_frame_floats(int n) { return kFrameStride * (n - kVerifiedWindow + 1); }
+// (kVerifiedWindow, kVerifiedBack, the frame's layout and the host / prologue side of the table: acmpc_frames.h)
 
-// The window part: index of the window's first minimum and whether the frame test certifies it as global.
-__device__ __forceinline__ int nearest_verified_window(float X, float Y, const float* abc, const float* frames, int n,
-                                                       int j_prev, bool& certified) {
-  const int lo = max(min(j_prev - kVerifiedBack, n - kVerifiedWindow), 0);
-  float best;
-  const int j = nearest_in_window<kVerifiedWindow>(X, Y, abc, lo, &best);
+// The frame test for the window that starts at `lo`: is the first minimum `best` (a key) of that window the global one?
+__device__ __forceinline__ bool frame_certifies(float X, float Y, float best, const float* frames, int lo) {
   const f32x4* f = reinterpret_cast<const f32x4*>(frames) + (kFrameStride / 4) * lo;   // (16-byte aligned)
   const f32x4 t = f[0], ext = f[1];
   const float alpha = fma_(t[0], X, fma_(t[1], Y, t[2]));    // along the chord, from the plane behind the window
@@ -391,10 +376,19 @@ __device__ __forceinline__ int nearest_verified_window(float X, float Y, const f
   const float across = __builtin_amdgcn_fmed3f(__builtin_fabsf(beta) - ext[1], 0.0f, kFrameAcrossMax);
   const float bound = __builtin_fminf(fma_(across, across, fma_(along, along, ext[3])), ext[2]);
   // (the magnitude: a pose so far out that its keys overflow to -inf must not pass - and costs nothing, a source modifier)
-  certified = __builtin_fabsf(distance2_of_key(X, Y, best)) < bound;
 #ifdef ACMPC_DEBUG_ALWAYS_CERTIFIED   // (timing experiment only: what the kernel costs without its fallback; WRONG results)
-  certified = true;
+  return true;
 #endif
+  return __builtin_fabsf(distance2_of_key(X, Y, best)) < bound;
+}
+
+// The window part: index of the window's first minimum and whether the frame test certifies it as global.
+__device__ __forceinline__ int nearest_verified_window(float X, float Y, const float* abc, const float* frames, int n,
+                                                       int j_prev, bool& certified) {
+  const int lo = max(min(j_prev - kVerifiedBack, n - kVerifiedWindow), 0);
+  float best;
+  const int j = nearest_in_window<kVerifiedWindow>(X, Y, abc, lo, &best);
+  certified = frame_certifies(X, Y, best, frames, lo);
   return j;
 }
 
@@ -633,29 +627,44 @@ __device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float
 // every instruction costs the same ~2 ns, scalar ones included, so the unrolled windows use the plain `d < best` chain
 // (three vector instructions per waypoint) instead of nearest_in_window's min chain + equality masks, whose ~30 scalar
 // mask operations are free only where other waves fill the gaps.  The same first minimum either way.
+template <int W>
+__device__ __forceinline__ int nearest_in_window_chain(float X, float Y, const float* abc, int lo, float& best) {
+  const float* first = abc + kKeyStride * lo;
+  float d[W];
+#pragma unroll
+  for (int m = 0; m < W; ++m)
+    d[m] = search_key<float>(X, Y, first[kKeyStride * m], first[kKeyStride * m + 1], first[kKeyStride * m + 2]);
+  best = __builtin_inff();
+  int j = lo;
+#pragma unroll
+  for (int m = 0; m < W; ++m) {
+    const bool better = d[m] < best;
+    best = better ? d[m] : best;
+    j = better ? lo + m : j;
+  }
+  return j;
+}
+
+// (kSearchVerified: exhaustive semantics through the frames of the verified window search - must be reached by every lane
+// of the wave, like nearest_verified(); without frames it is the scan of all waypoints)
 template <int SEARCH>
-__device__ __forceinline__ int search_temporal_as(float X, float Y, const float* abc, int n, const Weights& w, int j_prev) {
-  if constexpr (SEARCH == kSearchExhaustive || SEARCH == kSearchVerified) {
+__device__ __forceinline__ int search_temporal_as(float X, float Y, const float* abc, int n, const Weights& w, int j_prev,
+                                                  const float* frames = nullptr) {
+  if constexpr (SEARCH == kSearchVerified) {
+    const int lo = max(min(j_prev - kVerifiedBack, n - kVerifiedWindow), 0);
+    float best;
+    const int j = nearest_in_window_chain<kVerifiedWindow>(X, Y, abc, lo, best);
+    // (all-NaN keys: `best` stays +inf, the recovered distance is not below any bound: the scan decides, as it must)
+    return nearest_cooperative_fix(X, Y, frame_certifies(X, Y, best, frames, lo), j, abc, n);
+  } else if constexpr (SEARCH == kSearchExhaustive) {
     StateT probe{};
     probe.X = X;
     probe.Y = Y;
     return temporal_nearest<float>(probe, abc, n);
   } else if constexpr (SEARCH > 0) {
     const int lo = max(min(j_prev - w.nn_back, n - SEARCH), 0);
-    const float* first = abc + kKeyStride * lo;
-    float d[SEARCH];
-#pragma unroll
-    for (int m = 0; m < SEARCH; ++m)
-      d[m] = search_key<float>(X, Y, first[kKeyStride * m], first[kKeyStride * m + 1], first[kKeyStride * m + 2]);
-    float best = __builtin_inff();
-    int j = lo;
-#pragma unroll
-    for (int m = 0; m < SEARCH; ++m) {
-      const bool better = d[m] < best;
-      best = better ? d[m] : best;
-      j = better ? lo + m : j;
-    }
-    return j;
+    float best;
+    return nearest_in_window_chain<SEARCH>(X, Y, abc, lo, best);
   } else {
     return temporal_nearest_window<SEARCH>(X, Y, abc, n, j_prev, w.nn_back, w.nn_ahead);
   }

@@ -1706,6 +1706,11 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
 
   // ---- the other two waves put the waypoint tables into LDS (the pose wave does not read them) ----
   stage_temporal_tables(coef, n, static_cast<int>(threadIdx.x), 2 * kWave, s_wp, s_abc);
+  float* s_frames = s_wp + ((n * (kCoefT + kKeyStride) + 3) & ~3);   // exhaustive search: its frames, when given
+  if (a.nn_frames != nullptr) {
+    const float* __restrict__ frames = a.nn_frames + static_cast<size_t>(p) * verified_frame_floats(n);
+    for (int e = static_cast<int>(threadIdx.x); e < verified_frame_floats(n); e += 2 * kWave) s_frames[e] = frames[e];
+  }
   if (wave == 1) {
     // ---- search: one chunk behind the poses ----
     int j_prev = 0;
@@ -1724,13 +1729,13 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
 #pragma unroll
         for (int q = 0; q < kTrioChunk; ++q) {
           if (first + q < n) {   // (wave-uniform)
-            j_prev = search_temporal_as<decltype(kind)::value>(X[q], Y[q], s_abc, n, w, j_prev);
+            j_prev = search_temporal_as<decltype(kind)::value>(X[q], Y[q], s_abc, n, w, j_prev, s_frames);
             s_index[(first + q) * kWave + lane] = j_prev;
           }
         }
         __syncthreads();   // chunk t - 1 searched (and, while t < chunks, chunk t of the poses is in)
       }
-    });
+    }, a.nn_frames != nullptr);
     return;
   }
 
@@ -2557,7 +2562,8 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
   }
   if (mode == 1 && traced && std::getenv("ACMPC_NO_TRIO_ROUNDS") == nullptr) {
     // three waves per workgroup: tables | trace | uniform operands (centre, reference, weights) | nearest indices
-    const size_t tables = (static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3);
+    const size_t tables = ((static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3)) +
+                          (rollout.nn_frames != nullptr ? static_cast<size_t>(verified_frame_floats(n)) : 0);
     const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
     const size_t uniform = (static_cast<size_t>(n) * 5 + 4 + 3) & ~static_cast<size_t>(3);
     const size_t index = static_cast<size_t>(n) * kWave;

@@ -55,6 +55,8 @@ struct PrologueArgs {
   float* u_ref;               // [n][2]     out: reference controls clipped to the input box
   float* coef;                // [n][12]    out: packed mode-S table (mode T: [n][8] = x, y, cos psi, sin psi, psi,
                               //            kappa, v, width / 2 - margin, as acmpc_set_paths packs it)
+  float* frames;              // mode T, exhaustive search: [verified_frame_floats(n)] out, frames of the verified window
+                              //            search (acmpc_frames.h); nullptr otherwise
   float* centre;              // [n][2]     out: the sequence round 0 samples round (centre_in or u_ref)
   uint32_t* seed;             // [2]        out: Philox key of this solve (the rollout kernels' seed_ptr)
   double* table_out;          // [7][n]     out, pinned host memory

@@ -18,7 +18,10 @@
 // float64 bit; everything else (+, -, *, /, sqrt, fmod, comparisons) is IEEE-exact on both sides.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "acmpc_admm.h"
+#include "acmpc_frames.h"
 #include "acmpc_prologue.h"
 
 #pragma clang fp contract(off)
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   const TickHeader h = (a.header_by_value != 0) ? a.header_value : *a.header;
   ACMPC_PSTAMP(0);
   const int lane = static_cast<int>(threadIdx.x);
-  const int H = h.horizon;
+  const int H = __builtin_amdgcn_readfirstlane(h.horizon);   // (wave-uniform: loop bounds on the scalar unit)
   const int n = H - 1;
   const int m = n - 1;
   // LDS: table [7][n] | v_hi [n] | psi_seg [n + 1] (heading of every segment incl. the closing one) | v [n] |
@@ -293,6 +296,147 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     // a solve without a previous plan samples round the reference controls
     a.centre[2 * i] = (h.centre_is_reference != 0) ? static_cast<float>(uv) : centre_in_v[q];
     a.centre[2 * i + 1] = (h.centre_is_reference != 0) ? static_cast<float>(uk) : centre_in_k[q];
+  }
+  // ---- mode T with the exhaustive nearest-waypoint search: the frames of its verified window search (acmpc_frames.h, the
+  // arithmetic acmpc_set_paths runs on the host), one or two windows per lane, from the float32 positions just written ----
+  if (a.frames != nullptr && n >= kVerifiedWindow) {
+    constexpr int W = kVerifiedWindow;
+    const int windows = n - W + 1;
+    const double inf = __builtin_huge_val();
+    // LDS the solver is done with: the positions as the rollout sees them (float32, widened), and [n][W] gap minima (floats)
+    double* xr = v_hi;
+    double* yr = seg;
+    double* gap_doubles = qy + 2 * n;   // (the ADMM workspace: 8 n + 8 doubles)
+    team.sync();
+    for (int i = lane; i < n; i += 64) {
+      xr[i] = static_cast<double>(static_cast<float>(tx[i]));
+      yr[i] = static_cast<double>(static_cast<float>(ty[i]));
+    }
+    team.sync();
+    auto at = [&](int mm, double& x, double& y) {
+      x = xr[mm];
+      y = yr[mm];
+    };
+    double wn = 0.0;
+    bool finite = true;
+    for (int i = lane; i < n; i += 64) {
+      const double x = xr[i], y = yr[i];
+      finite = finite && (fabs(x) < inf) && (fabs(y) < inf);
+      const double norm = sqrt(x * x + y * y);
+      wn = (norm > wn) ? norm : wn;
+    }
+    wn = team.max(wn, nullptr);
+    finite = __ballot(!finite) == 0ull;
+    // The far split for near = kNearFirst, every window at once.  far_distance() walks (far waypoint, window waypoint)
+    // pairs window by window - up to 200 per window, on one lane.  Turned round: waypoint q = lo + j of a window needs the
+    // nearest waypoint m >= q + near + W - j ahead and m <= q - near - 1 - j behind, j = 0 .. W - 1; the lane that holds
+    // waypoint q finds those 2 W minima in one sweep over the path (n pairs), and a window's R^2 is the minimum over its
+    // W waypoints' entries.  The same pairs through the same squared_gap(): the same minimum, whatever the order.  The
+    // sweep's index is wave-uniform, so waypoint m comes out of its lane's registers (v_readlane), not out of LDS: this is
+    // one wavefront, and every LDS round trip it cannot overlap it waits for.
+    constexpr int kSlots = (kPrologueMaxSteps + 63) / 64;   // waypoints (and windows) per lane
+    const int slots = (n + 63) / 64;                         // (wave-uniform)
+    float own_x[kSlots], own_y[kSlots];
+#pragma unroll
+    for (int r = 0; r < kSlots; ++r) {
+      const int q = min(lane + 64 * r, n - 1);
+      own_x[r] = static_cast<float>(xr[q]);
+      own_y[r] = static_cast<float>(yr[q]);
+    }
+    auto lane_value = [](float v, int src) {   // v of lane `src` (wave-uniform)
+      return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+    };
+    auto waypoint = [&](int mm, float& x, float& y) {   // mm wave-uniform
+      const int src = mm & 63;
+      x = lane_value((mm < 64) ? own_x[0] : own_x[kSlots - 1], src);
+      y = lane_value((mm < 64) ? own_y[0] : own_y[kSlots - 1], src);
+    };
+    static_assert(kSlots <= 2, "waypoint(): two slots per lane");
+    float* gap = reinterpret_cast<float*>(gap_doubles);   // [n][W] minima of one sweep, + one slot nobody reads
+    const int nowhere = n * W;
+    const float finf = __builtin_inff();
+    float r2[kSlots];
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) r2[q] = finf;
+    // (no branch inside a sweep: a lone wavefront pays tens of cycles for each; what does not apply is stored `nowhere`)
+    auto sweep = [&](auto slots_tag, auto pass_tag) {
+      constexpr int kLive = decltype(slots_tag)::value;   // slots in use: 1 up to 64 waypoints, 2 beyond
+      constexpr bool kAhead = decltype(pass_tag)::value == 0;
+      float running[kLive];
+#pragma unroll
+      for (int r = 0; r < kLive; ++r) running[r] = finf;
+      const int count = n - 1 - frames::kNearFirst;
+      for (int it = 0, mm = kAhead ? n - 1 : 0; it < count; ++it, mm += kAhead ? -1 : 1) {
+        float xm, ym;
+        waypoint(mm, xm, ym);
+#pragma unroll
+        for (int r = 0; r < kLive; ++r) {
+          const int q = lane + 64 * r;
+          // ahead: m > q + near, entry j = q + near + W - m (< W);  behind: m < q - near, entry j = q - near - 1 - m (>= 0)
+          const int j = kAhead ? q + frames::kNearFirst + W - mm : q - frames::kNearFirst - 1 - mm;
+          const int applies = static_cast<int>(q < n) & static_cast<int>(kAhead ? mm > q + frames::kNearFirst
+                                                                                : mm < q - frames::kNearFirst);
+          const float d2 = frames::squared_gap(xm, ym, own_x[r], own_y[r]);
+          running[r] = ((applies & static_cast<int>(d2 < running[r])) != 0) ? d2 : running[r];
+          const int kept = applies & static_cast<int>(j >= 0) & static_cast<int>(j < W);
+          gap[(kept != 0) ? q * W + j : nowhere] = running[r];
+        }
+      }
+    };
+    auto sweep_either = [&](auto pass_tag) {
+      if (slots == 1) {
+        sweep(std::integral_constant<int, 1>{}, pass_tag);
+      } else {
+        sweep(std::integral_constant<int, kSlots>{}, pass_tag);
+      }
+    };
+    for (int pass = 0; pass < 2; ++pass) {   // 0: the waypoints ahead, 1: those behind (one [n][W] buffer for both)
+      for (int e = lane; e < n * W; e += 64) gap[e] = finf;
+      team.sync();
+      if (pass == 0) {
+        sweep_either(std::integral_constant<int, 0>{});
+      } else {
+        sweep_either(std::integral_constant<int, 1>{});
+      }
+      team.sync();
+#pragma unroll
+      for (int q = 0; q < kSlots; ++q) {
+        const int lo = lane + 64 * q;
+        if (lo < windows) {
+          float g[W];
+#pragma unroll
+          for (int j = 0; j < W; ++j) g[j] = gap[(lo + j) * W + j];
+#pragma unroll
+          for (int j = 0; j < W; ++j) r2[q] = (g[j] < r2[q]) ? g[j] : r2[q];
+        }
+      }
+      team.sync();
+    }
+    frames::Geometry geometry[kSlots];
+    double slab_max = 0.0;
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      const int lo = lane + 64 * q;
+      geometry[q].usable = false;
+      const bool mine = lo < windows;
+      double R = (mine && finite) ? frames::far_from_squared(r2[q]) : inf;
+      const int near = (mine && finite) ? frames::choose_near(at, n, lo, R) : frames::kNearFirst;
+      // (the usual case - every window's first choice of `near` stands - takes the unrolled form)
+      if (__ballot(mine && near != frames::kNearFirst) == 0ull) {
+        if (mine) geometry[q] = frames::window_geometry<frames::kNearFirst>(at, n, lo, finite, near, R);
+      } else if (mine) {
+        geometry[q] = frames::window_geometry<0>(at, n, lo, finite, near, R);
+      }
+      const double slab = geometry[q].aA - geometry[q].aB;
+      if (mine && geometry[q].usable) slab_max = (slab > slab_max) ? slab : slab_max;
+    }
+    slab_max = team.max(slab_max, nullptr);
+    const frames::Scale scale = frames::path_scale(wn, slab_max);
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      const int lo = lane + 64 * q;
+      if (lo < windows) frames::frame_row(geometry[q], scale, a.frames + static_cast<size_t>(kFrameStride) * lo);
+    }
   }
   ACMPC_PSTAMP(6);
   // the 7 x n table for the caller (pinned host memory: posted writes, visible once the stream has drained)

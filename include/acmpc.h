@@ -281,9 +281,13 @@ int acmpc_control_tick(acmpc_ctx* ctx, const acmpc_tick* tick, const double* coo
 /* Test hooks of the tick path.  acmpc_tick_read_device_tables copies what the last tick's prologue left on the device
  * for the rollout - x0 [3], u_ref [n][2], the packed table [n][ACMPC_COEF_STRIDE_SPATIAL or _TEMPORAL, by the handle's
  * mode] - back to the host.
+ * acmpc_tick_read_device_frames: the frames of the verified nearest-waypoint search the prologue tabulated for that
+ * table (mode T handles with the exhaustive search; acmpc_search_frame_floats(n) floats) - the same arithmetic as
+ * acmpc_search_frames, run by the prologue's lanes.
  * acmpc_speed_profile_qp_device runs the prologue's ADMM alone on the GPU (host pointers, blocking): same arguments
  * and, bit for bit, the same results as acmpc_speed_profile_qp. */
 int acmpc_tick_read_device_tables(acmpc_ctx* ctx, float* x0, float* u_ref, float* coef);
+int acmpc_tick_read_device_frames(acmpc_ctx* ctx, float* out, int64_t capacity_floats);
 int acmpc_speed_profile_qp_device(acmpc_ctx* ctx, const double* v_hi, const double* ds, int32_t n, double a_min,
                                   double a_max, double v_min, int32_t max_iter, int32_t check_every, double eps_abs,
                                   double eps_rel, double* v, double* y, int32_t warm_start, int32_t* iterations);

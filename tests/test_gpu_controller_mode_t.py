@@ -161,7 +161,8 @@ def test_mode_t_tick_forms_agree(monkeypatch):
     for nn_window in ((2, 5), None, (3, 6)):      # the unrolled 8-waypoint window, every waypoint, a generic width
         reference = run(nn_window)
         for switches in (("ACMPC_NO_TRIO_ROUNDS",), ("ACMPC_NO_TRIO_ROUNDS", "ACMPC_NO_CHAINED_ROUNDS"),
-                         ("ACMPC_NO_CHAINED_ROUNDS",), ("ACMPC_NO_TRACED_FINALIZE",)):
+                         ("ACMPC_NO_CHAINED_ROUNDS",), ("ACMPC_NO_TRACED_FINALIZE",),
+                         ("ACMPC_NO_VERIFIED_SEARCH",)):   # (every waypoint: the scan instead of the verified window)
             for name in switches:
                 monkeypatch.setenv(name, "1")
             for want, got in zip(reference, run(nn_window)):
@@ -169,3 +170,29 @@ def test_mode_t_tick_forms_agree(monkeypatch):
                     np.testing.assert_array_equal(want[key], got[key], err_msg="%s with %s, window %s" % (key, switches, nn_window))
             for name in switches:
                 monkeypatch.delenv(name)
+
+
+@pytest.mark.parametrize("H", [9, 20, 50, 81, 129])
+def test_the_prologue_tabulates_the_frames_the_host_would(H):
+    """Mode T with the exhaustive search through the tick: the prologue's lanes leave the frames of the verified window
+    search beside the waypoint rows - the arithmetic of acmpc_set_paths (csrc/acmpc_frames.h), so the same bits as
+    `acmpc_search_frames` gives for the table the device wrote."""
+    from acmpc_amd import _capi
+    n = H - 1
+    y = np.linspace(0, 2.45 * H, H)
+    coords = np.stack([0.004 * y ** 2 + 3.0 * np.sin(y / 17.0), y, np.linspace(10, 6, H)], axis=1)
+    cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=28.0)
+    eng = _engine(n, 1024, None)
+    out = eng.control_tick(_tick(H, cons, 1024, 2, -0.3, 3), coords, None)
+    assert out["info"][4] == 0
+    _, _, coef = eng.tick_device_tables(n)
+    frames = eng.tick_device_frames(n)
+    want = _capi.search_frames(coef[None])[0]
+    np.testing.assert_array_equal(frames, want)
+    assert np.isfinite(frames[4::8]).all() and (frames[4::8] > 0).all()   # every window of this path is usable
+    eng.close()
+    windowed = _engine(n, 1024, (2, 5))
+    windowed.control_tick(_tick(H, cons, 1024, 2, -0.3, 3), coords, None)
+    with pytest.raises(_capi.EngineError):
+        windowed.tick_device_frames(n)
+    windowed.close()
