@@ -420,7 +420,7 @@ def single_solve(workloads, Engine, track, H, N, mode, layout, device, iters=300
     return out
 
 
-def closed_loop_replay(workloads, track_name="silverstone", poses=2000, rollout_mode="S"):
+def closed_loop_replay(workloads, track_name="silverstone", poses=2000, rollout_mode="S", nn_window="default"):
     """BASELINE.json configs[4]: the drop-in controller against consecutive poses along the synthetic Silverstone
     circuit - one full MPC solve per pose, each ONE call into the library: the reference path is cut out of the map on
     the device (150 m window in the vehicle frame, 500 -> H downsample), then waypoints, speed-profile QP, Frenet start
@@ -433,6 +433,8 @@ def closed_loop_replay(workloads, track_name="silverstone", poses=2000, rollout_
     cfg = copy.deepcopy(workloads.RACING_CONTROL[track_name])
     cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])  # controller.py:241-243
     cfg["rollout_mode"] = rollout_mode
+    if nn_window != "default":   # mode T: None = the nearest of ALL waypoints at every step (the verified window search)
+        cfg["nn_window"] = nn_window
     track = workloads.synthetic_track(track_name)
     H = cfg["horizon"]
     stride = 2  # 1 m between consecutive poses at 0.5 m map spacing (~30 m/s at 30 Hz perception)
@@ -462,7 +464,9 @@ def closed_loop_replay(workloads, track_name="silverstone", poses=2000, rollout_
     return {
         "workload": "%s (synthetic circuit): %d consecutive poses, one SpatialMPC solve per pose (path from the map, "
                     "prologue and rounds on the device), horizon %d, %d candidates x %d rounds, rollout mode %s"
-                    % (track_name, poses, H, mpc._control_solver._n_candidates, mpc._control_solver._rounds, rollout_mode),
+                    % (track_name, poses, H, mpc._control_solver._n_candidates, mpc._control_solver._rounds,
+                       rollout_mode + ("" if nn_window == "default" else ", nearest waypoint of all (nn_window: None)"
+                                       if nn_window is None else ", nn_window %s" % (nn_window,))),
         "solve_ms_p50": float(np.percentile(wall, 50) * 1e3), "solve_ms_p99": float(np.percentile(wall, 99) * 1e3),
         "solve_ms_max": float(wall.max() * 1e3), "sustainable_hz": float(1.0 / np.percentile(wall, 99)),
         "infeasible_solves": int(mpc.infeasibility_counter),
@@ -859,6 +863,8 @@ def main():
             out["closed_loop_replay"] = closed_loop_replay(workloads)
             # the same loop with north_star's literal rollout (Cartesian bicycle + nearest waypoint) behind get_control
             out["closed_loop_replay_mode_T"] = closed_loop_replay(workloads, poses=1000, rollout_mode="T")
+            out["closed_loop_replay_mode_T_exhaustive"] = closed_loop_replay(workloads, poses=1000, rollout_mode="T",
+                                                                             nn_window=None)
             # the second half of BASELINE.json's metric ("+ MPC solve p50 latency"): the drop-in get_control
             out["mpc_solve_latency_ms"] = {"p50": out["closed_loop_replay"]["solve_ms_p50"],
                                            "p99": out["closed_loop_replay"]["solve_ms_p99"],
