@@ -118,6 +118,43 @@ def test_an_accepted_index_is_the_exhaustive_one(name):
         assert accepted_any > 0
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_paths(seed):
+    """Paths nobody designed: random walks with drift, arcs of random curvature and step, points thrown into a box,
+    circles with jitter, gentle curves kilometres from the origin - 15 of each kind per seed."""
+    rng = np.random.default_rng(9000 + seed)
+    width, back = _capi.search_window()
+    accepted = total = 0
+    for trial in range(15):
+        n1 = int(rng.integers(9, 120))
+        kind = trial % 5
+        if kind == 0:
+            xy = np.cumsum(rng.normal(0, 1, (n1, 2)) * rng.uniform(0.1, 5) + rng.normal(0, 2, 2), axis=0)
+        elif kind == 1:
+            heading = np.cumsum(rng.normal(0, rng.uniform(0.01, 0.6), n1))
+            xy = np.cumsum(np.column_stack([np.cos(heading), np.sin(heading)]) * rng.uniform(0.5, 4), axis=0)
+        elif kind == 2:
+            xy = rng.uniform(-30, 30, (n1, 2))
+        elif kind == 3:
+            turn = np.linspace(0, rng.uniform(1, 12), n1)
+            xy = rng.uniform(3, 60) * np.column_stack([np.cos(turn), np.sin(turn)]) + rng.normal(0, 0.01, (n1, 2))
+        else:
+            heading = np.cumsum(rng.normal(0, 0.05, n1))
+            xy = np.cumsum(np.column_stack([np.cos(heading), np.sin(heading)]) * 3, axis=0) + rng.uniform(-1e4, 1e4, 2)
+        coef = _coef(xy.astype(np.float32).astype(np.float64))
+        n = coef.shape[0]
+        frames = _capi.search_frames(coef[None])[0]
+        X, Y, near = _poses(coef, rng, 3000)
+        truth = _exhaustive(coef, X, Y)
+        for shift in (-5, -2, 0, 1, 4):
+            lo = np.clip(near + shift - back, 0, n - width)
+            j, ok = _accepted(coef, frames, X, Y, lo)
+            np.testing.assert_array_equal(j[ok], truth[ok], err_msg="seed %d trial %d shift %d" % (seed, trial, shift))
+            accepted += int(np.count_nonzero(ok))
+            total += len(ok)
+    assert accepted > 0.05 * total
+
+
 def test_non_finite_poses_and_paths_are_never_accepted():
     coef = _coef(_paths()["racing_0"])
     n = coef.shape[0]
