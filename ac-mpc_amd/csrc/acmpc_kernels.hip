@@ -2562,21 +2562,28 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
   }
   if (mode == 1 && traced && std::getenv("ACMPC_NO_TRIO_ROUNDS") == nullptr) {
     // three waves per workgroup: tables | trace | uniform operands (centre, reference, weights) | nearest indices
-    const size_t tables = ((static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3)) +
-                          (rollout.nn_frames != nullptr ? static_cast<size_t>(verified_frame_floats(n)) : 0);
+    const size_t plain_tables = (static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3);
     const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
     const size_t uniform = (static_cast<size_t>(n) * 5 + 4 + 3) & ~static_cast<size_t>(3);
     const size_t index = static_cast<size_t>(n) * kWave;
+    // the frames of the verified search ride along when they fit beside the rest (they do up to n = 100); a longer
+    // horizon keeps the three waves and scans every waypoint, as it did before there were frames
+    RolloutArgs rollout_trio = rollout;
+    size_t tables = plain_tables + (rollout.nn_frames != nullptr ? static_cast<size_t>(verified_frame_floats(n)) : 0);
+    if ((tables + trace + uniform + index) * sizeof(float) > 160u * 1024u) {
+      rollout_trio.nn_frames = nullptr;
+      tables = plain_tables;
+    }
     const size_t trio_lds = (tables + trace + uniform + index) * sizeof(float);
     if (trio_lds <= 160u * 1024u) {
       hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&rollout_sampled_trio_kernel), 11, trio_lds);
       if (e != hipSuccess) return e;
       if (e0 != nullptr && e1 != nullptr) {
         hipExtLaunchKernelGGL(rollout_sampled_trio_kernel, grid, dim3(3 * kWave), static_cast<std::uint32_t>(trio_lds), s, e0,
-                              e1, 0, rollout, sample, fused, static_cast<int>(tables), static_cast<int>(tables + trace),
+                              e1, 0, rollout_trio, sample, fused, static_cast<int>(tables), static_cast<int>(tables + trace),
                               static_cast<int>(tables + trace + uniform));
       } else {
-        hipLaunchKernelGGL(rollout_sampled_trio_kernel, grid, dim3(3 * kWave), trio_lds, s, rollout, sample, fused,
+        hipLaunchKernelGGL(rollout_sampled_trio_kernel, grid, dim3(3 * kWave), trio_lds, s, rollout_trio, sample, fused,
                            static_cast<int>(tables), static_cast<int>(tables + trace),
                            static_cast<int>(tables + trace + uniform));
       }

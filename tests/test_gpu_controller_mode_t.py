@@ -39,7 +39,9 @@ def _tick(H, cons, n_candidates, rounds, offset, seed):
 
 
 @pytest.mark.parametrize("nn_window", [(2, 5), (1, 2), None])
-@pytest.mark.parametrize("H,N,rounds", [(50, 4096, 3), (20, 1000, 2), (81, 2048, 2)])
+@pytest.mark.parametrize("H,N,rounds", [(50, 4096, 3), (20, 1000, 2), (81, 2048, 2),
+                                        (101, 1024, 2),    # the mapping controller's horizon: the frames still fit the LDS
+                                        (105, 1024, 2)])   # ... and no longer do: three waves without them
 def test_tick_equals_set_paths_plus_optimize_in_mode_t(nn_window, H, N, rounds):
     """tick(T) == set_paths + optimize(T), bit for bit: the prologue's pose and waypoint rows handed to the two-call
     path (same seed, same spread) give the same winner's record; and the record is what the oracle rolls."""
@@ -172,7 +174,7 @@ def test_mode_t_tick_forms_agree(monkeypatch):
                 monkeypatch.delenv(name)
 
 
-@pytest.mark.parametrize("H", [9, 20, 50, 81, 129])
+@pytest.mark.parametrize("H", [9, 20, 50, 81, 101, 129])
 def test_the_prologue_tabulates_the_frames_the_host_would(H):
     """Mode T with the exhaustive search through the tick: the prologue's lanes leave the frames of the verified window
     search beside the waypoint rows - the arithmetic of acmpc_set_paths (csrc/acmpc_frames.h), so the same bits as
