@@ -125,8 +125,8 @@ struct FusedFinalize {
   unsigned* done;
   unsigned done_value;
   // rollout_solo_kernel only
-  int64_t* keys_out;   // [P] winners' keys, or nullptr
-  int ticket_groups;   // power of two <= kTicketGroupsMax (set by the launcher)
+  int64_t* keys_out = nullptr;   // [P] winners' keys, or nullptr
+  int ticket_groups = 0;         // power of two <= kTicketGroupsMax (set by the launcher)
 };
 
 // sample + rollout + cost (+ finalize) fused: candidates are drawn inside the rollout kernel and never touch memory
