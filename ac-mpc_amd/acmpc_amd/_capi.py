@@ -336,7 +336,9 @@ class Engine:
                  w_bound: float = 1.0e6, softmin_lambda: float = 1.0, device: int = -1, nn_window=None,
                  centre_update: str = "argmin"):
         """`nn_window=(back, ahead)` restricts mode T's nearest-waypoint search to that many waypoints round the
-        previous step's nearest index; None = exhaustive scan."""
+        previous step's nearest index; None = the nearest of ALL waypoints at every step (localiser.py:282-289's
+        semantics: the kernels search an 8-waypoint window whose winner a certificate accepts as the global one, and
+        scan every waypoint where it does not - the same index either way, see csrc/acmpc_frames.h)."""
         self._lib = load_library()
         p = Params()
         p.struct_size = C.sizeof(Params)
