@@ -15,6 +15,10 @@ def rss_mb():
 
 solves = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"]); cfg["speed_profile_constraints"]["v_max"] = 32.0
+if os.environ.get("TICK_MODE"):      # S | T, and for T the search window ("none" = the nearest of all waypoints)
+    cfg["rollout_mode"] = os.environ["TICK_MODE"]
+if os.environ.get("TICK_WINDOW"):
+    cfg["nn_window"] = None if os.environ["TICK_WINDOW"] == "none" else tuple(int(v) for v in os.environ["TICK_WINDOW"].split(","))
 mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
 track = workloads.synthetic_track("silverstone")
 paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % 11000), 50) for i in range(2000)]
