@@ -104,6 +104,141 @@ __device__ __forceinline__ void map_path_row(const double* centre, int M, int fi
   row[2] = (r == H - 1) ? 6.0 : 10.0 + static_cast<double>(r) * ((6.0 - 10.0) / static_cast<double>(H - 1));
 }
 
+// ---- mode T with the exhaustive nearest-waypoint search: the frames of its verified window search (acmpc_frames.h, the
+// arithmetic acmpc_set_paths runs on the host), one or two windows per lane.  xr / yr: the n float32 waypoint positions the
+// rollout sees, widened (LDS); gap_doubles: 4 n + 1 doubles of LDS scratch.  One wavefront: a workgroup of its own in the
+// prologue's launch (the frames need the path, not the speed profile: they are ready before the first workgroup is) ----
+__device__ void tabulate_frames(const double* xr, const double* yr, double* gap_doubles, int n, int lane, float* out) {
+  const WaveTeam team;
+  constexpr int W = kVerifiedWindow;
+  const int windows = n - W + 1;
+  const double inf = __builtin_huge_val();
+  auto at = [&](int mm, double& x, double& y) {
+    x = xr[mm];
+    y = yr[mm];
+  };
+  double wn = 0.0;
+  bool finite = true;
+  for (int i = lane; i < n; i += 64) {
+    const double x = xr[i], y = yr[i];
+    finite = finite && (fabs(x) < inf) && (fabs(y) < inf);
+    const double norm = sqrt(x * x + y * y);
+    wn = (norm > wn) ? norm : wn;
+  }
+  wn = team.max(wn, nullptr);
+  finite = __ballot(!finite) == 0ull;
+  // The far split for near = kNearFirst, every window at once.  far_distance() walks (far waypoint, window waypoint)
+  // pairs window by window - up to 200 per window, on one lane.  Turned round: waypoint q = lo + j of a window needs the
+  // nearest waypoint m >= q + near + W - j ahead and m <= q - near - 1 - j behind, j = 0 .. W - 1; the lane that holds
+  // waypoint q finds those 2 W minima in one sweep over the path (n pairs), and a window's R^2 is the minimum over its
+  // W waypoints' entries.  The same pairs through the same squared_gap(): the same minimum, whatever the order.  The
+  // sweep's index is wave-uniform, so waypoint m comes out of its lane's registers (v_readlane), not out of LDS: this is
+  // one wavefront, and every LDS round trip it cannot overlap it waits for.
+  constexpr int kSlots = (kPrologueMaxSteps + 63) / 64;   // waypoints (and windows) per lane
+  const int slots = (n + 63) / 64;                         // (wave-uniform)
+  float own_x[kSlots], own_y[kSlots];
+#pragma unroll
+  for (int r = 0; r < kSlots; ++r) {
+    const int q = min(lane + 64 * r, n - 1);
+    own_x[r] = static_cast<float>(xr[q]);
+    own_y[r] = static_cast<float>(yr[q]);
+  }
+  auto lane_value = [](float v, int src) {   // v of lane `src` (wave-uniform)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+  };
+  auto waypoint = [&](int mm, float& x, float& y) {   // mm wave-uniform
+    const int src = mm & 63;
+    x = lane_value((mm < 64) ? own_x[0] : own_x[kSlots - 1], src);
+    y = lane_value((mm < 64) ? own_y[0] : own_y[kSlots - 1], src);
+  };
+  static_assert(kSlots <= 2, "waypoint(): two slots per lane");
+  float* gap = reinterpret_cast<float*>(gap_doubles);   // [n][W] minima of one sweep, + one slot nobody reads
+  const int nowhere = n * W;
+  const float finf = __builtin_inff();
+  float r2[kSlots];
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q) r2[q] = finf;
+  // (no branch inside a sweep: a lone wavefront pays tens of cycles for each; what does not apply is stored `nowhere`)
+  auto sweep = [&](auto slots_tag, auto pass_tag) {
+    constexpr int kLive = decltype(slots_tag)::value;   // slots in use: 1 up to 64 waypoints, 2 beyond
+    constexpr bool kAhead = decltype(pass_tag)::value == 0;
+    float running[kLive];
+#pragma unroll
+    for (int r = 0; r < kLive; ++r) running[r] = finf;
+    const int count = n - 1 - frames::kNearFirst;
+    for (int it = 0, mm = kAhead ? n - 1 : 0; it < count; ++it, mm += kAhead ? -1 : 1) {
+      float xm, ym;
+      waypoint(mm, xm, ym);
+#pragma unroll
+      for (int r = 0; r < kLive; ++r) {
+        const int q = lane + 64 * r;
+        // ahead: m > q + near, entry j = q + near + W - m (< W);  behind: m < q - near, entry j = q - near - 1 - m (>= 0)
+        const int j = kAhead ? q + frames::kNearFirst + W - mm : q - frames::kNearFirst - 1 - mm;
+        const int applies = static_cast<int>(q < n) & static_cast<int>(kAhead ? mm > q + frames::kNearFirst
+                                                                              : mm < q - frames::kNearFirst);
+        const float d2 = frames::squared_gap(xm, ym, own_x[r], own_y[r]);
+        running[r] = ((applies & static_cast<int>(d2 < running[r])) != 0) ? d2 : running[r];
+        const int kept = applies & static_cast<int>(j >= 0) & static_cast<int>(j < W);
+        gap[(kept != 0) ? q * W + j : nowhere] = running[r];
+      }
+    }
+  };
+  auto sweep_either = [&](auto pass_tag) {
+    if (slots == 1) {
+      sweep(std::integral_constant<int, 1>{}, pass_tag);
+    } else {
+      sweep(std::integral_constant<int, kSlots>{}, pass_tag);
+    }
+  };
+  for (int pass = 0; pass < 2; ++pass) {   // 0: the waypoints ahead, 1: those behind (one [n][W] buffer for both)
+    for (int e = lane; e < n * W; e += 64) gap[e] = finf;
+    team.sync();
+    if (pass == 0) {
+      sweep_either(std::integral_constant<int, 0>{});
+    } else {
+      sweep_either(std::integral_constant<int, 1>{});
+    }
+    team.sync();
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      const int lo = lane + 64 * q;
+      if (lo < windows) {
+        float g[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) g[j] = gap[(lo + j) * W + j];
+#pragma unroll
+        for (int j = 0; j < W; ++j) r2[q] = (g[j] < r2[q]) ? g[j] : r2[q];
+      }
+    }
+    team.sync();
+  }
+  frames::Geometry geometry[kSlots];
+  double slab_max = 0.0;
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q) {
+    const int lo = lane + 64 * q;
+    geometry[q].usable = false;
+    const bool mine = lo < windows;
+    double R = (mine && finite) ? frames::far_from_squared(r2[q]) : inf;
+    const int near = (mine && finite) ? frames::choose_near(at, n, lo, R) : frames::kNearFirst;
+    // (the usual case - every window's first choice of `near` stands - takes the unrolled form)
+    if (__ballot(mine && near != frames::kNearFirst) == 0ull) {
+      if (mine) geometry[q] = frames::window_geometry<frames::kNearFirst>(at, n, lo, finite, near, R);
+    } else if (mine) {
+      geometry[q] = frames::window_geometry<0>(at, n, lo, finite, near, R);
+    }
+    const double slab = geometry[q].aA - geometry[q].aB;
+    if (mine && geometry[q].usable) slab_max = (slab > slab_max) ? slab : slab_max;
+  }
+  slab_max = team.max(slab_max, nullptr);
+  const frames::Scale scale = frames::path_scale(wn, slab_max);
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q) {
+    const int lo = lane + 64 * q;
+    if (lo < windows) frames::frame_row(geometry[q], scale, out + static_cast<size_t>(kFrameStride) * lo);
+  }
+}
+
 __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   // ONE read of the head (kernel arguments, or the pinned block over the host link); everything below uses the copy
@@ -113,6 +248,31 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   const int H = __builtin_amdgcn_readfirstlane(h.horizon);   // (wave-uniform: loop bounds on the scalar unit)
   const int n = H - 1;
   const int m = n - 1;
+  if (blockIdx.x == 1) {
+    // ---- the second workgroup (launched for mode T with the exhaustive search): the search frames, from the path alone ----
+    if (a.frames == nullptr || n < kVerifiedWindow) return;
+    double* xr = s_mem;
+    double* yr = s_mem + n;
+    if (h.use_map != 0) {   // the rows of the map window, as the first workgroup computes them
+      int first = (h.map_index < 0) ? a.map_first[0] : h.map_index;
+      first = ((first % a.map_M) + a.map_M) % a.map_M;
+      const MapFrame frame = map_frame(a.map_centre, a.map_M, first);
+      for (int r = lane; r < n; r += 64) {
+        double row[3];
+        map_path_row(a.map_centre, a.map_M, first, a.map_count, a.map_points, H, r, h.lateral_offset, frame, row);
+        xr[r] = static_cast<double>(static_cast<float>(row[0]));
+        yr[r] = static_cast<double>(static_cast<float>(row[1]));
+      }
+    } else {
+      for (int r = lane; r < n; r += 64) {   // construct_waypoints: x, y = the first n points of the path
+        xr[r] = static_cast<double>(static_cast<float>(a.coords[3 * r]));
+        yr[r] = static_cast<double>(static_cast<float>(a.coords[3 * r + 1]));
+      }
+    }
+    __syncthreads();
+    tabulate_frames(xr, yr, s_mem + 2 * n, n, lane, a.frames);
+    return;
+  }
   // LDS: table [7][n] | v_hi [n] | psi_seg [n + 1] (heading of every segment incl. the closing one) | v [n] |
   //      y [2n - 1] | ADMM workspace
   double* table = s_mem;
@@ -297,147 +457,6 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
     a.centre[2 * i] = (h.centre_is_reference != 0) ? static_cast<float>(uv) : centre_in_v[q];
     a.centre[2 * i + 1] = (h.centre_is_reference != 0) ? static_cast<float>(uk) : centre_in_k[q];
   }
-  // ---- mode T with the exhaustive nearest-waypoint search: the frames of its verified window search (acmpc_frames.h, the
-  // arithmetic acmpc_set_paths runs on the host), one or two windows per lane, from the float32 positions just written ----
-  if (a.frames != nullptr && n >= kVerifiedWindow) {
-    constexpr int W = kVerifiedWindow;
-    const int windows = n - W + 1;
-    const double inf = __builtin_huge_val();
-    // LDS the solver is done with: the positions as the rollout sees them (float32, widened), and [n][W] gap minima (floats)
-    double* xr = v_hi;
-    double* yr = seg;
-    double* gap_doubles = qy + 2 * n;   // (the ADMM workspace: 8 n + 8 doubles)
-    team.sync();
-    for (int i = lane; i < n; i += 64) {
-      xr[i] = static_cast<double>(static_cast<float>(tx[i]));
-      yr[i] = static_cast<double>(static_cast<float>(ty[i]));
-    }
-    team.sync();
-    auto at = [&](int mm, double& x, double& y) {
-      x = xr[mm];
-      y = yr[mm];
-    };
-    double wn = 0.0;
-    bool finite = true;
-    for (int i = lane; i < n; i += 64) {
-      const double x = xr[i], y = yr[i];
-      finite = finite && (fabs(x) < inf) && (fabs(y) < inf);
-      const double norm = sqrt(x * x + y * y);
-      wn = (norm > wn) ? norm : wn;
-    }
-    wn = team.max(wn, nullptr);
-    finite = __ballot(!finite) == 0ull;
-    // The far split for near = kNearFirst, every window at once.  far_distance() walks (far waypoint, window waypoint)
-    // pairs window by window - up to 200 per window, on one lane.  Turned round: waypoint q = lo + j of a window needs the
-    // nearest waypoint m >= q + near + W - j ahead and m <= q - near - 1 - j behind, j = 0 .. W - 1; the lane that holds
-    // waypoint q finds those 2 W minima in one sweep over the path (n pairs), and a window's R^2 is the minimum over its
-    // W waypoints' entries.  The same pairs through the same squared_gap(): the same minimum, whatever the order.  The
-    // sweep's index is wave-uniform, so waypoint m comes out of its lane's registers (v_readlane), not out of LDS: this is
-    // one wavefront, and every LDS round trip it cannot overlap it waits for.
-    constexpr int kSlots = (kPrologueMaxSteps + 63) / 64;   // waypoints (and windows) per lane
-    const int slots = (n + 63) / 64;                         // (wave-uniform)
-    float own_x[kSlots], own_y[kSlots];
-#pragma unroll
-    for (int r = 0; r < kSlots; ++r) {
-      const int q = min(lane + 64 * r, n - 1);
-      own_x[r] = static_cast<float>(xr[q]);
-      own_y[r] = static_cast<float>(yr[q]);
-    }
-    auto lane_value = [](float v, int src) {   // v of lane `src` (wave-uniform)
-      return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-    };
-    auto waypoint = [&](int mm, float& x, float& y) {   // mm wave-uniform
-      const int src = mm & 63;
-      x = lane_value((mm < 64) ? own_x[0] : own_x[kSlots - 1], src);
-      y = lane_value((mm < 64) ? own_y[0] : own_y[kSlots - 1], src);
-    };
-    static_assert(kSlots <= 2, "waypoint(): two slots per lane");
-    float* gap = reinterpret_cast<float*>(gap_doubles);   // [n][W] minima of one sweep, + one slot nobody reads
-    const int nowhere = n * W;
-    const float finf = __builtin_inff();
-    float r2[kSlots];
-#pragma unroll
-    for (int q = 0; q < kSlots; ++q) r2[q] = finf;
-    // (no branch inside a sweep: a lone wavefront pays tens of cycles for each; what does not apply is stored `nowhere`)
-    auto sweep = [&](auto slots_tag, auto pass_tag) {
-      constexpr int kLive = decltype(slots_tag)::value;   // slots in use: 1 up to 64 waypoints, 2 beyond
-      constexpr bool kAhead = decltype(pass_tag)::value == 0;
-      float running[kLive];
-#pragma unroll
-      for (int r = 0; r < kLive; ++r) running[r] = finf;
-      const int count = n - 1 - frames::kNearFirst;
-      for (int it = 0, mm = kAhead ? n - 1 : 0; it < count; ++it, mm += kAhead ? -1 : 1) {
-        float xm, ym;
-        waypoint(mm, xm, ym);
-#pragma unroll
-        for (int r = 0; r < kLive; ++r) {
-          const int q = lane + 64 * r;
-          // ahead: m > q + near, entry j = q + near + W - m (< W);  behind: m < q - near, entry j = q - near - 1 - m (>= 0)
-          const int j = kAhead ? q + frames::kNearFirst + W - mm : q - frames::kNearFirst - 1 - mm;
-          const int applies = static_cast<int>(q < n) & static_cast<int>(kAhead ? mm > q + frames::kNearFirst
-                                                                                : mm < q - frames::kNearFirst);
-          const float d2 = frames::squared_gap(xm, ym, own_x[r], own_y[r]);
-          running[r] = ((applies & static_cast<int>(d2 < running[r])) != 0) ? d2 : running[r];
-          const int kept = applies & static_cast<int>(j >= 0) & static_cast<int>(j < W);
-          gap[(kept != 0) ? q * W + j : nowhere] = running[r];
-        }
-      }
-    };
-    auto sweep_either = [&](auto pass_tag) {
-      if (slots == 1) {
-        sweep(std::integral_constant<int, 1>{}, pass_tag);
-      } else {
-        sweep(std::integral_constant<int, kSlots>{}, pass_tag);
-      }
-    };
-    for (int pass = 0; pass < 2; ++pass) {   // 0: the waypoints ahead, 1: those behind (one [n][W] buffer for both)
-      for (int e = lane; e < n * W; e += 64) gap[e] = finf;
-      team.sync();
-      if (pass == 0) {
-        sweep_either(std::integral_constant<int, 0>{});
-      } else {
-        sweep_either(std::integral_constant<int, 1>{});
-      }
-      team.sync();
-#pragma unroll
-      for (int q = 0; q < kSlots; ++q) {
-        const int lo = lane + 64 * q;
-        if (lo < windows) {
-          float g[W];
-#pragma unroll
-          for (int j = 0; j < W; ++j) g[j] = gap[(lo + j) * W + j];
-#pragma unroll
-          for (int j = 0; j < W; ++j) r2[q] = (g[j] < r2[q]) ? g[j] : r2[q];
-        }
-      }
-      team.sync();
-    }
-    frames::Geometry geometry[kSlots];
-    double slab_max = 0.0;
-#pragma unroll
-    for (int q = 0; q < kSlots; ++q) {
-      const int lo = lane + 64 * q;
-      geometry[q].usable = false;
-      const bool mine = lo < windows;
-      double R = (mine && finite) ? frames::far_from_squared(r2[q]) : inf;
-      const int near = (mine && finite) ? frames::choose_near(at, n, lo, R) : frames::kNearFirst;
-      // (the usual case - every window's first choice of `near` stands - takes the unrolled form)
-      if (__ballot(mine && near != frames::kNearFirst) == 0ull) {
-        if (mine) geometry[q] = frames::window_geometry<frames::kNearFirst>(at, n, lo, finite, near, R);
-      } else if (mine) {
-        geometry[q] = frames::window_geometry<0>(at, n, lo, finite, near, R);
-      }
-      const double slab = geometry[q].aA - geometry[q].aB;
-      if (mine && geometry[q].usable) slab_max = (slab > slab_max) ? slab : slab_max;
-    }
-    slab_max = team.max(slab_max, nullptr);
-    const frames::Scale scale = frames::path_scale(wn, slab_max);
-#pragma unroll
-    for (int q = 0; q < kSlots; ++q) {
-      const int lo = lane + 64 * q;
-      if (lo < windows) frames::frame_row(geometry[q], scale, a.frames + static_cast<size_t>(kFrameStride) * lo);
-    }
-  }
   ACMPC_PSTAMP(6);
   // the 7 x n table for the caller (pinned host memory: posted writes, visible once the stream has drained)
   for (int e = lane; e < 7 * n; e += 64) a.table_out[e] = table[e];
@@ -528,7 +547,8 @@ size_t prologue_lds_bytes(int n) {
 
 hipError_t launch_prologue(const PrologueArgs& args, int n, hipStream_t s) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(prologue_kernel, dim3(1), dim3(64), prologue_lds_bytes(n), s, args);
+  // (a second workgroup tabulates the search frames of mode T's exhaustive search while the first solves the speed profile)
+  hipLaunchKernelGGL(prologue_kernel, dim3(args.frames != nullptr ? 2 : 1), dim3(64), prologue_lds_bytes(n), s, args);
   return hipGetLastError();
 }
 

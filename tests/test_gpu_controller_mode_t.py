@@ -198,3 +198,30 @@ def test_the_prologue_tabulates_the_frames_the_host_would(H):
     with pytest.raises(_capi.EngineError):
         windowed.tick_device_frames(n)
     windowed.close()
+
+
+def test_frames_from_the_bound_map():
+    """The path cut out of the bound map (get_control_at): the second workgroup of the prologue computes the window's
+    rows itself, as the first does - its frames are those of the table the first one wrote, at a map index and at a pose."""
+    from acmpc_amd import _capi, workloads
+    from acmpc_amd.mpc import build_mpc
+    cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"])
+    cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
+    cfg.update(rollout_mode="T", nn_window=None, n_candidates=2048)
+    mpc = build_mpc(cfg, PlaceholderVehicle())
+    track = workloads.synthetic_track("silverstone")
+    mpc.bind_map(track)
+    n = cfg["horizon"] - 1
+    for step in range(6):
+        if step % 2 == 0:
+            mpc.get_control_at(map_index=1234 + 700 * step, lateral_offset=0.3, offset=0.3)
+        else:
+            centre = track["centre"]
+            at = 800 * step
+            tangent = centre[at + 1] - centre[at]
+            normal = np.array([-tangent[1], tangent[0]]) / np.linalg.norm(tangent)
+            mpc.get_control_at(pose=tuple(centre[at] + 0.4 * normal), lateral_offset=0.4, offset=0.4)
+        assert mpc.infeasibility_counter == 0
+        engine = mpc._control_solver._engine
+        _, _, coef = engine.tick_device_tables(n)
+        np.testing.assert_array_equal(engine.tick_device_frames(n), _capi.search_frames(coef[None])[0])
