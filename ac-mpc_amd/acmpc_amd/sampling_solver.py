@@ -14,7 +14,7 @@ from optional config keys (`n_candidates`, `sampling_rounds`, `sampling_sigma`, 
 `rollout_mode: "T"` (default "S") scores the candidates with the Cartesian rollout instead - BASELINE.json north_star's
 literal shape: kinematic bicycle (localisation/localiser.py:66-95) advanced by `rollout_dt` seconds per step (0.05),
 nearest waypoint of the path (localiser.py:282-289) within `nn_window: [back, ahead]` waypoints of the previous step's
-(default [2, 5]; `null` = the nearest of all waypoints, 0.080 ms per solve instead of 0.063), Frenet errors against it (dynamics.py:23-40), the same weights and bounds.
+(default [2, 5]; `null` = the nearest of all waypoints, 0.070 ms per solve instead of 0.063), Frenet errors against it (dynamics.py:23-40), the same weights and bounds.
 The plan is then a TIME-indexed one (control i holds from i * dt), which is what `TemporalCommandSelector` consumes.
 """
 from __future__ import annotations
