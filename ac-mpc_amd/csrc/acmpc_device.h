@@ -645,13 +645,35 @@ __device__ __forceinline__ int nearest_in_window_chain(float X, float Y, const f
   return j;
 }
 
+__device__ __forceinline__ int verified_window_start(int j_prev, int n) {
+  return max(min(j_prev - kVerifiedBack, n - kVerifiedWindow), 0);
+}
+
+// The verified search in two halves, for kernels whose search runs on a wavefront of its own (the three-wave round): the
+// searching wave only PROPOSES - the first minimum of the window that starts at verified_window_start(previous
+// proposal) - and moves on; a wave with time to spare CONFIRMS: the proposal's key is recomputed (the same expression:
+// the same bits), the frame of the window it came from decides, and what is not certified is scanned by the whole
+// wave.  The result does not depend on where the window was - it is the nearest of all waypoints either way - so a
+// proposal that turns out wrong only costs the following windows their good position, never the answer.
+__device__ __forceinline__ int propose_nearest(float X, float Y, const float* abc, int n, int proposal_before) {
+  float best;
+  return nearest_in_window_chain<kVerifiedWindow>(X, Y, abc, verified_window_start(proposal_before, n), best);
+}
+__device__ __forceinline__ int confirm_nearest(float X, float Y, const float* abc, const float* frames, int n,
+                                               int proposal_before, int proposal) {
+  const float* e = abc + kKeyStride * proposal;
+  const float best = search_key<float>(X, Y, e[0], e[1], e[2]);
+  const int lo = verified_window_start(proposal_before, n);
+  return nearest_cooperative_fix(X, Y, frame_certifies(X, Y, best, frames, lo), proposal, abc, n);
+}
+
 // (kSearchVerified: exhaustive semantics through the frames of the verified window search - must be reached by every lane
 // of the wave, like nearest_verified(); without frames it is the scan of all waypoints)
 template <int SEARCH>
 __device__ __forceinline__ int search_temporal_as(float X, float Y, const float* abc, int n, const Weights& w, int j_prev,
                                                   const float* frames = nullptr) {
   if constexpr (SEARCH == kSearchVerified) {
-    const int lo = max(min(j_prev - kVerifiedBack, n - kVerifiedWindow), 0);
+    const int lo = verified_window_start(j_prev, n);
     float best;
     const int j = nearest_in_window_chain<kVerifiedWindow>(X, Y, abc, lo, best);
     // (all-NaN keys: `best` stays +inf, the recovered distance is not below any bound: the scan decides, as it must)

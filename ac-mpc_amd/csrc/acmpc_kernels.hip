@@ -1729,7 +1729,11 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
 #pragma unroll
         for (int q = 0; q < kTrioChunk; ++q) {
           if (first + q < n) {   // (wave-uniform)
-            j_prev = search_temporal_as<decltype(kind)::value>(X[q], Y[q], s_abc, n, w, j_prev, s_frames);
+            if constexpr (decltype(kind)::value == kSearchVerified) {
+              j_prev = propose_nearest(X[q], Y[q], s_abc, n, j_prev);   // (confirmed by the cost wave)
+            } else {
+              j_prev = search_temporal_as<decltype(kind)::value>(X[q], Y[q], s_abc, n, w, j_prev, s_frames);
+            }
             s_index[(first + q) * kWave + lane] = j_prev;
           }
         }
@@ -1740,6 +1744,7 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
   }
 
   // ---- costs: two chunks behind the poses ----
+  const bool confirm = search_kind(w, n, a.nn_frames != nullptr) == kSearchVerified;
   StateT st = start_temporal<float>(x0);
   __syncthreads();   // chunk time 0
   __syncthreads();   // chunk time 1: chunk 0 searched
@@ -1752,7 +1757,11 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
         st.X = col[(2 * n + 3 * i) * kWave];
         st.Y = col[(2 * n + 3 * i + 1) * kWave];
         st.phi = col[(2 * n + 3 * i + 2) * kWave];
-        const int j = s_index[i * kWave + lane];
+        int j = s_index[i * kWave + lane];
+        if (confirm) {   // (wave-uniform) the search wave's proposal, held against the frame of its window
+          const int before = (i == 0) ? 0 : s_index[(i - 1) * kWave + lane];
+          j = confirm_nearest(st.X, st.Y, s_abc, s_frames, n, before, j);
+        }
         temporal_cost(st, s_wp + j * kCoefT, col[(2 * i) * kWave], col[(2 * i + 1) * kWave], w);
       }
     }

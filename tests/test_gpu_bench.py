@@ -55,9 +55,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert out["roofline"]["traffic_measured_in_this_run"] is False
     loop_t = out["closed_loop_replay_mode_T"]
     assert "rollout mode T" in loop_t["workload"] and loop_t["infeasible_solves"] == 0 and loop_t["solve_ms_p50"] > 0
-    loop_all = out["closed_loop_replay_mode_T_exhaustive"]   # nearest of ALL waypoints: the verified search in the rounds
-    assert "nn_window: None" in loop_all["workload"] and loop_all["infeasible_solves"] == 0
-    assert loop_all["solve_ms_p50"] < 2.0 * loop_t["solve_ms_p50"]      # (a scan of every waypoint took 2.5 x)
+    assert "nearest waypoint of all" in loop_t["workload"]             # the default: the verified search in the rounds
+    loop_w = out["closed_loop_replay_mode_T_window_2_5"]
+    assert "nn_window (2, 5)" in loop_w["workload"] and loop_w["infeasible_solves"] == 0
+    assert loop_t["solve_ms_p50"] < 1.5 * loop_w["solve_ms_p50"]        # (a scan of every waypoint took 2.5 x the window)
     assert out["single_solve"]["device_resident_us_p50"] < 16.0      # one launch (round 2: two launches, 19 us)
     assert out["config3_single"]["device_resident_us_p50"] > 0 and out["config4_share"]["device_resident_us_p50"] > 0
     five = out["config5_host_pointer"]

@@ -11,7 +11,7 @@ echo "profile.sh done"
 (cd /tmp && export TMPDIR=/tmp && rm -rf $ROOT/gpurun_out/allk_$TAG && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/allk_$TAG -- python3 $ROOT/bench.py --steps 50 --warmup 10 > $ROOT/gpurun_out/allk_$TAG.json 2> $ROOT/gpurun_out/allk_$TAG.err)
 echo "all-kernels trace done"
 for spec in "f_S50 S 50 - -" "f_S25 S 25 - -" "f_S100 S 100 - -" "f_S50_pair S 50 ACMPC_NO_QUAD_ROUNDS -" "f_T50 T 50 - -" \
-            "f_T50_one T 50 ACMPC_NO_TRIO_ROUNDS -" "f_T50_all T 50 - none"; do
+            "f_T50_one T 50 ACMPC_NO_TRIO_ROUNDS -" "f_T50_w25 T 50 - 2,5"; do
   set -- $spec
   rm -rf $ROOT/gpurun_out/trace_$1
   ( export TICK_MODE=$2 TICK_H=$3; [ "$4" != "-" ] && export $4=1; [ "$5" != "-" ] && export TICK_WINDOW=$5; $ROOT/tools/tick_trace.sh $1 | head -1 )

@@ -1,5 +1,5 @@
 """Development probe (GPU box): closed-loop get_control latency on consecutive poses (TICK_H = horizon, default 50;
-TICK_MODE = S | T, the controller's rollout_mode; TICK_WINDOW = "back,ahead" or "none" = mode T's nn_window)."""
+TICK_MODE = S | T, the controller's rollout_mode; TICK_WINDOW = "back,ahead" or "none" = mode T's nn_window; unset: the controller's default, the nearest of all)."""
 import copy, os, sys, time
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
