@@ -662,23 +662,16 @@ __device__ __forceinline__ int propose_nearest(float X, float Y, const float* ab
 __device__ __forceinline__ int confirm_nearest(float X, float Y, const float* abc, const float* frames, int n,
                                                int proposal_before, int proposal) {
   const float* e = abc + kKeyStride * proposal;
-  const float best = search_key<float>(X, Y, e[0], e[1], e[2]);
+  const float best = search_key<float>(X, Y, e[0], e[1], e[2]);   // (a NaN key is below no bound: the scan decides, as it must)
   const int lo = verified_window_start(proposal_before, n);
   return nearest_cooperative_fix(X, Y, frame_certifies(X, Y, best, frames, lo), proposal, abc, n);
 }
 
-// (kSearchVerified: exhaustive semantics through the frames of the verified window search - must be reached by every lane
-// of the wave, like nearest_verified(); without frames it is the scan of all waypoints)
+// (the verified search of a lone searching wave is propose_nearest() + confirm_nearest() above)
 template <int SEARCH>
-__device__ __forceinline__ int search_temporal_as(float X, float Y, const float* abc, int n, const Weights& w, int j_prev,
-                                                  const float* frames = nullptr) {
-  if constexpr (SEARCH == kSearchVerified) {
-    const int lo = verified_window_start(j_prev, n);
-    float best;
-    const int j = nearest_in_window_chain<kVerifiedWindow>(X, Y, abc, lo, best);
-    // (all-NaN keys: `best` stays +inf, the recovered distance is not below any bound: the scan decides, as it must)
-    return nearest_cooperative_fix(X, Y, frame_certifies(X, Y, best, frames, lo), j, abc, n);
-  } else if constexpr (SEARCH == kSearchExhaustive) {
+__device__ __forceinline__ int search_temporal_as(float X, float Y, const float* abc, int n, const Weights& w, int j_prev) {
+  static_assert(SEARCH != kSearchVerified, "propose_nearest / confirm_nearest");
+  if constexpr (SEARCH == kSearchExhaustive) {
     StateT probe{};
     probe.X = X;
     probe.Y = Y;

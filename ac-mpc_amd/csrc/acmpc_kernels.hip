@@ -1732,7 +1732,7 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
             if constexpr (decltype(kind)::value == kSearchVerified) {
               j_prev = propose_nearest(X[q], Y[q], s_abc, n, j_prev);   // (confirmed by the cost wave)
             } else {
-              j_prev = search_temporal_as<decltype(kind)::value>(X[q], Y[q], s_abc, n, w, j_prev, s_frames);
+              j_prev = search_temporal_as<decltype(kind)::value>(X[q], Y[q], s_abc, n, w, j_prev);
             }
             s_index[(first + q) * kWave + lane] = j_prev;
           }
