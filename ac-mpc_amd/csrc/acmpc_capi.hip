@@ -183,10 +183,17 @@ void verified_frames(const float* coef, int P, int n, std::vector<float>* out) {
       finite = finite && std::isfinite(x) && std::isfinite(y);
       wn = std::max(wn, std::sqrt(x * x + y * y));
     }
+    float largest_gap2 = 0.0f;
+    for (int m = 0; m + 1 < n; ++m) {
+      const float gap2 = acmpc::frames::squared_gap(t[(m + 1) * acmpc::kCoefT], t[(m + 1) * acmpc::kCoefT + 1],
+                                                    t[m * acmpc::kCoefT], t[m * acmpc::kCoefT + 1]);
+      largest_gap2 = (gap2 > largest_gap2) ? gap2 : largest_gap2;
+    }
+    const int first = acmpc::frames::near_first(largest_gap2);
     double slab_max = 0.0;
     for (int lo = 0; lo < windows; ++lo) {
-      double R = finite ? acmpc::frames::far_distance(at, n, lo, acmpc::frames::kNearFirst) : 0.0;
-      const int near = finite ? acmpc::frames::choose_near(at, n, lo, R) : acmpc::frames::kNearFirst;
+      double R = finite ? acmpc::frames::far_distance(at, n, lo, first) : 0.0;
+      const int near = finite ? acmpc::frames::choose_near(at, n, lo, first, R) : first;
       geometry[lo] = acmpc::frames::window_geometry<0>(at, n, lo, finite, near, R);
       if (geometry[lo].usable) slab_max = std::max(slab_max, geometry[lo].aA - geometry[lo].aB);
     }

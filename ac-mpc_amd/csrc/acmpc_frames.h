@@ -32,8 +32,8 @@ namespace frames {
 // and certifies the window's winner j when  |r_j^2 recovered from its key|  <  min(along^2 + across^2 - slack, far).
 //
 // The outside waypoints are split by index: NEAR = within `near` waypoints of the window's ends, FAR = the rest; `near`
-// is the smallest of 16, 24, 32, ... for which the far ones are at least kFarReach from the window (all of them near when
-// none is: a path that comes back to the window).
+// is the smallest of first, first + 8, ... for which the far ones are at least kFarReach from the window (all of them near
+// when none is: a path that comes back to the window); first = 16, 32 or 64 by the path's spacing (near_first()).
 //
 // Near waypoints: why the slab-and-tube bound is sound.  t is the float32 direction of the window's chord scaled so that
 // |t| <= 1, and n has the same norm, so for any waypoint w: (t.(w - p))^2 + (n.(w - p))^2 <= |w - p|^2.  Every near
@@ -58,7 +58,10 @@ namespace frames {
 //
 // A window whose chord has no length, or a path with a non-finite waypoint: slab = -1, tube = +inf, far = 0 - never
 // certified.  O(n W) per window and choice of `near`, O(n^2) per path.
-constexpr double kFarReach = 50.0;   // [m]: poses up to half of this from the winner are not cut off by the far bound
+#ifndef ACMPC_FRAME_FAR_REACH
+#define ACMPC_FRAME_FAR_REACH 45.0
+#endif
+constexpr double kFarReach = ACMPC_FRAME_FAR_REACH;   // [m]: poses up to half of this from the winner are not cut off by the far bound
 constexpr double kUlp = 5.9604644775390625e-08;   // 2^-24: half an ulp of a float32 of magnitude 1, one rounding's relative error
 
 struct Geometry {
@@ -79,7 +82,12 @@ __host__ __device__ inline float squared_gap(float x_far, float y_far, float x_w
 }
 __host__ __device__ inline double far_from_squared(float R2) { return sqrt(static_cast<double>(R2)) * (1.0 - 1.0e-6); }
 
-constexpr int kNearFirst = 16;   // the first choice of `near`; then 24, 32, ...
+// The first choice of `near` (then + 8, + 16, ...): 16 waypoints at the spacing of a racing line's reference path (150 m in
+// 50 points), 32 / 64 on denser paths (the mapping controller's 100 points) - the next ~45 m of path either side.  Decided
+// by the path's largest gap between neighbours, taken with squared_gap(): a maximum, the same whatever order it is taken in.
+__host__ __device__ inline int near_first(float largest_gap2) {
+  return (largest_gap2 >= 2.5f * 2.5f) ? 16 : (largest_gap2 >= 1.25f * 1.25f) ? 32 : 64;
+}
 
 template <typename At>
 __host__ __device__ inline double far_distance(const At& at, int n, int lo, int near) {
@@ -102,11 +110,11 @@ __host__ __device__ inline double far_distance(const At& at, int n, int lo, int 
   return far_from_squared(R2);
 }
 
-// `near` = the smallest of kNearFirst, + 8, ... that leaves the far waypoints at least kFarReach from the window.  On
-// entry R is the far distance for near = kNearFirst; on return for the `near` chosen.
+// `near` = the smallest of first, first + 8, ... that leaves the far waypoints at least kFarReach from the window.  On
+// entry R is the far distance for near = first; on return for the `near` chosen.
 template <typename At>
-__host__ __device__ inline int choose_near(const At& at, int n, int lo, double& R) {
-  int near = kNearFirst;
+__host__ __device__ inline int choose_near(const At& at, int n, int lo, int first, double& R) {
+  int near = first;
   while (R < kFarReach) {
     near += 8;
     R = far_distance(at, n, lo, near);   // (+inf once nothing is far)

@@ -127,7 +127,19 @@ __device__ void tabulate_frames(const double* xr, const double* yr, double* gap_
   }
   wn = team.max(wn, nullptr);
   finite = __ballot(!finite) == 0ull;
-  // The far split for near = kNearFirst, every window at once.  far_distance() walks (far waypoint, window waypoint)
+  float largest_gap2 = 0.0f;   // (between neighbours: decides the first choice of `near`, acmpc_frames.h)
+  for (int i = lane; i + 1 < n; i += 64) {
+    const float gap2 = frames::squared_gap(static_cast<float>(xr[i + 1]), static_cast<float>(yr[i + 1]),
+                                           static_cast<float>(xr[i]), static_cast<float>(yr[i]));
+    largest_gap2 = (gap2 > largest_gap2) ? gap2 : largest_gap2;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float other = __shfl_xor(largest_gap2, m, 64);
+    largest_gap2 = (other > largest_gap2) ? other : largest_gap2;
+  }
+  const int near0 = __builtin_amdgcn_readfirstlane(frames::near_first(largest_gap2));
+  // The far split for near = near0 (the path's first choice), every window at once.  far_distance() walks (far waypoint, window waypoint)
   // pairs window by window - up to 200 per window, on one lane.  Turned round: waypoint q = lo + j of a window needs the
   // nearest waypoint m >= q + near + W - j ahead and m <= q - near - 1 - j behind, j = 0 .. W - 1; the lane that holds
   // waypoint q finds those 2 W minima in one sweep over the path (n pairs), and a window's R^2 is the minimum over its
@@ -165,7 +177,7 @@ __device__ void tabulate_frames(const double* xr, const double* yr, double* gap_
     float running[kLive];
 #pragma unroll
     for (int r = 0; r < kLive; ++r) running[r] = finf;
-    const int count = n - 1 - frames::kNearFirst;
+    const int count = n - 1 - near0;
     for (int it = 0, mm = kAhead ? n - 1 : 0; it < count; ++it, mm += kAhead ? -1 : 1) {
       float xm, ym;
       waypoint(mm, xm, ym);
@@ -173,9 +185,9 @@ __device__ void tabulate_frames(const double* xr, const double* yr, double* gap_
       for (int r = 0; r < kLive; ++r) {
         const int q = lane + 64 * r;
         // ahead: m > q + near, entry j = q + near + W - m (< W);  behind: m < q - near, entry j = q - near - 1 - m (>= 0)
-        const int j = kAhead ? q + frames::kNearFirst + W - mm : q - frames::kNearFirst - 1 - mm;
-        const int applies = static_cast<int>(q < n) & static_cast<int>(kAhead ? mm > q + frames::kNearFirst
-                                                                              : mm < q - frames::kNearFirst);
+        const int j = kAhead ? q + near0 + W - mm : q - near0 - 1 - mm;
+        const int applies = static_cast<int>(q < n) & static_cast<int>(kAhead ? mm > q + near0
+                                                                              : mm < q - near0);
         const float d2 = frames::squared_gap(xm, ym, own_x[r], own_y[r]);
         running[r] = ((applies & static_cast<int>(d2 < running[r])) != 0) ? d2 : running[r];
         const int kept = applies & static_cast<int>(j >= 0) & static_cast<int>(j < W);
@@ -220,10 +232,13 @@ __device__ void tabulate_frames(const double* xr, const double* yr, double* gap_
     geometry[q].usable = false;
     const bool mine = lo < windows;
     double R = (mine && finite) ? frames::far_from_squared(r2[q]) : inf;
-    const int near = (mine && finite) ? frames::choose_near(at, n, lo, R) : frames::kNearFirst;
-    // (the usual case - every window's first choice of `near` stands - takes the unrolled form)
-    if (__ballot(mine && near != frames::kNearFirst) == 0ull) {
-      if (mine) geometry[q] = frames::window_geometry<frames::kNearFirst>(at, n, lo, finite, near, R);
+    const int near = (mine && finite) ? frames::choose_near(at, n, lo, near0, R) : near0;
+    // (the usual cases - every window's first choice of `near` stands, 16 or 32 waypoints - take the unrolled forms)
+    const bool first_choice_stands = __ballot(mine && near != near0) == 0ull;
+    if (first_choice_stands && near0 == 16) {
+      if (mine) geometry[q] = frames::window_geometry<16>(at, n, lo, finite, near, R);
+    } else if (first_choice_stands && near0 == 32) {
+      if (mine) geometry[q] = frames::window_geometry<32>(at, n, lo, finite, near, R);
     } else if (mine) {
       geometry[q] = frames::window_geometry<0>(at, n, lo, finite, near, R);
     }
