@@ -174,14 +174,15 @@ def test_mode_t_tick_forms_agree(monkeypatch):
                 monkeypatch.delenv(name)
 
 
-@pytest.mark.parametrize("H", [9, 20, 50, 81, 101, 129])
-def test_the_prologue_tabulates_the_frames_the_host_would(H):
+@pytest.mark.parametrize("H,metres_per_point", [(9, 2.45), (20, 2.45), (50, 2.45), (81, 2.45), (101, 2.45), (129, 2.45),
+                                                (50, 3.0), (100, 1.5), (100, 0.7), (128, 1.2)])   # (the first choice
+def test_the_prologue_tabulates_the_frames_the_host_would(H, metres_per_point):                  # of `near`: 16 / 32 / 64)
     """Mode T with the exhaustive search through the tick: the prologue's lanes leave the frames of the verified window
     search beside the waypoint rows - the arithmetic of acmpc_set_paths (csrc/acmpc_frames.h), so the same bits as
     `acmpc_search_frames` gives for the table the device wrote."""
     from acmpc_amd import _capi
     n = H - 1
-    y = np.linspace(0, 2.45 * H, H)
+    y = np.linspace(0, metres_per_point * H, H)
     coords = np.stack([0.004 * y ** 2 + 3.0 * np.sin(y / 17.0), y, np.linspace(10, 6, H)], axis=1)
     cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=28.0)
     eng = _engine(n, 1024, None)
