@@ -13,9 +13,10 @@ from optional config keys (`n_candidates`, `sampling_rounds`, `sampling_sigma`, 
 
 `rollout_mode: "T"` (default "S") scores the candidates with the Cartesian rollout instead - BASELINE.json north_star's
 literal shape: kinematic bicycle (localisation/localiser.py:66-95) advanced by `rollout_dt` seconds per step (0.05),
-nearest waypoint of the path at every step (localiser.py:282-289: the nearest of ALL waypoints - the default,
-`nn_window: null`; `nn_window: [back, ahead]` searches only that many waypoints round the previous step's, 0.064 ms per
-solve instead of 0.066), Frenet errors against it (dynamics.py:23-40), the same weights and bounds.
+nearest waypoint of the path at every step (localiser.py:282-289: the nearest of ALL waypoints - `nn_window: null`, the
+default up to horizon 101; `nn_window: [back, ahead]` searches only that many waypoints round the previous step's, 0.064 ms
+per solve instead of 0.066, and is the default beyond), Frenet errors against it (dynamics.py:23-40), the same weights and
+bounds.
 The plan is then a TIME-indexed one (control i holds from i * dt), which is what `TemporalCommandSelector` consumes.
 """
 from __future__ import annotations
@@ -77,7 +78,9 @@ class ControlSolver:
             raise ValueError("rollout_mode must be 'S' or 'T'")
         self.temporal = mode == "T"
         self._dt = float(config.get("rollout_dt", 0.05))
-        window = config.get("nn_window", None)   # None: the nearest of all waypoints (the verified window search)
+        # None: the nearest of all waypoints (the verified window search).  Absent: that, up to the 100 steps whose search
+        # frames fit the round's LDS; a longer horizon gets the (2,5) window, which costs it a third of a scan of every waypoint
+        window = config["nn_window"] if "nn_window" in config else (None if self._n_horizon <= 100 else (2, 5))
         self._nn_window = None if window is None else (int(window[0]), int(window[1]))
         self.pose = (0.0, 0.0, np.pi / 2)   # mode T start state: set by SpatialMPC before `solve` (spatial_mpc.py:185)
 
