@@ -14,7 +14,7 @@ for spec in "f_S50 S 50 - -" "f_S25 S 25 - -" "f_S100 S 100 - -" "f_S50_pair S 5
             "f_T50_one T 50 ACMPC_NO_TRIO_ROUNDS -" "f_T50_w25 T 50 - 2,5"; do
   set -- $spec
   rm -rf $ROOT/gpurun_out/trace_$1
-  ( export TICK_MODE=$2 TICK_H=$3; [ "$4" != "-" ] && export $4=1; [ "$5" != "-" ] && export TICK_WINDOW=$5; $ROOT/tools/tick_trace.sh $1 | head -1 )
+  ( export TICK_MODE=$2 TICK_H=$3; [ "$4" != "-" ] && export $4=1; [ "$5" != "-" ] && export TICK_WINDOW=$5; $ROOT/tools/tick_trace.sh $1 | sed -n 1p )
 done
 echo "tick traces done"
 rm -rf $ROOT/gpurun_out/pmc_${TAG}_T_*
