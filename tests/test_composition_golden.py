@@ -9,7 +9,7 @@ import pytest
 
 import acmpc_oracle as orc
 import c_oracle
-from test_support import RACING, engine_kwargs, full_size_controls, make_problem
+from test_support import engine_kwargs, full_size_controls, make_problem
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "composition.npz")
 

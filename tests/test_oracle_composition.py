@@ -7,7 +7,6 @@ constant `1/2 sum u_ref' R u_ref` - with P, q, A, l taken from the golden file, 
 from types import SimpleNamespace
 
 import numpy as np
-import pytest
 
 import acmpc_oracle as orc
 from test_support import make_problem

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ac-mpc_amd"))
 from acmpc_amd import workloads
-from acmpc_amd.mpc import build_mpc, SOLVED
+from acmpc_amd.mpc import build_mpc
 
 cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"]); cfg["speed_profile_constraints"]["v_max"] = 32.0
 mpc = build_mpc(cfg, workloads.PlaceholderVehicle())
