@@ -266,11 +266,21 @@ template <typename F, typename G>
 __device__ __forceinline__ F search_key(F X, F Y, G a, G b, G c) {
   return fma_(Y, F(b), fma_(X, F(a), F(c)));
 }
-// floats per waypoint in the key table: a, b, c side by side, read with ds_read2_b32 from one address.  (Padded to 16 bytes
-// and read with ds_read_b128 - 8 LDS instructions per search instead of 12, a third more bytes - the 8-waypoint kernel took
-// 161 us against 138-152; accumulating the key with two v_fmac_f32 in the register its c arrived in, by inline asm,
-// instead of the compiler's v_fma_f32 + v_fmac_f32: no gain either.  Measured round 3, not kept.)
-constexpr int kKeyStride = 3;
+// The key table in LDS, one 32-byte entry per waypoint m (round 4):
+//     [a_m, b_m, a_m+1, b_m+1 | c_m, c_m+1, c_m+2, c_m+3]
+// - the entry of waypoint m repeats what its successors' entries hold, so that a search window that starts at ANY
+// waypoint reads its keys with 16-byte loads from 16-byte aligned addresses: an 8-waypoint window is four ds_read_b128
+// of (a, b) pairs (entries lo, lo + 2, lo + 4, lo + 6) and two of c (entries lo, lo + 4) - six LDS instructions of four
+// LDS-array cycles each (MI355X_MICROARCH.md, LDS table: ds_read_b128 moves 256 B per clock, ds_read2_b32 128) where
+// the (a, b, c)-side-by-side table of round 3 took twelve ds_read2_b32 of four cycles.  The mode T rollout kernel keeps
+// the CU's LDS array busy for 70 % of its run time (profiles/r03_mode_T_sq_counters.json); the keys were three quarters of it.
+// Entries past the path's end repeat the last waypoint (never searched: a window ends at waypoint n - 1).
+// Loops that visit one waypoint at a time read a_m, b_m, c_m at kKeyStride * m + 0, kKeyB, kKeyC.
+// (Measured before, round 3, on the side-by-side table and not kept: padding (a, b, c) to 16 bytes, 161 us against
+// 138-152; (a, b) pairs + planar c through ds_read2_b64 / ds_read2_b32 - the same LDS cycles as before: a wash.)
+constexpr int kKeyStride = 8;
+constexpr int kKeyB = 1;
+constexpr int kKeyC = 4;
 
 // the key's table entries for one waypoint (x, y): a, b, c
 __device__ __forceinline__ void search_entry(float x, float y, float& a, float& b, float& c) {
@@ -295,13 +305,42 @@ __device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const Stat
   using I = typename IndexOf<F>::type;
   F best = splat<F>(__builtin_inff());
   I j = I(0);
-  for (int i = 0; i < n; ++i) {
-    const F d = search_key<F>(s.X, s.Y, abc[kKeyStride * i], abc[kKeyStride * i + 1], abc[kKeyStride * i + 2]);
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {   // four waypoints per trip: three 16-byte reads (entry i: a, b of i, i + 1 and c of i .. i + 3)
+    const f32x4* e = reinterpret_cast<const f32x4*>(abc + kKeyStride * i);
+    const f32x4 ab0 = e[0], c = e[1], ab1 = e[4];
+    const float a[4] = {ab0[0], ab0[2], ab1[0], ab1[2]}, b[4] = {ab0[1], ab0[3], ab1[1], ab1[3]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const F d = search_key<F>(s.X, s.Y, a[q], b[q], c[q]);
+      const auto better = d < best;
+      best = better ? d : best;
+      j = better ? I(i + q) : j;
+    }
+  }
+  for (; i < n; ++i) {
+    const F d = search_key<F>(s.X, s.Y, abc[kKeyStride * i], abc[kKeyStride * i + kKeyB], abc[kKeyStride * i + kKeyC]);
     const auto better = d < best;
     best = better ? d : best;
     j = better ? I(i) : j;
   }
   return j;
+}
+
+// The keys of the W consecutive waypoints from `lo` (W = 4, 8, 16): W / 2 + W / 4 ds_read_b128 from one address (see
+// kKeyStride), then two fused multiply-adds per waypoint.
+template <int W>
+__device__ __forceinline__ void window_keys(float X, float Y, const float* abc, int lo, float (&d)[W]) {
+  static_assert(W % 4 == 0, "whole 16-byte groups of c");
+  const f32x4* first = reinterpret_cast<const f32x4*>(abc + kKeyStride * lo);   // (16-byte aligned: 32-byte entries)
+  f32x4 ab[W / 2], c[W / 4];
+#pragma unroll
+  for (int m = 0; m < W / 2; ++m) ab[m] = first[4 * m];        // entry lo + 2m: a, b of waypoints lo + 2m, lo + 2m + 1
+#pragma unroll
+  for (int m = 0; m < W / 4; ++m) c[m] = first[8 * m + 1];     // entry lo + 4m: c of waypoints lo + 4m .. lo + 4m + 3
+#pragma unroll
+  for (int m = 0; m < W; ++m)
+    d[m] = search_key<float>(X, Y, ab[m / 2][2 * (m & 1)], ab[m / 2][2 * (m & 1) + 1], c[m / 4][m & 3]);
 }
 
 // The same search restricted to W = back + ahead + 1 consecutive waypoints starting at
@@ -312,11 +351,7 @@ __device__ __forceinline__ typename IndexOf<F>::type temporal_nearest(const Stat
 template <int W>
 __device__ __forceinline__ int nearest_in_window(float X, float Y, const float* abc, int lo, float* best_out = nullptr) {
   float d[W];
-  const float* first = abc + kKeyStride * lo;   // one address; the W entries at constant offsets
-#pragma unroll
-  for (int m = 0; m < W; ++m) {
-    d[m] = search_key<float>(X, Y, first[kKeyStride * m], first[kKeyStride * m + 1], first[kKeyStride * m + 2]);
-  }
+  window_keys<W>(X, Y, abc, lo, d);
   float best = d[0];
 #pragma unroll
   for (int m = 1; m < W; ++m) best = __builtin_fminf(best, d[m]);  // NaN keys are skipped, like `d < best`
@@ -411,7 +446,7 @@ __device__ __forceinline__ int nearest_cooperative_fix(float X, float Y, bool ce
       // one waypoint per lane: the smallest key (keys order as their sign-flipped bit patterns), then the first lane
       // that holds it - a ballot instead of a second reduction
       const int m = min(lane, n - 1);
-      const float d = search_key<float>(px, py, abc[kKeyStride * m], abc[kKeyStride * m + 1], abc[kKeyStride * m + 2]);
+      const float d = search_key<float>(px, py, abc[kKeyStride * m], abc[kKeyStride * m + kKeyB], abc[kKeyStride * m + kKeyC]);
       const int bits = __float_as_int(d);
       const int ordered = (lane < n && d < __builtin_inff()) ? ((bits >= 0) ? bits : (bits ^ 0x7fffffff)) : kNothing;
       const int least = wave_min_int(ordered);
@@ -421,7 +456,7 @@ __device__ __forceinline__ int nearest_cooperative_fix(float X, float Y, bool ce
       float best = __builtin_inff();
       int jj = 0x7fffffff;
       for (int m = lane; m < n; m += kWave) {
-        const float d = search_key<float>(px, py, abc[kKeyStride * m], abc[kKeyStride * m + 1], abc[kKeyStride * m + 2]);
+        const float d = search_key<float>(px, py, abc[kKeyStride * m], abc[kKeyStride * m + kKeyB], abc[kKeyStride * m + kKeyC]);
         const bool better = d < best;
         best = better ? d : best;
         jj = better ? m : jj;
@@ -469,7 +504,7 @@ __device__ __forceinline__ int temporal_nearest_window(float X, float Y, const f
     float best = __builtin_inff();
     int j = lo;
     for (int i = lo; i < hi; ++i) {
-      const float d = search_key<float>(X, Y, abc[kKeyStride * i], abc[kKeyStride * i + 1], abc[kKeyStride * i + 2]);
+      const float d = search_key<float>(X, Y, abc[kKeyStride * i], abc[kKeyStride * i + kKeyB], abc[kKeyStride * i + kKeyC]);
       const bool better = d < best;
       best = better ? d : best;
       j = better ? i : j;
@@ -481,7 +516,7 @@ __device__ __forceinline__ int temporal_nearest_window(float X, float Y, const f
 // The waypoint rows as the kernels keep them in LDS, derived from the table's [x, y, cos psi, sin psi, psi, k_ref, v_ref,
 // w/2 - margin] once per workgroup: [s x - c y, -s, c, psi, k_ref, v_ref, w/2 - margin, 0], so that the lateral error
 // e_y = c (Y - y) - s (X - x) (dynamics.py:23-40) is two fused multiply-adds on the pose; and the search key's entries
-// (search_entry), three floats per waypoint side by side.  `threads` lanes of a workgroup cooperate.
+// (search_entry) in the 32-byte entries described at kKeyStride.  `threads` lanes of a workgroup cooperate.
 __device__ __forceinline__ void stage_temporal_tables(const float* __restrict__ coef, int n, int tid, int threads,
                                                       float* rows, float* abc) {
   for (int m = tid; m < n; m += threads) {
@@ -496,7 +531,15 @@ __device__ __forceinline__ void stage_temporal_tables(const float* __restrict__ 
     r[5] = g[6];
     r[6] = g[7];
     r[7] = 0.0f;
-    search_entry(x, y, abc[kKeyStride * m], abc[kKeyStride * m + 1], abc[kKeyStride * m + 2]);
+    float* e = abc + kKeyStride * m;
+    float unused_a, unused_b;
+    search_entry(x, y, e[0], e[1], e[kKeyC]);
+    const float* g1 = coef + min(m + 1, n - 1) * kCoefT;
+    search_entry(g1[0], g1[1], e[2], e[3], e[kKeyC + 1]);
+    const float* g2 = coef + min(m + 2, n - 1) * kCoefT;
+    search_entry(g2[0], g2[1], unused_a, unused_b, e[kKeyC + 2]);
+    const float* g3 = coef + min(m + 3, n - 1) * kCoefT;
+    search_entry(g3[0], g3[1], unused_a, unused_b, e[kKeyC + 3]);
   }
 }
 
@@ -528,9 +571,24 @@ __device__ __forceinline__ void temporal_cost(StateT_<F>& s, const F (&g)[kCoefT
   s.V = fma_(hc, hc, s.V);
 }
 
+// A derived waypoint row: two 16-byte LDS reads.  (Left to itself the compiler reads the second half - whose last float is
+// padding - with ds_read_b96: eight LDS-array cycles where ds_read_b128 takes four.  The empty asm makes all four lanes of
+// the vector live.)
+__device__ __forceinline__ void load_row(const float* wp, int j, float (&row)[kCoefT]) {
+  const f32x4* r = reinterpret_cast<const f32x4*>(wp + j * kCoefT);
+  f32x4 lo = r[0], hi = r[1];
+  asm volatile("" : "+v"(hi));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    row[q] = lo[q];
+    row[4 + q] = hi[q];
+  }
+}
+
 // one-candidate form used by the finalize kernel and the tile kernel
 __device__ __forceinline__ void temporal_cost(StateT& s, const float* g, float v, float k, const Weights& w) {
-  const float row[kCoefT] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]};
+  float row[kCoefT];
+  load_row(g, 0, row);
   temporal_cost<float>(s, row, v, k, w);
 }
 
@@ -541,8 +599,9 @@ __device__ __forceinline__ void temporal_settle(StateT& s, const float* wp, int 
 __device__ __forceinline__ void temporal_settle(StateT_<f32x2>& s, const float* wp, i32x2 j, f32x2 v, f32x2 k,
                                                 const Weights& w) {
   f32x2 g[kCoefT];
-  const float* g0 = wp + j[0] * kCoefT;
-  const float* g1 = wp + j[1] * kCoefT;
+  float g0[kCoefT], g1[kCoefT];
+  load_row(wp, j[0], g0);
+  load_row(wp, j[1], g1);
 #pragma unroll
   for (int q = 0; q < kCoefT; ++q) {
     g[q][0] = g0[q];
@@ -611,15 +670,7 @@ __device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float
     j[0] = temporal_nearest_window<SEARCH>(s.X[0], s.Y[0], abc, n, j_prev[0], w.nn_back, w.nn_ahead);
     j[1] = temporal_nearest_window<SEARCH>(s.X[1], s.Y[1], abc, n, j_prev[1], w.nn_back, w.nn_ahead);
   }
-  f32x2 g[kCoefT];
-  const float* g0 = wp + j[0] * kCoefT;
-  const float* g1 = wp + j[1] * kCoefT;
-#pragma unroll
-  for (int q = 0; q < kCoefT; ++q) {
-    g[q][0] = g0[q];
-    g[q][1] = g1[q];
-  }
-  temporal_cost<f32x2>(s, g, v, k, w);
+  temporal_settle(s, wp, j, v, k, w);
   return j;
 }
 
@@ -629,11 +680,8 @@ __device__ __forceinline__ i32x2 step_temporal_as(StateT_<f32x2>& s, const float
 // mask operations are free only where other waves fill the gaps.  The same first minimum either way.
 template <int W>
 __device__ __forceinline__ int nearest_in_window_chain(float X, float Y, const float* abc, int lo, float& best) {
-  const float* first = abc + kKeyStride * lo;
   float d[W];
-#pragma unroll
-  for (int m = 0; m < W; ++m)
-    d[m] = search_key<float>(X, Y, first[kKeyStride * m], first[kKeyStride * m + 1], first[kKeyStride * m + 2]);
+  window_keys<W>(X, Y, abc, lo, d);
   best = __builtin_inff();
   int j = lo;
 #pragma unroll
@@ -662,7 +710,7 @@ __device__ __forceinline__ int propose_nearest(float X, float Y, const float* ab
 __device__ __forceinline__ int confirm_nearest(float X, float Y, const float* abc, const float* frames, int n,
                                                int proposal_before, int proposal) {
   const float* e = abc + kKeyStride * proposal;
-  const float best = search_key<float>(X, Y, e[0], e[1], e[2]);   // (a NaN key is below no bound: the scan decides, as it must)
+  const float best = search_key<float>(X, Y, e[0], e[kKeyB], e[kKeyC]);   // (a NaN key is below no bound: the scan decides, as it must)
   const int lo = verified_window_start(proposal_before, n);
   return nearest_cooperative_fix(X, Y, frame_certifies(X, Y, best, frames, lo), proposal, abc, n);
 }

@@ -855,7 +855,7 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
     }
     __syncthreads();
     const int mine_at = kKeyStride * min(lane, n - 1);   // the search key's entries of "this lane's" waypoint
-    const float my_a = s_abc[mine_at], my_b = s_abc[mine_at + 1], my_c = s_abc[mine_at + 2];
+    const float my_a = s_abc[mine_at], my_b = s_abc[mine_at + kKeyB], my_c = s_abc[mine_at + kKeyC];
     int j_prev = 0;
     for (int base = 0; base < n; base += kWave) {
       const int mine = base + lane;
@@ -878,7 +878,7 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
         float best = (lane >= win_lo && lane <= win_hi) ? search_key<float>(st.X, st.Y, my_a, my_b, my_c) : __builtin_inff();
         int j = lane;
         for (int m = lane + kWave; m <= win_hi; m += kWave) {
-          const float d = (m >= win_lo) ? search_key<float>(st.X, st.Y, s_abc[kKeyStride * m], s_abc[kKeyStride * m + 1], s_abc[kKeyStride * m + 2])
+          const float d = (m >= win_lo) ? search_key<float>(st.X, st.Y, s_abc[kKeyStride * m], s_abc[kKeyStride * m + kKeyB], s_abc[kKeyStride * m + kKeyC])
                                         : __builtin_inff();
           const bool better = d < best;
           best = better ? d : best;
