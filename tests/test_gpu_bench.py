@@ -46,12 +46,16 @@ def test_single_gpu_line_has_the_contract_fields():
     # instruction-bound kernels carry the roof they are under (VALU issue), the fused sampled round at scale too
     for name in ("mode_T_exhaustive_search", "mode_T_window_2_5", "mode_T_window_1_2", "mode_T_window_2_5_16M",
                  "mode_T_exhaustive_search_16M"):
-        valu = second[name]["roofline_valu"]
-        assert valu["bound"] == "valu" and valu["frac"] > 0 and valu["valu_instructions_per_candidate_step"] > 20
-        assert valu["instruction_count_source"].startswith("profiles/")
+        valu, lds = second[name]["roofline_valu"], second[name]["roofline_lds"]
+        # an issue-time roof (per-opcode issue times measured at the kernel's occupancy x its opcode mix): a roof, so <= 1
+        assert valu["bound"] == "valu_issue" and 0.3 < valu["frac"] <= 1.0, (name, valu["frac"])
+        assert valu["valu_instructions_per_candidate_step"] > 20 and 0.9 < valu["mean_issue_ns_per_instruction_per_simd"] < 2.5
+        assert valu["instruction_count_source"].startswith("profiles/") and valu["opcode_mix_source"].startswith("profiles/")
+        assert valu["opcode_mix_matches_loaded_sources"] is True, "profiles/*_isa_mix.json is stale: python3 tools/isa_mix.py"
+        assert lds["bound"] == "lds_array" and 0 < lds["frac"] <= 1.0
     fused = second["sampled_fused_16M"]
     assert fused["kernel_us"] > 0 and fused["candidate_trajectories_per_s"] > 1e9 and fused["winners_finite"]
-    assert fused["roofline_valu"]["frac"] > 0
+    assert 0.3 < fused["roofline_valu"]["frac"] <= 1.0
     assert out["roofline"]["traffic_measured_in_this_run"] is False
     loop_t = out["closed_loop_replay_mode_T"]
     assert "rollout mode T" in loop_t["workload"] and loop_t["infeasible_solves"] == 0 and loop_t["solve_ms_p50"] > 0
