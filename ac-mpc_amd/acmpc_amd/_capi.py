@@ -40,7 +40,7 @@ class Params(C.Structure):
         ("nn_back", C.c_int32),
         ("nn_ahead", C.c_int32),
         ("centre_update", C.c_int32),
-        ("reserved", C.c_int32),
+        ("lq_candidate", C.c_int32),
         ("step_cost", C.c_double * 3),
         ("r_term", C.c_double * 2),
         ("final_cost", C.c_double * 3),
@@ -129,9 +129,13 @@ SIGNATURES = {
     "acmpc_version": (C.c_char_p, []),
     "acmpc_create": (C.c_int, [C.POINTER(Params), C.POINTER(_CTX)]),
     "acmpc_destroy": (None, [_CTX]),
+    "acmpc_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_char_p]),
+    "acmpc_lq_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
     "acmpc_last_error": (C.c_char_p, [_CTX]),
     "acmpc_set_paths": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
     "acmpc_get_coefficients": (C.c_int, [_CTX, C.c_int32, _F32P, C.c_int32]),
+    "acmpc_set_coefficients": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
     "acmpc_record_floats": (C.c_int32, [C.c_int32]),
     "acmpc_solve": (C.c_int, [_CTX, _F32P, _F32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F32P, _I32P, _F32P]),
     "acmpc_solve_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -269,6 +273,20 @@ def split_record(rec: np.ndarray, n: int):
                 owner=rec[..., REC_OWNER], u=u, x=x)
 
 
+def lq_plan(table: np.ndarray, x0, step_cost, r_term, final_cost, u_min, u_max):
+    """The LQ plan of one path on the host (acmpc_lq_plan): table [7, n] float64, x0 = (e_y, e_psi, t) -> [n, 2] float32
+    (v, kappa), or None when the problem has no finite plan."""
+    lib = load_library()
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    n = table.shape[1]
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x0, step_cost, r_term, final_cost)]
+    box = [np.ascontiguousarray(a, dtype=np.float32) for a in (u_min, u_max)]
+    plan = np.empty((n, 2), dtype=np.float32)
+    rc = lib.acmpc_lq_plan(table.ctypes.data, n, *(a.ctypes.data for a in args), *(b.ctypes.data for b in box),
+                           plan.ctypes.data)
+    return plan if rc == OK else None
+
+
 class _TickBuffers:
     """Everything `Engine.control_tick` hands to the library for one horizon, allocated once: the inputs are copied
     into fixed arrays (taking an array's address through `.ctypes` costs more than copying 150 doubles), the outputs
@@ -334,11 +352,13 @@ class Engine:
     def __init__(self, *, mode: int, max_problems: int, max_candidates: int, max_steps: int, step_cost, r_term,
                  final_cost, u_min, u_max, margin: float, wheelbase: float, t_min: float = 0.01, dt: float = 0.05,
                  w_bound: float = 1.0e6, softmin_lambda: float = 1.0, device: int = -1, nn_window=None,
-                 centre_update: str = "argmin"):
+                 centre_update: str = "argmin", lq_candidate: bool = False):
         """`nn_window=(back, ahead)` restricts mode T's nearest-waypoint search to that many waypoints round the
         previous step's nearest index; None = the nearest of ALL waypoints at every step (localiser.py:282-289's
         semantics: the kernels search an 8-waypoint window whose winner a certificate accepts as the global one, and
-        scan every waypoint where it does not - the same index either way, see csrc/acmpc_frames.h)."""
+        scan every waypoint where it does not - the same index either way, see csrc/acmpc_frames.h).
+        `lq_candidate`: the last sampling round of `optimize` / `control_tick` also holds the LQ plan (the optimum of the
+        reference's control QP without its box rows, rolled forward and clipped: csrc/acmpc_lq.h) as candidate 2."""
         self._lib = load_library()
         p = Params()
         p.struct_size = C.sizeof(Params)
@@ -346,6 +366,7 @@ class Engine:
         p.max_problems, p.max_candidates, p.max_steps = max_problems, max_candidates, max_steps
         p.nn_back, p.nn_ahead = (-1, -1) if nn_window is None else (int(nn_window[0]), int(nn_window[1]))
         p.centre_update = {"argmin": 0, "softmin": 1}[centre_update]
+        p.lq_candidate = 1 if lq_candidate else 0
         p.step_cost[:] = [float(v) for v in step_cost]
         p.r_term[:] = [float(v) for v in r_term]
         p.final_cost[:] = [float(v) for v in final_cost]
@@ -366,6 +387,11 @@ class Engine:
     def _check(self, rc: int):
         if rc != OK:
             raise EngineError(rc, (self._lib.acmpc_last_error(self._ctx) or b"").decode())
+
+    def set_option(self, name: str, value=None):
+        """One of the handle's A/B switches (tools/README.md; `name` as the environment spells it, e.g. "ACMPC_NO_SOLO").
+        They are read from the environment once, when the handle is created; this sets one afterwards.  None = default."""
+        self._check(self._lib.acmpc_set_option(self._ctx, name.encode(), None if value is None else str(value).encode()))
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -388,6 +414,18 @@ class Engine:
             raise ValueError("tables must be [P, 7, n]")
         self._check(self._lib.acmpc_set_paths(self._ctx, t.ctypes.data, t.shape[0], t.shape[2]))
         self.P, self.n = t.shape[0], t.shape[2]
+
+    def set_coefficients(self, coef: np.ndarray):
+        """The packed float32 tables themselves, [P, n, 12] (mode S) / [P, n, 8] (mode T) or one [n, stride] table
+        (acmpc_set_coefficients): e.g. what `tick_device_tables` read back."""
+        coef = np.ascontiguousarray(coef, dtype=np.float32)
+        if coef.ndim == 2:
+            coef = coef[None]
+        P, n, stride = coef.shape
+        if stride != COEF_STRIDE[self.mode]:
+            raise ValueError("coefficient rows must have %d floats" % COEF_STRIDE[self.mode])
+        self._check(self._lib.acmpc_set_coefficients(self._ctx, coef.ctypes.data, P, n))
+        self.P, self.n = P, n
 
     def coefficients(self, problem: int = 0) -> np.ndarray:
         out = np.empty((self.n, COEF_STRIDE[self.mode]), dtype=np.float32)

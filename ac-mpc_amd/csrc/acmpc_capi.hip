@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <limits>
 #include <new>
 #include <string>
@@ -19,6 +20,7 @@
 #include "../../include/acmpc.h"
 #include "acmpc_frames.h"
 #include "acmpc_kernels.h"
+#include "acmpc_lq.h"
 #include "acmpc_prologue.h"
 
 namespace {
@@ -126,6 +128,22 @@ struct acmpc_ctx {
   double* d_warm = nullptr;             // speed-profile iterate of the two solvers, kept between ticks
   int warm_stride = 0;
   int tick_last_n = 0;
+
+  // the LQ plan (csrc/acmpc_lq.h; acmpc_params::lq_candidate): candidate 2 of the LAST sampling round
+  std::vector<double> h_tables;         // the float64 tables of acmpc_set_paths: [P][7][n]
+  float* h_lq = nullptr;                // pinned [max_problems][max_steps][2]: the plans, read by the last round in place
+  std::vector<double> tick_prev_table;  // what the previous acmpc_control_tick solved: its 7 x n table ...
+  double tick_prev_x0[3] = {0.0, 0.0, 0.0};   // ... and its start state (Frenet)
+  std::vector<double> tick_lq_table;    // scratch: this tick's waypoints with the previous tick's speed profile
+  int tick_prev_n = 0;                  // 0: nothing usable (first tick, or a tick that did not end with a finite plan)
+
+  // A/B switches of the tests and the tools: read from the environment ONCE, by acmpc_create, or set with acmpc_set_option;
+  // nothing on a launch path calls getenv
+  acmpc::LaunchOptions opt;
+  struct Switches {
+    bool no_verified_search = false, no_solo = false, no_fused_finalize = false, no_traced_finalize = false,
+         no_chained_rounds = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false;
+  } sw;
 
   // optional timing of the rollout dispatches (acmpc_profile_*): event pairs attached to the launches
   std::vector<hipEvent_t> prof_start, prof_stop;
@@ -296,12 +314,12 @@ int check_shape(acmpc_ctx* c, int P, int N, int n, int layout) {
 
 int rollout(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int n, int layout, int64_t offset,
             float* d_costs, hipStream_t s, acmpc::LaunchShape* shape_out) {
-  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout, c->prm.mode, n);
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout, c->prm.mode, n, c->opt);
   acmpc::RolloutArgs a{};
   a.U = d_U;
   a.x0 = d_x0;
   a.coef = c->d_coef;
-  a.nn_frames = (!c->h_nn_frames.empty() && std::getenv("ACMPC_NO_VERIFIED_SEARCH") == nullptr) ? c->d_nn_frames : nullptr;
+  a.nn_frames = (!c->h_nn_frames.empty() && !c->sw.no_verified_search) ? c->d_nn_frames : nullptr;
   a.costs = d_costs;
   a.partial_keys = c->d_partial_keys;
   a.partial_feas = c->d_partial_feas;
@@ -326,6 +344,7 @@ struct Regenerate {
   int centre_stride;
   const float* d_uref;
   acmpc::SampleSpec spec;
+  const float* d_extra = nullptr;   // candidate 2's controls (the LQ plan), or nullptr
 };
 
 int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const float* d_x0, const float* d_U, int P,
@@ -337,6 +356,7 @@ int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const 
     a.centre = regen->d_centre;
     a.centre_stride = regen->centre_stride;
     a.u_ref = regen->d_uref;
+    a.u_extra = regen->d_extra;
     a.spec = regen->spec;
   }
   a.U = d_U;
@@ -401,12 +421,13 @@ acmpc::SampleSpec make_spec(const acmpc_ctx* c, double sigma_v, double sigma_k, 
 
 int sample(acmpc_ctx* c, const float* d_centre, int centre_stride, const float* d_uref, int P, int N, int n,
            int layout, int64_t offset, double sigma_v, double sigma_k, uint64_t seed, uint32_t round, float* d_U,
-           hipStream_t s, const uint32_t* d_seed = nullptr) {
+           hipStream_t s, const uint32_t* d_seed = nullptr, const float* d_extra = nullptr) {
   const int rc = upload_segments(c, n, s);  // no-op once the table for this n is resident
   if (rc != ACMPC_OK) return rc;
   acmpc::SampleArgs a{};
   a.centre = d_centre;
   a.u_ref = d_uref;
+  a.u_extra = d_extra;
   a.U = d_U;
   a.centre_stride = centre_stride;
   a.P = P;
@@ -444,7 +465,7 @@ int ensure_tail_buffers(acmpc_ctx* c) {
 // argmin and the winner's record without rolling the winner a second time.  ACMPC_NO_SOLO keeps the two launches.
 bool use_solo(const acmpc_ctx* c, int P, int N, int n, int layout) {
   static_assert(kTraceBlocks >= acmpc::kSoloBlocks, "the trace buffer holds one trace per workgroup");
-  return c->prm.mode == ACMPC_MODE_SPATIAL && std::getenv("ACMPC_NO_SOLO") == nullptr && acmpc::solo_fits(P, N, n, layout);
+  return c->prm.mode == ACMPC_MODE_SPATIAL && !c->sw.no_solo && acmpc::solo_fits(P, N, n, layout, c->opt);
 }
 
 int solve_solo(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int n, int layout, float* d_costs,
@@ -475,7 +496,7 @@ int solve_solo(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, 
     e1 = c->prof_stop[c->prof_used];
     ++c->prof_used;
   }
-  ACMPC_HIP(c, acmpc::launch_rollout_solo(layout, a, ff, s, e0, e1));
+  ACMPC_HIP(c, acmpc::launch_rollout_solo(layout, a, ff, s, e0, e1, c->opt));
   return ACMPC_OK;
 }
 
@@ -497,8 +518,53 @@ int ensure_staging(acmpc_ctx* c) {
   if (rc_tail != ACMPC_OK) return rc_tail;
   ACMPC_HIP(c, host_alloc_once(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
   ACMPC_HIP(c, host_alloc_once(&c->h_io, static_cast<size_t>(p.max_problems) * (3 + acmpc_record_floats(p.max_steps)) * sizeof(float)));
+  if (p.lq_candidate != 0 && c->h_lq == nullptr) {
+    const size_t lq_bytes = static_cast<size_t>(p.max_problems) * p.max_steps * 2 * sizeof(float);
+    ACMPC_HIP(c, host_alloc_once(&c->h_lq, lq_bytes));
+    std::memset(c->h_lq, 0, lq_bytes);
+  }
   c->staging_ready = true;
   return ACMPC_OK;
+}
+
+// ---- A/B switches: names as the environment spells them; a null or empty value, or "0" for the boolean ones, is the default
+const char* const kOptionNames[] = {
+    "ACMPC_SHAPE", "ACMPC_T_PACK", "ACMPC_NO_TILE", "ACMPC_TILE_ROWS", "ACMPC_TILE_TABLE", "ACMPC_NO_TRIO_ROUNDS",
+    "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
+    "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
+    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG"};
+
+bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
+  const std::string key(name);
+  const bool present = value != nullptr && value[0] != '\0';
+  const bool on = present && !(value[0] == '0' && value[1] == '\0');
+  auto tri = [&](int* field) { *field = present ? (value[0] == '1' ? 1 : 0) : -1; return true; };
+  acmpc::LaunchOptions& o = c->opt;
+  if (key == "ACMPC_SHAPE") {
+    o.shape_block = o.shape_cpt = 0;
+    if (present && std::sscanf(value, "%d,%d", &o.shape_block, &o.shape_cpt) != 2) o.shape_block = o.shape_cpt = 0;
+    return true;
+  }
+  if (key == "ACMPC_T_PACK") { o.temporal_pack = present ? (value[0] == '1' ? 1 : 2) : 0; return true; }
+  if (key == "ACMPC_NO_TILE") { o.no_tile = on; return true; }
+  if (key == "ACMPC_TILE_ROWS") { o.tile_rows = present ? std::atoi(value) : -1; return true; }
+  if (key == "ACMPC_TILE_TABLE") { o.tile_table = present ? (value[0] == 'l' ? 1 : 2) : 0; return true; }
+  if (key == "ACMPC_NO_TRIO_ROUNDS") { o.no_trio_rounds = on; return true; }
+  if (key == "ACMPC_NO_QUAD_ROUNDS") { o.no_quad_rounds = on; return true; }
+  if (key == "ACMPC_NO_PAIR_ROUNDS") { o.no_pair_rounds = on; return true; }
+  if (key == "ACMPC_SOLO_REGISTERS") return tri(&o.solo_registers);
+  if (key == "ACMPC_SOLO_SPLIT") return tri(&o.solo_split);
+  acmpc_ctx::Switches& w = c->sw;
+  if (key == "ACMPC_NO_VERIFIED_SEARCH") { w.no_verified_search = on; return true; }
+  if (key == "ACMPC_NO_SOLO") { w.no_solo = on; return true; }
+  if (key == "ACMPC_NO_FUSED_FINALIZE") { w.no_fused_finalize = on; return true; }
+  if (key == "ACMPC_NO_TRACED_FINALIZE") { w.no_traced_finalize = on; return true; }
+  if (key == "ACMPC_NO_CHAINED_ROUNDS") { w.no_chained_rounds = on; return true; }
+  if (key == "ACMPC_NO_GRAPH") { w.no_graph = on; return true; }
+  if (key == "ACMPC_NO_FUSED_SAMPLING") { w.no_fused_sampling = on; return true; }
+  if (key == "ACMPC_TICK_GRAPH") { w.tick_graph = on; return true; }
+  if (key == "ACMPC_TICK_NO_FLAG") { w.tick_no_flag = on; return true; }
+  return false;
 }
 
 }  // namespace
@@ -508,6 +574,14 @@ extern "C" {
 const char* acmpc_version(void) { return "acmpc-hip 0.1 gfx950"; }
 
 int32_t acmpc_record_floats(int32_t n) { return ACMPC_REC_HEADER + 2 * n + 3 * (n + 1); }
+
+int acmpc_lq_plan(const double* table, int32_t n, const double x0[3], const double step_cost[3], const double r_term[2],
+                  const double final_cost[3], const float u_min[2], const float u_max[2], float* plan) {
+  if (table == nullptr || x0 == nullptr || step_cost == nullptr || r_term == nullptr || final_cost == nullptr ||
+      u_min == nullptr || u_max == nullptr || plan == nullptr || n < 1)
+    return ACMPC_EINVAL;
+  return acmpc::lq::plan(table, n, x0, step_cost, r_term, final_cost, u_min, u_max, plan) ? ACMPC_OK : ACMPC_ESTATE;
+}
 
 int64_t acmpc_pack_key(float cost, uint32_t index) { return acmpc::pack_key(cost, index); }
 
@@ -535,6 +609,8 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
     return fail(nullptr, ACMPC_EINVAL, "nearest-waypoint window: need nn_back >= 0 and at most 64 waypoints");
   if (params->centre_update != 0 && params->centre_update != 1)
     return fail(nullptr, ACMPC_EINVAL, "centre_update must be 0 (argmin) or 1 (softmin mean)");
+  if (params->lq_candidate != 0 && params->lq_candidate != 1)
+    return fail(nullptr, ACMPC_EINVAL, "lq_candidate must be 0 or 1");
   if (params->max_steps > 1024)
     return fail(nullptr, ACMPC_EINVAL, "the waypoint table and the winner record are staged in LDS: max_steps <= 1024");
   if (params->max_problems > 65535)
@@ -568,7 +644,28 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
   w.dt = static_cast<float>(params->dt);
   w.nn_back = params->nn_back;
   w.nn_ahead = params->nn_ahead;
+  // the A/B switches of the tests and the tools (tools/README.md): the environment is read HERE, once per handle
+  for (const char* name : kOptionNames) {
+    const char* value = std::getenv(name);
+    if (value != nullptr) (void)apply_option(c, name, value);
+  }
   *out = c;
+  return ACMPC_OK;
+}
+
+int acmpc_set_option(acmpc_ctx* c, const char* name, const char* value) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (name == nullptr) return fail(c, ACMPC_EINVAL, "null option name");
+  if (!apply_option(c, name, value)) return fail(c, ACMPC_EINVAL, std::string("unknown option or bad value: ") + name);
+  // captured graphs hold the launch forms they were captured with
+  for (hipGraphExec_t& g : c->opt_graph) {
+    if (g != nullptr) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
+  for (hipGraphExec_t& g : c->tick_graph) {
+    if (g != nullptr) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
   return ACMPC_OK;
 }
 
@@ -593,6 +690,7 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_nn_frames);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
     if (c->h_io != nullptr) (void)hipHostFree(c->h_io);
+    if (c->h_lq != nullptr) (void)hipHostFree(c->h_lq);
     for (hipGraphExec_t g : c->opt_graph)
       if (g != nullptr) (void)hipGraphExecDestroy(g);
     for (hipGraphExec_t g : c->tick_graph)
@@ -652,6 +750,24 @@ int acmpc_set_paths(acmpc_ctx* c, const double* tables, int32_t P, int32_t n) {
       }
     }
   }
+  if (c->prm.lq_candidate != 0) c->h_tables.assign(tables, tables + static_cast<size_t>(P) * 7 * n);
+  c->h_nn_frames.clear();
+  if (c->prm.mode == ACMPC_MODE_TEMPORAL && c->prm.nn_ahead < 0 && n >= acmpc::kVerifiedWindow && n <= kMaxVerifiedSteps)
+    verified_frames(c->h_coef.data(), P, n, &c->h_nn_frames);
+  c->P_set = P;
+  c->n_set = n;
+  c->tables_dirty = true;
+  c->frames_dirty = !c->h_nn_frames.empty();
+  return ACMPC_OK;
+}
+
+int acmpc_set_coefficients(acmpc_ctx* c, const float* coef, int32_t P, int32_t n) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (coef == nullptr) return fail(c, ACMPC_EINVAL, "null coefficients");
+  if (P < 1 || n < 2) return fail(c, ACMPC_EINVAL, "need P >= 1 and n >= 2");
+  if (P > c->prm.max_problems || n > c->prm.max_steps) return fail(c, ACMPC_ECAPACITY, "P or n exceeds capacity");
+  c->h_coef.assign(coef, coef + static_cast<size_t>(P) * n * c->coef_stride);
+  if (c->h_tables.size() != static_cast<size_t>(P) * 7 * n) c->h_tables.clear();   // (no float64 tables for these paths)
   c->h_nn_frames.clear();
   if (c->prm.mode == ACMPC_MODE_TEMPORAL && c->prm.nn_ahead < 0 && n >= acmpc::kVerifiedWindow && n <= kMaxVerifiedSteps)
     verified_frames(c->h_coef.data(), P, n, &c->h_nn_frames);
@@ -729,7 +845,7 @@ int acmpc_finalize_device(acmpc_ctx* c, const int64_t* d_keys, const float* d_x0
   int rc = check_shape(c, P, N, n, layout);
   if (rc != ACMPC_OK) return rc;
   if (!c->device_ready) return fail(c, ACMPC_ESTATE, "acmpc_rollout_device must run first");
-  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout, c->prm.mode, n);
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout, c->prm.mode, n, c->opt);
   return finalize(c, d_keys, nullptr, d_x0, d_U, P, N, n, layout, index_offset, d_records, shape.blocks_per_problem,
                   static_cast<hipStream_t>(stream));
 }
@@ -844,7 +960,7 @@ int acmpc_finalize_sampled_device(acmpc_ctx* c, const int64_t* d_keys, const flo
   rc = upload_segments(c, n, s);
   if (rc != ACMPC_OK) return rc;
   Regenerate regen{d_centre, centre_stride, d_u_ref, make_spec(c, sigma_v, sigma_kappa, seed, round)};
-  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, ACMPC_LAYOUT_STEP_MAJOR, c->prm.mode, n);
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, ACMPC_LAYOUT_STEP_MAJOR, c->prm.mode, n, c->opt);
   return finalize(c, d_keys, nullptr, d_x0, nullptr, P, N, n, ACMPC_LAYOUT_STEP_MAJOR, 0, d_records,
                   shape.blocks_per_problem, s, &regen);
 }
@@ -861,20 +977,44 @@ struct OptInputs {
   const float* uref;  // or nullptr
   const float* coef;
   const float* frames = nullptr;  // mode T, exhaustive search: the verified search's frames of these paths, or nullptr
+  // the LQ plans [P][n][2] (device-visible), candidate 2 of the LAST round, or nullptr; `before_last` - when set - runs on
+  // the host right before that round is enqueued and fills them (acmpc_control_tick plans while the earlier launches
+  // execute) and returns false when there is no plan after all
+  const float* extra = nullptr;
+  std::function<bool()> before_last;
 };
 
 // the handle's own frames (acmpc_set_paths), for the rounds that read the handle's own table
 const float* own_frames(const acmpc_ctx* c) { return c->h_nn_frames.empty() ? nullptr : c->d_nn_frames; }
 
 bool use_fused_finalize(const acmpc_ctx* c, int n) {
-  return std::getenv("ACMPC_NO_FUSED_FINALIZE") == nullptr && acmpc::fused_finalize_fits(c->prm.mode, n);
+  return !c->sw.no_fused_finalize && acmpc::fused_finalize_fits(c->prm.mode, n);
 }
 
 // The fused finalize copies the record out of the winning workgroup's trace when the launch is small enough for the
 // trace buffer (closed-loop rounds are: 256 workgroups) and the trace fits the LDS; else it re-draws and re-rolls.
 bool use_traced_finalize(const acmpc_ctx* c, int P, int N, int n) {
-  return std::getenv("ACMPC_NO_TRACED_FINALIZE") == nullptr && acmpc::traced_finalize_fits(c->prm.mode, n) &&
+  return !c->sw.no_traced_finalize && acmpc::traced_finalize_fits(c->prm.mode, n) &&
          static_cast<long long>(P) * ((N + 63) / 64) <= kTraceBlocks;
+}
+
+// One LQ plan (csrc/acmpc_lq.h) into `out` [n][2]: the path's 7 x n float64 table, the start state as the rollouts take it
+// (mode S: the Frenet state; mode T: the pose, moved into the Frenet frame of the first waypoint here).  Without a finite
+// plan (a singular step, a speed profile that was never solved) `out` gets the reference controls clipped into the box -
+// candidate 1 again, harmless - and false comes back.
+bool lq_plan_into(const acmpc_ctx* c, const double* table, int n, const double start[3], float* out,
+                  bool start_is_pose = false) {
+  double x0[3] = {start[0], start[1], start[2]};
+  if (start_is_pose || c->prm.mode == ACMPC_MODE_TEMPORAL) acmpc::lq::frenet_start(table, n, start, x0);
+  const float lo[2] = {c->w.ulo0, c->w.ulo1}, hi[2] = {c->w.uhi0, c->w.uhi1};
+  const bool finite_start = std::isfinite(x0[0]) && std::isfinite(x0[1]) && std::isfinite(x0[2]);
+  if (finite_start && acmpc::lq::plan(table, n, x0, c->prm.step_cost, c->prm.r_term, c->prm.final_cost, lo, hi, out)) return true;
+  const double *kappa = table + 3 * static_cast<size_t>(n), *vel = table + 6 * static_cast<size_t>(n);
+  for (int i = 0; i < n; ++i) {
+    out[2 * i] = std::fmin(std::fmax(static_cast<float>(vel[i]), lo[0]), hi[0]);
+    out[2 * i + 1] = std::fmin(std::fmax(static_cast<float>(kappa[i]), lo[1]), hi[1]);
+  }
+  return false;
 }
 
 // `final_records`: where the LAST round's records go when the fused finalize writes them (device memory, or pinned
@@ -892,6 +1032,8 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     const float* d_c = (r == 0) ? in.centre : c->d_records + ACMPC_REC_HEADER;
     const int stride = (r == 0) ? 2 * n : rec_floats;
     const float* d_ref = has_uref ? in.uref : nullptr;
+    const float* d_extra = nullptr;   // the LQ plan competes in the last round only
+    if (r + 1 == rounds && in.extra != nullptr && (!in.before_last || in.before_last())) d_extra = in.extra;
     if (!fused) {  // (only with the handle's own buffers: in.coef == c->d_coef)
       const bool softmin = c->prm.centre_update == 1;
       // softmin rounds: candidate 0 = the weighted mean of the previous round (written into d_centre below),
@@ -903,7 +1045,7 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
                                       static_cast<size_t>(2 * n) * sizeof(float), P, hipMemcpyDeviceToDevice, s));
       int rc = sample(c, mean_round ? c->d_centre : d_c, mean_round ? 2 * n : stride, mean_round ? c->d_uref : d_ref, P,
                       N, n, layout, 0, sigma_v * scale, sigma_k * scale, seed, static_cast<uint32_t>(r), c->d_U, s,
-                      d_seed);
+                      d_seed, d_extra);
       if (rc != ACMPC_OK) return rc;
       acmpc::LaunchShape shape;
       rc = rollout(c, in.x0, c->d_U, P, N, n, layout, 0, softmin ? c->d_costs : nullptr, s, &shape);
@@ -937,14 +1079,14 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     // two sets, since a round reads its predecessor's while it writes its own.
     const int blocks = (N + 63) / 64;
     const bool traced = fused_finalize && use_traced_finalize(c, P, N, n);
-    const bool chain = traced && blocks <= acmpc::kChainBlocks && std::getenv("ACMPC_NO_CHAINED_ROUNDS") == nullptr;
+    const bool chain = traced && blocks <= acmpc::kChainBlocks && !c->sw.no_chained_rounds;
     const size_t set = (chain && (r & 1)) ? 1 : 0;
     const size_t trace_set_floats = static_cast<size_t>(kTraceBlocks) * acmpc::trace_floats(c->prm.max_steps);
     float* d_trace = c->d_trace + set * trace_set_floats;
     acmpc::RolloutArgs ra{};
     ra.x0 = in.x0;
     ra.coef = in.coef;
-    ra.nn_frames = (std::getenv("ACMPC_NO_VERIFIED_SEARCH") == nullptr) ? in.frames : nullptr;
+    ra.nn_frames = !c->sw.no_verified_search ? in.frames : nullptr;
     ra.partial_keys = c->d_partial_keys + set * c->partial_slots;
     ra.partial_feas = c->d_partial_feas + set * c->partial_slots;
     ra.P = P;
@@ -956,6 +1098,7 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
     sa.centre = d_c;
     sa.centre_stride = stride;
     sa.u_ref = d_ref;
+    sa.u_extra = d_extra;
     sa.P = P;
     sa.N = N;
     sa.n = n;
@@ -985,10 +1128,10 @@ int enqueue_rounds(acmpc_ctx* c, const OptInputs& in, int P, int N, int n, int r
                                     (last && final_records != nullptr) ? final_records : c->d_records, !last,
                                     traced ? d_trace : nullptr, acmpc::trace_floats(n),
                                     last ? done : nullptr, done_value};
-      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, ff, s, e0, e1));
+      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, ff, s, e0, e1, c->opt));
     } else {
-      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, acmpc::FusedFinalize{nullptr, nullptr, false, nullptr, 0, nullptr, 0}, s, e0, e1));
-      Regenerate regen{d_c, stride, d_ref, sa.spec};
+      ACMPC_HIP(c, acmpc::launch_rollout_sampled(c->prm.mode, ra, sa, acmpc::FusedFinalize{nullptr, nullptr, false, nullptr, 0, nullptr, 0}, s, e0, e1, c->opt));
+      Regenerate regen{d_c, stride, d_ref, sa.spec, d_extra};
       rc = finalize(c, nullptr, nullptr, in.x0, nullptr, P, N, n, layout, 0, c->d_records, (N + 63) / 64, s, &regen,
                     in.coef);
       if (rc != ACMPC_OK) return rc;
@@ -1019,17 +1162,26 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   const size_t table_bytes = static_cast<size_t>(P) * n * c->coef_stride * sizeof(float);
   const size_t rec_bytes = static_cast<size_t>(P) * acmpc_record_floats(n) * sizeof(float);
   const bool has_uref = u_ref != nullptr;
+  // the LQ plans of these paths from these start states: candidate 2 of the last round (acmpc_params::lq_candidate)
+  const bool has_extra = c->prm.lq_candidate != 0 && c->h_tables.size() == static_cast<size_t>(P) * 7 * n;
+  if (has_extra) {
+    for (int p = 0; p < P; ++p) {
+      const double start[3] = {x0[3 * p], x0[3 * p + 1], x0[3 * p + 2]};
+      (void)lq_plan_into(c, c->h_tables.data() + static_cast<size_t>(p) * 7 * n, n, start, c->h_lq + static_cast<size_t>(p) * n * 2);
+    }
+  }
 
   // Eager path: when rollout launches are being timed (event pairs cannot be captured) or on request.
-  if (c->prof_used < c->prof_start.size() || std::getenv("ACMPC_NO_GRAPH") != nullptr) {
+  if (c->prof_used < c->prof_start.size() || c->sw.no_graph) {
     rc = upload_tables(c, s);
     if (rc != ACMPC_OK) return rc;
     ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, x0, x0_bytes, hipMemcpyHostToDevice, s));
     ACMPC_HIP(c, hipMemcpyAsync(c->d_centre, centre, path_bytes, hipMemcpyHostToDevice, s));
     if (has_uref) ACMPC_HIP(c, hipMemcpyAsync(c->d_uref, u_ref, path_bytes, hipMemcpyHostToDevice, s));
-    const OptInputs in{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef, own_frames(c)};
+    OptInputs in{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef, own_frames(c)};
+    in.extra = has_extra ? c->h_lq : nullptr;   // (pinned: the last round reads the plans in place)
     rc = enqueue_rounds(c, in, P, N, n, rounds, sigma[0], sigma[1], shrink, seed, nullptr, s,
-                        std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr && c->prm.centre_update == 0);
+                        !c->sw.no_fused_sampling && c->prm.centre_update == 0);
     if (rc != ACMPC_OK) return rc;
     ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
     ACMPC_HIP(c, hipStreamSynchronize(s));
@@ -1058,7 +1210,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   key.N = N;
   key.n = n;
   key.rounds = rounds;
-  key.has_uref = has_uref ? 1 : 0;
+  key.has_uref = (has_uref ? 1 : 0) | (has_extra ? 2 : 0);
   key.sigma_v = sigma[0];
   key.sigma_k = sigma[1];
   key.shrink = shrink;
@@ -1080,10 +1232,11 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     // ONE host-to-device copy brings x0, centre, u_ref, the table and the seed; the kernels read them in place
     const size_t in_bytes = off_seed + 2 * sizeof(uint32_t);
     hipError_t e = hipMemcpyAsync(c->d_opt, c->h_opt, in_bytes, hipMemcpyHostToDevice, s);
-    const bool fused = std::getenv("ACMPC_NO_FUSED_SAMPLING") == nullptr && c->prm.centre_update == 0;
+    const bool fused = !c->sw.no_fused_sampling && c->prm.centre_update == 0;
     OptInputs in{reinterpret_cast<const float*>(c->d_opt + off_x0), reinterpret_cast<const float*>(c->d_opt + off_centre),
                  has_uref ? reinterpret_cast<const float*>(c->d_opt + off_uref) : nullptr,
                  reinterpret_cast<const float*>(c->d_opt + off_table), own_frames(c)};
+    in.extra = has_extra ? c->h_lq : nullptr;
     if (!fused) {  // the three-kernel form runs on the handle's own buffers: copy the block's parts there
       auto spread = [&](void* dst, size_t off, size_t bytes) {
         if (e == hipSuccess) e = hipMemcpyAsync(dst, c->d_opt + off, bytes, hipMemcpyDeviceToDevice, s);
@@ -1093,6 +1246,7 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
       if (has_uref) spread(c->d_uref, off_uref, path_bytes);
       spread(c->d_coef, off_table, table_bytes);
       in = OptInputs{c->d_x0, c->d_centre, has_uref ? c->d_uref : nullptr, c->d_coef, own_frames(c)};
+      in.extra = has_extra ? c->h_lq : nullptr;
     }
     int rc_rounds = ACMPC_OK;
     // with the fused finalize the last round writes the winners straight into the pinned host buffer (posted
@@ -1307,8 +1461,26 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   // host memory, and this call polls it - the record is here a microsecond after it was written, where the launch's
   // completion signal (hipStreamSynchronize) takes the driver's path.  The stream is only synchronised when the flag
   // does not come (a fault), and before a host buffer the kernels read is rewritten by a DIFFERENT kind of call.
-  static const bool use_graph = std::getenv("ACMPC_TICK_GRAPH") != nullptr;
-  const bool flagged = direct && !use_graph && std::getenv("ACMPC_TICK_NO_FLAG") == nullptr;
+  const bool use_graph = c->sw.tick_graph;
+  // The LQ plan (acmpc_params::lq_candidate), computed on the host while this tick's prologue and earlier rounds run and
+  // read by the last round in place from pinned memory.  The tick's own table is being built on the device right now; what
+  // the host has is this tick's PATH - so the plan is for the waypoints of `coords` (acmpc_waypoint_table, the host
+  // statement of the prologue's first step) with the speed profile the previous tick solved (the QP is warm-started from
+  // it and moves little from tick to tick) and the start state of this tick's pose (offset, 0, pi / 2).  With the path cut
+  // out of the map on the device (coords = NULL) the host does not have it: the plan is then the previous tick's problem's.
+  const bool lq_on = c->prm.lq_candidate != 0;
+  const double lq_offset = t->offset;
+  auto plan_previous = [c, n, H, coords, lq_offset]() -> bool {
+    if (c->tick_prev_n != n) return false;   // first tick, another horizon, or a previous tick without a finite plan
+    if (coords == nullptr) return lq_plan_into(c, c->tick_prev_table.data(), n, c->tick_prev_x0, c->h_lq);
+    c->tick_lq_table.resize(static_cast<size_t>(7) * n);
+    if (acmpc_waypoint_table(coords, H, kEps, c->tick_lq_table.data()) != ACMPC_OK) return false;
+    std::memcpy(c->tick_lq_table.data() + static_cast<size_t>(6) * n, c->tick_prev_table.data() + static_cast<size_t>(6) * n,
+                static_cast<size_t>(n) * sizeof(double));
+    const double pose[3] = {lq_offset, 0.0, M_PI / 2.0};
+    return lq_plan_into(c, c->tick_lq_table.data(), n, pose, c->h_lq, true);
+  };
+  const bool flagged = direct && !use_graph && !c->sw.tick_no_flag;
   unsigned* done_flag = reinterpret_cast<unsigned*>(c->h_tick_out + out.done);
   const unsigned done_value = ++c->tick_sequence;
   // prologue -> rounds (-> copy of the record when the fused finalize cannot write it to the host itself)
@@ -1317,7 +1489,11 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     hipError_t e = (from_map && t->map_index < 0) ? acmpc::launch_map_window(ma, q) : hipSuccess;
     if (e == hipSuccess) e = acmpc::launch_prologue(pa, n, q);
     if (e != hipSuccess) return e;
-    const OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef, pa.frames};
+    OptInputs oi{pa.x0, pa.centre, pa.u_ref, pa.coef, pa.frames};
+    if (lq_on) {
+      oi.extra = c->h_lq;
+      if (!use_graph) oi.before_last = plan_previous;   // (a captured graph: planned before the replay, below)
+    }
     // (launched directly the rounds take the seed by value: read from the device block, as a replayed graph must, it is
     // a dependent load in front of every round's first Philox draw)
     *rc_rounds = enqueue_rounds(c, oi, 1, N, n, t->rounds, t->sigma[0], t->sigma[1], t->shrink,
@@ -1408,6 +1584,11 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   if (!from_map) std::memcpy(c->h_tick + in.coords, coords, static_cast<size_t>(H) * 3 * sizeof(double));
   if (centre != nullptr) std::memcpy(c->h_tick + in.centre_in, centre, static_cast<size_t>(n) * 2 * sizeof(float));
   if (use_graph) {
+    if (lq_on && !plan_previous()) {
+      // no plan for the replayed graph's candidate 2: it reads the centre sequence instead (candidate 0 again)
+      if (centre != nullptr && t->centre_is_reference == 0)
+        std::memcpy(c->h_lq, centre, static_cast<size_t>(n) * 2 * sizeof(float));
+    }
     ACMPC_HIP(c, hipGraphLaunch(c->tick_graph[slot], s));
   } else {
     pa.header_by_value = 1;
@@ -1472,6 +1653,13 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   info[5] = status[1];
   info[6] = from_map ? static_cast<double>(status[2]) : -1.0;   // first map index of the window
   info[7] = finite ? 0.0 : 1.0;   // a non-finite cost, violation or plan entry (max |dec.x| above skips NaNs)
+  if (lq_on) {   // what the next tick plans for: this tick's table and start state (the record's x_0: Frenet state or pose)
+    c->tick_prev_n = (finite && status[0] == 0) ? n : 0;
+    if (c->tick_prev_n != 0) {
+      c->tick_prev_table.assign(table, table + static_cast<size_t>(7) * n);
+      for (int q = 0; q < 3; ++q) c->tick_prev_x0[q] = static_cast<double>(rx[q]);
+    }
+  }
   if (coords_out != nullptr)
     std::memcpy(coords_out, from_map ? reinterpret_cast<const void*>(c->h_tick_out + out.coords)
                                      : reinterpret_cast<const void*>(coords),

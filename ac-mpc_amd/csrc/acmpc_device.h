@@ -801,14 +801,56 @@ __device__ __forceinline__ float uniform_open(uint32_t bits) {
   return static_cast<float>(bits >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
 }
 
-// Box-Muller on two uniforms -> two standard normals, on the hardware transcendental units: v_log_f32 for the
-// radius and v_sin_f32 / v_cos_f32, which take their argument in turns - exactly u2, no 2*pi multiply to round.
-// (Absolute error ~1e-6 on a unit normal: noise for a sampler; the library log/sincos cost 10x the instructions and
-// made this kernel the longest of an optimisation round.)
+// ---- the sampler's normals, specified bit for bit (round 4) -------------------------------------------------------
+// Box-Muller on two uniforms -> two standard normals with a FIXED operation sequence, so that oracle sample_candidates()
+// reproduces every candidate of acmpc_sample_device / the fused rounds exactly, on any part (rounds 1-3 used v_log_f32 /
+// v_sin_f32 / v_cos_f32: ~1e-6 apart from any restatement, and not portable):
+//   ln u      u = m 2^e with m in [sqrt(1/2), sqrt(2)) read off the bit pattern, f = m - 1 (exact),
+//             ln u = f - f^2/2 + f^3 P(f) + e ln 2 with the degree-8 P of Cephes' logf (Moshier) and ln 2 in two parts,
+//             every multiply-add below ONE fmaf.  u is a uniform_open() value: normal, in (0, 1].
+//   radius    sqrt(-2 ln u): IEEE multiply and correctly rounded square root (hipcc's default for float32).
+//   angle     sin / cos of 2 pi u2 reduced in TURNS: k = rint(2 u2) off a magic-number sum, r = u2 - k/2 (exact),
+//             x = 2 pi r in [-pi/2, pi/2], the rollout's own polynomials (kSinC, kCosC), sign (-1)^k.
+constexpr float kLogC[9] = {7.0376836292e-2f, -1.1514610310e-1f, 1.1676998740e-1f, -1.2420140846e-1f, 1.4249322787e-1f,
+                            -1.6668057665e-1f, 2.0000714765e-1f, -2.4999993993e-1f, 3.3333331174e-1f};
+constexpr float kLn2Hi = 0.693359375f;         // 9 significant bits: e * kLn2Hi is exact
+constexpr float kLn2Lo = -2.12194440e-4f;      // ln 2 - kLn2Hi
+
+__device__ __forceinline__ float log_spec(float u) {
+  const int bits = __float_as_int(u);
+  const int e = (bits - 0x3f3504f3) >> 23;                 // arithmetic shift: floor(log2(u / sqrt(1/2)))
+  const float m = __int_as_float(bits - (e << 23));        // u / 2^e in [sqrt(1/2), sqrt(2))
+  const float f = m - 1.0f;
+  const float ef = static_cast<float>(e);
+  const float z = f * f;
+  float p = fma_(kLogC[0], f, kLogC[1]);
+#pragma unroll
+  for (int q = 2; q < 9; ++q) p = fma_(p, f, kLogC[q]);
+  float y = (f * z) * p;
+  y = fma_(ef, kLn2Lo, y);
+  y = fma_(-0.5f, z, y);
+  return fma_(ef, kLn2Hi, f + y);
+}
+
 __device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float& z1) {
-  const float r = __builtin_sqrtf(-2.0f * __logf(u1));
-  z0 = r * __builtin_amdgcn_cosf(u2);
-  z1 = r * __builtin_amdgcn_sinf(u2);
+  const float radius = __builtin_sqrtf(-2.0f * log_spec(u1));
+  const float t = fma_(u2, 2.0f, 12582912.0f);             // k = rint(2 u2) in the low mantissa bits
+  const float k = t - 12582912.0f;
+  const float r = fma_(k, -0.5f, u2);                       // exact
+  const float x = r * 6.28318530717959f;
+  const float x2 = x * x;
+  float ps = fma_(x2, kSinC[3], kSinC[2]);
+  ps = fma_(x2, ps, kSinC[1]);
+  ps = fma_(x2, ps, kSinC[0]);
+  const float sn = fma_(x * x2, ps, x);
+  float pc = fma_(x2, kCosC[4], kCosC[3]);
+  pc = fma_(x2, pc, kCosC[2]);
+  pc = fma_(x2, pc, kCosC[1]);
+  pc = fma_(x2, pc, kCosC[0]);
+  const float cs = fma_(x2, pc, 1.0f);
+  const int sign = __float_as_int(t) << 31;
+  z0 = radius * __int_as_float(__float_as_int(cs) ^ sign);
+  z1 = radius * __int_as_float(__float_as_int(sn) ^ sign);
 }
 
 constexpr int kKnots = 8;  // raised-cosine knots along the horizon (== kSampleKnots)

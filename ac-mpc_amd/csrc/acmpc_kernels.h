@@ -37,6 +37,7 @@ struct FinalizeArgs {
   bool controls_only;
   const float* centre;
   const float* u_ref;
+  const float* u_extra;         // [P][n][2] or nullptr: candidate 2 (see SampleArgs)
   int centre_stride;
   SampleSpec spec;
   int blocks_per_problem;
@@ -62,6 +63,8 @@ constexpr int kSampleKnots = kKnots;
 struct SampleArgs {
   const float* centre;     // [P] x centre_stride floats, first 2n of each = (v, kappa) per step
   const float* u_ref;      // [P][n][2] or nullptr: becomes candidate 1
+  const float* u_extra;    // [P][n][2] or nullptr: becomes candidate 2 (the LQ plan of csrc/acmpc_lq.h: the unconstrained
+                           // optimum of the QP, rolled forward with its feedback and clipped into the input box)
   float* U;                // out, layout per `layout`
   int centre_stride;
   int P, N, n;
@@ -77,6 +80,19 @@ struct SampleArgs {
 constexpr int kTileRowsMaxSteps = 80;   // longest horizon of rollout_tile_rows_kernel (2 VGPRs per step)
 constexpr int kChainBlocks = 256;   // four keys per lane
 
+// The A/B switches of the tests and the tools.  They are read from the environment ONCE, by acmpc_create (ACMPC_* variables,
+// tools/README.md), or set through acmpc_set_option, and travel with the handle: nothing on a launch path calls getenv, and
+// an environment variable that appears later changes nothing.  The defaults are the shipped forms.
+struct LaunchOptions {
+  int shape_block = 0, shape_cpt = 0;   // ACMPC_SHAPE="<block>,<cpt>": the rollout's launch shape
+  int temporal_pack = 0;                // ACMPC_T_PACK: 1 = plain float32 states, 2 = packed pairs (0: the default, plain)
+  bool no_tile = false;                 // ACMPC_NO_TILE
+  int tile_rows = -1;                   // ACMPC_TILE_ROWS: 4 = the rows-in-registers tile kernel, 0 = not (-1: by size)
+  int tile_table = 0;                   // ACMPC_TILE_TABLE: 1 = lds, 2 = scalar (0: by shape)
+  bool no_trio_rounds = false, no_quad_rounds = false, no_pair_rounds = false;
+  int solo_registers = -1, solo_split = -1;   // ACMPC_SOLO_REGISTERS / ACMPC_SOLO_SPLIT: 0 / 1 (-1: by size / split)
+};
+
 struct LaunchShape {
   int block;              // threads per workgroup
   int cpt;                // candidates per thread
@@ -84,10 +100,11 @@ struct LaunchShape {
   bool tile;              // candidate-major LDS-tile kernel
   int tile_waves;         // tile kernel with the rows in registers: waves per workgroup sharing one LDS tile (0: not used)
   int pack;               // mode T, cpt >= 2: candidates per arithmetic state (2 = v_pk_* pairs, 1 = plain float32)
+  int tile_table = 0;     // rows-in-registers tile kernel: 1 = table rows from LDS, 2 = by scalar loads (0: by shape)
 };
 
 // Picks workgroup size / candidates per thread for (P, N, layout); pure function, also used to size workspaces.
-LaunchShape choose_shape(int P, int N, int layout, int mode, int n);
+LaunchShape choose_shape(int P, int N, int layout, int mode, int n, const LaunchOptions& opt = LaunchOptions());
 int max_blocks_per_problem(int N);
 size_t tile_lds_bytes(int mode, int n);
 
@@ -133,15 +150,16 @@ struct FusedFinalize {
 // (the closed-loop solve, where every launch is ~10 us of latency-bound work)
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
                                   const FusedFinalize& fused, hipStream_t s, hipEvent_t start = nullptr,
-                                  hipEvent_t stop = nullptr);
+                                  hipEvent_t stop = nullptr, const LaunchOptions& opt = LaunchOptions());
 // acmpc_solve_device in ONE launch (mode S, at most kSoloBlocks workgroups of 64 candidates): rollout, argmin and the
 // winner's record assembled from the winning workgroup's state trace - `fused.trace` [P][workgroups][trace_pitch >=
 // solo_trace_floats(n)], `fused.tickets` [P][ticket_groups + 1] counters (kTicketStride ints apart) zero before and after.  `fused.records` may be
 // null (keys only).
-bool solo_fits(int P, int N, int n, int layout);
+bool solo_fits(int P, int N, int n, int layout, const LaunchOptions& opt = LaunchOptions());
 int solo_trace_floats(int n);
 hipError_t launch_rollout_solo(int layout, const RolloutArgs& args, const FusedFinalize& fused, hipStream_t s,
-                               hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+                               hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
+                               const LaunchOptions& opt = LaunchOptions());
 int trace_floats(int n);
 bool traced_finalize_fits(int mode, int n);
 // whether rollout + fused finalize fit one workgroup's 64 KB of LDS (mode T at the longest horizons does not)

@@ -393,10 +393,12 @@ __global__ void __launch_bounds__(256) sample_kernel(const SampleArgs a) {
   const uint32_t gidx = static_cast<uint32_t>(a.index_offset + c);
   float z[kKnots][2];
   draw_normals(sp, gidx, static_cast<uint32_t>(p), z);
-  const bool use_ref = (gidx == 1u) && (a.u_ref != nullptr);
+  // candidate 1 = the reference controls, candidate 2 = `u_extra` (the LQ plan), each when given: amplitude 0, own centre
+  const float* alt = (gidx == 1u) ? a.u_ref : (gidx == 2u) ? a.u_extra : nullptr;
+  const bool use_ref = alt != nullptr;
   const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
   const float* __restrict__ centre =
-      use_ref ? a.u_ref + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
+      use_ref ? alt + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
   // blend weights and the centre sequence -> LDS once per workgroup; the knot boundaries are kernel arguments, so
   // neither the loop bounds nor the per-step operands wait on a dependent scalar/global load (those dependencies used
   // to make this the longest kernel of an optimisation round)
@@ -461,6 +463,7 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   const float* __restrict__ x0 = a.x0 + p * 3;
   const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
   const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
+  const float* __restrict__ extra = (smp.u_extra != nullptr) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
   const float* __restrict__ knot_weight = sp.segments;
   float* s_wp = s_fused;
   float* s_xy = s_wp + n * kCoefT;
@@ -479,12 +482,13 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   float* s_row = s_uni;
   float* s_centre = s_row + ((MODE == 0) ? n * kCoefS : 0);
   float* s_ref = s_centre + 2 * n;
-  float* s_weight = s_ref + 2 * n;
+  float* s_extra = s_ref + 2 * n;    // candidate 2's controls (smp.u_extra: the LQ plan), when given
+  float* s_weight = s_extra + 2 * n;
   const bool chained = smp.prev_keys != nullptr;   // wave-uniform
   constexpr int kRowQuads = (kStagedSteps * kCoefS / 4 + kWave - 1) / kWave;   // table quads per lane
   constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;                    // (v, kappa) pairs per lane
   f32x4 g_row[kRowQuads];
-  f32x2 g_centre[kPairs], g_ref[kPairs], g_weight[kPairs];
+  f32x2 g_centre[kPairs], g_ref[kPairs], g_extra[kPairs], g_weight[kPairs];
 #pragma unroll
   for (int q = 0; q < kRowQuads; ++q) {
     if constexpr (MODE == 0)
@@ -495,6 +499,7 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     const int j = min(lane + q * kWave, n - 1);
     if (!chained) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[j];
     if (ref != nullptr) g_ref[q] = reinterpret_cast<const f32x2*>(ref)[j];
+    if (extra != nullptr) g_extra[q] = reinterpret_cast<const f32x2*>(extra)[j];
     g_weight[q] = reinterpret_cast<const f32x2*>(knot_weight)[j];   // (knot, weight) pairs: the weight is [1]
   }
   // chained rounds: the previous launch's partial keys, four per lane, requested with the rest
@@ -543,6 +548,7 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     if (j < n) {
       reinterpret_cast<f32x2*>(s_centre)[j] = g_centre[q];
       reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? g_ref[q] : g_centre[q];
+      if (extra != nullptr) reinterpret_cast<f32x2*>(s_extra)[j] = g_extra[q];
       s_weight[j] = g_weight[q][1];
     }
   }
@@ -554,12 +560,16 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
       const f32x2 cj = reinterpret_cast<const f32x2*>(centre)[j];
       reinterpret_cast<f32x2*>(s_centre)[j] = cj;
       reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? reinterpret_cast<const f32x2*>(ref)[j] : cj;
+      if (extra != nullptr) reinterpret_cast<f32x2*>(s_extra)[j] = reinterpret_cast<const f32x2*>(extra)[j];
       s_weight[j] = knot_weight[2 * j + 1];
     }
   }
   __syncthreads();   // one wave: orders the staging above before the reads below
   if (active) {
-    const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
+    // candidate 1 = the reference controls, candidate 2 = `u_extra` (the LQ plan), each when given: amplitude 0, own centre
+    const bool use_extra = (gidx == 2u) && (smp.u_extra != nullptr);
+    const bool use_ref = ((gidx == 1u) && (smp.u_ref != nullptr)) || use_extra;
+    const f32x2* s_alt = reinterpret_cast<const f32x2*>(use_extra ? s_extra : s_ref);   // (per lane)
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     StateS ss{x0[0], x0[1], x0[2], 0.0f, 0.0f};
     StateT ts = start_temporal<float>(x0);
@@ -574,7 +584,7 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     auto request = [&](int i) {
       StepOperands o;
       o.centre = reinterpret_cast<const f32x2*>(s_centre)[i];
-      o.ref = reinterpret_cast<const f32x2*>(s_ref)[i];
+      o.ref = s_alt[i];
       o.weight = s_weight[i];
       if constexpr (MODE == 0) {
         o.lo = *reinterpret_cast<const f32x4*>(s_row + i * kCoefS);
@@ -734,9 +744,10 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
   const float* centre = nullptr;
   if (a.regenerate) {
     draw_normals(a.spec, gidx, static_cast<uint32_t>(p), z);
-    const bool use_ref = (gidx == 1u) && (a.u_ref != nullptr);
+    const float* alt = (gidx == 1u) ? a.u_ref : (gidx == 2u) ? a.u_extra : nullptr;
+    const bool use_ref = alt != nullptr;
     amp = use_ref ? 0.0f : candidate_amplitude(gidx);
-    centre = use_ref ? a.u_ref + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
+    centre = use_ref ? alt + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
   }
   auto winner_control = [&](int step, float& v, float& k) {
     if (a.regenerate) {
@@ -1058,6 +1069,7 @@ __device__ __forceinline__ void fused_tail(const RolloutArgs& a, const SampleArg
   f.controls_only = fused.controls_only;
   f.centre = smp.centre;
   f.u_ref = smp.u_ref;
+  f.u_extra = smp.u_extra;
   f.centre_stride = smp.centre_stride;
   f.spec = smp.spec;
   f.blocks_per_problem = static_cast<int>(gridDim.x);
@@ -1108,7 +1120,8 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
   const int n = a.n;
   float* s_centre = s_row + n * kCoefS;
   float* s_ref = s_centre + 2 * n;
-  float* s_weight = s_ref + 2 * n;
+  float* s_extra = s_ref + 2 * n;    // candidate 2's controls (smp.u_extra: the LQ plan), when given
+  float* s_weight = s_extra + 2 * n;
   float* s_exchange = s_fused + exchange_lds_floats + lane;   // [buffer][step of the chunk][v | kappa][lane]
   constexpr int kStepFloats = kPairValues * kWave, kBufferFloats = kPairChunk * kStepFloats;
   const int c = blockIdx.x * kWave + lane;
@@ -1120,15 +1133,17 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
     const SampleSpec sp = smp.spec;
     const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
     const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ extra = (smp.u_extra != nullptr) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
     const float* __restrict__ knot_weight = sp.segments;
     const bool chained = smp.prev_keys != nullptr;
     constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
-    f32x2 g_centre[kPairs], g_ref[kPairs], g_weight[kPairs];
+    f32x2 g_centre[kPairs], g_ref[kPairs], g_extra[kPairs], g_weight[kPairs];
 #pragma unroll
     for (int q = 0; q < kPairs; ++q) {
       const int j = min(lane + q * kWave, n - 1);
       if (!chained) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[j];
       if (ref != nullptr) g_ref[q] = reinterpret_cast<const f32x2*>(ref)[j];
+      if (extra != nullptr) g_extra[q] = reinterpret_cast<const f32x2*>(extra)[j];
       g_weight[q] = reinterpret_cast<const f32x2*>(knot_weight)[j];
     }
     int64_t prev_key[kChainBlocks / kWave];
@@ -1160,6 +1175,7 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
       if (j < n) {
         reinterpret_cast<f32x2*>(s_centre)[j] = g_centre[q];
         reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? g_ref[q] : g_centre[q];
+        if (extra != nullptr) reinterpret_cast<f32x2*>(s_extra)[j] = g_extra[q];
         s_weight[j] = g_weight[q][1];
       }
     }
@@ -1167,10 +1183,14 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
       const f32x2 cj = reinterpret_cast<const f32x2*>(centre)[j];
       reinterpret_cast<f32x2*>(s_centre)[j] = cj;
       reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? reinterpret_cast<const f32x2*>(ref)[j] : cj;
+      if (extra != nullptr) reinterpret_cast<f32x2*>(s_extra)[j] = reinterpret_cast<const f32x2*>(extra)[j];
       s_weight[j] = knot_weight[2 * j + 1];
     }
     __syncthreads();   // (0) the consumer has put the table rows in, this wave the rest
-    const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
+    // candidate 1 = the reference controls, candidate 2 = `u_extra` (the LQ plan), each when given: amplitude 0, own centre
+    const bool use_extra = (gidx == 2u) && (smp.u_extra != nullptr);
+    const bool use_ref = ((gidx == 1u) && (smp.u_ref != nullptr)) || use_extra;
+    const f32x2* s_alt = reinterpret_cast<const f32x2*>(use_extra ? s_extra : s_ref);   // (per lane)
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     struct Operands {
       f32x2 centre, ref;
@@ -1179,7 +1199,7 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
     auto request = [&](int i) {   // (one step past the end is read - inside the block - and never used)
       Operands o;
       o.centre = reinterpret_cast<const f32x2*>(s_centre)[i];
-      o.ref = reinterpret_cast<const f32x2*>(s_ref)[i];
+      o.ref = s_alt[i];
       o.weight = s_weight[i];
       return o;
     };
@@ -1314,7 +1334,8 @@ __global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kerne
   const int n = a.n;
   float* s_centre = s_row + n * kCoefS;
   float* s_ref = s_centre + 2 * n;
-  float* s_weight = s_ref + 2 * n;
+  float* s_extra = s_ref + 2 * n;    // candidate 2's controls (smp.u_extra: the LQ plan), when given
+  float* s_weight = s_extra + 2 * n;
   float* s_z = s_fused + normals_lds_floats;          // [knot][component][lane]
   float* s_j = s_z + 2 * kKnots * kWave;
   const int c = blockIdx.x * kWave + lane;
@@ -1342,7 +1363,10 @@ __global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kerne
   // the controls of the steps i = parity, parity + 2, ... (every step with one control wave's worth of work halved): blend,
   // leave (v, kappa) in the trace; one barrier per chunk, taken by both control waves
   auto produce_controls = [&](const float (&z)[kKnots][2], const int parity) {
-    const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
+    // candidate 1 = the reference controls, candidate 2 = `u_extra` (the LQ plan), each when given: amplitude 0, own centre
+    const bool use_extra = (gidx == 2u) && (smp.u_extra != nullptr);
+    const bool use_ref = ((gidx == 1u) && (smp.u_ref != nullptr)) || use_extra;
+    const f32x2* s_alt = reinterpret_cast<const f32x2*>(use_extra ? s_extra : s_ref);   // (per lane)
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     struct Operands {
       f32x2 centre, ref;
@@ -1351,7 +1375,7 @@ __global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kerne
     auto request = [&](int i) {   // (up to two steps past the end are read - inside the block's padding - and never used)
       Operands o;
       o.centre = reinterpret_cast<const f32x2*>(s_centre)[i];
-      o.ref = reinterpret_cast<const f32x2*>(s_ref)[i];
+      o.ref = s_alt[i];
       o.weight = s_weight[i];
       return o;
     };
@@ -1396,15 +1420,17 @@ __global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kerne
     // ---- controls: requests, its quarter of the draws, the uniform operands of the control waves into LDS, then chunk by chunk ----
     const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
     const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ extra = (smp.u_extra != nullptr) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
     const float* __restrict__ knot_weight = sp.segments;
     const bool chained = smp.prev_keys != nullptr;
     constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
-    f32x2 g_centre[kPairs], g_ref[kPairs], g_weight[kPairs];
+    f32x2 g_centre[kPairs], g_ref[kPairs], g_extra[kPairs], g_weight[kPairs];
 #pragma unroll
     for (int q = 0; q < kPairs; ++q) {
       const int j = min(lane + q * kWave, n - 1);
       if (!chained) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[j];
       if (ref != nullptr) g_ref[q] = reinterpret_cast<const f32x2*>(ref)[j];
+      if (extra != nullptr) g_extra[q] = reinterpret_cast<const f32x2*>(extra)[j];
       g_weight[q] = reinterpret_cast<const f32x2*>(knot_weight)[j];
     }
     int64_t prev_key[kChainBlocks / kWave];
@@ -1433,6 +1459,7 @@ __global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kerne
       if (j < n) {
         reinterpret_cast<f32x2*>(s_centre)[j] = g_centre[q];
         reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? g_ref[q] : g_centre[q];
+        if (extra != nullptr) reinterpret_cast<f32x2*>(s_extra)[j] = g_extra[q];
         s_weight[j] = g_weight[q][1];
       }
     }
@@ -1440,6 +1467,7 @@ __global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kerne
       const f32x2 cj = reinterpret_cast<const f32x2*>(centre)[j];
       reinterpret_cast<f32x2*>(s_centre)[j] = cj;
       reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? reinterpret_cast<const f32x2*>(ref)[j] : cj;
+      if (extra != nullptr) reinterpret_cast<f32x2*>(s_extra)[j] = reinterpret_cast<const f32x2*>(extra)[j];
       s_weight[j] = knot_weight[2 * j + 1];
     }
     __syncthreads();   // (S) every wave's normals and the table rows are in
@@ -1578,7 +1606,7 @@ __global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kerne
 // p50 at chunks of 10 / 7 / 4 / 3 / 2 steps: 67.1 / 65.5 / 63.0 / 61.8 / 62.7 us (one wave per workgroup: 86.3).  Same operations on the same operands: same bits
 // (test_tick_forms_agree with ACMPC_NO_TRIO_ROUNDS).
 // LDS: [waypoint rows n x 8 | key table n x 3] [trace [5n + 2][64]] [uniform operands: centre, reference, knot weights]
-//      [nearest indices [n][64]].
+//      [nearest indices [n][64], 16-bit].
 #ifndef ACMPC_TRIO_CHUNK
 #define ACMPC_TRIO_CHUNK 3
 #endif
@@ -1599,8 +1627,11 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
   float* s_trace = s_fused + trace_lds_floats;
   float* s_centre = s_fused + uniform_lds_floats;
   float* s_ref = s_centre + 2 * n;
-  float* s_weight = s_ref + 2 * n;
-  int* s_index = reinterpret_cast<int*>(s_fused + index_lds_floats);
+  float* s_extra = s_ref + 2 * n;    // candidate 2's controls (smp.u_extra: the LQ plan), when given
+  float* s_weight = s_extra + 2 * n;
+  // (16-bit entries: horizons go to 1 025 steps; as 32-bit ones the frames of the verified search stopped fitting beside the
+  // trace at the mapping controller's horizon of 100 once the key table grew to 32 bytes per waypoint)
+  unsigned short* s_index = reinterpret_cast<unsigned short*>(s_fused + index_lds_floats);
   const int c = blockIdx.x * kWave + lane;
   const bool active = c < a.N;
   const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kCoefT;
@@ -1613,15 +1644,17 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
     const SampleSpec sp = smp.spec;
     const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
     const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ extra = (smp.u_extra != nullptr) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
     const float* __restrict__ knot_weight = sp.segments;
     const bool chained = smp.prev_keys != nullptr;
     constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
-    f32x2 g_centre[kPairs], g_ref[kPairs], g_weight[kPairs];
+    f32x2 g_centre[kPairs], g_ref[kPairs], g_extra[kPairs], g_weight[kPairs];
 #pragma unroll
     for (int q = 0; q < kPairs; ++q) {
       const int j = min(lane + q * kWave, n - 1);
       if (!chained) g_centre[q] = reinterpret_cast<const f32x2*>(centre)[j];
       if (ref != nullptr) g_ref[q] = reinterpret_cast<const f32x2*>(ref)[j];
+      if (extra != nullptr) g_extra[q] = reinterpret_cast<const f32x2*>(extra)[j];
       g_weight[q] = reinterpret_cast<const f32x2*>(knot_weight)[j];
     }
     int64_t prev_key[kChainBlocks / kWave];
@@ -1653,6 +1686,7 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
       if (j < n) {
         reinterpret_cast<f32x2*>(s_centre)[j] = g_centre[q];
         reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? g_ref[q] : g_centre[q];
+        if (extra != nullptr) reinterpret_cast<f32x2*>(s_extra)[j] = g_extra[q];
         s_weight[j] = g_weight[q][1];
       }
     }
@@ -1660,12 +1694,16 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
       const f32x2 cj = reinterpret_cast<const f32x2*>(centre)[j];
       reinterpret_cast<f32x2*>(s_centre)[j] = cj;
       reinterpret_cast<f32x2*>(s_ref)[j] = (ref != nullptr) ? reinterpret_cast<const f32x2*>(ref)[j] : cj;
+      if (extra != nullptr) reinterpret_cast<f32x2*>(s_extra)[j] = reinterpret_cast<const f32x2*>(extra)[j];
       s_weight[j] = knot_weight[2 * j + 1];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave reads what its own lanes staged
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const bool use_ref = (gidx == 1u) && (smp.u_ref != nullptr);
+    // candidate 1 = the reference controls, candidate 2 = `u_extra` (the LQ plan), each when given: amplitude 0, own centre
+    const bool use_extra = (gidx == 2u) && (smp.u_extra != nullptr);
+    const bool use_ref = ((gidx == 1u) && (smp.u_ref != nullptr)) || use_extra;
+    const f32x2* s_alt = reinterpret_cast<const f32x2*>(use_extra ? s_extra : s_ref);   // (per lane)
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     StateT pose = start_temporal<float>(x0);
     struct Operands {
@@ -1675,7 +1713,7 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
     auto request = [&](int i) {   // (one step past the end is read - inside the block - and never used)
       Operands o;
       o.centre = reinterpret_cast<const f32x2*>(s_centre)[i];
-      o.ref = reinterpret_cast<const f32x2*>(s_ref)[i];
+      o.ref = s_alt[i];
       o.weight = s_weight[i];
       return o;
     };
@@ -1734,7 +1772,7 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
             } else {
               j_prev = search_temporal_as<decltype(kind)::value>(X[q], Y[q], s_abc, n, w, j_prev);
             }
-            s_index[(first + q) * kWave + lane] = j_prev;
+            s_index[(first + q) * kWave + lane] = static_cast<unsigned short>(j_prev);
           }
         }
         __syncthreads();   // chunk t - 1 searched (and, while t < chunks, chunk t of the poses is in)
@@ -2361,8 +2399,7 @@ hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const Rollou
   //   H = 50:  256 problems 92 / 92 us, 1 024: 335 / 389, 4 096: 1 258 / 1 457   (more tables in flight, more scalar misses)
   //   H = 30:  256: 51.5 / 47.8, 1 024: 212 / 216;   H = 20, 2 048 problems: 297 / 280
   //   H = 65:  256: 183 / 173, 1 024: 654 / 685;     H = 80: 256: 221 / 220, 1 024: 799 / 1 094
-  const char* ab = std::getenv("ACMPC_TILE_TABLE");   // (A/B switch: "lds" / "scalar")
-  const bool lds = ab != nullptr ? ab[0] == 'l' : (args.n > 32 && (args.n <= 50 || args.P >= 512));
+  const bool lds = shape.tile_table != 0 ? shape.tile_table == 1 : (args.n > 32 && (args.n <= 50 || args.P >= 512));   // (A/B: LaunchOptions::tile_table)
   if (lds) {
     if (args.n <= 32) return launch_rollout_tile_rows<32, 4, true>(shape, args, s, e0, e1);
     if (args.n <= 50) return launch_rollout_tile_rows<50, 4, true>(shape, args, s, e0, e1);
@@ -2401,16 +2438,17 @@ size_t tile_lds_bytes(int mode, int n) {
   return (tile + (mode == 1 ? static_cast<size_t>(n) * (kCoefT + kKeyStride) : 0)) * sizeof(float);
 }
 
-LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
+LaunchShape choose_shape(int P, int N, int layout, int mode, int n, const LaunchOptions& opt) {
   // Fill 256 CUs first (small batches: 64-thread workgroups, one candidate per lane), then widen the
   // per-lane work so that each wave load moves 16 B per lane (large step-major batches).
   LaunchShape s;
   s.tile = false;
   s.tile_waves = 0;
   s.pack = (mode == 1) ? 1 : 2;  // mode T: plain float32 states (see launch_rollout_temporal_plain)
-  if (const char* env = std::getenv("ACMPC_T_PACK")) s.pack = (env[0] == '1') ? 1 : 2;
+  if (opt.temporal_pack != 0) s.pack = opt.temporal_pack;
+  s.tile_table = opt.tile_table;
   const long long total = static_cast<long long>(P) * N;
-  if (layout == 0 && tile_lds_bytes(mode, n) <= 64 * 1024 && std::getenv("ACMPC_NO_TILE") == nullptr) {
+  if (layout == 0 && tile_lds_bytes(mode, n) <= 64 * 1024 && !opt.no_tile) {
     // candidate-major: one wave per workgroup stages its 64 rows in LDS (rollout_tile_kernel)
     s.tile = true;
     s.block = kWave;
@@ -2422,17 +2460,14 @@ LaunchShape choose_shape(int P, int N, int layout, int mode, int n) {
     if (mode == 0 && n <= kTileRowsMaxSteps && (P == 1 || (2LL * N * n) % 4 == 0) &&
         static_cast<long long>(P) * s.blocks_per_problem >= 2048) {
       s.tile_waves = 4;
-      if (const char* env = std::getenv("ACMPC_TILE_ROWS")) s.tile_waves = (std::atoi(env) == 4) ? 4 : 0;
+      if (opt.tile_rows >= 0) s.tile_waves = (opt.tile_rows == 4) ? 4 : 0;
     }
     return s;
   }
   // tuning override for experiments: ACMPC_SHAPE="<block>,<cpt>"
-  int fb = 0, fc = 0;
-  if (const char* env = std::getenv("ACMPC_SHAPE")) {
-    if (std::sscanf(env, "%d,%d", &fb, &fc) != 2) fb = fc = 0;
-    if (!((fb == 64 && fc == 1) || (fb == 256 && (fc == 1 || (layout == 1 && (fc == 2 || fc == 4) && N % fc == 0)))))
-      fb = fc = 0;
-  }
+  int fb = opt.shape_block, fc = opt.shape_cpt;
+  if (!((fb == 64 && fc == 1) || (fb == 256 && (fc == 1 || (layout == 1 && (fc == 2 || fc == 4) && N % fc == 0)))))
+    fb = fc = 0;
   if (fb != 0) {
     s.block = fb;
     s.cpt = fc;
@@ -2506,10 +2541,10 @@ namespace {
 size_t sampled_rollout_floats(int mode, int n) {
   return (mode == 1) ? ((static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3)) : 0;
 }
-// uniform operands of the steps staged in LDS: [n][12] table rows (mode S), centre, reference, knot weights (+ padding
+// uniform operands of the steps staged in LDS: [n][12] table rows (mode S), centre, reference, candidate 2's controls, knot weights (+ padding
 // for the read one step past the end)
 size_t sampled_uniform_floats(int mode, int n) {
-  return static_cast<size_t>(n) * ((mode == 0 ? kCoefS : 0) + 5) + 4;
+  return static_cast<size_t>(n) * ((mode == 0 ? kCoefS : 0) + 7) + 4;
 }
 size_t sampled_finalize_floats(int mode, int n) {
   const size_t rec_floats = static_cast<size_t>(4 + 2 * n + 3 * (n + 1));
@@ -2547,7 +2582,8 @@ static hipError_t raise_lds_limit(const void* kernel, int which, size_t lds) {
 }
 
 hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const SampleArgs& sample,
-                                  const FusedFinalize& fused, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                                  const FusedFinalize& fused, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                                  const LaunchOptions& opt) {
   clear_stale_error();
   const int n = rollout.n;
   const dim3 grid((rollout.N + kWave - 1) / kWave, rollout.P);
@@ -2569,13 +2605,13 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
                                          mode, lds);
     if (e != hipSuccess) return e;
   }
-  if (mode == 1 && traced && std::getenv("ACMPC_NO_TRIO_ROUNDS") == nullptr) {
+  if (mode == 1 && traced && !opt.no_trio_rounds) {
     // three waves per workgroup: tables | trace | uniform operands (centre, reference, weights) | nearest indices
     const size_t plain_tables = (static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3);
     const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
-    const size_t uniform = (static_cast<size_t>(n) * 5 + 4 + 3) & ~static_cast<size_t>(3);
-    const size_t index = static_cast<size_t>(n) * kWave;
-    // the frames of the verified search ride along when they fit beside the rest (they do up to n = 100); a longer
+    const size_t uniform = (static_cast<size_t>(n) * 7 + 4 + 3) & ~static_cast<size_t>(3);
+    const size_t index = (static_cast<size_t>(n) * kWave / 2 + 3) & ~static_cast<size_t>(3);   // 16-bit entries
+    // the frames of the verified search ride along when they fit beside the rest (they do up to n = 106); a longer
     // horizon keeps the three waves and scans every waypoint, as it did before there were frames
     RolloutArgs rollout_trio = rollout;
     size_t tables = plain_tables + (rollout.nn_frames != nullptr ? static_cast<size_t>(verified_frame_floats(n)) : 0);
@@ -2599,7 +2635,7 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
       return hipGetLastError();
     }
   }
-  if (mode == 0 && traced && std::getenv("ACMPC_NO_QUAD_ROUNDS") == nullptr && std::getenv("ACMPC_NO_PAIR_ROUNDS") == nullptr) {
+  if (mode == 0 && traced && !opt.no_quad_rounds && !opt.no_pair_rounds) {
     // four waves per workgroup: trace | uniform operands (table rows, centre, reference, weights) | normals | J
     const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
     const size_t uniform = (uniform_floats + 3) & ~static_cast<size_t>(3);
@@ -2617,7 +2653,7 @@ hipError_t launch_rollout_sampled(int mode, const RolloutArgs& rollout, const Sa
       return hipGetLastError();
     }
   }
-  if (mode == 0 && traced && std::getenv("ACMPC_NO_PAIR_ROUNDS") == nullptr) {
+  if (mode == 0 && traced && !opt.no_pair_rounds) {
     // two waves per workgroup: trace | uniform operands | exchange buffers (no mode T tables, no record image)
     const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
     const size_t exchange = static_cast<size_t>(2) * kPairChunk * kPairValues * kWave;
@@ -2659,23 +2695,23 @@ constexpr int kSoloRegisterSteps = 49;   // the horizon whose states stay in reg
 // so: registers up to 512 workgroups (no SIMD holds more than one wave), and in the candidate-major layout always -
 // there the 38 kB of states beside the 25 kB control tile would keep a launch of more than 512 workgroups from being
 // resident at once.
-static bool solo_in_registers(long long blocks, int n, int layout) {
+static bool solo_in_registers(long long blocks, int n, int layout, const LaunchOptions& opt) {
   if (n != kSoloRegisterSteps) return false;
-  if (const char* env = std::getenv("ACMPC_SOLO_REGISTERS")) return env[0] == '1';   // (A/B switch)
+  if (opt.solo_registers >= 0) return opt.solo_registers == 1;   // (A/B switch)
   return blocks <= 512 || layout == 0;
 }
 
-static size_t solo_lds_bytes(long long blocks, int layout, int n) {
-  const size_t states = solo_in_registers(blocks, n, layout) ? static_cast<size_t>((3 * n + 3) & ~3)
+static size_t solo_lds_bytes(long long blocks, int layout, int n, const LaunchOptions& opt) {
+  const size_t states = solo_in_registers(blocks, n, layout, opt) ? static_cast<size_t>((3 * n + 3) & ~3)
                                                              : static_cast<size_t>((3 * n) | 1) * kWave;
   return (states + kWave + (layout == 0 ? static_cast<size_t>(kWave) * 2 * n : 0)) * sizeof(float);
 }
 
-bool solo_fits(int P, int N, int n, int layout) {
+bool solo_fits(int P, int N, int n, int layout, const LaunchOptions& opt) {
   // every workgroup of the launch resident at once (256 CUs x 160 kB of LDS; eight two-wave workgroups per CU): a second
   // generation of workgroups would cost more than the second launch does
   const long long blocks = static_cast<long long>(P) * ((N + kWave - 1) / kWave);
-  const size_t lds = solo_lds_bytes(blocks, layout, n);
+  const size_t lds = solo_lds_bytes(blocks, layout, n, opt);
   return blocks <= kSoloBlocks && lds <= 160u * 1024u &&
          blocks <= 256LL * std::min<long long>(8, static_cast<long long>((160u * 1024u) / lds));
 }
@@ -2683,20 +2719,19 @@ bool solo_fits(int P, int N, int n, int layout) {
 int solo_trace_floats(int n) { return 3 * n + 2; }
 
 hipError_t launch_rollout_solo(int layout, const RolloutArgs& args, const FusedFinalize& fused_in, hipStream_t s,
-                               hipEvent_t e0, hipEvent_t e1) {
+                               hipEvent_t e0, hipEvent_t e1, const LaunchOptions& opt) {
   clear_stale_error();
   const int blocks = (args.N + kWave - 1) / kWave;
-  if (!solo_fits(args.P, args.N, args.n, layout) || fused_in.tickets == nullptr) return hipErrorInvalidValue;
+  if (!solo_fits(args.P, args.N, args.n, layout, opt) || fused_in.tickets == nullptr) return hipErrorInvalidValue;
   if (fused_in.records != nullptr && (fused_in.trace == nullptr || fused_in.trace_pitch < solo_trace_floats(args.n)))
     return hipErrorInvalidValue;
   FusedFinalize fused = fused_in;
   // ticket groups: 8 for launches of up to 256 workgroups, 32 above (a device-scope atomic on one address is ~13 ns)
   fused.ticket_groups = (args.P * blocks > 256 || blocks > 256) ? kTicketGroupsMax : kTicketGroups;
   // two waves per workgroup (see the kernel); ACMPC_SOLO_SPLIT=0 keeps one, for the tests' three-way comparison
-  bool split = true;
-  if (const char* env = std::getenv("ACMPC_SOLO_SPLIT")) split = env[0] == '1';
+  const bool split = opt.solo_split < 0 || opt.solo_split == 1;
   const long long all_blocks = static_cast<long long>(args.P) * blocks;
-  const size_t lds = solo_lds_bytes(all_blocks, layout, args.n);
+  const size_t lds = solo_lds_bytes(all_blocks, layout, args.n, opt);
   const dim3 grid(blocks, args.P);
   auto go = [&](auto kernel, int which, int threads) -> hipError_t {
     const hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel), which, lds);
@@ -2709,7 +2744,7 @@ hipError_t launch_rollout_solo(int layout, const RolloutArgs& args, const FusedF
     return hipGetLastError();
   };
   constexpr int R = kSoloRegisterSteps;
-  if (solo_in_registers(all_blocks, args.n, layout)) {
+  if (solo_in_registers(all_blocks, args.n, layout, opt)) {
     if (layout == 1) return split ? go(&rollout_solo_kernel<1, true, R>, 3, 2 * kWave) : go(&rollout_solo_kernel<1, false, R>, 4, kWave);
     if (layout == 0) return split ? go(&rollout_solo_kernel<0, true, R>, 5, 2 * kWave) : go(&rollout_solo_kernel<0, false, R>, 6, kWave);
   }

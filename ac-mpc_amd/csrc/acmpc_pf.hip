@@ -613,6 +613,7 @@ thread_local std::string g_pf_create_error;
 
 struct acmpc_pf {
   acmpc_pf_params prm{};
+  bool no_grid = false;   // ACMPC_PF_NO_GRID (A/B switch of the tests): read from the environment once, by acmpc_pf_create
   std::vector<double> h_track[3];
   double scale = 1.0;
   bool device_ready = false;
@@ -738,7 +739,7 @@ void build_grid(acmpc_pf* h) {
 // while the scan spreads every particle over a whole workgroup)
 constexpr int kGridParticles = 4096;
 bool use_grid(const acmpc_pf* h, int P) {
-  return h->grid_nx > 0 && P >= kGridParticles && std::getenv("ACMPC_PF_NO_GRID") == nullptr;
+  return h->grid_nx > 0 && P >= kGridParticles && !h->no_grid;
 }
 
 // the grid search in front of a scoring launch; fills `a.given_*`
@@ -824,6 +825,10 @@ int acmpc_pf_create(const acmpc_pf_params* params, const double* centre, int32_t
   acmpc_pf* h = new (std::nothrow) acmpc_pf();
   if (h == nullptr) return pf_fail(nullptr, ACMPC_EINVAL, "out of host memory");
   h->prm = *params;
+  {
+    const char* value = std::getenv("ACMPC_PF_NO_GRID");
+    h->no_grid = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
+  }
   h->h_track[0].assign(centre, centre + 2 * static_cast<size_t>(m_centre));
   h->h_track[1].assign(left, left + 2 * static_cast<size_t>(m_left));
   h->h_track[2].assign(right, right + 2 * static_cast<size_t>(m_right));

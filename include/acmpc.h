@@ -85,7 +85,15 @@ typedef struct acmpc_params {
                             1 = the softmin-weighted mean of the round's candidates (weights exp(-(cost - min) /
                             softmin_lambda), the weighted-reduction form of localiser.py:572-579); in both cases the
                             best candidate so far stays in the pool, so a round never loses it                  */
-  int32_t reserved;
+  int32_t lq_candidate;  /* acmpc_optimize / acmpc_control_tick: 1 = the LAST sampling round's candidate 2 is the LQ plan -
+                            the optimum of the reference's control QP (control.py:26-79) without its box rows, a backward
+                            Riccati pass over the linearised model (dynamics.py:65-103), rolled forward with its feedback
+                            and clipped into the input box (csrc/acmpc_lq.h; host, float64).  acmpc_optimize plans for the
+                            paths of acmpc_set_paths and the x0 it is given; acmpc_control_tick, whose table is built on
+                            the device, plans on the host meanwhile for this tick's path (acmpc_waypoint_table of `coords`)
+                            and pose with the speed profile its PREVIOUS call solved (with coords = NULL - the path cut
+                            out of the map on the device - for the previous call's problem as it was); no plan in a
+                            handle's first tick.  The argmin keeps the plan only when it wins.  0 = no such candidate */
   /* real-valued fields are doubles so that Python floats cross the ABI exactly; the device gets float32 */
   double step_cost[3];   /* Q  = diag(step_cost)  on (e_y, e_psi, t)     control.py:126               */
   double r_term[2];      /* R  = diag(r_term)     on (v, kappa)          control.py:127               */
@@ -105,6 +113,18 @@ typedef struct acmpc_params {
 int acmpc_create(const acmpc_params* params, acmpc_ctx** out);
 void acmpc_destroy(acmpc_ctx* ctx);
 
+/* The A/B switches of the tests and the tools (tools/README.md: ACMPC_NO_SOLO, ACMPC_TICK_GRAPH, ACMPC_SHAPE, ...) belong to
+ * the handle: acmpc_create reads them from the environment ONCE, and this call sets one afterwards (`name` as the
+ * environment spells it; value NULL, "" or - for the on / off ones - "0" restores the default).  No launch path reads the
+ * environment.  ACMPC_EINVAL for an unknown name. */
+int acmpc_set_option(acmpc_ctx* ctx, const char* name, const char* value);
+
+/* The LQ plan of acmpc_params::lq_candidate for one path, on the host (csrc/acmpc_lq.h): table [7][n] float64 in the
+ * reference's row order, x0 = (e_y, e_psi, t), weights as in acmpc_params, the input box as the kernels hold it;
+ * plan [n][2] float32 (v, kappa).  ACMPC_ESTATE when the problem has no finite plan.  No handle, no GPU work. */
+int acmpc_lq_plan(const double* table, int32_t n, const double x0[3], const double step_cost[3], const double r_term[2],
+                  const double final_cost[3], const float u_min[2], const float u_max[2], float* plan);
+
 /* Message of the last failing call on `ctx` (or of the last failing acmpc_create when ctx is NULL). */
 const char* acmpc_last_error(const acmpc_ctx* ctx);
 
@@ -114,6 +134,13 @@ const char* acmpc_last_error(const acmpc_ctx* ctx);
  * [x, y, psi, kappa, ds, width, v] (control/paths.py:4-72).  Coefficients are computed in float64 on the host,
  * stored as float32, and uploaded by the next device call.  No device work. */
 int acmpc_set_paths(acmpc_ctx* ctx, const double* tables, int32_t P, int32_t n);
+
+/* The packed float32 tables themselves ([P][n][ACMPC_COEF_STRIDE_* by the handle's mode], the layout
+ * acmpc_get_coefficients and acmpc_tick_read_device_tables hand out) instead of paths: for callers that keep their
+ * tables packed, and for the tests, which feed a tick's own device-built table to the two-call path so that
+ * `acmpc_control_tick == acmpc_set_paths + acmpc_optimize` holds bit for bit whatever the last float32 bit of a host
+ * cos / sin was.  The float64 tables of an earlier acmpc_set_paths of the same shape stay (the LQ plan reads them). */
+int acmpc_set_coefficients(acmpc_ctx* ctx, const float* coef, int32_t P, int32_t n);
 
 /* Copies the packed float32 table of problem `problem` (n rows of ACMPC_COEF_STRIDE_* floats) to `out`.
  * Host only; lets CPU tests pin the host-side arithmetic against the oracle. */

@@ -725,37 +725,233 @@ def sample_segments(n: int) -> np.ndarray:
     return np.stack([k0, w0], axis=1).astype(np.float32)
 
 
-def sample_candidates(centre, u_ref, n_candidates, index_offset, problem, round_, seed, sigma, u_lo, u_hi):
-    """Restates csrc sample_kernel for ONE problem in float64 (the device uses float32 with library log/sin/cos,
-    so agreement is to ~1e-6 relative, not bitwise).  centre/u_ref [n,2] -> U [N,n,2]."""
-    centre = np.asarray(centre, dtype=np.float32).astype(np.float64)
-    n = centre.shape[0]
+LOG_C = (7.0376836292e-2, -1.1514610310e-1, 1.1676998740e-1, -1.2420140846e-1, 1.4249322787e-1, -1.6668057665e-1,
+         2.0000714765e-1, -2.4999993993e-1, 3.3333331174e-1)   # Cephes logf (Moshier): ln(1 + f) = f - f^2/2 + f^3 P(f)
+LN2_HI, LN2_LO = 0.693359375, -2.12194440e-4
+
+
+def log_spec(u):
+    """ln u for float32 u in (0, 1] with the fixed operation sequence of csrc/acmpc_device.h: log_spec - u = m 2^e with
+    m in [sqrt(1/2), sqrt(2)) read off the bit pattern, f = m - 1, every multiply-add one fmaf.  Bit-identical to the kernel."""
+    T = np.float32
+    u = np.atleast_1d(np.asarray(u, dtype=T))
+    bits = u.view(np.int32)
+    e = (bits - np.int32(0x3F3504F3)) >> 23                      # arithmetic shift
+    m = (bits - (e << 23)).astype(np.int32).view(T)
+    f = m - T(1.0)
+    ef = e.astype(T)
+    z = f * f
+    p = fma32(T(LOG_C[0]), f, T(LOG_C[1]))
+    for c in LOG_C[2:]:
+        p = fma32(p, f, T(c))
+    y = (f * z) * p
+    y = fma32(ef, T(LN2_LO), y)
+    y = fma32(T(-0.5), z, y)
+    return fma32(ef, T(LN2_HI), f + y)
+
+
+def box_muller_spec(u1, u2):
+    """Two standard normals from two uniforms, bit-identical to csrc/acmpc_device.h: box_muller (round 4): spec'd
+    logarithm, correctly rounded square root, sin / cos of 2 pi u2 reduced in turns with the rollout's polynomials."""
+    T = np.float32
+    u1, u2 = np.atleast_1d(np.asarray(u1, dtype=T)), np.atleast_1d(np.asarray(u2, dtype=T))
+    with np.errstate(all="ignore"):
+        radius = np.sqrt(T(-2.0) * log_spec(u1)).astype(T)
+    t = fma32(u2, T(2.0), T(ROUND_MAGIC))
+    k = t - T(ROUND_MAGIC)
+    r = fma32(k, T(-0.5), u2)
+    x = r * T(TWO_PI_F)
+    x2 = x * x
+    ps = fma32(x2, T(SIN_C[3]), T(SIN_C[2]))
+    ps = fma32(x2, ps, T(SIN_C[1]))
+    ps = fma32(x2, ps, T(SIN_C[0]))
+    sn = fma32(x * x2, ps, x)
+    pc = fma32(x2, T(COS_C[4]), T(COS_C[3]))
+    pc = fma32(x2, pc, T(COS_C[2]))
+    pc = fma32(x2, pc, T(COS_C[1]))
+    pc = fma32(x2, pc, T(COS_C[0]))
+    cs = fma32(x2, pc, T(1.0))
+    odd = (np.atleast_1d(t).view(np.int32) & 1) != 0
+    cs, sn = np.where(odd, -cs, cs).astype(T), np.where(odd, -sn, sn).astype(T)
+    return radius * cs, radius * sn
+
+
+def uniform_open(bits):
+    """32 random bits -> float32 in (0, 1]: (bits >> 8) 2^-24 + 2^-25 in float32 (csrc/acmpc_device.h: uniform_open)."""
+    return (np.asarray(bits, dtype=np.uint32) >> 8).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)
+
+
+def candidate_normals(n_candidates, index_offset, problem, round_, seed):
+    """The SAMPLE_KNOTS x 2 standard normals of every candidate: Philox4x32-10 at counter (global index, problem, round,
+    draw q), two Box-Muller pairs per draw (csrc/acmpc_device.h: draw_normals).  float32, exact."""
     gidx = (np.arange(n_candidates, dtype=np.uint64) + np.uint64(index_offset)).astype(np.uint32)
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
-    z = np.zeros((n_candidates, SAMPLE_KNOTS, 2))
+    z = np.zeros((n_candidates, SAMPLE_KNOTS, 2), dtype=np.float32)
     for q in range(SAMPLE_KNOTS // 2):
         ctr = np.stack([gidx, np.full_like(gidx, problem), np.full_like(gidx, round_), np.full_like(gidx, q)], axis=1)
         r = philox4x32_10(ctr, np.broadcast_to(key, (n_candidates, 2)))
-        u = ((r >> 8).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)).astype(np.float64)
+        u = uniform_open(r)
         for half in range(2):
-            rad = np.sqrt(-2.0 * np.log(u[:, 2 * half]))
-            ang = 2.0 * np.pi * u[:, 2 * half + 1]
-            z[:, 2 * q + half, 0] = rad * np.cos(ang)
-            z[:, 2 * q + half, 1] = rad * np.sin(ang)
-    seg = sample_segments(n).astype(np.float64)
+            z[:, 2 * q + half, 0], z[:, 2 * q + half, 1] = box_muller_spec(u[:, 2 * half], u[:, 2 * half + 1])
+    return gidx, z
+
+
+def sample_candidates(centre, u_ref, n_candidates, index_offset, problem, round_, seed, sigma, u_lo, u_hi, u_extra=None):
+    """Restates csrc sample_kernel / the fused rounds' candidate generation for ONE problem, bit for bit (round 4: the
+    device's normals are specified - box_muller_spec - and the blend is float32 with one fixed association, no FMA):
+        U_c[i] = clip(centre[i] + (sigma amp_c) (w0_i z_c[k0_i] + (1 - w0_i) z_c[k0_i + 1]))
+    amp_c = ((c & 7) + 1) / 8; candidate 0 = the centre, candidate 1 = `u_ref` (when given), candidate 2 = `u_extra` (when
+    given: the LQ plan, lq_plan()) - each passed through the same clip.  centre / u_ref / u_extra [n, 2] -> U [N, n, 2] float32."""
+    T = np.float32
+    centre = np.asarray(centre, dtype=T)
+    n = centre.shape[0]
+    gidx, z = candidate_normals(n_candidates, index_offset, problem, round_, seed)
+    seg = sample_segments(n)
     k0 = seg[:, 0].astype(int)
-    w0 = seg[:, 1]
-    k1 = np.minimum(k0 + 1, SAMPLE_KNOTS - 1)
-    noise = w0[None, :, None] * z[:, k0, :] + (1.0 - w0)[None, :, None] * z[:, k1, :]   # [N,n,2]
-    amp = ((gidx & 7) + 1).astype(np.float64) * 0.125
-    amp[gidx == 0] = 0.0
-    sig = np.asarray(sigma, dtype=np.float32).astype(np.float64)
-    U = centre[None] + amp[:, None, None] * sig[None, None, :] * noise
+    w0 = seg[:, 1].astype(T)
+    w1 = T(1.0) - w0
+    amp = ((gidx & 7) + 1).astype(T) * T(0.125)
+    amp[gidx == 0] = T(0.0)
+    base = np.broadcast_to(centre, (n_candidates, n, 2)).copy()
     if u_ref is not None:
-        U[gidx == 1] = np.asarray(u_ref, dtype=np.float32).astype(np.float64)
-    lo = np.asarray(u_lo, dtype=np.float32).astype(np.float64)
-    hi = np.asarray(u_hi, dtype=np.float32).astype(np.float64)
-    return np.clip(U, lo, hi)
+        base[gidx == 1] = np.asarray(u_ref, dtype=T)
+        amp[gidx == 1] = T(0.0)
+    if u_extra is not None:
+        base[gidx == 2] = np.asarray(u_extra, dtype=T)
+        amp[gidx == 2] = T(0.0)
+    sig = np.asarray(sigma, dtype=T)
+    lo, hi = np.asarray(u_lo, dtype=T), np.asarray(u_hi, dtype=T)
+    # blend_control: v = cv + (sigma_v amp) (w0 z0v + w1 z1v), then fmin(fmax(v, lo), hi)
+    noise = w0[None, :, None] * z[:, k0, :] + w1[None, :, None] * z[:, k0 + 1, :]          # [N, n, 2]
+    scale = sig[None, :] * amp[:, None]                                                    # [N, 2]
+    U = base + scale[:, None, :] * noise
+    return np.fmin(np.fmax(U, lo), hi).astype(T)
+
+
+def optimize_restated(mode, start, coef, centre, u_ref, n_candidates, rounds, sigma, shrink, seed, Q, R, QN, u_lo, u_hi,
+                      w_bound=1.0e6, dt=0.05, nn_window=None, extra=None, problem=0):
+    """One whole solve of the sampling controller, restated (round 4): what acmpc_optimize and the rounds of
+    acmpc_control_tick compute for ONE problem, bit for bit -
+        for r in 0 .. rounds - 1:   candidates = sample_candidates(centre_r, u_ref, sigma shrink^r, round r;
+                                                 candidate 2 = `extra` - the LQ plan - in the LAST round)
+                                    costs      = rollout_spatial / rollout_temporal(candidates)        (float32 spec order)
+                                    winner     = first minimum, non-finite costs last (pick_best)
+                                    centre_r+1 = the winner's controls
+    - the seam the tick replaces in the reference is SpatialMPC.get_control's solver call (spatial_mpc.py:185-217).
+    `start`: mode 0 the Frenet state, mode 1 the pose; `coef`: the packed float32 table ([n, 12] / [n, 8]);
+    centre, u_ref, extra: [n, 2].  Returns the winner of the last round as the record holds it:
+    dict(cost, violation, n_feasible, index, u [n, 2], x [n + 1, 3]) plus `winners`, the index per round."""
+    T = np.float32
+    centre = np.asarray(centre, dtype=T)
+    winners = []
+    scale = 1.0
+    out = None
+    for r in range(rounds):
+        last = r + 1 == rounds
+        spread = (T(float(sigma[0]) * scale), T(float(sigma[1]) * scale))      # (double product, one rounding: make_spec)
+        U = sample_candidates(centre, u_ref, n_candidates, 0, problem, r, seed, spread, u_lo, u_hi,
+                              u_extra=extra if last else None)
+        if mode == 0:
+            cost, viol, X = rollout_spatial(start, coef, U, Q, R, QN, u_lo, u_hi, w_bound, dtype=T, return_states=True)
+        else:
+            cost, viol, X, _ = rollout_temporal(start, coef, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=T,
+                                                return_states=True, nn_window=nn_window)
+        best, _ = pick_best(cost)
+        winners.append(best)
+        centre = U[best]
+        out = dict(cost=cost[best], violation=viol[best], n_feasible=int(np.count_nonzero(viol == 0)), index=best,
+                   u=U[best].copy(), x=X[best].copy())
+        scale *= float(shrink)
+    out["winners"] = winners
+    return out
+
+
+def lq_plan(table, x0, Q, R, QN, u_lo, u_hi):
+    """The LQ plan (csrc/acmpc_lq.h, round 4): the reference's control QP (control/solvers/control.py:26-79) WITHOUT its box
+    rows is a finite-horizon LQ problem with the affine dynamics of linearise() (dynamics.py:65-103); a backward Riccati
+    pass gives its optimum as a feedback du_i = K_i x_i + k_i, which is rolled forward from x0 with every control rounded
+    to float32 and clipped into the input box as it goes.  Restated line by line in the library's operation order -
+    float64, no fused multiply-add: bit-identical to acmpc_lq_plan().  table [7, n] float64, x0 (e_y, e_psi, t) ->
+    [n, 2] float32 (v, kappa), or None where the library gives no plan."""
+    table = np.asarray(table, dtype=np.float64)
+    n = table.shape[1]
+    kappa, ds, vel = table[ROW_KAPPA], table[ROW_DS], table[ROW_V]
+    Q, R, QN = ([float(x) for x in w] for w in (Q, R, QN))
+    gains = np.zeros((n, 8))
+    P00, P01, P02, P11, P12, P22 = QN[0], 0.0, 0.0, QN[1], 0.0, QN[2]
+    p0 = p1 = p2 = 0.0
+    with np.errstate(all="ignore"):
+        for i in range(n - 1, -1, -1):
+            d = float(ds[i]); ki = float(kappa[i]); vi = float(vel[i])
+            a = -(ki * ki) * d
+            g = -ki / (vi * d + EPS)
+            b = -1.0 / (vi * vi * d + EPS)
+            c = 1.0 / (vi * d + EPS)
+            h0, h1, h2 = b * P02, b * P12, b * P22
+            m0, m1, m2 = d * P01, d * P11, d * P12
+            Quu00 = R[0] + b * h2
+            Quu01 = d * h1
+            Quu11 = R[1] + d * m1
+            S00, S01, S02 = (h0 + a * h1) + g * h2, d * h0 + h1, h2
+            S10, S11, S12 = (m0 + a * m1) + g * m2, d * m0 + m1, m2
+            w0, w1, w2 = c * P02 + p0, c * P12 + p1, c * P22 + p2
+            qu0, qu1 = b * w2, d * w1
+            det = Quu00 * Quu11 - Quu01 * Quu01
+            if not (det > 0.0) or not math.isfinite(det):
+                return None
+            inv = 1.0 / det
+            K00, K01, K02 = (-inv * (Quu11 * S00 - Quu01 * S10), -inv * (Quu11 * S01 - Quu01 * S11),
+                             -inv * (Quu11 * S02 - Quu01 * S12))
+            K10, K11, K12 = (-inv * (Quu00 * S10 - Quu01 * S00), -inv * (Quu00 * S11 - Quu01 * S01),
+                             -inv * (Quu00 * S12 - Quu01 * S02))
+            k0, k1 = -inv * (Quu11 * qu0 - Quu01 * qu1), -inv * (Quu00 * qu1 - Quu01 * qu0)
+            gains[i] = (K00, K01, K02, k0, K10, K11, K12, k1)
+            t00, t10, t20 = (P00 + a * P01) + g * P02, (P01 + a * P11) + g * P12, (P02 + a * P12) + g * P22
+            t01, t11, t21 = d * P00 + P01, d * P01 + P11, d * P02 + P12
+            t02, t12, t22 = P02, P12, P22
+            N00, N01, N02 = (t00 + a * t10) + g * t20, (t01 + a * t11) + g * t21, (t02 + a * t12) + g * t22
+            N11, N12, N22 = d * t01 + t11, d * t02 + t12, t22
+            n00 = (Q[0] + N00) + (S00 * K00 + S10 * K10)
+            n01 = N01 + (S00 * K01 + S10 * K11)
+            n02 = N02 + (S00 * K02 + S10 * K12)
+            n11 = (Q[1] + N11) + (S01 * K01 + S11 * K11)
+            n12 = N12 + (S01 * K02 + S11 * K12)
+            n22 = (Q[2] + N22) + (S02 * K02 + S12 * K12)
+            q0 = ((w0 + a * w1) + g * w2) + (S00 * k0 + S10 * k1)
+            q1 = (d * w0 + w1) + (S01 * k0 + S11 * k1)
+            q2 = w2 + (S02 * k0 + S12 * k1)
+            P00, P01, P02, P11, P12, P22 = n00, n01, n02, n11, n12, n22
+            p0, p1, p2 = q0, q1, q2
+        lo, hi = np.asarray(u_lo, dtype=np.float32), np.asarray(u_hi, dtype=np.float32)
+        ey, ep, t = (float(x) for x in x0)
+        out = np.zeros((n, 2), dtype=np.float32)
+        for i in range(n):
+            d = float(ds[i]); ki = float(kappa[i]); vi = float(vel[i])
+            a = -(ki * ki) * d
+            g = -ki / (vi * d + EPS)
+            b = -1.0 / (vi * vi * d + EPS)
+            c = 1.0 / (vi * d + EPS)
+            G = [float(x) for x in gains[i]]
+            dv = ((G[0] * ey + G[1] * ep) + G[2] * t) + G[3]
+            dk = ((G[4] * ey + G[5] * ep) + G[6] * t) + G[7]
+            v = np.fmin(np.fmax(np.float32(vi + dv), lo[0]), hi[0])
+            k = np.fmin(np.fmax(np.float32(ki + dk), lo[1]), hi[1])
+            out[i] = (v, k)
+            cv, ck = float(v) - vi, float(k) - ki
+            ey, ep, t = ey + d * ep, (ep + a * ey) + d * ck, ((t + g * ey) + b * cv) + c
+    return out if np.isfinite(out).all() else None
+
+
+def frenet_start(table, pose):
+    """Frenet start state of a pose w.r.t. the path's first waypoint (t2s, dynamics.py:23-40) as csrc/acmpc_lq.h computes it
+    for mode T handles: libm cos / sin / fmod on float64 scalars."""
+    xr, yr, psir = float(table[ROW_X, 0]), float(table[ROW_Y, 0]), float(table[ROW_PSI, 0])
+    x, y, psi = (float(v) for v in pose)
+    e_y = math.cos(psir) * (y - yr) - math.sin(psir) * (x - xr)
+    wrapped = math.fmod(psi - psir + math.pi, 2.0 * math.pi)
+    if wrapped < 0.0:
+        wrapped += 2.0 * math.pi
+    return np.array([e_y, wrapped - math.pi, 0.0])
 
 
 # ---------------------------------------------------------------------------
@@ -900,11 +1096,11 @@ def pf_resample_counter_based(states, scores, score, valid, n_desired, minimum_p
     for i in range(n_new):
         word = (int(r[i, 0]) << 32) | int(r[i, 1])
         picked[i] = bisect.bisect_right(cdf_list, (word * total) >> 64)
-    u = ((q >> 8).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)).astype(np.float64)
+    u = uniform_open(q)
     z = np.empty((n_new, 3))
-    rad0, ang0 = np.sqrt(-2.0 * np.log(u[:, 0])), 2.0 * np.pi * u[:, 1]
-    rad1, ang1 = np.sqrt(-2.0 * np.log(u[:, 2])), 2.0 * np.pi * u[:, 3]
-    z[:, 0], z[:, 1], z[:, 2] = rad0 * np.cos(ang0), rad0 * np.sin(ang0), rad1 * np.cos(ang1)
+    z0, z1 = box_muller_spec(u[:, 0], u[:, 1])
+    z2, _ = box_muller_spec(u[:, 2], u[:, 3])
+    z[:, 0], z[:, 1], z[:, 2] = z0, z1, z2
     kept_states = states[keep]
     fresh = (kept_states[picked].astype(np.float64) + z * np.asarray(noise_sigma, dtype=np.float64)).astype(np.float32)
     kept_scores = np.asarray(scores, dtype=np.float32)[keep]

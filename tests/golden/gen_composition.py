@@ -43,8 +43,52 @@ FULL = [
 ]
 
 
+# (name, mode, nn_window, seed): ONE WHOLE SOLVE at the closed-loop shape - 1 problem x 16 384 candidates x horizon 50, two
+# rounds at the controller's warm spread, the LQ plan as the last round's candidate 2 - by oracle.optimize_restated: what
+# acmpc_optimize / acmpc_control_tick must return bit for bit (tests/test_gpu_restated_solve.py)
+SOLVES = [
+    ("solve_monza_H50_S", 0, None, 0x5EED0001),
+    ("solve_monza_H50_T", 1, None, 0x5EED0002),
+    ("solve_monza_H50_T_window", 1, (2, 5), 0x5EED0003),
+]
+SOLVE_N, SOLVE_ROUNDS, SOLVE_SIGMA, SOLVE_SHRINK = 16384, 2, (0.5, 1.0e-3), 0.5
+
+
+def solves(out):
+    for name, mode, window, seed in SOLVES:
+        prob = make_problem(orc, "monza", 50, 4, seed=8100 + mode)
+        cfg = prob["cfg"]
+        margin = prob["limits"].margin
+        coef = orc.coefficients_spatial(prob["table"], margin) if mode == 0 else orc.coefficients_temporal(prob["table"], margin)
+        start = prob["x0"] if mode == 0 else prob["pose0"]
+        u_ref = np.stack([prob["table"][orc.ROW_V], prob["table"][orc.ROW_KAPPA]], axis=1).astype(np.float32)
+        centre = (u_ref + np.array([-0.6, 0.0015], dtype=np.float32)).astype(np.float32)
+        frenet = start.astype(np.float64) if mode == 0 else orc.frenet_start(prob["table"], start.astype(np.float64))
+        plan = orc.lq_plan(prob["table"], frenet, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], prob["u_lo"], prob["u_hi"])
+        won = orc.optimize_restated(mode, start, coef, centre, u_ref, SOLVE_N, SOLVE_ROUNDS, SOLVE_SIGMA, SOLVE_SHRINK, seed,
+                                    cfg["step_cost"], cfg["r_term"], cfg["final_cost"], prob["u_lo"], prob["u_hi"], 1.0e6, 0.05,
+                                    window, extra=plan)
+        k = name + "/"
+        out[k + "table"], out[k + "start"], out[k + "centre"], out[k + "u_ref"], out[k + "coef"] = (
+            prob["table"], start, centre, u_ref, coef)
+        out[k + "weights"] = np.array(list(cfg["step_cost"]) + list(cfg["r_term"]) + list(cfg["final_cost"]))
+        out[k + "box"] = np.array(list(prob["u_lo"]) + list(prob["u_hi"]))
+        out[k + "margin"], out[k + "mode"] = np.array(margin), np.array(mode)
+        out[k + "window"] = np.array(window if window is not None else (-1, -1))
+        out[k + "n_candidates"], out[k + "rounds"] = np.array(SOLVE_N), np.array(SOLVE_ROUNDS)
+        out[k + "sigma"], out[k + "shrink"], out[k + "seed"] = np.array(SOLVE_SIGMA), np.array(SOLVE_SHRINK), np.array(seed)
+        out[k + "plan"] = plan
+        out[k + "cost"], out[k + "violation"] = np.array(won["cost"]), np.array(won["violation"])
+        out[k + "n_feasible"], out[k + "index"] = np.array(won["n_feasible"]), np.array(won["index"])
+        out[k + "winners"] = np.array(won["winners"])
+        out[k + "u"], out[k + "x"] = won["u"], won["x"]
+        print("%s: winners %s cost %.6f" % (name, won["winners"], won["cost"]))
+
+
 def main():
-    out = {"cases": np.array([c[0] for c in CASES]), "full_cases": np.array([c[0] for c in FULL])}
+    out = {"cases": np.array([c[0] for c in CASES]), "full_cases": np.array([c[0] for c in FULL]),
+           "solves": np.array([c[0] for c in SOLVES])}
+    solves(out)
     for name, track, H, N, mode, window in CASES:
         prob = make_problem(orc, track, H, N, seed=7000 + H + N + mode)
         cfg = prob["cfg"]

@@ -116,3 +116,28 @@ def test_kernels_reproduce_the_full_size_digests(frozen, name):
     assert hashlib.sha256(out["costs"][0].tobytes()).hexdigest() == str(frozen[name + "/cost_sha256"])
     assert out["best_idx"][0] == int(frozen[name + "/best"])
     assert out["n_feasible"][0] == int(frozen[name + "/n_feasible"])
+
+
+@pytest.mark.parametrize("name", _names("solves"))
+def test_the_oracle_reproduces_the_frozen_solves(frozen, name):
+    """One whole solve (sample -> roll -> argmin -> recentre, two rounds of 16 384 candidates, the LQ plan in the last):
+    oracle.optimize_restated still returns the frozen record, and the library's host-side LQ plan (acmpc_lq_plan) is the
+    frozen one bit for bit.  The GPU half is tests/test_gpu_restated_solve.py."""
+    from acmpc_amd import _capi
+    g = {k.split("/", 1)[1]: frozen[k] for k in frozen.files if k.startswith(name + "/")}
+    mode = int(g["mode"])
+    window = tuple(int(v) for v in g["window"])
+    window = None if window[0] < 0 else window
+    Q, R, QN = g["weights"][:3], g["weights"][3:5], g["weights"][5:]
+    lo, hi = g["box"][:2], g["box"][2:]
+    frenet = g["start"].astype(np.float64) if mode == 0 else orc.frenet_start(g["table"], g["start"].astype(np.float64))
+    plan = orc.lq_plan(g["table"], frenet, Q, R, QN, lo, hi)
+    np.testing.assert_array_equal(plan, g["plan"])
+    np.testing.assert_array_equal(_capi.lq_plan(g["table"], frenet, Q, R, QN, lo, hi), g["plan"])
+    won = orc.optimize_restated(mode, g["start"], g["coef"], g["centre"], g["u_ref"], int(g["n_candidates"]), int(g["rounds"]),
+                                tuple(g["sigma"]), float(g["shrink"]), int(g["seed"]), Q, R, QN, lo, hi, 1.0e6, 0.05, window,
+                                extra=plan)
+    assert won["cost"] == g["cost"] and won["violation"] == g["violation"] and won["n_feasible"] == int(g["n_feasible"])
+    assert won["winners"] == [int(v) for v in g["winners"]]
+    np.testing.assert_array_equal(won["u"], g["u"])
+    np.testing.assert_array_equal(won["x"], g["x"])

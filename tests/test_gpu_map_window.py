@@ -67,7 +67,9 @@ def test_get_control_at_equals_get_control_on_the_same_path():
     track = workloads.synthetic_track("silverstone")
     cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"])
     cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
-    cfg.update(n_candidates=4096)
+    # (without the LQ candidate: with the path cut out of the map on the device the host plans for the previous tick's
+    # problem, with the path handed in for this tick's - tests/test_gpu_restated_solve.py pins both; here the paths are compared)
+    cfg.update(n_candidates=4096, lq_candidate=False)
     a, b = build_mpc(copy.deepcopy(cfg), PlaceholderVehicle()), build_mpc(copy.deepcopy(cfg), PlaceholderVehicle())
     a.bind_map(track)
     for i in range(30):

@@ -207,7 +207,8 @@ def test_device_resampling_matches_its_restatement(golden, n, n_desired):
     assert out["n_valid"] == n_valid and out["n_particles"] == want_states.shape[0] == got_states.shape[0]
     np.testing.assert_array_equal(got_states[:n_valid], want_states[:n_valid])          # kept, in order
     np.testing.assert_array_equal(got_scores, want_scores)                                # scores follow the picks exactly
-    np.testing.assert_allclose(got_states[n_valid:], want_states[n_valid:], rtol=0, atol=2e-4)
+    # (round 4: the sampler's normals are specified bit for bit - oracle box_muller_spec - so the fresh particles are exact too)
+    np.testing.assert_array_equal(got_states[n_valid:], want_states[n_valid:])
     assert len(np.unique(picked)) > 1
     est, max_d, max_a = scorer.estimate_location(got_scores, got_states)
     np.testing.assert_allclose(out["estimate"], est, rtol=1e-9)

@@ -24,9 +24,13 @@ pytestmark = pytest.mark.gpu
 
 FAMILIES = [("hairpin", np.linspace(10, 100, 7), -np.pi / 6), ("chicane", np.linspace(40, 100, 7), 0.1),
             ("curve", np.linspace(-0.02, 0.02, 7), 0.1), ("straight", np.linspace(40, 200, 7), 0.1)]
-# what the shipped schedule holds on these scenarios (measured round 3: cold max 0.0062, warm max 0.0056, medians 4e-4;
-# excess over the optimum's tracking cost: median 0.25-0.3, worst 15x on hairpin(100), whose optimum tracks to 0.13)
-COLD_MAX, WARM_MAX, WARM_MEDIAN_MAX, TRACKING_MEDIAN_MAX = 0.02, 0.015, 0.002, 0.6
+# what the shipped schedule holds on these scenarios (measured round 3, before the LQ plan: cold max 0.0062, warm max 0.0056,
+# medians 4e-4; excess over the optimum's tracking cost: median 0.25-0.3, worst 15x on hairpin(100), whose optimum tracks to 0.13)
+COLD_MAX, WARM_MAX, WARM_MEDIAN_MAX = 0.02, 0.015, 0.002
+# round 4: the last round of a warm solve holds the LQ plan (csrc/acmpc_lq.h) - the QP's optimum wherever no box row is
+# active - so the excess over the optimum's TRACKING cost has a bound on every quantile, the worst case included
+# (measured: median 0.000, p90 0.007, worst 0.011 for the plan alone)
+TRACKING_MEDIAN_MAX, TRACKING_P90_MAX, TRACKING_WORST_MAX = 0.05, 0.3, 1.0
 
 
 def _qp_optimum(mpc, cfg):
@@ -111,4 +115,6 @@ def test_shipped_schedule_against_the_qp_optimum():
     of_tracking = np.array([r["warm_4_of_tracking_cost"] for r in rows])
     print("warm 4 excess over the optimum's tracking cost: median %.3f p90 %.3f max %.3f"
           % (np.median(of_tracking), np.percentile(of_tracking, 90), of_tracking.max()))
-    assert np.median(of_tracking) <= TRACKING_MEDIAN_MAX
+    assert np.median(of_tracking) <= TRACKING_MEDIAN_MAX, of_tracking
+    assert np.percentile(of_tracking, 90) <= TRACKING_P90_MAX, of_tracking
+    assert of_tracking.max() <= TRACKING_WORST_MAX, of_tracking
