@@ -698,18 +698,17 @@ def free_port():
 
 
 def launch_ranks(args):
-    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process has not touched the
-    GPU yet (torch.cuda.device_count() does not initialise it) and becomes the launcher - it starts
-    `python -m torch.distributed.run --nproc-per-node N bench.py <the same arguments>` as a CHILD (never exec: see
-    the pool's rules), lets rank 0's JSON line through on the inherited stdout and returns the child's exit code."""
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the launcher - it
+    starts `python -m torch.distributed.run --nproc-per-node N bench.py <the same arguments>` as a CHILD (never an exec
+    of itself: see the pool's rules), lets rank 0's JSON line through on the inherited stdout and returns the child's exit
+    code.  It only COUNTS devices (`torch.cuda.device_count()`: NVML / amdsmi where torch has them, else the runtime's
+    device count - which may initialise the runtime in THIS process; harmless, it launches nothing on the GPU and never
+    replaces itself).  With `--backend gloo` (the rehearsal on fewer cards than ranks) the ranks check for a GPU themselves."""
     import subprocess
     visible = torch.cuda.device_count()
     if args.backend == "nccl" and visible < args.gpus:
         print("bench: --gpus %d but only %d GPU(s) visible (one rank per device over RCCL); not running a smaller job "
               "under that label" % (args.gpus, visible), file=sys.stderr)
-        return 2
-    if visible < 1:
-        print("bench: no GPU visible - the rollout path has no CPU fallback", file=sys.stderr)
         return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -729,7 +728,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
-        raise SystemExit("bench: no GPU visible - the rollout path has no CPU fallback")
+        raise SystemExit("bench: no GPU visible (rank %d of %d) - the rollout path has no CPU fallback" % (rank, world))
     if args.backend == "gloo":
         local_rank = min(local_rank, torch.cuda.device_count() - 1)   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)

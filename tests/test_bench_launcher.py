@@ -27,3 +27,20 @@ def test_world_size_must_match_the_gpus_flag():
     assert proc.returncode != 0 and "WORLD_SIZE=1" in proc.stderr
     proc = _run(["--gpus", "1", "--steps", "2"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     assert proc.returncode != 0 and "WORLD_SIZE=2" in proc.stderr
+
+
+def test_gloo_rehearsal_starts_every_rank_and_returns_their_exit_code():
+    """`--gpus 8 --backend gloo` on a box WITHOUT a GPU: the launcher starts eight ranks (torch.distributed.run as a child),
+    the ranks receive the arguments and their place in the world, the first to look finds no GPU and says so, and the launcher hands the
+    failure back as its own exit code - the spawn path, the argument forwarding and the exit-code propagation of the 8-GPU
+    run, with nothing but RCCL itself left untested (on a box with a GPU the same command runs the bench: tests/test_gpu_bench.py)."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the ranks would run the bench (tests/test_gpu_bench.py does that)")
+    proc = _run(["--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1"])
+    assert proc.returncode != 0 and "{" not in proc.stdout
+    # (the first rank to fail makes torch.distributed.run stop the others: its summary still lists all eight)
+    assert "no GPU visible (rank " in proc.stderr and " of 8)" in proc.stderr, proc.stderr[-2000:]
+    for rank in range(8):
+        assert "(local_rank: %d)" % rank in proc.stderr, proc.stderr[-3000:]
