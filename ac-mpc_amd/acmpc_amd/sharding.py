@@ -144,9 +144,28 @@ class ShardedRollout:
                                         self.offset, self.records.data_ptr(), stream)
         return self.records
 
-    def step(self, x0: torch.Tensor, U: torch.Tensor, stream: int):
-        self.rollout(x0, U, stream)
-        return self.select(x0, U, stream)
+    def step(self, x0: torch.Tensor, U: torch.Tensor, stream: int, seed: Optional[int] = None,
+             round_: Optional[int] = None):
+        """rollout + select.  A rank that holds ALL the candidates has no collective between the two: it makes ONE call
+        into the library (acmpc_solve_sampled_device / acmpc_solve_device), which is one launch where the shape allows it."""
+        if self.distributed or self.offset != 0:   # (a slice with an index offset belongs to a wider selection)
+            self.rollout(x0, U, stream)
+            return self.select(x0, U, stream, seed=seed, round_=round_)
+        costs = self.costs.data_ptr() if self.costs is not None else 0
+        keys = self.keys.data_ptr() if self.want_keys else 0
+        if self.sampler is not None:
+            sp = self.sampler
+            centre = sp["centre"]
+            stride = centre.shape[-2] * 2 if centre.dim() == 3 else centre.shape[-1]
+            self.engine.solve_sampled_device(x0.data_ptr(), U.data_ptr(), centre.data_ptr(), stride,
+                                             sp["u_ref"].data_ptr() if sp["u_ref"] is not None else 0, self.P, self.N,
+                                             self.n, self.layout, sp["sigma"], sp["seed"] if seed is None else seed,
+                                             sp["round"] if round_ is None else round_, costs, keys,
+                                             self.records.data_ptr(), stream)
+        else:
+            self.engine.solve_device(x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n, self.layout, costs, keys,
+                                     self.records.data_ptr(), stream)
+        return self.records
 
     def softmin(self, U: torch.Tensor, stream: int):
         """Softmin-weighted mean control sequence over the candidates of ALL ranks (the weighted-reduction form of

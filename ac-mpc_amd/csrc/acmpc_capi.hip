@@ -142,7 +142,8 @@ struct acmpc_ctx {
   acmpc::LaunchOptions opt;
   struct Switches {
     bool no_verified_search = false, no_solo = false, no_fused_finalize = false, no_traced_finalize = false,
-         no_chained_rounds = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false;
+         no_chained_rounds = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false,
+         tailed_rollout = false;
   } sw;
 
   // optional timing of the rollout dispatches (acmpc_profile_*): event pairs attached to the launches
@@ -500,6 +501,70 @@ int solve_solo(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, 
   return ACMPC_OK;
 }
 
+// The batched solve: rollout_kernel + finalize_kernel, or - ACMPC_TAILED_ROLLOUT=1, where the shape allows it (mode S,
+// step-major, the 256-thread launch shapes) - both in ONE launch (rollout_tailed_kernel: the last workgroup of a problem
+// finalizes it).  The same bits either way (tests/test_gpu_tailed_rollout.py).  The one launch is NOT the default: measured
+// on the headline's batch (4 096 x 4 096 x 49, same box) it ends the step's launch gap - ms_per_step 1.145 against a
+// kernel of 1.138 - but the kernel grows by 47 us (every workgroup's first wave waits for its ticket's round trip before
+// it retires, 16 384 times, and 4 096 lone-wave re-rolls take issue slots from the streaming waves), more than the 29 us
+// finalize_kernel + gap it replaces: 1.125 ms per step in two launches.  `regen`: the winner re-drawn from its index
+// (counter-based candidates) instead of read from U.
+int solve_batched(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int n, int layout, float* d_costs,
+                  int64_t* d_keys, float* d_records, hipStream_t s, const Regenerate* regen) {
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout, c->prm.mode, n, c->opt);
+  if (!c->sw.tailed_rollout || d_records == nullptr || !acmpc::tailed_rollout_fits(c->prm.mode, layout, shape, n)) {
+    acmpc::LaunchShape used;
+    int rc = rollout(c, d_x0, d_U, P, N, n, layout, 0, d_costs, s, &used);
+    if (rc != ACMPC_OK) return rc;
+    return finalize(c, nullptr, d_keys, d_x0, regen != nullptr ? nullptr : d_U, P, N, n, layout, 0, d_records,
+                    used.blocks_per_problem, s, regen);
+  }
+  int rc = ensure_tail_buffers(c);
+  if (rc != ACMPC_OK) return rc;
+  acmpc::RolloutArgs a{};
+  a.U = d_U;
+  a.x0 = d_x0;
+  a.coef = c->d_coef;
+  a.costs = d_costs;
+  a.partial_keys = c->d_partial_keys;
+  a.partial_feas = c->d_partial_feas;
+  a.P = P;
+  a.N = N;
+  a.n = n;
+  a.index_offset = 0;
+  a.w = c->w;
+  acmpc::FinalizeArgs f{};
+  if (regen != nullptr) {
+    f.regenerate = true;
+    f.centre = regen->d_centre;
+    f.centre_stride = regen->centre_stride;
+    f.u_ref = regen->d_uref;
+    f.u_extra = regen->d_extra;
+    f.spec = regen->spec;
+  }
+  f.U = d_U;
+  f.x0 = d_x0;
+  f.coef = c->d_coef;
+  f.partial_keys = c->d_partial_keys;
+  f.partial_feas = c->d_partial_feas;
+  f.keys_out = d_keys;
+  f.records = d_records;
+  f.blocks_per_problem = shape.blocks_per_problem;
+  f.P = P;
+  f.N = N;
+  f.n = n;
+  f.index_offset = 0;
+  f.w = c->w;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof_used < c->prof_start.size()) {
+    e0 = c->prof_start[c->prof_used];
+    e1 = c->prof_stop[c->prof_used];
+    ++c->prof_used;
+  }
+  ACMPC_HIP(c, acmpc::launch_rollout_tailed(layout, shape, a, f, c->d_tickets, s, e0, e1));
+  return ACMPC_OK;
+}
+
 int ensure_staging(acmpc_ctx* c) {
   if (c->staging_ready) return ACMPC_OK;
   c->touched_device = true;
@@ -532,7 +597,7 @@ const char* const kOptionNames[] = {
     "ACMPC_SHAPE", "ACMPC_T_PACK", "ACMPC_NO_TILE", "ACMPC_TILE_ROWS", "ACMPC_TILE_TABLE", "ACMPC_NO_TRIO_ROUNDS",
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
-    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG"};
+    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TAILED_ROLLOUT"};
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   const std::string key(name);
@@ -564,6 +629,7 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_NO_FUSED_SAMPLING") { w.no_fused_sampling = on; return true; }
   if (key == "ACMPC_TICK_GRAPH") { w.tick_graph = on; return true; }
   if (key == "ACMPC_TICK_NO_FLAG") { w.tick_no_flag = on; return true; }
+  if (key == "ACMPC_TAILED_ROLLOUT") { w.tailed_rollout = on; return true; }
   return false;
 }
 
@@ -863,10 +929,28 @@ int acmpc_solve_device(acmpc_ctx* c, const float* d_x0, const float* d_U, int32_
   rc = upload_tables(c, s);
   if (rc != ACMPC_OK) return rc;
   if (use_solo(c, P, N, n, layout)) return solve_solo(c, d_x0, d_U, P, N, n, layout, d_costs, d_keys, d_records, s);
-  acmpc::LaunchShape shape;
-  rc = rollout(c, d_x0, d_U, P, N, n, layout, 0, d_costs, s, &shape);
+  return solve_batched(c, d_x0, d_U, P, N, n, layout, d_costs, d_keys, d_records, s, nullptr);
+}
+
+int acmpc_solve_sampled_device(acmpc_ctx* c, const float* d_x0, const float* d_U, const float* d_centre,
+                               int32_t centre_stride, const float* d_u_ref, int32_t P, int32_t N, int32_t n, int32_t layout,
+                               double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round, float* d_costs,
+                               int64_t* d_keys, float* d_records, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (d_x0 == nullptr || d_U == nullptr || d_centre == nullptr || d_records == nullptr)
+    return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (centre_stride < 2 * n) return fail(c, ACMPC_EINVAL, "centre_stride must be at least 2 n");
+  int rc = check_shape(c, P, N, n, layout);
   if (rc != ACMPC_OK) return rc;
-  return finalize(c, nullptr, d_keys, d_x0, d_U, P, N, n, layout, 0, d_records, shape.blocks_per_problem, s);
+  rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = upload_tables(c, s);
+  if (rc != ACMPC_OK) return rc;
+  rc = upload_segments(c, n, s);
+  if (rc != ACMPC_OK) return rc;
+  const Regenerate regen{d_centre, centre_stride, d_u_ref, make_spec(c, sigma_v, sigma_kappa, seed, round)};
+  return solve_batched(c, d_x0, d_U, P, N, n, layout, d_costs, d_keys, d_records, s, &regen);
 }
 
 int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_t N, int32_t n, int32_t layout,

@@ -118,6 +118,12 @@ hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const Rollout
 hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                                           hipEvent_t start, hipEvent_t stop);
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
+// rollout + finalize in ONE launch for the batched solve (mode S, step-major, 256-thread shapes): the last workgroup of
+// every problem writes its record (`fin`: a FinalizeArgs as launch_finalize takes it, partial keys = the rollout's own;
+// `tickets` [P][kTicketGroups + 1] counters, kTicketStride ints apart, zero before and after)
+bool tailed_rollout_fits(int mode, int layout, const LaunchShape& shape, int n);
+hipError_t launch_rollout_tailed(int layout, const LaunchShape& shape, const RolloutArgs& args, const FinalizeArgs& fin,
+                                 int* tickets, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_sample(int layout, const SampleArgs& args, hipStream_t s);
 // Optional tail of the fused launch: the workgroup that finishes a problem LAST (two levels of ticket counters per
 // problem) also runs the finalize for it, in the same launch - argmin over the partial keys, record written.  With

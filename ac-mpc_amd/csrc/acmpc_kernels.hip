@@ -116,9 +116,8 @@ __device__ __forceinline__ void published() {
 // but the 8-waypoint window 134.9 / 141.3 us (its waves already queue for the LDS: an eighth wave per SIMD adds to the
 // queue what it saves on the tail), so the launcher caps every search but that one.  (The verified search, since round 3
 // an 8-waypoint window + its certificate: 190 us capped, 225 us uncapped.)
-template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1), int WAVES = 1>
-__global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK, bool PUBLISH>
+__device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned char* smem) {
   // carve: [0,32) wave keys | [32,48) wave feasible counts | [64, ...) mode-T waypoint table
   int64_t* s_key = reinterpret_cast<int64_t*>(smem);
   int* s_feas = reinterpret_cast<int*>(smem + 32);
@@ -292,9 +291,20 @@ __global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs
   }
   if (tid == 0) {
     const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;
-    a.partial_keys[slot] = key;
-    a.partial_feas[slot] = nfeas;
+    if constexpr (PUBLISH) {   // read by another workgroup of THIS launch (rollout_tailed_kernel): to the coherence point
+      publish(&a.partial_keys[slot], key);
+      publish(&a.partial_feas[slot], nfeas);
+    } else {
+      a.partial_keys[slot] = key;
+      a.partial_feas[slot] = nfeas;
+    }
   }
+}
+
+template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1), int WAVES = 1>
+__global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  rollout_block<MODE, LAYOUT, CPT, BLOCK, PACK, false>(a, smem);
 }
 
 // Candidate-major control matrix U[P][N][n][2] (what NumPy host code holds): a wave's 64 candidates are 64
@@ -1040,6 +1050,28 @@ __device__ __forceinline__ bool last_workgroup_of_problem(int* tickets, const in
   ACMPC_STAMP(7);
   if (threadIdx.x == 0) publish(&tickets[groups_cfg * kTicketStride], 0);  // the launch leaves the counters as it found them
   return true;
+}
+
+// rollout_kernel with the finalize in its own launch (round 4): the workgroup that finishes a problem LAST (tickets, as in
+// the fused rounds) also takes the argmin over the problem's partial keys and writes the winner's record - re-rolled by
+// its first wave with the step functions of the rollout, as finalize_kernel does (finalize_problem: the same bits).  The
+// batched solve (4 096 problems x 4 096 candidates) used to follow its 1.09 ms rollout with a finalize_kernel of 4 096
+// single-wave workgroups: 29 us + a launch gap, 3.4 % of the step.  Here the re-rolls of all problems but the last few
+// run in the shadow of other workgroups' streaming (the kernel is HBM-bound: the vector pipes have room), and only the
+// final ones - ~9 us of a lone wave - are exposed.  Mode S, step-major, 256-thread workgroups; one candidate's states per
+// lane would not fit the headline kernel's 46 registers, so no trace: the winner is rolled again.
+// LDS: [64 bytes: wave keys, counts] [record image 4 + 2n + 3(n + 1) floats].
+#ifndef ACMPC_TAILED_WAVES
+#define ACMPC_TAILED_WAVES 8   // waves per SIMD asked for: caps the allocation at 64 VGPRs (the tail's re-roll would take 78)
+#endif
+template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK>
+__global__ void __launch_bounds__(BLOCK, ACMPC_TAILED_WAVES) rollout_tailed_kernel(const RolloutArgs a, const FinalizeArgs f, int* tickets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  rollout_block<MODE, LAYOUT, CPT, BLOCK, PACK, true>(a, smem);
+  if (threadIdx.x >= kWave) return;   // the tail is the first wave's (the one that published the workgroup's partials)
+  const int p = blockIdx.y;
+  if (!last_workgroup_of_problem(tickets + static_cast<size_t>(p) * (kTicketGroups + 1) * kTicketStride, kTicketGroups)) return;
+  finalize_problem<MODE, LAYOUT>(f, p, reinterpret_cast<float*>(smem + 64));
 }
 
 // Optional tail of a fused round (one wave, threadIdx.x = its lanes): see FusedFinalize.
@@ -2501,6 +2533,31 @@ hipError_t launch_rollout(int mode, int layout, const LaunchShape& shape, const 
   if (mode == 1 && layout == 0) return launch_rollout_ml<1, 0>(shape, args, s, e0, e1);
   if (mode == 1 && layout == 1) return launch_rollout_ml<1, 1>(shape, args, s, e0, e1);
   return hipErrorInvalidValue;
+}
+
+bool tailed_rollout_fits(int mode, int layout, const LaunchShape& shape, int n) {
+  const size_t rec_floats = static_cast<size_t>(4 + 2 * n + 3 * (n + 1));
+  return mode == 0 && layout == 1 && !shape.tile && shape.block == 256 && (shape.cpt == 1 || shape.cpt == 2 || shape.cpt == 4) &&
+         64 + rec_floats * sizeof(float) <= 64 * 1024;
+}
+
+hipError_t launch_rollout_tailed(int layout, const LaunchShape& shape, const RolloutArgs& args, const FinalizeArgs& fin,
+                                 int* tickets, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  clear_stale_error();
+  if (!tailed_rollout_fits(0, layout, shape, args.n) || tickets == nullptr) return hipErrorInvalidValue;
+  const dim3 grid(shape.blocks_per_problem, args.P);
+  const size_t lds = 64 + static_cast<size_t>(4 + 2 * args.n + 3 * (args.n + 1)) * sizeof(float);
+  auto go = [&](auto kernel) -> hipError_t {
+    if (e0 != nullptr && e1 != nullptr) {
+      hipExtLaunchKernelGGL(kernel, grid, dim3(256), static_cast<std::uint32_t>(lds), s, e0, e1, 0, args, fin, tickets);
+    } else {
+      hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, args, fin, tickets);
+    }
+    return hipGetLastError();
+  };
+  if (shape.cpt == 1) return go(rollout_tailed_kernel<0, 1, 1, 256, 1>);
+  if (shape.cpt == 2) return go(rollout_tailed_kernel<0, 1, 2, 256, 2>);
+  return go(rollout_tailed_kernel<0, 1, 4, 256, 2>);
 }
 
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s) {

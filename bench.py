@@ -799,8 +799,9 @@ def main():
                     self.slot.use_sampler(u_ref, u_ref, SAMPLE_SIGMA, seeds[0], 0)
 
             def step(self, x0_, U_, seed=None):
-                self.slot.rollout(x0_, U_, stream)
-                self.slot.select(x0_, U_, stream, seed=seed)
+                # one rank: one call (rollout, argmin and the winners' records in one launch); N ranks: rollout, the
+                # all-reduce(MIN) of the keys, the records
+                self.slot.step(x0_, U_, stream, seed=seed)
                 return self.slot
 
             def drain(self):

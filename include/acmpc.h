@@ -229,6 +229,17 @@ int acmpc_finalize_sampled_device(acmpc_ctx* ctx, const int64_t* d_keys, const f
                                   double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round,
                                   float* d_records, void* stream);
 
+/* acmpc_rollout_device + acmpc_finalize_sampled_device as ONE call for a rank that has all the candidates (no all-reduce
+ * between them): `d_U` holds what acmpc_sample_device wrote for (centre, u_ref, sigma, seed, round); rollout, argmin and
+ * the winners' records - re-drawn from their indices - without a host round trip between them: two launches, or with
+ * the handle's ACMPC_TAILED_ROLLOUT option one (mode S, step-major: the last workgroup of every problem finalizes it,
+ * csrc/acmpc_kernels.hip rollout_tailed_kernel - measured slower on the headline's batch, so not the default).
+ * d_costs [P][N] or NULL, d_keys [P] or NULL, d_records [P][acmpc_record_floats(n)].  The same bits either way. */
+int acmpc_solve_sampled_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, const float* d_centre,
+                               int32_t centre_stride, const float* d_u_ref, int32_t P, int32_t N, int32_t n, int32_t layout,
+                               double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round, float* d_costs,
+                               int64_t* d_keys, float* d_records, void* stream);
+
 /* The one collective of the multi-GPU step, for hosts that drive RCCL themselves rather than through
  * torch.distributed: in-place all-reduce(MIN) of the P packed keys over `rccl_comm` (an `ncclComm_t` the host
  * created, one rank per GPU), enqueued on `stream`.  Call between acmpc_rollout_device and
