@@ -190,9 +190,11 @@ void verified_frames(const float* coef, int P, int n, std::vector<float>* out) {
   std::vector<acmpc::frames::Geometry> geometry(static_cast<size_t>(windows));
   for (int p = 0; p < P; ++p) {
     const float* t = coef + static_cast<size_t>(p) * n * acmpc::kCoefT;
-    auto at = [t](int m, double& x, double& y) {
-      x = static_cast<double>(t[m * acmpc::kCoefT]);
-      y = static_cast<double>(t[m * acmpc::kCoefT + 1]);
+    // positions in the path's own frame, as the kernels take them (acmpc_device.h: start_temporal): float32 differences
+    const float ox = t[0], oy = t[1];
+    auto at = [t, ox, oy](int m, double& x, double& y) {
+      x = static_cast<double>(t[m * acmpc::kCoefT] - ox);
+      y = static_cast<double>(t[m * acmpc::kCoefT + 1] - oy);
     };
     double wn = 0.0;   // largest norm of a waypoint
     bool finite = true;
@@ -204,8 +206,8 @@ void verified_frames(const float* coef, int P, int n, std::vector<float>* out) {
     }
     float largest_gap2 = 0.0f;
     for (int m = 0; m + 1 < n; ++m) {
-      const float gap2 = acmpc::frames::squared_gap(t[(m + 1) * acmpc::kCoefT], t[(m + 1) * acmpc::kCoefT + 1],
-                                                    t[m * acmpc::kCoefT], t[m * acmpc::kCoefT + 1]);
+      const float gap2 = acmpc::frames::squared_gap(t[(m + 1) * acmpc::kCoefT] - ox, t[(m + 1) * acmpc::kCoefT + 1] - oy,
+                                                    t[m * acmpc::kCoefT] - ox, t[m * acmpc::kCoefT + 1] - oy);
       largest_gap2 = (gap2 > largest_gap2) ? gap2 : largest_gap2;
     }
     const int first = acmpc::frames::near_first(largest_gap2);

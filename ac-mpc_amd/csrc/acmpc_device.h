@@ -229,10 +229,20 @@ struct StateT_ {
 };
 using StateT = StateT_<float>;
 
+// Mode T works in the PATH'S OWN FRAME (round 4): every position - the pose, the waypoints, the search keys, the frames of
+// the verified search - is taken relative to the path's first waypoint (x_0, y_0), subtracted in float32 when the tables
+// are staged and when the pose is read, and added back where a pose leaves a kernel (records, traces).  Dynamics and cost
+// only see differences of positions, so nothing else changes; but the search key |p - w|^2 - |p|^2 = c + a X + b Y cancels
+// catastrophically in float32 when |p| is large: given in a frame 4 km from its origin, a path made the key pick a
+// non-nearest waypoint for 5 % of the poses within 8 m of it (up to 1.2 m farther than the nearest).  In the path's own
+// frame the coordinates are the path's extent (<= ~200 m) wherever the caller put it.  `coef` = the problem's packed table,
+// whose first row holds (x_0, y_0).  For a path that starts at the origin - every path in the vehicle frame whose first
+// point is the car's - x - 0 = x: the same bits as before.
 template <typename F>
-__device__ __forceinline__ StateT_<F> start_temporal(const float* __restrict__ pose) {
+__device__ __forceinline__ StateT_<F> start_temporal(const float* __restrict__ pose, const float* __restrict__ coef) {
   const F zero = splat<F>(0.0f);
-  return StateT_<F>{splat<F>(pose[0]), splat<F>(pose[1]), splat<F>(pose[2]), zero, zero, zero, zero, zero, zero, zero};
+  return StateT_<F>{splat<F>(pose[0] - coef[0]), splat<F>(pose[1] - coef[1]), splat<F>(pose[2]), zero, zero, zero, zero, zero,
+                    zero, zero};
 }
 
 // explicit Euler on the rear-axle kinematic bicycle (localiser.py:66-95); phi_dot = v * kappa
@@ -519,9 +529,10 @@ __device__ __forceinline__ int temporal_nearest_window(float X, float Y, const f
 // (search_entry) in the 32-byte entries described at kKeyStride.  `threads` lanes of a workgroup cooperate.
 __device__ __forceinline__ void stage_temporal_tables(const float* __restrict__ coef, int n, int tid, int threads,
                                                       float* rows, float* abc) {
+  const float ox = coef[0], oy = coef[1];   // the path's own frame: see start_temporal()
   for (int m = tid; m < n; m += threads) {
     const float* g = coef + m * kCoefT;
-    const float x = g[0], y = g[1], c = g[2], sn = g[3];
+    const float x = g[0] - ox, y = g[1] - oy, c = g[2], sn = g[3];
     float* r = rows + m * kCoefT;
     r[0] = fma_(sn, x, -(c * y));
     r[1] = -sn;
@@ -535,11 +546,11 @@ __device__ __forceinline__ void stage_temporal_tables(const float* __restrict__ 
     float unused_a, unused_b;
     search_entry(x, y, e[0], e[1], e[kKeyC]);
     const float* g1 = coef + min(m + 1, n - 1) * kCoefT;
-    search_entry(g1[0], g1[1], e[2], e[3], e[kKeyC + 1]);
+    search_entry(g1[0] - ox, g1[1] - oy, e[2], e[3], e[kKeyC + 1]);
     const float* g2 = coef + min(m + 2, n - 1) * kCoefT;
-    search_entry(g2[0], g2[1], unused_a, unused_b, e[kKeyC + 2]);
+    search_entry(g2[0] - ox, g2[1] - oy, unused_a, unused_b, e[kKeyC + 2]);
     const float* g3 = coef + min(m + 3, n - 1) * kCoefT;
-    search_entry(g3[0], g3[1], unused_a, unused_b, e[kKeyC + 3]);
+    search_entry(g3[0] - ox, g3[1] - oy, unused_a, unused_b, e[kKeyC + 3]);
   }
 }
 

@@ -204,7 +204,7 @@ __device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned cha
       I nearest[kGroups];
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
-        st[g] = start_temporal<F>(x0);
+        st[g] = start_temporal<F>(x0, coef);
         nearest[g] = I(0);
       }
       with_search_kind(w, n, [&](auto kind) {
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(kWave) rollout_tile_kernel(const RolloutArgs a
       cost = finish_spatial(st, w);
       feas = st.V == 0.0f;
     } else {
-      StateT st = start_temporal<float>(x0);
+      StateT st = start_temporal<float>(x0, coef);
       int nearest = 0;
       for (int i = 0; i < n; ++i) {
         const f32x2 vk = row[i];
@@ -582,7 +582,7 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
     const f32x2* s_alt = reinterpret_cast<const f32x2*>(use_extra ? s_extra : s_ref);   // (per lane)
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     StateS ss{x0[0], x0[1], x0[2], 0.0f, 0.0f};
-    StateT ts = start_temporal<float>(x0);
+    StateT ts = start_temporal<float>(x0, coef);
     int nearest = 0;
     struct StepOperands {
       f32x2 centre, ref;
@@ -625,8 +625,8 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
           float* col = s_trace + lane;
           col[(2 * i) * kWave] = v;
           col[(2 * i + 1) * kWave] = k;
-          col[(2 * n + 3 * i) * kWave] = (MODE == 0) ? ss.ey : ts.X;
-          col[(2 * n + 3 * i + 1) * kWave] = (MODE == 0) ? ss.ep : ts.Y;
+          col[(2 * n + 3 * i) * kWave] = (MODE == 0) ? ss.ey : ts.X + coef[0];       // (poses leave in the caller's frame)
+          col[(2 * n + 3 * i + 1) * kWave] = (MODE == 0) ? ss.ep : ts.Y + coef[1];
           col[(2 * n + 3 * i + 2) * kWave] = (MODE == 0) ? ss.t : ts.phi;
         }
       }
@@ -864,14 +864,14 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
       s_rec[1] = V;
     }
   } else {
-    StateT st = start_temporal<float>(x0);
+    StateT st = start_temporal<float>(x0, coef);
     // waypoint table -> LDS (behind the record image); each lane also keeps "its" waypoint's (x, y) in registers
     float* s_wp = s_rec + ((rec_floats + 3) & ~3);
     float* s_abc = s_wp + n * kCoefT;
     stage_temporal_tables(coef, n, lane, kWave, s_wp, s_abc);
     if (lane == 0) {
-      sx[0] = st.X;
-      sx[1] = st.Y;
+      sx[0] = st.X + coef[0];   // (poses leave in the caller's frame: start_temporal())
+      sx[1] = st.Y + coef[1];
       sx[2] = st.phi;
     }
     __syncthreads();
@@ -917,8 +917,8 @@ __device__ __forceinline__ void finalize_problem(const FinalizeArgs& a, const in
         j_prev = j;
         temporal_cost(st, s_wp + j * kCoefT, vi, ki, w);
         if (lane == 0) {
-          sx[3 * (base + i + 1)] = st.X;
-          sx[3 * (base + i + 1) + 1] = st.Y;
+          sx[3 * (base + i + 1)] = st.X + coef[0];
+          sx[3 * (base + i + 1) + 1] = st.Y + coef[1];
           sx[3 * (base + i + 1) + 2] = st.phi;
         }
       }
@@ -1737,7 +1737,7 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
     const bool use_ref = ((gidx == 1u) && (smp.u_ref != nullptr)) || use_extra;
     const f32x2* s_alt = reinterpret_cast<const f32x2*>(use_extra ? s_extra : s_ref);   // (per lane)
     const float amp = use_ref ? 0.0f : candidate_amplitude(gidx);
-    StateT pose = start_temporal<float>(x0);
+    StateT pose = start_temporal<float>(x0, coef);
     struct Operands {
       f32x2 centre, ref;
       float weight;
@@ -1815,7 +1815,7 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
 
   // ---- costs: two chunks behind the poses ----
   const bool confirm = search_kind(w, n, a.nn_frames != nullptr) == kSearchVerified;
-  StateT st = start_temporal<float>(x0);
+  StateT st = start_temporal<float>(x0, coef);
   __syncthreads();   // chunk time 0
   __syncthreads();   // chunk time 1: chunk 0 searched
   for (int t = 2; t <= chunks + 1; ++t) {
@@ -1848,7 +1848,15 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
   {
     __syncthreads();   // this wave alone by now: orders its column writes before the row reads
     float* trace_out = fused.trace + (static_cast<size_t>(p) * gridDim.x + blockIdx.x) * fused.trace_pitch;
-    for (int e = lane; e < 5 * n + 2; e += kWave) publish(&trace_out[e], s_trace[e * kWave + best_lane]);
+    // (the waves exchanged the poses in the path's own frame - start_temporal() - and they leave in the caller's: rows
+    // 2n + 3i and 2n + 3i + 1 of the trace are X and Y after step i)
+    const float ox = coef[0], oy = coef[1];
+    for (int e = lane; e < 5 * n + 2; e += kWave) {
+      const int k = e - 2 * n;
+      const bool is_x = k >= 0 && k < 3 * n && k % 3 == 0, is_y = k >= 0 && k < 3 * n && k % 3 == 1;
+      const float value = s_trace[e * kWave + best_lane];
+      publish(&trace_out[e], is_x ? value + ox : is_y ? value + oy : value);   // (the same add as every other form's)
+    }
   }
   if (lane == 0) {
     const size_t slot = static_cast<size_t>(p) * gridDim.x + blockIdx.x;

@@ -285,6 +285,15 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
       }
     }
     __syncthreads();
+    {   // the path's own frame, as the kernels take it (acmpc_device.h: start_temporal): float32 differences to waypoint 0
+      const float ox = static_cast<float>(xr[0]), oy = static_cast<float>(yr[0]);
+      __syncthreads();
+      for (int r = lane; r < n; r += 64) {
+        xr[r] = static_cast<double>(static_cast<float>(xr[r]) - ox);
+        yr[r] = static_cast<double>(static_cast<float>(yr[r]) - oy);
+      }
+      __syncthreads();
+    }
     tabulate_frames(xr, yr, s_mem + 2 * n, n, lane, a.frames);
     return;
   }

@@ -305,6 +305,39 @@ def particle_filter_block(workloads, iters=20):
             entry.update(nearest_point_search="uniform grid, exact (certified rings, wave-wide scan for the rest)")
         out["particles_%d" % P] = entry
     scorer.close()
+    # What bounds the kernels: kernel durations from the committed rocprofv3 summary of
+    # tools/bench_pf.py (profiles/*_pf_kernel_stats.json, tools/profile_pf.sh), the work they do, and the roofs it is held
+    # against: the float64 vector rate (78.6 TFLOP/s: half the guide's 157.3 TFLOP/s float32 vector peak) and the L2's
+    # bandwidth for rows every workgroup shares (guide: 16.8-18.8 TB/s).  Both kernels are latency-bound: a few hundred
+    # workgroups of dependent loads - the fractions say how far.
+    stats, stats_path = newest_profile("pf_kernel_stats.json")
+    if stats is not None:
+        m = len(centre)
+        map_bytes = 3 * m * 2 * 8                                     # three polylines of float64 (x, y)
+        bounds = {"source": stats_path, "measured_in_this_run": False, "fp64_vector_peak_TFLOPs": 78.6,
+                  "l2_shared_rows_peak_TBps": 17.8}
+        small = stats["sizes"].get("500", {}).get("pf_score_kernel<1>")
+        if small is not None:
+            t = small["average_us"] * 1e-6
+            pairs = 500 * 3 * m
+            bounds["pf_score_kernel<1>_at_500"] = {
+                "kernel_us": small["average_us"], "distance_evaluations_per_s": pairs / t,
+                "fp64_TFLOPs": pairs * 5 / t / 1e12, "frac_of_fp64_vector_peak": pairs * 5 / t / 78.6e12,
+                "l2_bytes": 500 * map_bytes, "l2_TBps": 500 * map_bytes / t / 1e12,
+                "frac_of_l2_bandwidth": 500 * map_bytes / t / 17.8e12,
+                "note": "one workgroup per particle scans the whole %d kB map out of the L2" % (map_bytes // 1000)}
+        big = stats["sizes"].get("100000", {}).get("pf_nearest_kernel")
+        if big is not None:
+            t = big["average_us"] * 1e-6
+            gathered = 100000 * 3 * 150 * 16                          # ~150 map points of 16 bytes per (particle, polyline) query
+            bounds["pf_nearest_kernel_at_100000"] = {
+                "kernel_us": big["average_us"], "queries_per_s": 300000 / t, "bytes_gathered": gathered,
+                "l2_TBps": gathered / t / 1e12, "frac_of_l2_bandwidth": gathered / t / 17.8e12,
+                "note": "uniform-grid search: ~150 points of its cells per (particle, polyline) query, dependent loads ring by ring"}
+            score = stats["sizes"]["100000"].get("pf_score_kernel<8>")
+            if score is not None:
+                bounds["pf_score_kernel<8>_at_100000"] = {"kernel_us": score["average_us"]}
+        out["kernel_bounds"] = bounds
     return out
 
 

@@ -219,12 +219,14 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
   const float hqn0 = 0.5f * w->qn[0], hqn1 = 0.5f * w->qn[1], hqn2 = 0.5f * w->qn[2];
 #pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < N; ++c) {
-    float X = pose0[0], Y = pose0[1], phi = pose0[2], ey = 0.0f, ep = 0.0f, V = 0.0f;
+    /* the path's own frame (csrc/acmpc_device.h: start_temporal): positions relative to waypoint 0, float32 differences */
+    const float ox = wp[0], oy = wp[1];
+    float X = pose0[0] - ox, Y = pose0[1] - oy, phi = pose0[2], ey = 0.0f, ep = 0.0f, V = 0.0f;
     float S0 = 0.0f, S1 = 0.0f, S2 = 0.0f, S3 = 0.0f; /* sums of e_y^2, e_psi^2, dv^2, dkappa^2: weights applied at the end */
     int j_prev = 0;
     if (states) {
       float* s = states + c * (n + 1) * 3;
-      s[0] = X, s[1] = Y, s[2] = phi;
+      s[0] = X + ox, s[1] = Y + oy, s[2] = phi;
     }
     for (int i = 0; i < n; ++i) {
       float v, k, sn, cs;
@@ -247,7 +249,7 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       }
       for (int m = lo; m <= hi; ++m) {
         /* search key (csrc/acmpc_device.h: search_key): |p - w_m|^2 less |p|^2, two fused multiply-adds */
-        const float wx = wp[m * CT + 0], wy = wp[m * CT + 1];
+        const float wx = wp[m * CT + 0] - ox, wy = wp[m * CT + 1] - oy;
         const float d = fmaf(Y, -2.0f * wy, fmaf(X, -2.0f * wx, fmaf(wy, wy, wx * wx)));
         if (d < best) {
           best = d;
@@ -257,7 +259,7 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       j_prev = j;
       const float* g = wp + j * CT;
       /* e_y = c (Y - y) - s (X - x) as the kernels' derived rows evaluate it: fma(c, Y, fma(-s, X, s x - c y)) */
-      ey = fmaf(g[2], Y, fmaf(-g[3], X, fmaf(g[3], g[0], -(g[2] * g[1]))));
+      ey = fmaf(g[2], Y, fmaf(-g[3], X, fmaf(g[3], g[0] - ox, -(g[2] * (g[1] - oy)))));
       ep = wrap_spec(phi - g[4]);
       const float dv = v - g[6];
       const float dk = k - g[5];
@@ -274,7 +276,7 @@ void acmpc_oracle_rollout_temporal(const float* pose0, const float* wp, const fl
       V = fmaf(hc, hc, V);
       if (states) {
         float* s = states + (c * (n + 1) + i + 1) * 3;
-        s[0] = X, s[1] = Y, s[2] = phi;
+        s[0] = X + ox, s[1] = Y + oy, s[2] = phi;
       }
     }
     const float tN = (float)n * w->dt;

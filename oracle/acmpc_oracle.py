@@ -569,8 +569,12 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
     half, zero, wb, dtT = T(0.5), T(0.0), T(w_bound), T(dt)
     fma = _fma_for(T)
     hQ, hR, hQN = half * Q, half * R, half * QN   # the halved weights (products in `dtype`, exact)
-    X = np.full(N, T(pose0[0]), dtype=T)
-    Y = np.full(N, T(pose0[1]), dtype=T)
+    # the path's own frame (csrc/acmpc_device.h: start_temporal): every position relative to waypoint 0, float32 differences
+    # - the search key cancels catastrophically far from the origin; poses are reported back in the caller's frame
+    ox, oy = wp[0, CT_X], wp[0, CT_Y]
+    wx, wy = wp[:, CT_X] - ox, wp[:, CT_Y] - oy
+    X = np.full(N, T(pose0[0]) - ox, dtype=T)
+    Y = np.full(N, T(pose0[1]) - oy, dtype=T)
     phi = np.full(N, T(pose0[2]), dtype=T)
     J = np.zeros(N, dtype=T)
     V = np.zeros(N, dtype=T)
@@ -580,14 +584,14 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
     ep = np.zeros(N, dtype=T)
     j_prev = np.zeros(N, dtype=np.int64)
     if return_states:
-        S[:, 0, 0], S[:, 0, 1], S[:, 0, 2] = X, Y, phi
+        S[:, 0, 0], S[:, 0, 1], S[:, 0, 2] = X + ox, Y + oy, phi
     # the nearest-waypoint search key (csrc/acmpc_device.h: search_key): e_m = fma(Y, b_m, fma(X, a_m, c_m)) with
     # a = -2 x, b = -2 y, c = fma(y, y, x x) - the squared distance less |p|^2, which no waypoint's share of changes
-    key_a, key_b = T(-2.0) * wp[:, CT_X], T(-2.0) * wp[:, CT_Y]
-    key_c = fma(wp[:, CT_Y], wp[:, CT_Y], wp[:, CT_X] * wp[:, CT_X])
+    key_a, key_b = T(-2.0) * wx, T(-2.0) * wy
+    key_c = fma(wy, wy, wx * wx)
     # the waypoint rows as the kernels derive them once per workgroup (stage_temporal_tables): e_y = c (Y - y) - s (X - x)
     # becomes fma(c, Y, fma(-s, X, s x - c y))
-    row_k = fma(wp[:, CT_SIN], wp[:, CT_X], -(wp[:, CT_COS] * wp[:, CT_Y]))
+    row_k = fma(wp[:, CT_SIN], wx, -(wp[:, CT_COS] * wy))
     row_ns = -wp[:, CT_SIN]
     S0, S1, S2, S3 = (np.zeros(N, dtype=T) for _ in range(4))   # sums of e_y^2, e_psi^2, dv^2, dkappa^2
     for i in range(n):
@@ -642,7 +646,7 @@ def rollout_temporal(pose0, wp, U, Q, R, QN, u_lo, u_hi, w_bound, dt, dtype=np.f
         hc = np.fmax(np.abs(ey) - g[:, CT_HALF], zero)           # outside the corridor |e_y| <= w/2 - margin
         V = fma(hc, hc, V)
         if return_states:
-            S[:, i + 1, 0], S[:, i + 1, 1], S[:, i + 1, 2] = X, Y, phi
+            S[:, i + 1, 0], S[:, i + 1, 1], S[:, i + 1, 2] = X + ox, Y + oy, phi
             J_idx[:, i] = j
     tN = T(n) * dtT
     J = hQ[0] * S0

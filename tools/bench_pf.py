@@ -19,7 +19,8 @@ rng = np.random.default_rng(0)
 centre = track["centre"]
 left = np.stack([-4.7 + rng.normal(0, 0.1, 100), np.linspace(0, 49, 100)], axis=1).astype(np.float32)
 right = np.stack([4.7 + rng.normal(0, 0.1, 100), np.linspace(0, 49, 100)], axis=1).astype(np.float32)
-for P in (500, 5000, 100000):
+SIZES = [int(a) for a in sys.argv[1:]] or [500, 5000, 100000]   # (tools/profile_pf.sh profiles one size per run)
+for P in SIZES:
     seeds = rng.integers(0, len(centre), P)
     states = np.concatenate([centre[seeds] + rng.normal(0, 2.0, (P, 2)), rng.uniform(-3, 3, (P, 1))], axis=1).astype(np.float32)
     scorer.update_particles(states, [left, right])
