@@ -19,7 +19,7 @@ the optimum of the reference's QP without its box rows - a backward Riccati pass
 `rollout_mode: "T"` (default "S") scores the candidates with the Cartesian rollout instead - BASELINE.json north_star's
 literal shape: kinematic bicycle (localisation/localiser.py:66-95) advanced by `rollout_dt` seconds per step (0.05),
 nearest waypoint of the path at every step (localiser.py:282-289: the nearest of ALL waypoints - `nn_window: null`, the
-default up to horizon 101; `nn_window: [back, ahead]` searches only that many waypoints round the previous step's, 0.064 ms
+default up to horizon 107; `nn_window: [back, ahead]` searches only that many waypoints round the previous step's, 0.064 ms
 per solve instead of 0.066, and is the default beyond), Frenet errors against it (dynamics.py:23-40), the same weights and
 bounds.
 The plan is then a TIME-indexed one (control i holds from i * dt), which is what `TemporalCommandSelector` consumes.
@@ -29,10 +29,14 @@ from __future__ import annotations
 from types import SimpleNamespace
 from typing import Dict
 
+import logging
+
 import numpy as np
 
 from . import _capi
 from .reference_path import ReferencePath
+
+logger = logging.getLogger(__name__)
 
 SOLVED = "solved"
 # Defaults from tools/sweep_solver_settings.py (600 warm-started solves along the synthetic Silverstone circuit, the
@@ -92,8 +96,15 @@ class ControlSolver:
         self._dt = float(config.get("rollout_dt", 0.05))
         # None: the nearest of all waypoints (the verified window search).  Absent: that, up to the 100 steps whose search
         # frames fit the round's LDS; a longer horizon gets the (2,5) window, which costs it a third of a scan of every waypoint
-        window = config["nn_window"] if "nn_window" in config else (None if self._n_horizon <= 100 else (2, 5))
+        window = config["nn_window"] if "nn_window" in config else (None if self._n_horizon <= 106 else (2, 5))
         self._nn_window = None if window is None else (int(window[0]), int(window[1]))
+        if self.temporal and "nn_window" not in config and window is not None:
+            # not silently: beyond 106 steps the search frames do not fit the round's LDS, and the nearest of ALL waypoints
+            # would be a scan of every waypoint at every step; the (2, 5) window is not exhaustive (it can pick another
+            # waypoint where a path folds back on itself) - say which semantics this controller runs with
+            logger.warning("rollout_mode T at horizon %d: nearest waypoint searched in the window nn_window=(2, 5) round the "
+                           "previous step's (pass nn_window=None for the nearest of all waypoints, or a window of your own)",
+                           self._n_horizon + 1)
         self.pose = (0.0, 0.0, np.pi / 2)   # mode T start state: set by SpatialMPC before `solve` (spatial_mpc.py:185)
 
     # QP input box, widened by 0.1 m/s like the reference (control.py:130-139)

@@ -376,7 +376,7 @@ int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const 
   a.n = n;
   a.index_offset = offset;
   a.w = c->w;
-  ACMPC_HIP(c, acmpc::launch_finalize(c->prm.mode, layout, a, s));
+  ACMPC_HIP(c, acmpc::launch_finalize(c->prm.mode, layout, a, s, c->opt));
   return ACMPC_OK;
 }
 
@@ -599,7 +599,7 @@ const char* const kOptionNames[] = {
     "ACMPC_SHAPE", "ACMPC_T_PACK", "ACMPC_NO_TILE", "ACMPC_TILE_ROWS", "ACMPC_TILE_TABLE", "ACMPC_NO_TRIO_ROUNDS",
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
-    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TAILED_ROLLOUT"};
+    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_LANE_FINALIZE"};
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   const std::string key(name);
@@ -621,6 +621,7 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_NO_PAIR_ROUNDS") { o.no_pair_rounds = on; return true; }
   if (key == "ACMPC_SOLO_REGISTERS") return tri(&o.solo_registers);
   if (key == "ACMPC_SOLO_SPLIT") return tri(&o.solo_split);
+  if (key == "ACMPC_NO_LANE_FINALIZE") { o.no_lane_finalize = on; return true; }
   acmpc_ctx::Switches& w = c->sw;
   if (key == "ACMPC_NO_VERIFIED_SEARCH") { w.no_verified_search = on; return true; }
   if (key == "ACMPC_NO_SOLO") { w.no_solo = on; return true; }
@@ -1528,8 +1529,12 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   pa.x0 = reinterpret_cast<float*>(c->d_tick + in.x0);
   pa.u_ref = reinterpret_cast<float*>(c->d_tick + in.uref);
   pa.coef = reinterpret_cast<float*>(c->d_tick + in.coef);
-  pa.frames = (temporal && c->prm.nn_ahead < 0 && n >= acmpc::kVerifiedWindow) ? reinterpret_cast<float*>(c->d_tick + in.frames)
-                                                                              : nullptr;
+  // the frames of the verified search: tabulated (by the prologue's second workgroup) only when the rounds can take them
+  // - beyond 106 steps they no longer fit the three-wave round's LDS and the search wave scans every waypoint
+  pa.frames = (temporal && c->prm.nn_ahead < 0 && n >= acmpc::kVerifiedWindow && acmpc::trio_frames_fit(n) &&
+               !c->opt.no_trio_rounds && !c->sw.no_verified_search)
+                  ? reinterpret_cast<float*>(c->d_tick + in.frames)
+                  : nullptr;
   pa.centre = reinterpret_cast<float*>(c->d_tick + in.centre);
   pa.seed = reinterpret_cast<uint32_t*>(c->d_tick + in.seed);
   pa.table_out = reinterpret_cast<double*>(c->h_tick_out + out.table);
@@ -1814,8 +1819,9 @@ int acmpc_tick_read_device_frames(acmpc_ctx* c, float* out, int64_t capacity_flo
   if (out == nullptr) return fail(c, ACMPC_EINVAL, "null output");
   if (!c->tick_ready || c->tick_last_n == 0) return fail(c, ACMPC_ESTATE, "acmpc_control_tick has not run");
   const int n = c->tick_last_n;
-  if (c->prm.mode != ACMPC_MODE_TEMPORAL || c->prm.nn_ahead >= 0 || n < acmpc::kVerifiedWindow)
-    return fail(c, ACMPC_ESTATE, "the last tick had no verified search (mode T with the exhaustive search, n >= the window)");
+  if (c->prm.mode != ACMPC_MODE_TEMPORAL || c->prm.nn_ahead >= 0 || n < acmpc::kVerifiedWindow || !acmpc::trio_frames_fit(n) ||
+      c->opt.no_trio_rounds || c->sw.no_verified_search)
+    return fail(c, ACMPC_ESTATE, "the last tick tabulated no frames (mode T with the exhaustive search, window <= n <= 106 steps)");
   const int floats = acmpc::verified_frame_floats(n);
   if (capacity_floats < floats) return fail(c, ACMPC_ECAPACITY, "output buffer too small");
   const TickLayout in(n, c->coef_stride);

@@ -91,6 +91,7 @@ struct LaunchOptions {
   int tile_table = 0;                   // ACMPC_TILE_TABLE: 1 = lds, 2 = scalar (0: by shape)
   bool no_trio_rounds = false, no_quad_rounds = false, no_pair_rounds = false;
   int solo_registers = -1, solo_split = -1;   // ACMPC_SOLO_REGISTERS / ACMPC_SOLO_SPLIT: 0 / 1 (-1: by size / split)
+  bool no_lane_finalize = false;              // ACMPC_NO_LANE_FINALIZE: a wavefront per problem at any problem count
 };
 
 struct LaunchShape {
@@ -117,7 +118,8 @@ hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const Rollout
                                          hipEvent_t start, hipEvent_t stop);
 hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                                           hipEvent_t start, hipEvent_t stop);
-hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s);
+hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s,
+                           const LaunchOptions& opt = LaunchOptions());
 // rollout + finalize in ONE launch for the batched solve (mode S, step-major, 256-thread shapes): the last workgroup of
 // every problem writes its record (`fin`: a FinalizeArgs as launch_finalize takes it, partial keys = the rollout's own;
 // `tickets` [P][kTicketGroups + 1] counters, kTicketStride ints apart, zero before and after)
@@ -167,6 +169,7 @@ hipError_t launch_rollout_solo(int layout, const RolloutArgs& args, const FusedF
                                hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
                                const LaunchOptions& opt = LaunchOptions());
 int trace_floats(int n);
+bool trio_frames_fit(int n);   // mode T three-wave round: do the verified search's frames fit its LDS at this horizon?
 bool traced_finalize_fits(int mode, int n);
 // whether rollout + fused finalize fit one workgroup's 64 KB of LDS (mode T at the longest horizons does not)
 bool fused_finalize_fits(int mode, int n);

@@ -22,6 +22,19 @@
 
 #pragma clang fp contract(off)
 
+// gfx950 (MI355X) only, on purpose.  Three things in this file lean on what that hardware does rather than on what HIP
+// promises, and must not be compiled for anything else without being revisited:
+//   - the multi-wave rounds and the one-launch solve let waves of a workgroup END while the others keep meeting at
+//     s_barrier (rollout_sampled_trio / quad / pair kernels, rollout_solo_kernel<SPLIT>): the hardware takes a terminated
+//     wave out of the barrier's count, HIP leaves a barrier that not every thread reaches undefined;
+//   - values that cross workgroups inside a launch are published with relaxed agent-scope atomics ordered by s_waitcnt
+//     vmcnt(0) (publish / observe / published, last_workgroup_of_problem): sound because an sc1 store is acknowledged at
+//     the memory-side coherence point on gfx942 / gfx950, a data race under the HSA memory model;
+//   - the DPP reductions spell out the wait states the hazard recogniser would insert (acmpc_device.h).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "acmpc kernels are written for gfx950 (MI355X): see the note above before building for another architecture"
+#endif
+
 namespace acmpc {
 
 namespace {
@@ -940,6 +953,119 @@ template <int MODE, int LAYOUT>
 __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_finalize[];
   finalize_problem<MODE, LAYOUT>(a, blockIdx.x, s_finalize);
+}
+
+// The batched solve's finalize, mode S: ONE LANE PER PROBLEM (round 4).  finalize_kernel gives every problem a wavefront,
+// which re-rolls its winner in lock-step on broadcast inputs - a fine use of a wave when there is one problem, and 4 096
+// lone-wave walks when there are 4 096: 29 us behind the headline's 1.09 ms rollout, as much vector-pipe time as 3 % of it.
+// Here a lane takes the argmin over its problem's partial keys (a handful per problem), fetches - or re-draws - the
+// winner's controls and its problem's table rows a chunk of steps ahead, and walks its winner with step_spatial(): the same
+// operations in the same order, so the same record bit for bit, with 1/64 of the instructions.  Records are written a
+// float at a time from 64 lanes into 64 records (1 kB apart): a megabyte of partial lines per 4 096 problems, which the
+// L2 merges.  For launches of at least kLaneFinalizeProblems problems; fewer leave the CUs idle either way and keep the
+// wave-per-problem form, whose latency is the shorter.
+constexpr int kLaneFinalizeProblems = 256;
+constexpr int kLaneChunk = 7;   // steps whose operands are requested together
+
+template <int LAYOUT>
+__global__ void __launch_bounds__(kWave) finalize_lanes_kernel(const FinalizeArgs a) {
+  const int p = static_cast<int>(blockIdx.x) * kWave + static_cast<int>(threadIdx.x);
+  if (p >= a.P) return;
+  const int n = a.n;
+  int nfeas = 0;
+  int64_t key = kKeyMax;
+  for (int b = 0; b < a.blocks_per_problem; ++b) {
+    const size_t slot = static_cast<size_t>(p) * a.blocks_per_problem + b;
+    nfeas += a.partial_feas[slot];
+    const int64_t kb = a.partial_keys[slot];
+    key = (kb < key) ? kb : key;
+  }
+  if (a.keys_in != nullptr) key = a.keys_in[p];
+  if (a.keys_out != nullptr) a.keys_out[p] = key;
+  if (a.records == nullptr) return;
+  const int rec_floats = 4 + 2 * n + 3 * (n + 1);
+  float* __restrict__ rec = a.records + static_cast<size_t>(p) * rec_floats;
+  const int64_t local = static_cast<int64_t>(static_cast<uint32_t>(key & 0xffffffffLL)) - a.index_offset;
+  const bool owner = a.regenerate || (local >= 0 && local < a.N);
+  if (!owner) {
+    for (int e = 0; e < rec_floats; ++e) rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
+    return;
+  }
+  const Weights w = a.w;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kCoefS;
+  const float* __restrict__ x0 = a.x0 + p * 3;
+  const int c = static_cast<int>(local);
+  const uint32_t gidx = static_cast<uint32_t>(key & 0xffffffffLL);
+  float z[kKnots][2] = {};
+  float amp = 0.0f;
+  const float* centre = nullptr;
+  if (a.regenerate) {
+    draw_normals(a.spec, gidx, static_cast<uint32_t>(p), z);
+    const float* alt = (gidx == 1u) ? a.u_ref : (gidx == 2u) ? a.u_extra : nullptr;
+    const bool use_ref = alt != nullptr;
+    amp = use_ref ? 0.0f : candidate_amplitude(gidx);
+    centre = use_ref ? alt + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
+  }
+  float* __restrict__ ru = rec + 4;
+  float* __restrict__ rx = rec + 4 + 2 * n;
+  StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
+  for (int base = 0; base < n; base += kLaneChunk) {
+    // the chunk's operands first (none depends on the walk), then its steps
+    f32x4 lo[kLaneChunk], hi[kLaneChunk];
+    float last[kLaneChunk], v[kLaneChunk], k[kLaneChunk], cen[kLaneChunk][2], seg[kLaneChunk][2];
+#pragma unroll
+    for (int q = 0; q < kLaneChunk; ++q) {
+      const int i = min(base + q, n - 1);
+      const float* row = coef + i * kCoefS;
+      lo[q] = *reinterpret_cast<const f32x4*>(row);
+      hi[q] = *reinterpret_cast<const f32x4*>(row + 4);
+      last[q] = row[8];
+      if (a.regenerate) {
+        cen[q][0] = centre[2 * i];
+        cen[q][1] = centre[2 * i + 1];
+        seg[q][0] = a.spec.segments[2 * i];
+        seg[q][1] = a.spec.segments[2 * i + 1];
+      } else {
+        float vv[1], kk[1];
+        load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, vv, kk);
+        v[q] = vv[0];
+        k[q] = kk[0];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kLaneChunk; ++q) {
+      const int i = base + q;
+      if (i < n) {
+        if (a.regenerate) {   // regenerate_control()'s arithmetic on the operands fetched above
+          const int k0 = static_cast<int>(seg[q][0]);
+          float z0v = z[0][0], z0k = z[0][1], z1v = z[1][0], z1k = z[1][1];
+#pragma unroll
+          for (int knot = 1; knot < kKnots - 1; ++knot) {
+            const bool hit = (k0 == knot);
+            z0v = hit ? z[knot][0] : z0v;
+            z0k = hit ? z[knot][1] : z0k;
+            z1v = hit ? z[knot + 1][0] : z1v;
+            z1k = hit ? z[knot + 1][1] : z1k;
+          }
+          blend_control(a.spec, amp, seg[q][1], cen[q][0], cen[q][1], z0v, z0k, z1v, z1k, v[q], k[q]);
+        }
+        ru[2 * i] = v[q];
+        ru[2 * i + 1] = k[q];
+        rx[3 * i] = st.ey;
+        rx[3 * i + 1] = st.ep;
+        rx[3 * i + 2] = st.t;
+        const float row[9] = {lo[q][0], lo[q][1], lo[q][2], lo[q][3], hi[q][0], hi[q][1], hi[q][2], hi[q][3], last[q]};
+        step_spatial<float>(st, row, v[q], k[q], w);
+      }
+    }
+  }
+  rx[3 * n] = st.ey;
+  rx[3 * n + 1] = st.ep;
+  rx[3 * n + 2] = st.t;
+  rec[0] = finish_spatial<float>(st, w);
+  rec[1] = st.V;
+  rec[2] = static_cast<float>(nfeas);
+  rec[3] = 1.0f;
 }
 
 // Record of problem p out of the winning workgroup's trace (see rollout_sampled_body): argmin over the partial keys,
@@ -2568,8 +2694,19 @@ hipError_t launch_rollout_tailed(int layout, const LaunchShape& shape, const Rol
   return go(rollout_tailed_kernel<0, 1, 4, 256, 2>);
 }
 
-hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s) {
+hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s, const LaunchOptions& opt) {
   clear_stale_error();
+  if (mode == 0 && !args.controls_only && args.P >= kLaneFinalizeProblems && !opt.no_lane_finalize &&
+      (layout == 0 || layout == 1)) {
+    // many problems: one lane per problem (finalize_lanes_kernel)
+    const dim3 lanes_grid((args.P + kWave - 1) / kWave);
+    if (layout == 0) {
+      hipLaunchKernelGGL((finalize_lanes_kernel<0>), lanes_grid, dim3(kWave), 0, s, args);
+    } else {
+      hipLaunchKernelGGL((finalize_lanes_kernel<1>), lanes_grid, dim3(kWave), 0, s, args);
+    }
+    return hipGetLastError();
+  }
   const dim3 grid(args.P), block(kWave);
   // record image, then (mode T) the waypoint table
   const size_t rec_floats = static_cast<size_t>(4 + 2 * args.n + 3 * (args.n + 1));
@@ -2623,6 +2760,18 @@ bool fused_finalize_fits(int mode, int n) {
 }
 
 int trace_floats(int n) { return 5 * n + 2; }
+
+// whether the frames of the verified search fit beside the three-wave mode T round's tables, trace, operands and indices
+// (launch_rollout_sampled drops them otherwise and the search wave scans every waypoint): they do up to n = 106
+bool trio_frames_fit(int n) {
+  if (n < kVerifiedWindow) return false;
+  const size_t tables = ((static_cast<size_t>(n) * (kCoefT + kKeyStride) + 3) & ~static_cast<size_t>(3)) +
+                        static_cast<size_t>(verified_frame_floats(n));
+  const size_t trace = static_cast<size_t>(trace_floats(n)) * kWave;
+  const size_t uniform = (static_cast<size_t>(n) * 7 + 4 + 3) & ~static_cast<size_t>(3);
+  const size_t index = (static_cast<size_t>(n) * kWave / 2 + 3) & ~static_cast<size_t>(3);
+  return (tables + trace + uniform + index) * sizeof(float) <= 160u * 1024u;
+}
 
 // The traced form keeps [5n + 2][64] floats in LDS per workgroup (63 kB at H = 50): up to the CU's 160 kB.
 bool traced_finalize_fits(int mode, int n) {

@@ -175,8 +175,8 @@ def test_mode_t_tick_forms_agree(monkeypatch):
                 monkeypatch.delenv(name)
 
 
-@pytest.mark.parametrize("H,metres_per_point", [(9, 2.45), (20, 2.45), (50, 2.45), (81, 2.45), (101, 2.45), (129, 2.45),
-                                                (50, 3.0), (100, 1.5), (100, 0.7), (128, 1.2)])   # (the first choice
+@pytest.mark.parametrize("H,metres_per_point", [(9, 2.45), (20, 2.45), (50, 2.45), (81, 2.45), (101, 2.45), (107, 2.45),
+                                                (50, 3.0), (100, 1.5), (100, 0.7), (107, 1.2)])   # (the first choice
 def test_the_prologue_tabulates_the_frames_the_host_would(H, metres_per_point):                  # of `near`: 16 / 32 / 64)
     """Mode T with the exhaustive search through the tick: the prologue's lanes leave the frames of the verified window
     search beside the waypoint rows - the arithmetic of acmpc_set_paths (csrc/acmpc_frames.h), so the same bits as

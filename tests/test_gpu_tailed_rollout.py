@@ -1,5 +1,7 @@
-"""The batched solve with the finalize inside the rollout's launch (rollout_tailed_kernel, round 4): the last workgroup of
-every problem takes the argmin and re-rolls the winner while other problems are still streaming.  The records must be
+"""The batched solve's finalize in its three forms (round 4): a wavefront per problem (finalize_kernel), a LANE per problem
+from 256 problems up (finalize_lanes_kernel, the default there), and inside the rollout's launch (rollout_tailed_kernel: the
+last workgroup of every problem takes the argmin and re-rolls the winner while other problems are still streaming).  The
+records must be
 the two-launch form's (rollout_kernel + finalize_kernel, the default: it is the faster of the two on the headline's batch,
 csrc/acmpc_capi.hip solve_batched; ACMPC_TAILED_ROLLOUT=1 selects the one launch) bit for bit, and the oracle's."""
 import numpy as np
@@ -14,10 +16,10 @@ pytestmark = pytest.mark.gpu
 def _solve(monkeypatch, switch, problems, P, N, n, sampled):
     import torch
     from acmpc_amd import Engine, _capi
+    for name in ("ACMPC_TAILED_ROLLOUT", "ACMPC_NO_LANE_FINALIZE"):
+        monkeypatch.delenv(name, raising=False)
     if switch:
-        monkeypatch.setenv("ACMPC_TAILED_ROLLOUT", "1")
-    else:
-        monkeypatch.delenv("ACMPC_TAILED_ROLLOUT", raising=False)
+        monkeypatch.setenv(switch, "1")
     dev = torch.device("cuda", 0)
     eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))      # (the switch is read when the handle is created)
     eng.set_paths(np.stack([p["table"] for p in problems]))
@@ -57,10 +59,12 @@ def test_tailed_rollout_equals_two_launches_and_the_oracle(monkeypatch, P, N, H,
     from acmpc_amd import _capi
     n = H - 1
     problems = [make_problem(orc, "monza", H, 4, seed=900 + p % 7) for p in range(P)]
-    one = _solve(monkeypatch, True, problems, P, N, n, sampled)
-    two = _solve(monkeypatch, False, problems, P, N, n, sampled)
-    for a, b, what in zip(one, two, ("records", "keys", "costs", "controls")):
-        np.testing.assert_array_equal(a, b, err_msg=what)
+    one = _solve(monkeypatch, "ACMPC_TAILED_ROLLOUT", problems, P, N, n, sampled)
+    two = _solve(monkeypatch, None, problems, P, N, n, sampled)                       # (the default: two launches; from
+    waves = _solve(monkeypatch, "ACMPC_NO_LANE_FINALIZE", problems, P, N, n, sampled)  # 256 problems a lane per problem)
+    for other in (two, waves):
+        for a, b, what in zip(one, other, ("records", "keys", "costs", "controls")):
+            np.testing.assert_array_equal(a, b, err_msg=what)
     rec, keys, costs, U = one
     for p in (0, P // 2, P - 1):
         prob, cfg = problems[p], problems[p]["cfg"]
