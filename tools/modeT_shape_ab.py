@@ -1,0 +1,37 @@
+"""A/B of launch shapes for the mode T kernel at several batch sizes (same box, interleaved repeats)."""
+import copy, os, sys
+ROOT = "/root/repo"
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ac-mpc_amd"))
+import numpy as np, torch
+import bench
+from acmpc_amd import Engine, workloads
+device = torch.device("cuda", 0); torch.cuda.set_device(0)
+H, N, n = 50, 4096, 49
+base = workloads.problem_batch("monza", 256, H, seed=0)
+stream = torch.cuda.current_stream().cuda_stream
+res = {}
+for rep in range(3):
+    for P in (256, 1024, 4096):
+        for name, window in (("exhaustive", None), ("window_2_5", (2, 5)), ("window_1_2", (1, 2))):
+            for shape in ("256,1", "256,2"):
+                batch = copy.copy(base); reps = P // 256
+                batch.tables, batch.x0, batch.pose0 = (np.tile(base.tables, (reps, 1, 1)), np.tile(base.x0, (reps, 1)), np.tile(base.pose0, (reps, 1)))
+                u_ref = torch.tensor(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=torch.float32, device=device).contiguous()
+                costs = torch.empty(P, N, device=device)
+                eng = Engine(**workloads.engine_kwargs(batch, 1, N, device=0, nn_window=window))
+                eng.set_option("ACMPC_SHAPE", shape)
+                eng.set_paths(batch.tables); eng.sync_tables(stream)
+                x0 = torch.tensor(batch.pose0, device=device)
+                U = torch.empty((P, n, 2, N), device=device)
+                eng.sample_device(u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, 1, 0, bench.SAMPLE_SIGMA, 77, 0, U.data_ptr(), stream)
+                for _ in range(3):
+                    eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, costs.data_ptr(), 0, stream)
+                eng.profile_enable(15)
+                for _ in range(15):
+                    eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, costs.data_ptr(), 0, stream)
+                torch.cuda.synchronize()
+                ms = float(np.median(eng.profile_collect()))
+                res.setdefault((P, name, shape), []).append(ms * 1e3)
+                eng.close(); del U, costs
+for k in sorted(res):
+    print(k, ["%.1f" % v for v in res[k]], "frac %.3f" % (k[0] * N * 396 / (np.median(res[k]) * 1e-6) / 8e12), flush=True)
