@@ -133,10 +133,14 @@ def main():
             "kernel_us_unprofiled_same_box": plain.get(spec),
         }
         result[name] = {"counters_mean_per_launch": merged, "derived": derived}
-    result["note"] = ("SQ_INSTS_VALU x 4 cycles / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 XCDs (the counter is summed over the "
-                      "dies): how much of the kernel the vector pipe is issuing for.  Round 2's form of the kernel (squared "
-                      "distances in packed pairs, weighted stage cost per step) counted 96.8 VALU instructions per "
-                      "candidate-step with window (2,5); see r02_mode_T_sq_counters.json.")
+    result["note"] = ("valu_issue_cycles_per_simd_at_4_per_instruction (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs, against "
+                      "GRBM_GUI_ACTIVE / 8 XCDs - the counter is summed over the dies) is the uniform four-cycle estimate of "
+                      "rounds 2-3 and can exceed the active cycles: not every vector instruction takes four.  bench.py's "
+                      "roofline_valu prices the COUNTED instructions of this file with the per-opcode issue times of "
+                      "<tag>_valu_probe.json over the step loop's opcode mix of <tag>_isa_mix.json instead (DESIGN 4.1).  "
+                      "Round 2's kernel counted 96.8 VALU instructions per candidate-step with window (2,5), round 3's 84.4 with "
+                      "24 LDS instructions per wave-step and 21 % of the wave-cycles waiting for the LDS; this round's key table "
+                      "(32-byte entries, two ds_read_b128 per four waypoints) leaves 16 and under 2 %.")
     path = os.path.join(ROOT, "profiles", f"{tag}_mode_T_sq_counters.json")
     with open(path, "w") as handle:
         json.dump(result, handle, indent=1)
