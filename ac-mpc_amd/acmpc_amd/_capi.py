@@ -156,6 +156,10 @@ SIGNATURES = {
     "acmpc_solve_sampled_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                              C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
                                              C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acmpc_solve_stream_device": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
+                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acmpc_solve_stream_flush": (C.c_int, [_CTX, C.c_void_p]),
     "acmpc_reduce_across_ranks": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     # the closed-loop entry points take their buffers as plain addresses (arr.ctypes.data): half the marshalling cost
     # of typed pointers, which at these sizes is most of the call
@@ -482,6 +486,18 @@ class Engine:
         self._check(self._lib.acmpc_solve_sampled_device(self._ctx, d_x0, d_U, d_centre, centre_stride, d_u_ref or None, P,
                                                          N, n, layout, float(sigma[0]), float(sigma[1]), seed, round_,
                                                          d_costs or None, d_keys or None, d_records, stream or None))
+
+    def solve_stream_device(self, d_x0: int, d_U: int, d_centre: int, centre_stride: int, d_u_ref: int, P: int, N: int,
+                            n: int, layout: int, sigma, seed: int, round_: int, d_costs: int, d_keys: int, d_records: int,
+                            stream: int = 0):
+        """One batch of a stream of batches (acmpc_solve_stream_device): its rollout now, its argmin and records inside
+        the next call's launch or behind `solve_stream_flush`.  `d_centre` 0: the winners are read from `d_U`."""
+        self._check(self._lib.acmpc_solve_stream_device(self._ctx, d_x0, d_U, d_centre or None, centre_stride, d_u_ref or None,
+                                                        P, N, n, layout, float(sigma[0]), float(sigma[1]), seed, round_,
+                                                        d_costs or None, d_keys or None, d_records, stream or None))
+
+    def solve_stream_flush(self, stream: int = 0):
+        self._check(self._lib.acmpc_solve_stream_flush(self._ctx, stream or None))
 
     def optimize(self, x0: np.ndarray, centre: np.ndarray, u_ref, n_candidates: int, rounds: int, sigma,
                  shrink: float = 0.5, seed: int = 0):

@@ -88,6 +88,7 @@ class ShardedRollout:
         self.host_collectives = host_collectives
         self.want_keys = want_keys
         self._soft = None
+        self._records_b, self._stream_count = None, 0   # step_stream(): the second record buffer, batches so far
 
         self.engine, self.group = engine, group
         self.P, self.N, self.n, self.layout, self.offset = n_problems, n_local, n_steps, layout, index_offset
@@ -166,6 +167,36 @@ class ShardedRollout:
             self.engine.solve_device(x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n, self.layout, costs, keys,
                                      self.records.data_ptr(), stream)
         return self.records
+
+    def step_stream(self, x0: torch.Tensor, U: torch.Tensor, stream: int, seed: Optional[int] = None,
+                    round_: Optional[int] = None) -> torch.Tensor:
+        """One batch of a STREAM of batches on a rank that holds all the candidates (acmpc_solve_stream_device): the rollout
+        now, argmin and records inside the next batch's launch (or behind `flush`).  Returns the tensor that will hold this
+        batch's records - one of two, alternating, so that a consumer can read batch k while batch k + 1's are written;
+        `x0`, the sampler's centre / reference and - without a sampler - `U` stay as they are until then."""
+        if self.distributed or self.offset != 0:
+            raise RuntimeError("step_stream() is for a rank that holds all the candidates: use step()")
+        if self._records_b is None:
+            self._records_b = torch.empty_like(self.records)
+        self._stream_count += 1
+        out = self.records if self._stream_count % 2 else self._records_b
+        costs = self.costs.data_ptr() if self.costs is not None else 0
+        keys = self.keys.data_ptr() if self.want_keys else 0
+        if self.sampler is not None:
+            sp = self.sampler
+            centre = sp["centre"]
+            stride = centre.shape[-2] * 2 if centre.dim() == 3 else centre.shape[-1]
+            centre_ptr, ref_ptr = centre.data_ptr(), sp["u_ref"].data_ptr() if sp["u_ref"] is not None else 0
+            sigma, seed_, rnd = sp["sigma"], sp["seed"] if seed is None else seed, sp["round"] if round_ is None else round_
+        else:
+            centre_ptr, ref_ptr, stride, sigma, seed_, rnd = 0, 0, 2 * self.n, (0.0, 0.0), 0, 0
+        self.engine.solve_stream_device(x0.data_ptr(), U.data_ptr(), centre_ptr, stride, ref_ptr, self.P, self.N, self.n,
+                                        self.layout, sigma, seed_, rnd, costs, keys, out.data_ptr(), stream)
+        return out
+
+    def flush(self, stream: int):
+        """The last batch of a stream: its argmin and records, a launch of their own."""
+        self.engine.solve_stream_flush(stream)
 
     def softmin(self, U: torch.Tensor, stream: int):
         """Softmin-weighted mean control sequence over the candidates of ALL ranks (the weighted-reduction form of

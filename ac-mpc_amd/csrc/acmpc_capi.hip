@@ -50,6 +50,11 @@ struct acmpc_ctx {
   int64_t* d_partial_keys = nullptr;
   int* d_partial_feas = nullptr;
   size_t partial_slots = 0;  // slots of ONE set of partial keys / feasible counts (there are two)
+  // acmpc_solve_stream_device: the finalize the last call of the stream left for the next one (or for the flush)
+  bool stream_pending = false;
+  acmpc::FinalizeArgs stream_fin{};
+  int stream_fin_layout = 0;
+  int stream_set = 0;        // the half of the partial buffers the pending finalize reads
   double* d_soft_partial = nullptr;
   size_t soft_partial_doubles = 0;
 
@@ -142,7 +147,7 @@ struct acmpc_ctx {
   acmpc::LaunchOptions opt;
   struct Switches {
     bool no_verified_search = false, no_solo = false, no_fused_finalize = false, no_traced_finalize = false,
-         no_chained_rounds = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false,
+         no_chained_rounds = false, no_chained_stream = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false,
          tailed_rollout = false;
   } sw;
 
@@ -295,7 +300,9 @@ int upload_frames(acmpc_ctx* c, hipStream_t s) {
   return ACMPC_OK;
 }
 
-int check_shape(acmpc_ctx* c, int P, int N, int n, int layout) {
+int check_shape(acmpc_ctx* c, int P, int N, int n, int layout, bool stream_call = false) {
+  if (c->stream_pending && !stream_call)
+    return fail(c, ACMPC_ESTATE, "a batch of acmpc_solve_stream_device is pending: acmpc_solve_stream_flush first");
   if (P < 1 || N < 1 || n < 1) return fail(c, ACMPC_EINVAL, "P, N and n must be positive");
   if (layout != ACMPC_LAYOUT_CANDIDATE_MAJOR && layout != ACMPC_LAYOUT_STEP_MAJOR)
     return fail(c, ACMPC_EINVAL, "unknown layout");
@@ -599,7 +606,8 @@ const char* const kOptionNames[] = {
     "ACMPC_SHAPE", "ACMPC_T_PACK", "ACMPC_NO_TILE", "ACMPC_TILE_ROWS", "ACMPC_TILE_TABLE", "ACMPC_NO_TRIO_ROUNDS",
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
-    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_LANE_FINALIZE"};
+    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_LANE_FINALIZE", "ACMPC_NO_GROUP_FINALIZE",
+    "ACMPC_NO_CHAINED_STREAM"};
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   const std::string key(name);
@@ -622,12 +630,14 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_SOLO_REGISTERS") return tri(&o.solo_registers);
   if (key == "ACMPC_SOLO_SPLIT") return tri(&o.solo_split);
   if (key == "ACMPC_NO_LANE_FINALIZE") { o.no_lane_finalize = on; return true; }
+  if (key == "ACMPC_NO_GROUP_FINALIZE") { o.no_group_finalize = on; return true; }
   acmpc_ctx::Switches& w = c->sw;
   if (key == "ACMPC_NO_VERIFIED_SEARCH") { w.no_verified_search = on; return true; }
   if (key == "ACMPC_NO_SOLO") { w.no_solo = on; return true; }
   if (key == "ACMPC_NO_FUSED_FINALIZE") { w.no_fused_finalize = on; return true; }
   if (key == "ACMPC_NO_TRACED_FINALIZE") { w.no_traced_finalize = on; return true; }
   if (key == "ACMPC_NO_CHAINED_ROUNDS") { w.no_chained_rounds = on; return true; }
+  if (key == "ACMPC_NO_CHAINED_STREAM") { w.no_chained_stream = on; return true; }
   if (key == "ACMPC_NO_GRAPH") { w.no_graph = on; return true; }
   if (key == "ACMPC_NO_FUSED_SAMPLING") { w.no_fused_sampling = on; return true; }
   if (key == "ACMPC_TICK_GRAPH") { w.tick_graph = on; return true; }
@@ -954,6 +964,95 @@ int acmpc_solve_sampled_device(acmpc_ctx* c, const float* d_x0, const float* d_U
   if (rc != ACMPC_OK) return rc;
   const Regenerate regen{d_centre, centre_stride, d_u_ref, make_spec(c, sigma_v, sigma_kappa, seed, round)};
   return solve_batched(c, d_x0, d_U, P, N, n, layout, d_costs, d_keys, d_records, s, &regen);
+}
+
+int acmpc_solve_stream_flush(acmpc_ctx* c, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (!c->stream_pending) return ACMPC_OK;
+  c->stream_pending = false;
+  ACMPC_HIP(c, acmpc::launch_finalize(c->prm.mode, c->stream_fin_layout, c->stream_fin, static_cast<hipStream_t>(stream), c->opt));
+  return ACMPC_OK;
+}
+
+int acmpc_solve_stream_device(acmpc_ctx* c, const float* d_x0, const float* d_U, const float* d_centre,
+                              int32_t centre_stride, const float* d_u_ref, int32_t P, int32_t N, int32_t n, int32_t layout,
+                              double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round, float* d_costs,
+                              int64_t* d_keys, float* d_records, void* stream) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (d_x0 == nullptr || d_U == nullptr || d_records == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
+  if (d_centre != nullptr && centre_stride < 2 * n) return fail(c, ACMPC_EINVAL, "centre_stride must be at least 2 n");
+  int rc = check_shape(c, P, N, n, layout, true);
+  if (rc != ACMPC_OK) return rc;
+  rc = ensure_device(c);
+  if (rc != ACMPC_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // the pending finalize reads the tables its batch was rolled with: new ones go up behind it
+  if (c->stream_pending && (c->tables_dirty || c->frames_dirty)) {
+    rc = acmpc_solve_stream_flush(c, stream);
+    if (rc != ACMPC_OK) return rc;
+  }
+  rc = upload_tables(c, s);
+  if (rc != ACMPC_OK) return rc;
+  if (d_centre != nullptr) {
+    rc = upload_segments(c, n, s);
+    if (rc != ACMPC_OK) return rc;
+  }
+  const acmpc::LaunchShape shape = acmpc::choose_shape(P, N, layout, c->prm.mode, n, c->opt);
+  const int set = c->stream_pending ? (c->stream_set ^ 1) : 0;
+  acmpc::RolloutArgs a{};
+  a.U = d_U;
+  a.x0 = d_x0;
+  a.coef = c->d_coef;
+  a.nn_frames = (!c->h_nn_frames.empty() && !c->sw.no_verified_search) ? c->d_nn_frames : nullptr;
+  a.costs = d_costs;
+  a.partial_keys = c->d_partial_keys + set * c->partial_slots;
+  a.partial_feas = c->d_partial_feas + set * c->partial_slots;
+  a.P = P;
+  a.N = N;
+  a.n = n;
+  a.index_offset = 0;
+  a.w = c->w;
+  acmpc::FinalizeArgs f{};
+  if (d_centre != nullptr) {
+    f.regenerate = true;
+    f.centre = d_centre;
+    f.centre_stride = centre_stride;
+    f.u_ref = d_u_ref;
+    f.spec = make_spec(c, sigma_v, sigma_kappa, seed, round);
+  }
+  f.U = d_centre != nullptr ? nullptr : d_U;
+  f.x0 = d_x0;
+  f.coef = c->d_coef;
+  f.partial_keys = a.partial_keys;
+  f.partial_feas = a.partial_feas;
+  f.keys_out = d_keys;
+  f.records = d_records;
+  f.blocks_per_problem = shape.blocks_per_problem;
+  f.P = P;
+  f.N = N;
+  f.n = n;
+  f.index_offset = 0;
+  f.w = c->w;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof_used < c->prof_start.size()) {
+    e0 = c->prof_start[c->prof_used];
+    e1 = c->prof_stop[c->prof_used];
+    ++c->prof_used;
+  }
+  if (c->stream_pending &&
+      acmpc::chained_rollout_fits(c->prm.mode, layout, shape, P, c->stream_fin, c->stream_fin_layout) && !c->sw.no_chained_stream) {
+    c->stream_pending = false;
+    ACMPC_HIP(c, acmpc::launch_rollout_chained(layout, shape, a, c->stream_fin, c->stream_fin_layout, s, e0, e1));
+  } else {
+    rc = acmpc_solve_stream_flush(c, stream);
+    if (rc != ACMPC_OK) return rc;
+    ACMPC_HIP(c, acmpc::launch_rollout(c->prm.mode, layout, shape, a, s, e0, e1));
+  }
+  c->stream_fin = f;
+  c->stream_fin_layout = layout;
+  c->stream_set = set;
+  c->stream_pending = true;
+  return ACMPC_OK;
 }
 
 int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_t N, int32_t n, int32_t layout,
@@ -1479,6 +1578,8 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
       accelerations == nullptr || steer_rates == nullptr || info == nullptr)
     return fail(c, ACMPC_EINVAL, "null argument");
   if (t->struct_size != sizeof(acmpc_tick)) return fail(c, ACMPC_EINVAL, "acmpc_tick size mismatch");
+  if (c->stream_pending)
+    return fail(c, ACMPC_ESTATE, "a batch of acmpc_solve_stream_device is pending: acmpc_solve_stream_flush first");
   if (c->prm.centre_update != 0) return fail(c, ACMPC_ESTATE, "acmpc_control_tick needs a handle with centre_update = 0");
   const bool temporal = c->prm.mode == ACMPC_MODE_TEMPORAL;
   if (temporal && !(c->prm.dt > 0.0)) return fail(c, ACMPC_ESTATE, "mode T needs a positive dt");

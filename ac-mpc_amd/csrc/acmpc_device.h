@@ -880,6 +880,18 @@ struct SampleSpec {
 
 // the 8 x 2 standard normals of one candidate; draws Q0 .. Q1 - 1 of the kKnots / 2 (a caller with something to wait
 // for in between takes them in two halves)
+// one Philox block of a candidate's normals: the four of knots 2q and 2q + 1 - out = {z[2q][0], z[2q][1], z[2q+1][0],
+// z[2q+1][1]} as draw_normals() below fills them (q may be a run-time value: lanes that share a candidate share the draws)
+__device__ __forceinline__ void draw_normal_block(const SampleSpec& sp, uint32_t gidx, uint32_t p, uint32_t q, float (&out)[4]) {
+  const uint32_t key[2] = {sp.seed_ptr != nullptr ? sp.seed_ptr[0] : sp.seed_lo,
+                           sp.seed_ptr != nullptr ? sp.seed_ptr[1] : sp.seed_hi};
+  const uint32_t ctr[4] = {gidx, p, sp.round, q};
+  uint32_t r[4];
+  philox4x32_10(ctr, key, r);
+  box_muller(uniform_open(r[0]), uniform_open(r[1]), out[0], out[1]);
+  box_muller(uniform_open(r[2]), uniform_open(r[3]), out[2], out[3]);
+}
+
 template <int Q0 = 0, int Q1 = kKnots / 2>
 __device__ __forceinline__ void draw_normals(const SampleSpec& sp, uint32_t gidx, uint32_t p, float (&z)[kKnots][2]) {
   const uint32_t key[2] = {sp.seed_ptr != nullptr ? sp.seed_ptr[0] : sp.seed_lo,

@@ -92,6 +92,7 @@ struct LaunchOptions {
   bool no_trio_rounds = false, no_quad_rounds = false, no_pair_rounds = false;
   int solo_registers = -1, solo_split = -1;   // ACMPC_SOLO_REGISTERS / ACMPC_SOLO_SPLIT: 0 / 1 (-1: by size / split)
   bool no_lane_finalize = false;              // ACMPC_NO_LANE_FINALIZE: a wavefront per problem at any problem count
+  bool no_group_finalize = false;             // ACMPC_NO_GROUP_FINALIZE: the batched finalize before its sixteen-lanes-per-problem form
 };
 
 struct LaunchShape {
@@ -123,6 +124,9 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
 // rollout + finalize in ONE launch for the batched solve (mode S, step-major, 256-thread shapes): the last workgroup of
 // every problem writes its record (`fin`: a FinalizeArgs as launch_finalize takes it, partial keys = the rollout's own;
 // `tickets` [P][kTicketGroups + 1] counters, kTicketStride ints apart, zero before and after)
+bool chained_rollout_fits(int mode, int layout, const LaunchShape& shape, int P, const FinalizeArgs& fin, int fin_layout);
+hipError_t launch_rollout_chained(int layout, const LaunchShape& shape, const RolloutArgs& args, const FinalizeArgs& fin,
+                                  int fin_layout, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool tailed_rollout_fits(int mode, int layout, const LaunchShape& shape, int n);
 hipError_t launch_rollout_tailed(int layout, const LaunchShape& shape, const RolloutArgs& args, const FinalizeArgs& fin,
                                  int* tickets, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);

@@ -130,13 +130,12 @@ __device__ __forceinline__ void published() {
 // queue what it saves on the tail), so the launcher caps every search but that one.  (The verified search, since round 3
 // an 8-waypoint window + its certificate: 190 us capped, 225 us uncapped.)
 template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK, bool PUBLISH>
-__device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned char* smem) {
+__device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned char* smem, const int p) {
   // carve: [0,32) wave keys | [32,48) wave feasible counts | [64, ...) mode-T waypoint table
   int64_t* s_key = reinterpret_cast<int64_t*>(smem);
   int* s_feas = reinterpret_cast<int*>(smem + 32);
   float* s_wp = reinterpret_cast<float*>(smem + 64);
 
-  const int p = blockIdx.y;
   const int tid = threadIdx.x;
   const int c0 = (blockIdx.x * BLOCK + tid) * CPT;
   const bool active = c0 < a.N;  // N % CPT == 0 is guaranteed by the launcher
@@ -317,7 +316,7 @@ __device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned cha
 template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1), int WAVES = 1>
 __global__ void __launch_bounds__(BLOCK, WAVES) rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  rollout_block<MODE, LAYOUT, CPT, BLOCK, PACK, false>(a, smem);
+  rollout_block<MODE, LAYOUT, CPT, BLOCK, PACK, false>(a, smem, static_cast<int>(blockIdx.y));
 }
 
 // Candidate-major control matrix U[P][N][n][2] (what NumPy host code holds): a wave's 64 candidates are 64
@@ -1068,6 +1067,299 @@ __global__ void __launch_bounds__(kWave) finalize_lanes_kernel(const FinalizeArg
   rec[3] = 1.0f;
 }
 
+// The batched solve's finalize, mode S, as launched from round 4 on: SIXTEEN LANES PER PROBLEM, four problems per
+// wavefront.  A lane per problem (finalize_lanes_kernel above) still walks step_spatial()'s ~45 instructions per step on a
+// lone wave and sends every load and store of a wave to 64 different cache lines: 20 us behind the headline's 1.0 ms.
+// finalize_problem()'s decomposition does better and is taken over here on a quarter of a wave per problem:
+//   A  lane l of the problem's sixteen prepares steps l, l + 16, ...: the winner's controls (re-drawn - the four Philox
+//      blocks of its normals drawn by four of the lanes and shared through LDS - or loaded), the table row, everything of
+//      the step that does not depend on the state; the record's u block
+//   B  the 9-operation state recurrence, the only sequential part, on operands read from LDS eight steps ahead
+//   C  lane l again: stage cost and the two state-dependent bound terms of its steps from the states B left in LDS
+//   D  J and V accumulated in step order: the additions of step_spatial(), in its order - the same bits
+// and the four record images, contiguous in LDS as the four records are in memory, leave in 16-byte stores.
+constexpr int kGroupLanes = 16;
+constexpr int kGroupProblems = kWave / kGroupLanes;
+constexpr int kGroupRow = 8;     // floats per step in each of the two LDS tables
+constexpr int kGroupAhead = 8;   // steps whose LDS operands are requested together in B and D (the kernel of its own)
+constexpr int kGroupPass = 4;    // steps per lane whose memory operands are requested together in A (the kernel of its own)
+
+inline size_t group_finalize_floats(int n) {
+  const size_t records = (static_cast<size_t>(kGroupProblems) * (4 + 2 * n + 3 * (n + 1)) + 3) & ~static_cast<size_t>(3);
+  return records + kGroupProblems * (16 + 2 * static_cast<size_t>(n) * kGroupRow);
+}
+
+// One wavefront's four problems: threadIdx.x < 64 are its lanes, `group` its place in the batch.  kPass / kAhead: how far
+// ahead operands are requested (registers: 116 with 4 / 8, under 64 with 1 / 4 - what a launch shared with the rollout,
+// rollout_chained_kernel, can afford).
+template <int LAYOUT, int kPass, int kAhead>
+__device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int group, float* s_group) {
+  const int lane = static_cast<int>(threadIdx.x);
+  const int q = lane / kGroupLanes, sub = lane % kGroupLanes;
+  const int n = a.n;
+  const int rec_floats = 4 + 2 * n + 3 * (n + 1);
+  const int p_first = group * kGroupProblems;
+  const int p = p_first + q;
+  const bool live = p < a.P;
+  const int pl = live ? p : a.P - 1;   // a quarter without a problem repeats the last one's work and writes nothing
+  const float* __restrict__ x0 = a.x0 + pl * 3;
+  float ey = 0.0f, ep = 0.0f, t = 0.0f;
+  float rows_ahead[kPass][9] = {};
+  if (a.records != nullptr) {   // what does not depend on who won travels with the partial keys
+    ey = x0[0], ep = x0[1], t = x0[2];
+    const float* __restrict__ coef_ahead = a.coef + static_cast<size_t>(pl) * n * kCoefS;
+#pragma unroll
+    for (int j = 0; j < kPass; ++j) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) rows_ahead[j][e] = coef_ahead[min(j * kGroupLanes + sub, n - 1) * kCoefS + e];
+    }
+  }
+
+  int nfeas = 0;
+  int64_t key = kKeyMax;
+  for (int b = sub; b < a.blocks_per_problem; b += kGroupLanes) {
+    const size_t slot = static_cast<size_t>(pl) * a.blocks_per_problem + b;
+    nfeas += a.partial_feas[slot];
+    const int64_t kb = a.partial_keys[slot];
+    key = (kb < key) ? kb : key;
+  }
+#pragma unroll
+  for (int m = kGroupLanes / 2; m >= 1; m >>= 1) {
+    nfeas += __shfl_xor(nfeas, m, kGroupLanes);
+    const int64_t other = static_cast<int64_t>(__shfl_xor(static_cast<long long>(key), m, kGroupLanes));
+    key = (other < key) ? other : key;
+  }
+  if (a.keys_in != nullptr) key = a.keys_in[pl];
+  if (a.keys_out != nullptr && live && sub == 0) a.keys_out[p] = key;
+  if (a.records == nullptr) return;
+
+  float* s_rec = s_group + q * rec_floats;
+  float* s_tables = s_group + ((kGroupProblems * rec_floats + 3) & ~3);
+  float* s_z = s_tables + q * 16;
+  float* s_rows = s_tables + kGroupProblems * 16 + q * n * kGroupRow;                      // ds a21 a31 f3 | ds dk, b31 dv, lo, hi
+  float* s_terms = s_tables + kGroupProblems * 16 + (kGroupProblems + q) * n * kGroupRow;   // stage (r), hu0, hu1, hc | ht
+  float* su = s_rec + 4;
+  float* sx = s_rec + 4 + 2 * n;
+  const int64_t local = static_cast<int64_t>(static_cast<uint32_t>(key & 0xffffffffLL)) - a.index_offset;
+  const bool owner = a.regenerate || (local >= 0 && local < a.N);
+  const int c = owner ? static_cast<int>(local) : 0;
+  const uint32_t gidx = static_cast<uint32_t>(key & 0xffffffffLL);
+  const Weights w = a.w;
+  const float* __restrict__ coef = a.coef + static_cast<size_t>(pl) * n * kCoefS;
+  float amp = 0.0f;
+  const float* centre = nullptr;
+  if (a.regenerate) {
+    if (sub < kKnots / 2) {
+      float four[4];
+      draw_normal_block(a.spec, gidx, static_cast<uint32_t>(pl), static_cast<uint32_t>(sub), four);
+      *reinterpret_cast<f32x4*>(s_z + 4 * sub) = f32x4{four[0], four[1], four[2], four[3]};
+    }
+    const float* alt = (gidx == 1u) ? a.u_ref : (gidx == 2u) ? a.u_extra : nullptr;
+    const bool use_ref = alt != nullptr;
+    amp = use_ref ? 0.0f : candidate_amplitude(gidx);
+    centre = use_ref ? alt + static_cast<size_t>(pl) * n * 2 : a.centre + static_cast<size_t>(pl) * a.centre_stride;
+  }
+  __syncthreads();
+
+  // A: everything of a step that does not depend on the state, four steps per lane and pass; a pass's operands are all
+  // requested before the first is used (the first pass's table rows before the keys: rows_ahead above)
+  for (int base = 0; base < n; base += kPass * kGroupLanes) {
+    float rows[kPass][9], v[kPass], k[kPass], seg[kPass][2], cen[kPass][2];
+#pragma unroll
+    for (int j = 0; j < kPass; ++j) {
+      const int i = min(base + j * kGroupLanes + sub, n - 1);
+      if (a.regenerate) {
+        seg[j][0] = a.spec.segments[2 * i];
+        seg[j][1] = a.spec.segments[2 * i + 1];
+        cen[j][0] = centre[2 * i];
+        cen[j][1] = centre[2 * i + 1];
+      } else {
+        float vv[1], kk[1];
+        load_controls<LAYOUT, 1>(a.U, pl, a.N, n, i, c, vv, kk);
+        v[j] = vv[0];
+        k[j] = kk[0];
+      }
+#pragma unroll
+      for (int e = 0; e < 9; ++e) rows[j][e] = (base == 0) ? rows_ahead[j][e] : coef[i * kCoefS + e];
+    }
+#pragma unroll
+    for (int j = 0; j < kPass; ++j) {
+      const int i = base + j * kGroupLanes + sub;
+      if (i < n) {
+        if (a.regenerate) {   // regenerate_control()'s operands, the bracketing knots read from LDS
+          const int k0 = static_cast<int>(seg[j][0]);
+          const int knot = (k0 >= 1 && k0 <= kKnots - 2) ? k0 : 0;
+          const float* z = s_z + 2 * knot;
+          blend_control(a.spec, amp, seg[j][1], cen[j][0], cen[j][1], z[0], z[1], z[2], z[3], v[j], k[j]);
+        }
+        const float* row = rows[j];
+        const float dv = v[j] - row[5];
+        const float dk = k[j] - row[6];
+        const float term_ep = row[0] * dk;
+        const float term_t = row[3] * dv;
+        float r = quad(w.r0, dv);
+        r = r + quad(w.r1, dk);
+        const float hu0 = hinge2(w.ulo0 - v[j], v[j] - w.uhi0);
+        const float hu1 = hinge2(w.ulo1 - k[j], k[j] - w.uhi1);
+        *reinterpret_cast<f32x4*>(s_rows + i * kGroupRow) = f32x4{row[0], row[1], row[2], row[4]};
+        *reinterpret_cast<f32x4*>(s_rows + i * kGroupRow + 4) = f32x4{term_ep, term_t, row[7], row[8]};
+        *reinterpret_cast<f32x4*>(s_terms + i * kGroupRow) = f32x4{r, hu0, hu1, 0.0f};
+        su[2 * i] = v[j];
+        su[2 * i + 1] = k[j];
+      }
+    }
+  }
+  __syncthreads();
+
+  // B: the recurrence (every lane of the quarter runs it on the same LDS words; lane 0 of the quarter leaves the states)
+  for (int base = 0; base < n; base += kAhead) {
+    f32x4 lo[kAhead];
+    float te[kAhead], tt[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      const int i = min(base + j, n - 1);
+      lo[j] = *reinterpret_cast<const f32x4*>(s_rows + i * kGroupRow);
+      te[j] = s_rows[i * kGroupRow + 4];
+      tt[j] = s_rows[i * kGroupRow + 5];
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      const int i = base + j;
+      if (i < n) {
+        if (sub == 0) {
+          sx[3 * i] = ey;
+          sx[3 * i + 1] = ep;
+          sx[3 * i + 2] = t;
+        }
+        const float ey_n = ey + lo[j][0] * ep;
+        const float ep_n = (ep + lo[j][1] * ey) + te[j];
+        const float t_n = ((t + lo[j][2] * ey) + tt[j]) + lo[j][3];
+        ey = ey_n;
+        ep = ep_n;
+        t = t_n;
+      }
+    }
+  }
+  if (sub == 0) {
+    sx[3 * n] = ey;
+    sx[3 * n + 1] = ep;
+    sx[3 * n + 2] = t;
+  }
+  __syncthreads();
+
+  // C: what hangs off a state
+  for (int base = 0; base < n; base += kGroupLanes) {
+    const int i = base + sub;
+    if (i < n) {
+      const float my_ey = sx[3 * i], my_ep = sx[3 * i + 1], my_t = sx[3 * i + 2];
+      const float nx_ey = sx[3 * i + 3], nx_t = sx[3 * i + 5];
+      float s = quad(w.q0, my_ey);
+      s = s + quad(w.q1, my_ep);
+      s = s + quad(w.q2, my_t);
+      const float stage = 0.5f * (s + s_terms[i * kGroupRow]);
+      const float hc = hinge2(s_rows[i * kGroupRow + 6] - nx_ey, nx_ey - s_rows[i * kGroupRow + 7]);
+      const float tv = fmaxf(w.tmin - nx_t, 0.0f);
+      s_terms[i * kGroupRow] = stage;
+      s_terms[i * kGroupRow + 3] = hc;
+      s_terms[i * kGroupRow + 4] = tv * tv;
+    }
+  }
+  __syncthreads();
+
+  // D: step_spatial()'s additions in its order
+  float J = 0.0f, V = 0.0f;
+  for (int base = 0; base < n; base += kAhead) {
+    f32x4 first[kAhead];
+    float ht[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      const int i = min(base + j, n - 1);
+      first[j] = *reinterpret_cast<const f32x4*>(s_terms + i * kGroupRow);
+      ht[j] = s_terms[i * kGroupRow + 4];
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      if (base + j < n) {
+        J = J + first[j][0];
+        V = V + first[j][1];
+        V = V + first[j][2];
+        V = V + first[j][3];
+        V = V + ht[j];
+      }
+    }
+  }
+  __syncthreads();   // (the terms are read: a problem whose winner lives on another rank may now blank its image)
+  if (owner) {
+    if (sub == 0) {
+      const StateS st{ey, ep, t, J, V};
+      s_rec[0] = finish_spatial(st, w);
+      s_rec[1] = V;
+      s_rec[2] = static_cast<float>(nfeas);
+      s_rec[3] = 1.0f;
+    }
+  } else {
+    for (int e = sub; e < rec_floats; e += kGroupLanes) s_rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
+  }
+  __syncthreads();
+  const int count = min(kGroupProblems, a.P - p_first) * rec_floats;
+  float* __restrict__ out = a.records + static_cast<size_t>(p_first) * rec_floats;
+  const int whole = ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? (count & ~3) : 0;
+  for (int e = 4 * lane; e < whole; e += 4 * kWave) *reinterpret_cast<f32x4*>(out + e) = *reinterpret_cast<const f32x4*>(s_group + e);
+  for (int e = whole + lane; e < count; e += kWave) out[e] = s_group[e];
+}
+
+template <int LAYOUT>
+__global__ void __launch_bounds__(kWave) finalize_groups_kernel(const FinalizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_group[];
+  finalize_group<LAYOUT, kGroupPass, kGroupAhead>(a, static_cast<int>(blockIdx.x), s_group);
+}
+
+// A STREAM of batches (acmpc_solve_stream_device): batch k's rollout and batch k - 1's finalize in ONE launch.  Behind
+// the headline's rollout the finalize of its 4 096 problems is 13 us of lone waves plus a launch boundary - 1.8 % of the
+// step - and no form of it is fast enough to vanish (a lone wave issues an instruction every 4.2 cycles: finalize_group's
+// ~2 400 are 5 us before the first cache miss).  So it runs where nobody waits for it: 1 in every `period` rows of the
+// next rollout's grid is a row of finalize workgroups (four problems each on their first wave, the other waves retire at
+// once), spread over the launch so that they never hold more than a few of a CU's wave slots, each a lone wave among
+// thirty-one that stream.  Row y is a finalize row when y % period == period - 1 and y / period < fin_rows; the rollout's
+// problem of any other row is y less the finalize rows before it.  The two batches' partial keys live in different
+// halves of the handle's buffer.
+#ifndef ACMPC_CHAINED_PASS
+#define ACMPC_CHAINED_PASS 1    // (A/B builds) finalize_group's look-ahead inside the shared launch
+#endif
+#ifndef ACMPC_CHAINED_AHEAD
+#define ACMPC_CHAINED_AHEAD 4
+#endif
+template <int LAYOUT, int CPT, int BLOCK, int PACK>
+__global__ void __launch_bounds__(BLOCK, 8) rollout_chained_kernel(const RolloutArgs a, const FinalizeArgs f, const int fin_rows,
+                                                                   const int period) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int y = static_cast<int>(blockIdx.y);
+#ifdef ACMPC_CHAINED_INTERLEAVED
+  const int turn = y / period;
+  const bool finalize_row = y % period == period - 1 && turn < fin_rows;
+  const int p_rollout = y - min(fin_rows, turn);
+#else
+  const int turn = y - a.P;
+  const bool finalize_row = turn >= 0;
+  const int p_rollout = y;
+  (void)period;
+#endif
+  if (finalize_row) {
+#ifdef ACMPC_CHAINED_DEBUG_SKIP   // (timing experiment: what the finalize rows cost the launch - wrong records)
+    return;
+#endif
+    if (threadIdx.x >= kWave) return;
+    const int group = turn * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
+    if (group * kGroupProblems >= f.P) return;
+#ifndef ACMPC_CHAINED_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);   // a lone wave among seven that stream: it goes first whenever it has an instruction
+#endif
+    finalize_group<1, ACMPC_CHAINED_PASS, ACMPC_CHAINED_AHEAD>(f, group, reinterpret_cast<float*>(smem));
+    return;
+  }
+  rollout_block<0, LAYOUT, CPT, BLOCK, PACK, false>(a, smem, p_rollout);
+}
+
 // Record of problem p out of the winning workgroup's trace (see rollout_sampled_body): argmin over the partial keys,
 // then a copy - no arithmetic, so the record holds exactly the bits the winning lane computed, which are the bits a
 // re-roll of that candidate computes.  One wave.
@@ -1193,7 +1485,7 @@ __device__ __forceinline__ bool last_workgroup_of_problem(int* tickets, const in
 template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK>
 __global__ void __launch_bounds__(BLOCK, ACMPC_TAILED_WAVES) rollout_tailed_kernel(const RolloutArgs a, const FinalizeArgs f, int* tickets) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  rollout_block<MODE, LAYOUT, CPT, BLOCK, PACK, true>(a, smem);
+  rollout_block<MODE, LAYOUT, CPT, BLOCK, PACK, true>(a, smem, static_cast<int>(blockIdx.y));
   if (threadIdx.x >= kWave) return;   // the tail is the first wave's (the one that published the workgroup's partials)
   const int p = blockIdx.y;
   if (!last_workgroup_of_problem(tickets + static_cast<size_t>(p) * (kTicketGroups + 1) * kTicketStride, kTicketGroups)) return;
@@ -2694,11 +2986,60 @@ hipError_t launch_rollout_tailed(int layout, const LaunchShape& shape, const Rol
   return go(rollout_tailed_kernel<0, 1, 4, 256, 2>);
 }
 
+// rollout of one batch + finalize of the batch before it in one launch (rollout_chained_kernel): mode S, step-major
+// rollout on the 256-thread shapes; a pending finalize of the many-problem kind whose winners are re-drawn or read from a
+// step-major matrix, and whose LDS image leaves the rollout its eight workgroups per CU
+bool chained_rollout_fits(int mode, int layout, const LaunchShape& shape, int P, const FinalizeArgs& fin, int fin_layout) {
+  const int fin_groups = (fin.P + kGroupProblems - 1) / kGroupProblems;
+  const int rows = (fin_groups + std::max(shape.blocks_per_problem, 1) - 1) / std::max(shape.blocks_per_problem, 1);
+  return rows <= P && static_cast<long long>(P) + rows <= 65535 && mode == 0 && layout == 1 && !shape.tile && shape.block == 256 && (shape.cpt == 1 || shape.cpt == 2 || shape.cpt == 4) &&
+         !fin.controls_only && fin.records != nullptr && fin.keys_in == nullptr && fin.P >= 1 && (fin.regenerate || fin_layout == 1) &&
+         group_finalize_floats(fin.n) * sizeof(float) <= 20 * 1024;
+}
+
+hipError_t launch_rollout_chained(int layout, const LaunchShape& shape, const RolloutArgs& args, const FinalizeArgs& fin,
+                                  int fin_layout, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  clear_stale_error();
+  if (!chained_rollout_fits(0, layout, shape, args.P, fin, fin_layout)) return hipErrorInvalidValue;
+  const int groups = (fin.P + kGroupProblems - 1) / kGroupProblems;
+  const int fin_rows = (groups + shape.blocks_per_problem - 1) / shape.blocks_per_problem;
+  const int period = args.P / fin_rows + 1;   // fin_rows * period <= P + fin_rows: every finalize row lies inside the grid
+  const dim3 grid(shape.blocks_per_problem, args.P + fin_rows);
+#ifdef ACMPC_CHAINED_DEBUG_SMALL_LDS
+  const size_t lds = 64;
+#else
+  const size_t lds = std::max<size_t>(64, group_finalize_floats(fin.n) * sizeof(float));
+#endif
+  auto go = [&](auto kernel) -> hipError_t {
+    if (e0 != nullptr && e1 != nullptr) {
+      hipExtLaunchKernelGGL(kernel, grid, dim3(256), static_cast<std::uint32_t>(lds), s, e0, e1, 0, args, fin, fin_rows, period);
+    } else {
+      hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, args, fin, fin_rows, period);
+    }
+    return hipGetLastError();
+  };
+  if (shape.cpt == 1) return go(rollout_chained_kernel<1, 1, 256, 1>);
+  if (shape.cpt == 2) return go(rollout_chained_kernel<1, 2, 256, 2>);
+  return go(rollout_chained_kernel<1, 4, 256, 2>);
+}
+
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s, const LaunchOptions& opt) {
   clear_stale_error();
+  if (mode == 0 && !args.controls_only && args.P >= kLaneFinalizeProblems && !opt.no_group_finalize &&
+      (layout == 0 || layout == 1) && group_finalize_floats(args.n) * sizeof(float) <= 64 * 1024) {
+    // many problems: sixteen lanes per problem, four problems per wavefront (finalize_groups_kernel)
+    const dim3 groups_grid((args.P + kGroupProblems - 1) / kGroupProblems);
+    const size_t groups_lds = group_finalize_floats(args.n) * sizeof(float);
+    if (layout == 0) {
+      hipLaunchKernelGGL((finalize_groups_kernel<0>), groups_grid, dim3(kWave), groups_lds, s, args);
+    } else {
+      hipLaunchKernelGGL((finalize_groups_kernel<1>), groups_grid, dim3(kWave), groups_lds, s, args);
+    }
+    return hipGetLastError();
+  }
   if (mode == 0 && !args.controls_only && args.P >= kLaneFinalizeProblems && !opt.no_lane_finalize &&
       (layout == 0 || layout == 1)) {
-    // many problems: one lane per problem (finalize_lanes_kernel)
+    // (A/B: ACMPC_NO_GROUP_FINALIZE) one lane per problem (finalize_lanes_kernel)
     const dim3 lanes_grid((args.P + kWave - 1) / kWave);
     if (layout == 0) {
       hipLaunchKernelGGL((finalize_lanes_kernel<0>), lanes_grid, dim3(kWave), 0, s, args);

@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap argmin/record of batch i (side stream) with the rollout of batch i+1; measured "
                          "slower than plain stream order on MI355X (cross-queue dependencies cost ~10 us each)")
+    ap.add_argument("--no-stream", action="store_true",
+                    help="(one rank) argmin and records of every batch as a launch of their own behind its rollout, instead of "
+                         "inside the next batch's rollout launch")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the multi-rank path with the "
                          "collective payloads staged through the CPU (ranks may then share one GPU)")
@@ -831,19 +834,30 @@ def main():
                 if args.layout == 1:
                     self.slot.use_sampler(u_ref, u_ref, SAMPLE_SIGMA, seeds[0], 0)
 
+                # one rank, nothing to exchange between rollout and argmin: the batches are a STREAM (batch i's argmin and
+                # records inside batch i + 1's rollout launch, the last one's behind drain() - acmpc_solve_stream_device);
+                # all of it inside the timed region
+                self.streamed = not (self.slot.distributed or self.slot.offset != 0 or args.no_stream or
+                                     args.scaling == "strong")
+
             def step(self, x0_, U_, seed=None):
-                # one rank: one call (rollout, argmin and the winners' records in one launch); N ranks: rollout, the
-                # all-reduce(MIN) of the keys, the records
-                self.slot.step(x0_, U_, stream, seed=seed)
+                # N ranks: rollout, the all-reduce(MIN) of the keys, the records
+                if self.streamed:
+                    self.slot.step_stream(x0_, U_, stream, seed=seed)
+                else:
+                    self.slot.step(x0_, U_, stream, seed=seed)
                 return self.slot
 
             def drain(self):
-                pass
+                if self.streamed:
+                    self.slot.flush(stream)
 
         pipe = _Serial()
     else:
         pipe = PipelinedRollout(engines, P, N, n, args.layout, index_offset=rank * N, device=device)
         pipe.bind_stream(torch.cuda.current_stream())
+
+    streamed = bool(getattr(pipe, "streamed", False))
 
     def barrier():
         if world > 1:
@@ -953,16 +967,19 @@ def main():
                 "candidates_per_solve_per_gpu": N, "solves_per_step": P, "horizon": H, "mode": args.mode,
                 "layout": "U[P][n][2][N]" if args.layout == 1 else "U[P][N][n][2]",
                 "parallelism": "candidate-sharded x%d, one all-reduce(MIN) of %d packed keys per step" % (world, P),
-                "pipeline": "argmin/record of batch i overlaps rollout of batch i+1" if args.pipeline else "none (stream order)",
+                "pipeline": ("argmin/record of batch i overlaps rollout of batch i+1" if args.pipeline else
+                             "argmin/record of batch i inside the rollout launch of batch i+1, the last batch's behind it "
+                             "(acmpc_solve_stream_device)" if streamed else "none (stream order)"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "bound": "hbm", "kernel": "rollout_chained_kernel" if streamed else "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms,
             },
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
         }
-        traffic = latest_traffic(algorithmic_bytes, "rollout_kernel<%d, %d" % (mode, args.layout))
+        traffic = latest_traffic(algorithmic_bytes, "rollout_chained_kernel<%d" % args.layout if streamed else
+                                 "rollout_kernel<%d, %d" % (mode, args.layout))
         if traffic is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic
         # (PMC counters need rocprofv3 round the process: the bytes come from the committed profile of this same command)

@@ -240,6 +240,25 @@ int acmpc_solve_sampled_device(acmpc_ctx* ctx, const float* d_x0, const float* d
                                double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round, float* d_costs,
                                int64_t* d_keys, float* d_records, void* stream);
 
+/* A STREAM of batches on one rank: acmpc_solve_device (d_centre NULL: the winners are read from d_U) or
+ * acmpc_solve_sampled_device (d_centre given: re-drawn) with the argmin and the winners' records of one call DEFERRED -
+ * they are computed inside the NEXT call's rollout launch (csrc/acmpc_kernels.hip rollout_chained_kernel: one row in
+ * every few of the grid finalizes four problems of the previous batch per workgroup while the other rows stream), or by
+ * acmpc_solve_stream_flush behind the last one.  Behind the headline's rollout the finalize of 4 096 problems is a launch
+ * of its own - 13 us and a launch boundary per 1.0 ms step; inside the next rollout nobody waits for it.
+ *   d_keys / d_records of call k are complete once call k + 1 on the same stream, or the flush, has completed;
+ *   until then the caller leaves call k's d_x0, d_centre / d_u_ref - and d_U when d_centre is NULL - as they were;
+ *   d_costs of call k are complete with call k itself.
+ * The same bits as acmpc_solve_device / acmpc_solve_sampled_device (tests/test_gpu_tailed_rollout.py).  Shapes the one
+ * launch does not take (mode T, the candidate-major layout, horizons whose finalize would cost the rollout its
+ * occupancy) run the pending finalize as a launch of its own in front of the rollout.  While a batch is pending every
+ * other solve on the handle returns ACMPC_ESTATE; new tables (acmpc_set_paths) are uploaded behind the pending finalize. */
+int acmpc_solve_stream_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, const float* d_centre,
+                              int32_t centre_stride, const float* d_u_ref, int32_t P, int32_t N, int32_t n, int32_t layout,
+                              double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round, float* d_costs,
+                              int64_t* d_keys, float* d_records, void* stream);
+int acmpc_solve_stream_flush(acmpc_ctx* ctx, void* stream);
+
 /* The one collective of the multi-GPU step, for hosts that drive RCCL themselves rather than through
  * torch.distributed: in-place all-reduce(MIN) of the P packed keys over `rccl_comm` (an `ncclComm_t` the host
  * created, one rank per GPU), enqueued on `stream`.  Call between acmpc_rollout_device and

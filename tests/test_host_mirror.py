@@ -357,8 +357,9 @@ def test_steer_target_against_the_reference_vector():
 
 
 def test_mode_t_search_window_default_by_horizon():
-    """`rollout_mode: "T"` without an `nn_window` key: the nearest of all waypoints (None) up to 100 steps, the (2,5) window
-    beyond; an explicit key - null included - is taken as given."""
+    """`rollout_mode: "T"` without an `nn_window` key: the nearest of all waypoints (None) up to 106 steps (what the three-wave
+    round's LDS holds of the verified search's frames), the (2,5) window beyond - said in the log; an explicit key - null
+    included - is taken as given."""
     from acmpc_amd.sampling_solver import ControlSolver
     from test_support import RACING, PlaceholderVehicle
     from acmpc_amd.bicycle_model import SpatialBicycleModel
@@ -369,6 +370,6 @@ def test_mode_t_search_window_default_by_horizon():
         model = SpatialBicycleModel(PlaceholderVehicle(), {"min": cons["v_min"], "max": cons["v_max"]})
         return ControlSolver(cfg, model)._nn_window
 
-    assert window(horizon=50) is None and window(horizon=101) is None
-    assert window(horizon=102) == (2, 5) and window(horizon=129) == (2, 5)
+    assert window(horizon=50) is None and window(horizon=107) is None
+    assert window(horizon=108) == (2, 5) and window(horizon=129) == (2, 5)
     assert window(horizon=129, nn_window=None) is None and window(horizon=50, nn_window=[1, 2]) == (1, 2)
