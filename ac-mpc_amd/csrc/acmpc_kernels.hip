@@ -1315,14 +1315,18 @@ __global__ void __launch_bounds__(kWave) finalize_groups_kernel(const FinalizeAr
 }
 
 // A STREAM of batches (acmpc_solve_stream_device): batch k's rollout and batch k - 1's finalize in ONE launch.  Behind
-// the headline's rollout the finalize of its 4 096 problems is 13 us of lone waves plus a launch boundary - 1.8 % of the
+// the headline's rollout the finalize of its 4 096 problems is 14.6 us of lone waves plus a launch boundary - 1.8 % of the
 // step - and no form of it is fast enough to vanish (a lone wave issues an instruction every 4.2 cycles: finalize_group's
-// ~2 400 are 5 us before the first cache miss).  So it runs where nobody waits for it: 1 in every `period` rows of the
-// next rollout's grid is a row of finalize workgroups (four problems each on their first wave, the other waves retire at
-// once), spread over the launch so that they never hold more than a few of a CU's wave slots, each a lone wave among
-// thirty-one that stream.  Row y is a finalize row when y % period == period - 1 and y / period < fin_rows; the rollout's
-// problem of any other row is y less the finalize rows before it.  The two batches' partial keys live in different
-// halves of the handle's buffer.
+// ~2 400 are 5 us before the first cache miss).  So it runs where nobody waits for it: the LAST rows of the next rollout's
+// grid are rows of finalize workgroups (four problems each on their first wave, the other waves retire at once).  Rows
+// are dispatched in order, so these start when the grid has no rollout workgroup left to hand out - in the wave slots the
+// rollout's tail leaves empty.  Measured on the headline's batch (tools/chained_ab.py, launches alternating with the plain
+// kernel in one process): +6 to +12 us on the kernel for 18.8 us of finalize and launch boundary removed.  The same rows
+// spread evenly through the grid (one in seventeen) cost +25 us: every finalize workgroup then displaces a rollout
+// workgroup for its ~40 us - six dependent trips to a saturated memory system - and 1 024 of them are 19 us of the 2 048
+// resident workgroups' time; raising the lone waves' priority (s_setprio) changes nothing, looking further ahead for
+// operands (more registers: spills under the rollout's 64) makes it worse.  The two batches' partial keys live in
+// different halves of the handle's buffer.
 #ifndef ACMPC_CHAINED_PASS
 #define ACMPC_CHAINED_PASS 1    // (A/B builds) finalize_group's look-ahead inside the shared launch
 #endif
@@ -1330,34 +1334,17 @@ __global__ void __launch_bounds__(kWave) finalize_groups_kernel(const FinalizeAr
 #define ACMPC_CHAINED_AHEAD 4
 #endif
 template <int LAYOUT, int CPT, int BLOCK, int PACK>
-__global__ void __launch_bounds__(BLOCK, 8) rollout_chained_kernel(const RolloutArgs a, const FinalizeArgs f, const int fin_rows,
-                                                                   const int period) {
+__global__ void __launch_bounds__(BLOCK, 8) rollout_chained_kernel(const RolloutArgs a, const FinalizeArgs f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int y = static_cast<int>(blockIdx.y);
-#ifdef ACMPC_CHAINED_INTERLEAVED
-  const int turn = y / period;
-  const bool finalize_row = y % period == period - 1 && turn < fin_rows;
-  const int p_rollout = y - min(fin_rows, turn);
-#else
-  const int turn = y - a.P;
-  const bool finalize_row = turn >= 0;
-  const int p_rollout = y;
-  (void)period;
-#endif
-  if (finalize_row) {
-#ifdef ACMPC_CHAINED_DEBUG_SKIP   // (timing experiment: what the finalize rows cost the launch - wrong records)
-    return;
-#endif
+  if (y >= a.P) {
     if (threadIdx.x >= kWave) return;
-    const int group = turn * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
+    const int group = (y - a.P) * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
     if (group * kGroupProblems >= f.P) return;
-#ifndef ACMPC_CHAINED_NO_PRIO
-    __builtin_amdgcn_s_setprio(3);   // a lone wave among seven that stream: it goes first whenever it has an instruction
-#endif
     finalize_group<1, ACMPC_CHAINED_PASS, ACMPC_CHAINED_AHEAD>(f, group, reinterpret_cast<float*>(smem));
     return;
   }
-  rollout_block<0, LAYOUT, CPT, BLOCK, PACK, false>(a, smem, p_rollout);
+  rollout_block<0, LAYOUT, CPT, BLOCK, PACK, false>(a, smem, y);
 }
 
 // Record of problem p out of the winning workgroup's trace (see rollout_sampled_body): argmin over the partial keys,
@@ -3003,18 +2990,13 @@ hipError_t launch_rollout_chained(int layout, const LaunchShape& shape, const Ro
   if (!chained_rollout_fits(0, layout, shape, args.P, fin, fin_layout)) return hipErrorInvalidValue;
   const int groups = (fin.P + kGroupProblems - 1) / kGroupProblems;
   const int fin_rows = (groups + shape.blocks_per_problem - 1) / shape.blocks_per_problem;
-  const int period = args.P / fin_rows + 1;   // fin_rows * period <= P + fin_rows: every finalize row lies inside the grid
   const dim3 grid(shape.blocks_per_problem, args.P + fin_rows);
-#ifdef ACMPC_CHAINED_DEBUG_SMALL_LDS
-  const size_t lds = 64;
-#else
   const size_t lds = std::max<size_t>(64, group_finalize_floats(fin.n) * sizeof(float));
-#endif
   auto go = [&](auto kernel) -> hipError_t {
     if (e0 != nullptr && e1 != nullptr) {
-      hipExtLaunchKernelGGL(kernel, grid, dim3(256), static_cast<std::uint32_t>(lds), s, e0, e1, 0, args, fin, fin_rows, period);
+      hipExtLaunchKernelGGL(kernel, grid, dim3(256), static_cast<std::uint32_t>(lds), s, e0, e1, 0, args, fin);
     } else {
-      hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, args, fin, fin_rows, period);
+      hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, args, fin);
     }
     return hipGetLastError();
   };
