@@ -251,3 +251,41 @@ def test_new_tables_in_the_middle_of_a_stream(monkeypatch):
         np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
     assert not np.array_equal(want[0].cpu().numpy(), want[1].cpu().numpy())
     eng.close()
+
+
+@pytest.mark.parametrize("switch", ["", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_NO_GROUP_FINALIZE ACMPC_NO_LANE_FINALIZE"])
+def test_records_from_reduced_keys_equal_the_one_call_solve(monkeypatch, switch):
+    """The multi-rank step's last call - acmpc_finalize_sampled_device on the keys an all-reduce(MIN) left - at the
+    headline's problem count per launch shape: the records of the one-call solve, from the keys alone."""
+    import torch
+    from acmpc_amd import Engine, _capi
+    for name in ("ACMPC_NO_LANE_FINALIZE", "ACMPC_NO_GROUP_FINALIZE"):
+        monkeypatch.delenv(name, raising=False)
+    for name in switch.split():
+        monkeypatch.setenv(name, "1")
+    P, N, H = 333, 2048, 50
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 4, seed=900 + p % 7) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
+    eng.set_paths(np.stack([p["table"] for p in problems]))
+    s = torch.cuda.current_stream().cuda_stream
+    x0 = torch.tensor(np.stack([p["x0"] for p in problems]), device=dev)
+    u_ref = torch.tensor(np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]),
+                         dtype=torch.float32, device=dev).contiguous()
+    centre = (u_ref + torch.tensor([-0.4, 0.001], device=dev)).contiguous()
+    sigma, seed, rnd = (2.0, 0.01), 99, 3
+    U = torch.empty(P, n, 2, N, device=dev)
+    eng.sample_device(centre.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, 1, 0, sigma, seed, rnd, U.data_ptr(), s)
+    keys = torch.empty(P, dtype=torch.int64, device=dev)
+    one = torch.zeros(P, _capi.record_floats(n), device=dev)
+    eng.solve_sampled_device(x0.data_ptr(), U.data_ptr(), centre.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, 1, sigma, seed, rnd, 0,
+                             keys.data_ptr(), one.data_ptr(), s)
+    again = torch.zeros_like(one)
+    eng.finalize_sampled_device(keys.data_ptr(), x0.data_ptr(), centre.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, sigma, seed, rnd,
+                                again.data_ptr(), s)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(again.cpu().numpy(), one.cpu().numpy())
+    index = keys.cpu().numpy() & 0xffffffff
+    assert (index == 1).sum() < P and len(np.unique(index)) > 10     # (not all the reference controls: real winners)
+    eng.close()
