@@ -1089,6 +1089,15 @@ inline size_t group_finalize_floats(int n) {
   return records + kGroupProblems * (16 + 2 * static_cast<size_t>(n) * kGroupRow);
 }
 
+// finalize_group runs on ONE wavefront: what its lanes hand each other through LDS needs no workgroup barrier (a wave's LDS
+// instructions execute in order), only the compiler kept from moving the accesses across the hand-off - so the function
+// is the same inside a 256-thread workgroup whose other waves have retired (rollout_chained_kernel)
+__device__ __forceinline__ void wave_lds_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // One wavefront's four problems: threadIdx.x < 64 are its lanes, `group` its place in the batch.  kPass / kAhead: how far
 // ahead operands are requested (registers: 116 with 4 / 8, under 64 with 1 / 4 - what a launch shared with the rollout,
 // rollout_chained_kernel, can afford).
@@ -1159,7 +1168,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
     amp = use_ref ? 0.0f : candidate_amplitude(gidx);
     centre = use_ref ? alt + static_cast<size_t>(pl) * n * 2 : a.centre + static_cast<size_t>(pl) * a.centre_stride;
   }
-  __syncthreads();
+  wave_lds_handoff();
 
   // A: everything of a step that does not depend on the state, four steps per lane and pass; a pass's operands are all
   // requested before the first is used (the first pass's table rows before the keys: rows_ahead above)
@@ -1209,7 +1218,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
       }
     }
   }
-  __syncthreads();
+  wave_lds_handoff();
 
   // B: the recurrence (every lane of the quarter runs it on the same LDS words; lane 0 of the quarter leaves the states)
   for (int base = 0; base < n; base += kAhead) {
@@ -1245,7 +1254,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
     sx[3 * n + 1] = ep;
     sx[3 * n + 2] = t;
   }
-  __syncthreads();
+  wave_lds_handoff();
 
   // C: what hangs off a state
   for (int base = 0; base < n; base += kGroupLanes) {
@@ -1264,7 +1273,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
       s_terms[i * kGroupRow + 4] = tv * tv;
     }
   }
-  __syncthreads();
+  wave_lds_handoff();
 
   // D: step_spatial()'s additions in its order
   float J = 0.0f, V = 0.0f;
@@ -1288,7 +1297,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
       }
     }
   }
-  __syncthreads();   // (the terms are read: a problem whose winner lives on another rank may now blank its image)
+  wave_lds_handoff();   // (the terms are read: a problem whose winner lives on another rank may now blank its image)
   if (owner) {
     if (sub == 0) {
       const StateS st{ey, ep, t, J, V};
@@ -1300,7 +1309,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
   } else {
     for (int e = sub; e < rec_floats; e += kGroupLanes) s_rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
   }
-  __syncthreads();
+  wave_lds_handoff();
   const int count = min(kGroupProblems, a.P - p_first) * rec_floats;
   float* __restrict__ out = a.records + static_cast<size_t>(p_first) * rec_floats;
   const int whole = ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? (count & ~3) : 0;

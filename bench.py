@@ -394,6 +394,7 @@ def counted_valu(profile, entry):
         except (OSError, ValueError, KeyError):
             continue
         if derived.get("valu_instructions_per_candidate_step"):
+            derived = dict(derived, source_sha256=json.load(open(path)).get("source_sha256"))
             found = (float(derived["valu_instructions_per_candidate_step"]), os.path.relpath(path, ROOT), derived)
     return found
 
@@ -467,6 +468,9 @@ def valu_roofline(counted, candidates, steps, kernel_s, mix_entry=None, cpt=2):
            "peak_is": "1 024 SIMDs / the mean issue time of the step loop's opcode mix at eight waves per SIMD "
                       "(per-opcode wall-clock issue times of tools/valu_probe.hip x the static mix of tools/isa_mix.py)",
            "instruction_count_source": source, "instruction_count_measured_in_this_run": False,
+           # (the counters' summary names the sources they were collected from; None: an older summary without the record)
+           "instruction_count_matches_loaded_sources": (derived.get("source_sha256") == loaded_source_hash()
+                                                        if derived.get("source_sha256") else None),
            "opcode_mix_source": mix_path, "issue_cost_source": probe_path,
            "opcode_mix_matches_loaded_sources": mix.get("source_sha256") == loaded_source_hash()}
     lds_cycles = sum(count * LDS_ARRAY_CYCLES.get(op, 4) for op, count in entry["lds"].items())

@@ -1,8 +1,10 @@
 #!/bin/bash
 # The round's committed evidence in one call on the GPU box (about nine minutes): tools/profile.sh (headline kernel: trace,
-# counters, un-profiled bench line), the all-kernels trace of a full bench run, the tick timelines, the mode T counters.
+# counters, un-profiled bench line), the all-kernels trace of a full bench run, the tick timelines, the mode T counters, the
+# fused sampled round's counters, the particle filter's kernel traces.
 # usage: tools/final_profiles.sh <tag>      then, here:  python3 tools/summarize_profile.py <tag>; python3
-# tools/summarize_sq_counters.py <tag>; python3 tools/summarize_tick_trace.py <tag> mode_S_h50=f_S50 ... (profiles/README.md)
+# tools/summarize_sq_counters.py <tag>; python3 tools/summarize_sq_counters.py <tag> sampled; python3 tools/summarize_pf_profile.py
+# <tag>; python3 tools/summarize_tick_trace.py <tag> mode_S_h50=f_S50 ... (profiles/README.md)
 set -u
 TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -20,3 +22,8 @@ echo "tick traces done"
 rm -rf $ROOT/gpurun_out/pmc_${TAG}_T_*
 $ROOT/tools/pmc_modeT.sh $TAG > $ROOT/gpurun_out/pmc_modeT_run.log 2>&1
 tail -3 $ROOT/gpurun_out/pmc_modeT_run.log
+rm -rf $ROOT/gpurun_out/pmc_${TAG}_sampled_*
+$ROOT/tools/pmc_sampled.sh $TAG > $ROOT/gpurun_out/pmc_sampled_run.log 2>&1
+tail -1 $ROOT/gpurun_out/pmc_sampled_run.log
+$ROOT/tools/profile_pf.sh $TAG > $ROOT/gpurun_out/profile_pf_run.log 2>&1
+echo "particle filter traces done"

@@ -4,6 +4,8 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
+# (which sources these counters were collected from: bench.py compares it with the library it runs)
+python3 -c "import sys; sys.path[:0] = ['$ROOT', '$ROOT/ac-mpc_amd']; import bench; print(bench.loaded_source_hash())" > $ROOT/gpurun_out/pmc_${TAG}_T_source_sha256.txt 2>/dev/null
 for W in "2,5" "1,2" ""; do
   name=${W/,/_}; name=${name:-exhaustive}
   spec="T,1,256,4096,50${W:+,$W}"

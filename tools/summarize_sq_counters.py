@@ -35,6 +35,16 @@ def counters(directory, kernel="::rollout_kernel<1"):
     return means, launches, (sum(micros) / len(micros) if micros else None)
 
 
+def collected_from(tag, kind):
+    """sha256 of the sources the counters were collected from (written on the GPU box by tools/pmc_*.sh), or None."""
+    path = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{kind}_source_sha256.txt")
+    try:
+        value = open(path).read().strip()
+    except OSError:
+        return None
+    return value if re.fullmatch(r"[0-9a-f]{64}", value) else None
+
+
 def unprofiled(tag):
     out = {}
     path = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_T_unprofiled.log")
@@ -83,6 +93,7 @@ def sampled(tag, problems=1024, candidates=16384):
         "command": "tools/pmc_sampled.sh " + tag + ": two rocprofv3 --pmc passes with --kernel-trace round tools/run_sampled_fused.py, "
                    "then the same un-profiled",
         "fused_round": {"counters_mean_per_launch": merged, "derived": derived},
+        "source_sha256": collected_from(tag, "sampled"),
     }
     path = os.path.join(ROOT, "profiles", f"{tag}_sampled_sq_counters.json")
     with open(path, "w") as handle:
@@ -133,6 +144,7 @@ def main():
             "kernel_us_unprofiled_same_box": plain.get(spec),
         }
         result[name] = {"counters_mean_per_launch": merged, "derived": derived}
+    result["source_sha256"] = collected_from(tag, "T")
     result["note"] = ("valu_issue_cycles_per_simd_at_4_per_instruction (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs, against "
                       "GRBM_GUI_ACTIVE / 8 XCDs - the counter is summed over the dies) is the uniform four-cycle estimate of "
                       "rounds 2-3 and can exceed the active cycles: not every vector instruction takes four.  bench.py's "
