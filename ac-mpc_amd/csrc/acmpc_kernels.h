@@ -91,8 +91,7 @@ struct LaunchOptions {
   int tile_table = 0;                   // ACMPC_TILE_TABLE: 1 = lds, 2 = scalar (0: by shape)
   bool no_trio_rounds = false, no_quad_rounds = false, no_pair_rounds = false;
   int solo_registers = -1, solo_split = -1;   // ACMPC_SOLO_REGISTERS / ACMPC_SOLO_SPLIT: 0 / 1 (-1: by size / split)
-  bool no_lane_finalize = false;              // ACMPC_NO_LANE_FINALIZE: a wavefront per problem at any problem count
-  bool no_group_finalize = false;             // ACMPC_NO_GROUP_FINALIZE: the batched finalize before its sixteen-lanes-per-problem form
+  bool no_group_finalize = false;             // ACMPC_NO_GROUP_FINALIZE: a wavefront per problem in the batched finalize at any problem count
 };
 
 struct LaunchShape {

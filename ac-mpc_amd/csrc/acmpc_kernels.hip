@@ -954,130 +954,23 @@ __global__ void __launch_bounds__(kWave) finalize_kernel(const FinalizeArgs a) {
   finalize_problem<MODE, LAYOUT>(a, blockIdx.x, s_finalize);
 }
 
-// The batched solve's finalize, mode S: ONE LANE PER PROBLEM (round 4).  finalize_kernel gives every problem a wavefront,
-// which re-rolls its winner in lock-step on broadcast inputs - a fine use of a wave when there is one problem, and 4 096
-// lone-wave walks when there are 4 096: 29 us behind the headline's 1.09 ms rollout, as much vector-pipe time as 3 % of it.
-// Here a lane takes the argmin over its problem's partial keys (a handful per problem), fetches - or re-draws - the
-// winner's controls and its problem's table rows a chunk of steps ahead, and walks its winner with step_spatial(): the same
-// operations in the same order, so the same record bit for bit, with 1/64 of the instructions.  Records are written a
-// float at a time from 64 lanes into 64 records (1 kB apart): a megabyte of partial lines per 4 096 problems, which the
-// L2 merges.  For launches of at least kLaneFinalizeProblems problems; fewer leave the CUs idle either way and keep the
-// wave-per-problem form, whose latency is the shorter.
-constexpr int kLaneFinalizeProblems = 256;
-constexpr int kLaneChunk = 7;   // steps whose operands are requested together
+constexpr int kGroupFinalizeProblems = 256;   // from this many problems the batched finalize runs sixteen lanes per problem
 
-template <int LAYOUT>
-__global__ void __launch_bounds__(kWave) finalize_lanes_kernel(const FinalizeArgs a) {
-  const int p = static_cast<int>(blockIdx.x) * kWave + static_cast<int>(threadIdx.x);
-  if (p >= a.P) return;
-  const int n = a.n;
-  int nfeas = 0;
-  int64_t key = kKeyMax;
-  for (int b = 0; b < a.blocks_per_problem; ++b) {
-    const size_t slot = static_cast<size_t>(p) * a.blocks_per_problem + b;
-    nfeas += a.partial_feas[slot];
-    const int64_t kb = a.partial_keys[slot];
-    key = (kb < key) ? kb : key;
-  }
-  if (a.keys_in != nullptr) key = a.keys_in[p];
-  if (a.keys_out != nullptr) a.keys_out[p] = key;
-  if (a.records == nullptr) return;
-  const int rec_floats = 4 + 2 * n + 3 * (n + 1);
-  float* __restrict__ rec = a.records + static_cast<size_t>(p) * rec_floats;
-  const int64_t local = static_cast<int64_t>(static_cast<uint32_t>(key & 0xffffffffLL)) - a.index_offset;
-  const bool owner = a.regenerate || (local >= 0 && local < a.N);
-  if (!owner) {
-    for (int e = 0; e < rec_floats; ++e) rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
-    return;
-  }
-  const Weights w = a.w;
-  const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kCoefS;
-  const float* __restrict__ x0 = a.x0 + p * 3;
-  const int c = static_cast<int>(local);
-  const uint32_t gidx = static_cast<uint32_t>(key & 0xffffffffLL);
-  float z[kKnots][2] = {};
-  float amp = 0.0f;
-  const float* centre = nullptr;
-  if (a.regenerate) {
-    draw_normals(a.spec, gidx, static_cast<uint32_t>(p), z);
-    const float* alt = (gidx == 1u) ? a.u_ref : (gidx == 2u) ? a.u_extra : nullptr;
-    const bool use_ref = alt != nullptr;
-    amp = use_ref ? 0.0f : candidate_amplitude(gidx);
-    centre = use_ref ? alt + static_cast<size_t>(p) * n * 2 : a.centre + static_cast<size_t>(p) * a.centre_stride;
-  }
-  float* __restrict__ ru = rec + 4;
-  float* __restrict__ rx = rec + 4 + 2 * n;
-  StateS st{x0[0], x0[1], x0[2], 0.0f, 0.0f};
-  for (int base = 0; base < n; base += kLaneChunk) {
-    // the chunk's operands first (none depends on the walk), then its steps
-    f32x4 lo[kLaneChunk], hi[kLaneChunk];
-    float last[kLaneChunk], v[kLaneChunk], k[kLaneChunk], cen[kLaneChunk][2], seg[kLaneChunk][2];
-#pragma unroll
-    for (int q = 0; q < kLaneChunk; ++q) {
-      const int i = min(base + q, n - 1);
-      const float* row = coef + i * kCoefS;
-      lo[q] = *reinterpret_cast<const f32x4*>(row);
-      hi[q] = *reinterpret_cast<const f32x4*>(row + 4);
-      last[q] = row[8];
-      if (a.regenerate) {
-        cen[q][0] = centre[2 * i];
-        cen[q][1] = centre[2 * i + 1];
-        seg[q][0] = a.spec.segments[2 * i];
-        seg[q][1] = a.spec.segments[2 * i + 1];
-      } else {
-        float vv[1], kk[1];
-        load_controls<LAYOUT, 1>(a.U, p, a.N, n, i, c, vv, kk);
-        v[q] = vv[0];
-        k[q] = kk[0];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < kLaneChunk; ++q) {
-      const int i = base + q;
-      if (i < n) {
-        if (a.regenerate) {   // regenerate_control()'s arithmetic on the operands fetched above
-          const int k0 = static_cast<int>(seg[q][0]);
-          float z0v = z[0][0], z0k = z[0][1], z1v = z[1][0], z1k = z[1][1];
-#pragma unroll
-          for (int knot = 1; knot < kKnots - 1; ++knot) {
-            const bool hit = (k0 == knot);
-            z0v = hit ? z[knot][0] : z0v;
-            z0k = hit ? z[knot][1] : z0k;
-            z1v = hit ? z[knot + 1][0] : z1v;
-            z1k = hit ? z[knot + 1][1] : z1k;
-          }
-          blend_control(a.spec, amp, seg[q][1], cen[q][0], cen[q][1], z0v, z0k, z1v, z1k, v[q], k[q]);
-        }
-        ru[2 * i] = v[q];
-        ru[2 * i + 1] = k[q];
-        rx[3 * i] = st.ey;
-        rx[3 * i + 1] = st.ep;
-        rx[3 * i + 2] = st.t;
-        const float row[9] = {lo[q][0], lo[q][1], lo[q][2], lo[q][3], hi[q][0], hi[q][1], hi[q][2], hi[q][3], last[q]};
-        step_spatial<float>(st, row, v[q], k[q], w);
-      }
-    }
-  }
-  rx[3 * n] = st.ey;
-  rx[3 * n + 1] = st.ep;
-  rx[3 * n + 2] = st.t;
-  rec[0] = finish_spatial<float>(st, w);
-  rec[1] = st.V;
-  rec[2] = static_cast<float>(nfeas);
-  rec[3] = 1.0f;
-}
-
-// The batched solve's finalize, mode S, as launched from round 4 on: SIXTEEN LANES PER PROBLEM, four problems per
-// wavefront.  A lane per problem (finalize_lanes_kernel above) still walks step_spatial()'s ~45 instructions per step on a
-// lone wave and sends every load and store of a wave to 64 different cache lines: 20 us behind the headline's 1.0 ms.
-// finalize_problem()'s decomposition does better and is taken over here on a quarter of a wave per problem:
+// The batched solve's finalize, mode S, from 256 problems up (round 4): SIXTEEN LANES PER PROBLEM, four problems per
+// wavefront.  finalize_kernel gives every problem a wavefront, which re-rolls its winner in lock-step on broadcast inputs - a
+// fine use of a wave when there is one problem, and 4 096 lone-wave walks when there are 4 096: 29 us behind the headline's
+// 1.0 ms rollout.  (A LANE per problem - the argmin, the winner's controls and table rows fetched seven steps ahead,
+// step_spatial() per lane - was built first: 1/64 of the instructions, but every load and store of a wave goes to 64
+// different cache lines and step_spatial's ~45 instructions per step run on 64 lone waves: 20.5 us.)
+// finalize_problem()'s decomposition does better on a quarter of a wave per problem:
 //   A  lane l of the problem's sixteen prepares steps l, l + 16, ...: the winner's controls (re-drawn - the four Philox
 //      blocks of its normals drawn by four of the lanes and shared through LDS - or loaded), the table row, everything of
 //      the step that does not depend on the state; the record's u block
 //   B  the 9-operation state recurrence, the only sequential part, on operands read from LDS eight steps ahead
 //   C  lane l again: stage cost and the two state-dependent bound terms of its steps from the states B left in LDS
 //   D  J and V accumulated in step order: the additions of step_spatial(), in its order - the same bits
-// and the four record images, contiguous in LDS as the four records are in memory, leave in 16-byte stores.
+// and the four record images, contiguous in LDS as the four records are in memory, leave in 16-byte stores: 13.8 us.
+// Fewer problems leave the CUs idle either way and keep the wave-per-problem form, whose latency is the shorter.
 constexpr int kGroupLanes = 16;
 constexpr int kGroupProblems = kWave / kGroupLanes;
 constexpr int kGroupRow = 8;     // floats per step in each of the two LDS tables
@@ -3016,7 +2909,7 @@ hipError_t launch_rollout_chained(int layout, const LaunchShape& shape, const Ro
 
 hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipStream_t s, const LaunchOptions& opt) {
   clear_stale_error();
-  if (mode == 0 && !args.controls_only && args.P >= kLaneFinalizeProblems && !opt.no_group_finalize &&
+  if (mode == 0 && !args.controls_only && args.P >= kGroupFinalizeProblems && !opt.no_group_finalize &&
       (layout == 0 || layout == 1) && group_finalize_floats(args.n) * sizeof(float) <= 64 * 1024) {
     // many problems: sixteen lanes per problem, four problems per wavefront (finalize_groups_kernel)
     const dim3 groups_grid((args.P + kGroupProblems - 1) / kGroupProblems);
@@ -3025,17 +2918,6 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
       hipLaunchKernelGGL((finalize_groups_kernel<0>), groups_grid, dim3(kWave), groups_lds, s, args);
     } else {
       hipLaunchKernelGGL((finalize_groups_kernel<1>), groups_grid, dim3(kWave), groups_lds, s, args);
-    }
-    return hipGetLastError();
-  }
-  if (mode == 0 && !args.controls_only && args.P >= kLaneFinalizeProblems && !opt.no_lane_finalize &&
-      (layout == 0 || layout == 1)) {
-    // (A/B: ACMPC_NO_GROUP_FINALIZE) one lane per problem (finalize_lanes_kernel)
-    const dim3 lanes_grid((args.P + kWave - 1) / kWave);
-    if (layout == 0) {
-      hipLaunchKernelGGL((finalize_lanes_kernel<0>), lanes_grid, dim3(kWave), 0, s, args);
-    } else {
-      hipLaunchKernelGGL((finalize_lanes_kernel<1>), lanes_grid, dim3(kWave), 0, s, args);
     }
     return hipGetLastError();
   }

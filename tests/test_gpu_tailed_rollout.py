@@ -1,8 +1,8 @@
-"""The batched solve's finalize in its four forms (round 4): a wavefront per problem (finalize_kernel); from 256 problems up
-sixteen lanes per problem, four problems per wavefront (finalize_groups_kernel, the default there) or a LANE per problem
-(finalize_lanes_kernel, ACMPC_NO_GROUP_FINALIZE=1); and inside the rollout's launch (rollout_tailed_kernel: the
-last workgroup of every problem takes the argmin and re-rolls the winner while other problems are still streaming).  The
-records must be
+"""The batched solve's finalize in its forms (round 4): a wavefront per problem (finalize_kernel; ACMPC_NO_GROUP_FINALIZE=1
+keeps it at any problem count); from 256 problems up sixteen lanes per problem, four problems per wavefront
+(finalize_groups_kernel, the default there); inside the rollout's launch (rollout_tailed_kernel: the last workgroup of every
+problem takes the argmin and re-rolls the winner while other problems are still streaming); and - a stream of batches -
+inside the NEXT batch's rollout launch (rollout_chained_kernel).  The records must be
 the two-launch form's (rollout_kernel + finalize_kernel, the default: it is the faster of the two on the headline's batch,
 csrc/acmpc_capi.hip solve_batched; ACMPC_TAILED_ROLLOUT=1 selects the one launch) bit for bit, and the oracle's."""
 import numpy as np
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def _solve(monkeypatch, switch, problems, P, N, n, sampled):
     import torch
     from acmpc_amd import Engine, _capi
-    for name in ("ACMPC_TAILED_ROLLOUT", "ACMPC_NO_LANE_FINALIZE", "ACMPC_NO_GROUP_FINALIZE"):
+    for name in ("ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE"):
         monkeypatch.delenv(name, raising=False)
     for name in (switch or "").split():
         monkeypatch.setenv(name, "1")
@@ -63,9 +63,8 @@ def test_tailed_rollout_equals_two_launches_and_the_oracle(monkeypatch, P, N, H,
     problems = [make_problem(orc, "monza", H, 4, seed=900 + p % 7) for p in range(P)]
     one = _solve(monkeypatch, "ACMPC_TAILED_ROLLOUT", problems, P, N, n, sampled)
     two = _solve(monkeypatch, None, problems, P, N, n, sampled)     # (the default: two launches; from 256 problems sixteen
-    lanes = _solve(monkeypatch, "ACMPC_NO_GROUP_FINALIZE", problems, P, N, n, sampled)                      # lanes per problem)
-    waves = _solve(monkeypatch, "ACMPC_NO_GROUP_FINALIZE ACMPC_NO_LANE_FINALIZE", problems, P, N, n, sampled)
-    for other in (two, lanes, waves):
+    waves = _solve(monkeypatch, "ACMPC_NO_GROUP_FINALIZE", problems, P, N, n, sampled)                      # lanes per problem)
+    for other in (two, waves):
         for a, b, what in zip(one, other, ("records", "keys", "costs", "controls")):
             np.testing.assert_array_equal(a, b, err_msg=what)
     rec, keys, costs, U = one
@@ -87,7 +86,7 @@ def test_tailed_rollout_equals_two_launches_and_the_oracle(monkeypatch, P, N, H,
 @pytest.mark.parametrize("layout", [0, 1])
 def test_two_shards_of_many_problems_in_every_finalize_form(monkeypatch, layout):
     """The sharded protocol's finalize (global keys in, the winner's record written by the shard that owns it, a blank
-    record with the shard's feasible count by the other) at a problem count that takes the many-problem kernels: all three
+    record with the shard's feasible count by the other) at a problem count that takes the many-problem kernel: both
     forms write the same records, and the two shards' records add up to the unsharded solve's."""
     import torch
     from acmpc_amd import Engine, _capi
@@ -104,9 +103,8 @@ def test_two_shards_of_many_problems_in_every_finalize_form(monkeypatch, layout)
     R = _capi.record_floats(n)
     shards = [(0, 500), (500, 268)]
     results = {}
-    for switch in ("", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_NO_GROUP_FINALIZE ACMPC_NO_LANE_FINALIZE"):
-        for name in ("ACMPC_NO_LANE_FINALIZE", "ACMPC_NO_GROUP_FINALIZE"):
-            monkeypatch.delenv(name, raising=False)
+    for switch in ("", "ACMPC_NO_GROUP_FINALIZE"):
+        monkeypatch.delenv("ACMPC_NO_GROUP_FINALIZE", raising=False)
         for name in switch.split():
             monkeypatch.setenv(name, "1")
         full = Engine(**engine_kwargs(problems[0], 0, P, total, n))
@@ -253,14 +251,13 @@ def test_new_tables_in_the_middle_of_a_stream(monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("switch", ["", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_NO_GROUP_FINALIZE ACMPC_NO_LANE_FINALIZE"])
+@pytest.mark.parametrize("switch", ["", "ACMPC_NO_GROUP_FINALIZE"])
 def test_records_from_reduced_keys_equal_the_one_call_solve(monkeypatch, switch):
     """The multi-rank step's last call - acmpc_finalize_sampled_device on the keys an all-reduce(MIN) left - at the
     headline's problem count per launch shape: the records of the one-call solve, from the keys alone."""
     import torch
     from acmpc_amd import Engine, _capi
-    for name in ("ACMPC_NO_LANE_FINALIZE", "ACMPC_NO_GROUP_FINALIZE"):
-        monkeypatch.delenv(name, raising=False)
+    monkeypatch.delenv("ACMPC_NO_GROUP_FINALIZE", raising=False)
     for name in switch.split():
         monkeypatch.setenv(name, "1")
     P, N, H = 333, 2048, 50

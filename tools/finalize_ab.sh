@@ -10,7 +10,7 @@ pick() { python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(
 for rep in 1 2 3; do
   python3 $ROOT/bench.py --stream --no-cpu-baseline --no-single-solve --steps 300 --warmup 30 2>/dev/null | pick stream >> $OUT
   python3 $ROOT/bench.py --no-cpu-baseline --no-single-solve --steps 300 --warmup 30 2>/dev/null | pick groups >> $OUT
-  ACMPC_NO_GROUP_FINALIZE=1 python3 $ROOT/bench.py --no-cpu-baseline --no-single-solve --steps 300 --warmup 30 2>/dev/null | pick lanes >> $OUT
+  ACMPC_NO_GROUP_FINALIZE=1 python3 $ROOT/bench.py --no-cpu-baseline --no-single-solve --steps 300 --warmup 30 2>/dev/null | pick waves >> $OUT
 done
 (cd /tmp && export TMPDIR=/tmp && rm -rf $ROOT/gpurun_out/finalize_ab_trace && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/finalize_ab_trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-single-solve --steps 100 --warmup 10 > /dev/null 2> $ROOT/gpurun_out/finalize_ab_trace.err)
 for f in $ROOT/gpurun_out/finalize_ab_trace/*/*_kernel_stats.csv; do cut -d, -f1-4 $f | sed -n 1,4p >> $OUT; done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid (GPU box): the batched finalize of the headline's batch (4 096 problems) on its own - back to back (warm
 caches and address translations) and behind a 6.6 GB stream through HBM (as it runs in the headline step).
-usage: python3 tools/finalize_probe.py   (ACMPC_NO_GROUP_FINALIZE=1 for the lane-per-problem form)"""
+usage: python3 tools/finalize_probe.py   (ACMPC_NO_GROUP_FINALIZE=1 for a wavefront per problem)"""
 import os
 import sys
 
