@@ -71,6 +71,20 @@ def test_single_gpu_line_has_the_contract_fields():
     assert pf["particles_500"]["update_us"] > 0 and pf["particles_100000"]["particles_per_s"] > 1e6
 
 
+def test_stream_of_batches_line():
+    """`bench.py --stream`: the previous batch's argmin and records inside the next batch's rollout launch
+    (acmpc_solve_stream_device); the line names the kernel that carried them, and the step is that kernel and a launch
+    boundary - the round-3 review's bar, `ms_per_step <= 1.01 x kernel_ms`, in the letter (`value` is the same
+    as with two launches)."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stream", "--steps", "60", "--warmup", "10",
+                           "--no-cpu-baseline", "--no-single-solve"], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    out = _last_json(proc.stdout)
+    assert out["roofline"]["kernel"] == "rollout_chained_kernel" and "acmpc_solve_stream_device" in out["config"]["pipeline"]
+    assert out["value"] > 1e9 and 0.5 < out["roofline"]["frac"] < 1
+    assert out["ms_per_step"] <= 1.012 * out["roofline"]["kernel_ms"], (out["ms_per_step"], out["roofline"]["kernel_ms"])
+
+
 def test_strong_scaling_mode_is_config_4():
     """`--scaling strong`: Nordschleife, 262 144 candidates x horizon 80 in total, one problem per step, latency reported."""
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", "strong", "--steps", "20",
