@@ -887,6 +887,8 @@ int acmpc_get_coefficients(const acmpc_ctx* c, int32_t problem, float* out, int3
 
 int acmpc_sync_tables(acmpc_ctx* c, void* stream) {
   if (c == nullptr) return ACMPC_EINVAL;
+  if (c->stream_pending && (c->tables_dirty || c->frames_dirty))   // (the pending finalize reads the tables on the device)
+    return fail(c, ACMPC_ESTATE, "a batch of acmpc_solve_stream_device is pending: acmpc_solve_stream_flush first");
   int rc = ensure_device(c);
   if (rc != ACMPC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1123,7 +1125,9 @@ int acmpc_sample_device(acmpc_ctx* c, const float* d_centre, int32_t centre_stri
   if (d_centre == nullptr || d_U == nullptr) return fail(c, ACMPC_EINVAL, "null device pointer");
   if (centre_stride < 2 * n) return fail(c, ACMPC_EINVAL, "centre_stride must be at least 2 n");
   if (index_offset < 0 || index_offset + N > 0xffffffffLL) return fail(c, ACMPC_EINVAL, "global index exceeds 32 bits");
-  int rc = check_shape(c, P, N, n, layout);
+  // (allowed while a batch of acmpc_solve_stream_device is pending: drawing the next batch's candidates touches neither
+  // the tables nor the partial keys the pending finalize reads)
+  int rc = check_shape(c, P, N, n, layout, true);
   if (rc != ACMPC_OK) return rc;
   rc = ensure_device(c);
   if (rc != ACMPC_OK) return rc;

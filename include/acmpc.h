@@ -252,7 +252,8 @@ int acmpc_solve_sampled_device(acmpc_ctx* ctx, const float* d_x0, const float* d
  * The same bits as acmpc_solve_device / acmpc_solve_sampled_device (tests/test_gpu_tailed_rollout.py).  Shapes the one
  * launch does not take (mode T, the candidate-major layout, horizons whose finalize would cost the rollout its
  * occupancy) run the pending finalize as a launch of its own in front of the rollout.  While a batch is pending every
- * other solve on the handle returns ACMPC_ESTATE; new tables (acmpc_set_paths) are uploaded behind the pending finalize. */
+ * other solve on the handle returns ACMPC_ESTATE (acmpc_sample_device - drawing the next batch's candidates - is allowed);
+ * new tables (acmpc_set_paths) are uploaded behind the pending finalize. */
 int acmpc_solve_stream_device(acmpc_ctx* ctx, const float* d_x0, const float* d_U, const float* d_centre,
                               int32_t centre_stride, const float* d_u_ref, int32_t P, int32_t N, int32_t n, int32_t layout,
                               double sigma_v, double sigma_kappa, uint64_t seed, uint32_t round, float* d_costs,

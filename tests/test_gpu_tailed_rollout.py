@@ -191,6 +191,9 @@ def test_a_stream_of_batches_equals_one_call_per_batch(monkeypatch, P, N, H, sam
             eng.solve_stream_device(x0.data_ptr(), Us[k].data_ptr(), u_ref.data_ptr() if sampled else 0, 2 * n, u_ref.data_ptr(),
                                     P, N, n, 1, sigma, seeds[k], k, costs_s[k].data_ptr(), keys_s[k].data_ptr(),
                                     recs_s[k].data_ptr(), s)
+            if k == 1:   # (drawing candidates is allowed while a batch is pending: what a real stream does)
+                eng.sample_device(u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, 1, 0, sigma, seeds[k + 1], k + 1,
+                                  Us[k + 1].data_ptr(), s)
             if k == 2:   # nothing else runs on the handle while a batch is pending
                 with pytest.raises(_capi.EngineError, match="pending"):
                     eng.solve_device(x0.data_ptr(), Us[k].data_ptr(), P, N, n, 1, costs[k].data_ptr(), keys[k].data_ptr(),
