@@ -606,7 +606,7 @@ const char* const kOptionNames[] = {
     "ACMPC_SHAPE", "ACMPC_T_PACK", "ACMPC_NO_TILE", "ACMPC_TILE_ROWS", "ACMPC_TILE_TABLE", "ACMPC_NO_TRIO_ROUNDS",
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
-    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE",
+    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES",
     "ACMPC_NO_CHAINED_STREAM"};
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
@@ -630,6 +630,7 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_SOLO_REGISTERS") return tri(&o.solo_registers);
   if (key == "ACMPC_SOLO_SPLIT") return tri(&o.solo_split);
   if (key == "ACMPC_NO_GROUP_FINALIZE") { o.no_group_finalize = on; return true; }
+  if (key == "ACMPC_FINALIZE_WAVES") { o.finalize_waves = on; return true; }
   acmpc_ctx::Switches& w = c->sw;
   if (key == "ACMPC_NO_VERIFIED_SEARCH") { w.no_verified_search = on; return true; }
   if (key == "ACMPC_NO_SOLO") { w.no_solo = on; return true; }

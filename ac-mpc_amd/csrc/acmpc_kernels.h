@@ -92,6 +92,7 @@ struct LaunchOptions {
   bool no_trio_rounds = false, no_quad_rounds = false, no_pair_rounds = false;
   int solo_registers = -1, solo_split = -1;   // ACMPC_SOLO_REGISTERS / ACMPC_SOLO_SPLIT: 0 / 1 (-1: by size / split)
   bool no_group_finalize = false;             // ACMPC_NO_GROUP_FINALIZE: a wavefront per problem in the batched finalize at any problem count
+  bool finalize_waves = false;                // ACMPC_FINALIZE_WAVES: the many-problem finalize on a wavefront per problem, four per workgroup
 };
 
 struct LaunchShape {

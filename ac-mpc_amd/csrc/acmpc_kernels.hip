@@ -977,9 +977,12 @@ constexpr int kGroupRow = 8;     // floats per step in each of the two LDS table
 constexpr int kGroupAhead = 8;   // steps whose LDS operands are requested together in B and D (the kernel of its own)
 constexpr int kGroupPass = 4;    // steps per lane whose memory operands are requested together in A (the kernel of its own)
 
-inline size_t group_finalize_floats(int n) {
-  const size_t records = (static_cast<size_t>(kGroupProblems) * (4 + 2 * n + 3 * (n + 1)) + 3) & ~static_cast<size_t>(3);
-  return records + kGroupProblems * (16 + 2 * static_cast<size_t>(n) * kGroupRow);
+__device__ __forceinline__ int group_finalize_floats_device(int n) {   // one problem per wavefront
+  return ((4 + 2 * n + 3 * (n + 1) + 3) & ~3) + 16 + 2 * n * kGroupRow;
+}
+inline size_t group_finalize_floats(int n, int problems = kGroupProblems) {   // LDS floats of ONE wavefront
+  const size_t records = (static_cast<size_t>(problems) * (4 + 2 * n + 3 * (n + 1)) + 3) & ~static_cast<size_t>(3);
+  return records + problems * (16 + 2 * static_cast<size_t>(n) * kGroupRow);
 }
 
 // finalize_group runs on ONE wavefront: what its lanes hand each other through LDS needs no workgroup barrier (a wave's LDS
@@ -994,41 +997,49 @@ __device__ __forceinline__ void wave_lds_handoff() {
 // One wavefront's four problems: threadIdx.x < 64 are its lanes, `group` its place in the batch.  kPass / kAhead: how far
 // ahead operands are requested (registers: 116 with 4 / 8, under 64 with 1 / 4 - what a launch shared with the rollout,
 // rollout_chained_kernel, can afford).
-template <int LAYOUT, int kPass, int kAhead>
+template <int LAYOUT, int kPass, int kAhead, int kLanes = kGroupLanes>
 __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int group, float* s_group) {
-  const int lane = static_cast<int>(threadIdx.x);
-  const int q = lane / kGroupLanes, sub = lane % kGroupLanes;
+  constexpr int kProblems = kWave / kLanes;   // problems of this wavefront
+  const int lane = static_cast<int>(threadIdx.x) & (kWave - 1);
+  const int q = lane / kLanes, sub = lane % kLanes;
   const int n = a.n;
   const int rec_floats = 4 + 2 * n + 3 * (n + 1);
-  const int p_first = group * kGroupProblems;
+  const int p_first = group * kProblems;
   const int p = p_first + q;
   const bool live = p < a.P;
   const int pl = live ? p : a.P - 1;   // a quarter without a problem repeats the last one's work and writes nothing
   const float* __restrict__ x0 = a.x0 + pl * 3;
   float ey = 0.0f, ep = 0.0f, t = 0.0f;
-  float rows_ahead[kPass][9] = {};
+  float rows_ahead[kPass][9] = {}, seg_ahead[kPass][2] = {}, cen_ahead[kPass][2] = {};
   if (a.records != nullptr) {   // what does not depend on who won travels with the partial keys
     ey = x0[0], ep = x0[1], t = x0[2];
     const float* __restrict__ coef_ahead = a.coef + static_cast<size_t>(pl) * n * kCoefS;
 #pragma unroll
     for (int j = 0; j < kPass; ++j) {
+      const int i = min(j * kLanes + sub, n - 1);
 #pragma unroll
-      for (int e = 0; e < 9; ++e) rows_ahead[j][e] = coef_ahead[min(j * kGroupLanes + sub, n - 1) * kCoefS + e];
+      for (int e = 0; e < 9; ++e) rows_ahead[j][e] = coef_ahead[i * kCoefS + e];
+      if (a.regenerate) {   // (the centre every winner but candidates 1 and 2 is drawn round: those two fetch theirs below)
+        seg_ahead[j][0] = a.spec.segments[2 * i];
+        seg_ahead[j][1] = a.spec.segments[2 * i + 1];
+        cen_ahead[j][0] = a.centre[static_cast<size_t>(pl) * a.centre_stride + 2 * i];
+        cen_ahead[j][1] = a.centre[static_cast<size_t>(pl) * a.centre_stride + 2 * i + 1];
+      }
     }
   }
 
   int nfeas = 0;
   int64_t key = kKeyMax;
-  for (int b = sub; b < a.blocks_per_problem; b += kGroupLanes) {
+  for (int b = sub; b < a.blocks_per_problem; b += kLanes) {
     const size_t slot = static_cast<size_t>(pl) * a.blocks_per_problem + b;
     nfeas += a.partial_feas[slot];
     const int64_t kb = a.partial_keys[slot];
     key = (kb < key) ? kb : key;
   }
 #pragma unroll
-  for (int m = kGroupLanes / 2; m >= 1; m >>= 1) {
-    nfeas += __shfl_xor(nfeas, m, kGroupLanes);
-    const int64_t other = static_cast<int64_t>(__shfl_xor(static_cast<long long>(key), m, kGroupLanes));
+  for (int m = kLanes / 2; m >= 1; m >>= 1) {
+    nfeas += __shfl_xor(nfeas, m, kLanes);
+    const int64_t other = static_cast<int64_t>(__shfl_xor(static_cast<long long>(key), m, kLanes));
     key = (other < key) ? other : key;
   }
   if (a.keys_in != nullptr) key = a.keys_in[pl];
@@ -1036,10 +1047,10 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
   if (a.records == nullptr) return;
 
   float* s_rec = s_group + q * rec_floats;
-  float* s_tables = s_group + ((kGroupProblems * rec_floats + 3) & ~3);
+  float* s_tables = s_group + ((kProblems * rec_floats + 3) & ~3);
   float* s_z = s_tables + q * 16;
-  float* s_rows = s_tables + kGroupProblems * 16 + q * n * kGroupRow;                      // ds a21 a31 f3 | ds dk, b31 dv, lo, hi
-  float* s_terms = s_tables + kGroupProblems * 16 + (kGroupProblems + q) * n * kGroupRow;   // stage (r), hu0, hu1, hc | ht
+  float* s_rows = s_tables + kProblems * 16 + q * n * kGroupRow;                      // ds a21 a31 f3 | ds dk, b31 dv, lo, hi
+  float* s_terms = s_tables + kProblems * 16 + (kProblems + q) * n * kGroupRow;   // stage (r), hu0, hu1, hc | ht
   float* su = s_rec + 4;
   float* sx = s_rec + 4 + 2 * n;
   const int64_t local = static_cast<int64_t>(static_cast<uint32_t>(key & 0xffffffffLL)) - a.index_offset;
@@ -1050,6 +1061,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
   const float* __restrict__ coef = a.coef + static_cast<size_t>(pl) * n * kCoefS;
   float amp = 0.0f;
   const float* centre = nullptr;
+  bool use_alt = false;
   if (a.regenerate) {
     if (sub < kKnots / 2) {
       float four[4];
@@ -1057,24 +1069,34 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
       *reinterpret_cast<f32x4*>(s_z + 4 * sub) = f32x4{four[0], four[1], four[2], four[3]};
     }
     const float* alt = (gidx == 1u) ? a.u_ref : (gidx == 2u) ? a.u_extra : nullptr;
-    const bool use_ref = alt != nullptr;
-    amp = use_ref ? 0.0f : candidate_amplitude(gidx);
-    centre = use_ref ? alt + static_cast<size_t>(pl) * n * 2 : a.centre + static_cast<size_t>(pl) * a.centre_stride;
+    use_alt = alt != nullptr;
+    amp = use_alt ? 0.0f : candidate_amplitude(gidx);
+    centre = use_alt ? alt + static_cast<size_t>(pl) * n * 2 : a.centre + static_cast<size_t>(pl) * a.centre_stride;
   }
   wave_lds_handoff();
 
   // A: everything of a step that does not depend on the state, four steps per lane and pass; a pass's operands are all
   // requested before the first is used (the first pass's table rows before the keys: rows_ahead above)
-  for (int base = 0; base < n; base += kPass * kGroupLanes) {
+  for (int base = 0; base < n; base += kPass * kLanes) {
     float rows[kPass][9], v[kPass], k[kPass], seg[kPass][2], cen[kPass][2];
 #pragma unroll
     for (int j = 0; j < kPass; ++j) {
-      const int i = min(base + j * kGroupLanes + sub, n - 1);
+      const int i = min(base + j * kLanes + sub, n - 1);
       if (a.regenerate) {
-        seg[j][0] = a.spec.segments[2 * i];
-        seg[j][1] = a.spec.segments[2 * i + 1];
-        cen[j][0] = centre[2 * i];
-        cen[j][1] = centre[2 * i + 1];
+        if (base == 0) {
+          seg[j][0] = seg_ahead[j][0];
+          seg[j][1] = seg_ahead[j][1];
+        } else {
+          seg[j][0] = a.spec.segments[2 * i];
+          seg[j][1] = a.spec.segments[2 * i + 1];
+        }
+        if (base == 0 && !use_alt) {   // (per lane: a quarter whose winner is candidate 1 or 2 fetches its own centre)
+          cen[j][0] = cen_ahead[j][0];
+          cen[j][1] = cen_ahead[j][1];
+        } else {
+          cen[j][0] = centre[2 * i];
+          cen[j][1] = centre[2 * i + 1];
+        }
       } else {
         float vv[1], kk[1];
         load_controls<LAYOUT, 1>(a.U, pl, a.N, n, i, c, vv, kk);
@@ -1086,7 +1108,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
     }
 #pragma unroll
     for (int j = 0; j < kPass; ++j) {
-      const int i = base + j * kGroupLanes + sub;
+      const int i = base + j * kLanes + sub;
       if (i < n) {
         if (a.regenerate) {   // regenerate_control()'s operands, the bracketing knots read from LDS
           const int k0 = static_cast<int>(seg[j][0]);
@@ -1150,7 +1172,7 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
   wave_lds_handoff();
 
   // C: what hangs off a state
-  for (int base = 0; base < n; base += kGroupLanes) {
+  for (int base = 0; base < n; base += kLanes) {
     const int i = base + sub;
     if (i < n) {
       const float my_ey = sx[3 * i], my_ep = sx[3 * i + 1], my_t = sx[3 * i + 2];
@@ -1200,10 +1222,10 @@ __device__ __forceinline__ void finalize_group(const FinalizeArgs& a, const int 
       s_rec[3] = 1.0f;
     }
   } else {
-    for (int e = sub; e < rec_floats; e += kGroupLanes) s_rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
+    for (int e = sub; e < rec_floats; e += kLanes) s_rec[e] = (e == 2) ? static_cast<float>(nfeas) : 0.0f;
   }
   wave_lds_handoff();
-  const int count = min(kGroupProblems, a.P - p_first) * rec_floats;
+  const int count = min(kProblems, a.P - p_first) * rec_floats;
   float* __restrict__ out = a.records + static_cast<size_t>(p_first) * rec_floats;
   const int whole = ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? (count & ~3) : 0;
   for (int e = 4 * lane; e < whole; e += 4 * kWave) *reinterpret_cast<f32x4*>(out + e) = *reinterpret_cast<const f32x4*>(s_group + e);
@@ -1216,19 +1238,36 @@ __global__ void __launch_bounds__(kWave) finalize_groups_kernel(const FinalizeAr
   finalize_group<LAYOUT, kGroupPass, kGroupAhead>(a, static_cast<int>(blockIdx.x), s_group);
 }
 
+// The same with a whole wavefront per problem and four wavefronts per workgroup (A/B: ACMPC_FINALIZE_WAVES=1; and the
+// form the finalize takes inside rollout_chained_kernel): a lane per step in A and C - one pass up to 64 steps, every
+// operand requested before the keys are reduced -, B and D as before.
+constexpr int kFinalizeWaves = 4;
+
+template <int LAYOUT>
+__global__ void __launch_bounds__(kFinalizeWaves * kWave) finalize_waves_kernel(const FinalizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_group[];
+  const int wave = static_cast<int>(threadIdx.x) / kWave;
+  const int p = static_cast<int>(blockIdx.x) * kFinalizeWaves + wave;
+  if (p >= a.P) return;
+  finalize_group<LAYOUT, 1, kGroupAhead, kWave>(a, p, s_group + wave * group_finalize_floats_device(a.n));
+}
+
 // A STREAM of batches (acmpc_solve_stream_device): batch k's rollout and batch k - 1's finalize in ONE launch.  Behind
-// the headline's rollout the finalize of its 4 096 problems is 14.6 us of lone waves plus a launch boundary - 1.8 % of the
+// the headline's rollout the finalize of its 4 096 problems is 13-14 us of lone waves plus a launch boundary - 1.7 % of the
 // step - and no form of it is fast enough to vanish (a lone wave issues an instruction every 4.2 cycles: finalize_group's
 // ~2 400 are 5 us before the first cache miss).  So it runs where nobody waits for it: the LAST rows of the next rollout's
-// grid are rows of finalize workgroups (four problems each on their first wave, the other waves retire at once).  Rows
-// are dispatched in order, so these start when the grid has no rollout workgroup left to hand out - in the wave slots the
-// rollout's tail leaves empty.  Measured on the headline's batch (tools/chained_ab.py, launches alternating with the plain
-// kernel in one process): +6 to +12 us on the kernel for 18.8 us of finalize and launch boundary removed.  The same rows
-// spread evenly through the grid (one in seventeen) cost +25 us: every finalize workgroup then displaces a rollout
-// workgroup for its ~40 us - six dependent trips to a saturated memory system - and 1 024 of them are 19 us of the 2 048
-// resident workgroups' time; raising the lone waves' priority (s_setprio) changes nothing, looking further ahead for
-// operands (more registers: spills under the rollout's 64) makes it worse.  The two batches' partial keys live in
-// different halves of the handle's buffer.
+// grid are rows of finalize workgroups - four wavefronts, a problem each, a lane per step (finalize_group<..., 64>: one
+// pass, every operand requested before the keys are reduced, two trips to memory).  Rows are dispatched in order, so these
+// start when the grid has no rollout workgroup left to hand out, in the wave slots the rollout's last generation leaves
+// empty as it drains, and are done before it is.  Measured on the headline's batch (tools/chained_ab.py, launches
+// alternating with the plain kernel in one process; tools/finalize_ab.sh, interleaved bench runs): the kernel is as long
+// as the plain one (-4 .. +3 us), the step 9-15 us shorter than with two launches.  What did NOT work, same tools: the
+// sixteen-lane form on ONE wave per finalize workgroup in the same last rows, +11.5 us on the kernel (its six dependent
+// trips to memory outlast the tail: the step as long as with two launches); the same rows spread evenly through the grid
+// (one in seventeen), +25 us - every finalize workgroup then displaces a rollout workgroup for its ~40 us under a saturated
+// memory system, 1 024 of them 19 us of the 2 048 resident workgroups' time; raising the lone waves' priority (s_setprio)
+// changed nothing, looking further ahead for operands (more registers: spills under the rollout's 64) made it worse.  The
+// two batches' partial keys live in different halves of the handle's buffer.
 #ifndef ACMPC_CHAINED_PASS
 #define ACMPC_CHAINED_PASS 1    // (A/B builds) finalize_group's look-ahead inside the shared launch
 #endif
@@ -1240,10 +1279,12 @@ __global__ void __launch_bounds__(BLOCK, 8) rollout_chained_kernel(const Rollout
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int y = static_cast<int>(blockIdx.y);
   if (y >= a.P) {
-    if (threadIdx.x >= kWave) return;
-    const int group = (y - a.P) * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
-    if (group * kGroupProblems >= f.P) return;
-    finalize_group<1, ACMPC_CHAINED_PASS, ACMPC_CHAINED_AHEAD>(f, group, reinterpret_cast<float*>(smem));
+    static_assert(BLOCK == kFinalizeWaves * kWave, "a finalize workgroup is four wavefronts, a problem each");
+    const int wave = static_cast<int>(threadIdx.x) / kWave;
+    const int p = ((y - a.P) * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x)) * kFinalizeWaves + wave;
+    if (p >= f.P) return;
+    finalize_group<1, ACMPC_CHAINED_PASS, ACMPC_CHAINED_AHEAD, kWave>(
+        f, p, reinterpret_cast<float*>(smem) + wave * group_finalize_floats_device(f.n));
     return;
   }
   rollout_block<0, LAYOUT, CPT, BLOCK, PACK, false>(a, smem, y);
@@ -2879,21 +2920,21 @@ hipError_t launch_rollout_tailed(int layout, const LaunchShape& shape, const Rol
 // rollout on the 256-thread shapes; a pending finalize of the many-problem kind whose winners are re-drawn or read from a
 // step-major matrix, and whose LDS image leaves the rollout its eight workgroups per CU
 bool chained_rollout_fits(int mode, int layout, const LaunchShape& shape, int P, const FinalizeArgs& fin, int fin_layout) {
-  const int fin_groups = (fin.P + kGroupProblems - 1) / kGroupProblems;
+  const int fin_groups = (fin.P + kFinalizeWaves - 1) / kFinalizeWaves;
   const int rows = (fin_groups + std::max(shape.blocks_per_problem, 1) - 1) / std::max(shape.blocks_per_problem, 1);
   return rows <= P && static_cast<long long>(P) + rows <= 65535 && mode == 0 && layout == 1 && !shape.tile && shape.block == 256 && (shape.cpt == 1 || shape.cpt == 2 || shape.cpt == 4) &&
          !fin.controls_only && fin.records != nullptr && fin.keys_in == nullptr && fin.P >= 1 && (fin.regenerate || fin_layout == 1) &&
-         group_finalize_floats(fin.n) * sizeof(float) <= 20 * 1024;
+         kFinalizeWaves * group_finalize_floats(fin.n, 1) * sizeof(float) <= 20 * 1024;
 }
 
 hipError_t launch_rollout_chained(int layout, const LaunchShape& shape, const RolloutArgs& args, const FinalizeArgs& fin,
                                   int fin_layout, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   clear_stale_error();
   if (!chained_rollout_fits(0, layout, shape, args.P, fin, fin_layout)) return hipErrorInvalidValue;
-  const int groups = (fin.P + kGroupProblems - 1) / kGroupProblems;
+  const int groups = (fin.P + kFinalizeWaves - 1) / kFinalizeWaves;
   const int fin_rows = (groups + shape.blocks_per_problem - 1) / shape.blocks_per_problem;
   const dim3 grid(shape.blocks_per_problem, args.P + fin_rows);
-  const size_t lds = std::max<size_t>(64, group_finalize_floats(fin.n) * sizeof(float));
+  const size_t lds = std::max<size_t>(64, kFinalizeWaves * group_finalize_floats(fin.n, 1) * sizeof(float));
   auto go = [&](auto kernel) -> hipError_t {
     if (e0 != nullptr && e1 != nullptr) {
       hipExtLaunchKernelGGL(kernel, grid, dim3(256), static_cast<std::uint32_t>(lds), s, e0, e1, 0, args, fin);
@@ -2911,6 +2952,16 @@ hipError_t launch_finalize(int mode, int layout, const FinalizeArgs& args, hipSt
   clear_stale_error();
   if (mode == 0 && !args.controls_only && args.P >= kGroupFinalizeProblems && !opt.no_group_finalize &&
       (layout == 0 || layout == 1) && group_finalize_floats(args.n) * sizeof(float) <= 64 * 1024) {
+    if (opt.finalize_waves && kFinalizeWaves * group_finalize_floats(args.n, 1) * sizeof(float) <= 64 * 1024) {
+      const dim3 waves_grid((args.P + kFinalizeWaves - 1) / kFinalizeWaves);
+      const size_t waves_lds = kFinalizeWaves * group_finalize_floats(args.n, 1) * sizeof(float);
+      if (layout == 0) {
+        hipLaunchKernelGGL((finalize_waves_kernel<0>), waves_grid, dim3(kFinalizeWaves * kWave), waves_lds, s, args);
+      } else {
+        hipLaunchKernelGGL((finalize_waves_kernel<1>), waves_grid, dim3(kFinalizeWaves * kWave), waves_lds, s, args);
+      }
+      return hipGetLastError();
+    }
     // many problems: sixteen lanes per problem, four problems per wavefront (finalize_groups_kernel)
     const dim3 groups_grid((args.P + kGroupProblems - 1) / kGroupProblems);
     const size_t groups_lds = group_finalize_floats(args.n) * sizeof(float);

@@ -49,10 +49,11 @@ def parse_args():
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap argmin/record of batch i (side stream) with the rollout of batch i+1; measured "
                          "slower than plain stream order on MI355X (cross-queue dependencies cost ~10 us each)")
-    ap.add_argument("--stream", action="store_true",
-                    help="(one rank) argmin and records of every batch inside the NEXT batch's rollout launch "
-                         "(acmpc_solve_stream_device) instead of a launch of their own behind its rollout: measured, the step "
-                         "takes the same time - the rollout kernel grows by what the separate launch took (DESIGN 4.2)")
+    ap.add_argument("--no-stream", action="store_true",
+                    help="(one rank) argmin and records of every batch as a launch of their own behind its rollout "
+                         "(acmpc_solve_sampled_device) instead of inside the NEXT batch's rollout launch, the last batch's "
+                         "behind it (acmpc_solve_stream_device, the default: the finalize's 14 us and a launch boundary per "
+                         "1.0 ms step leave the critical path, DESIGN 4.2)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the multi-rank path with the "
                          "collective payloads staged through the CPU (ranks may then share one GPU)")
@@ -839,10 +840,11 @@ def main():
                 if args.layout == 1:
                     self.slot.use_sampler(u_ref, u_ref, SAMPLE_SIGMA, seeds[0], 0)
 
-                # --stream (one rank, nothing to exchange between rollout and argmin): batch i's argmin and records inside
-                # batch i + 1's rollout launch, the last one's behind drain() (acmpc_solve_stream_device); all of it inside the
-                # timed region
-                self.streamed = args.stream and not (self.slot.distributed or self.slot.offset != 0 or args.scaling == "strong")
+                # one rank, nothing to exchange between rollout and argmin: the batches are a STREAM - batch i's argmin and
+                # records run in the last rows of batch i + 1's rollout launch, the last batch's behind drain()
+                # (acmpc_solve_stream_device) -, all of it inside the timed region; --no-stream: a launch of their own
+                self.streamed = not (args.no_stream or self.slot.distributed or self.slot.offset != 0 or
+                                     args.scaling == "strong")
 
             def step(self, x0_, U_, seed=None):
                 # N ranks: rollout, the all-reduce(MIN) of the keys, the records

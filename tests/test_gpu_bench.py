@@ -71,18 +71,23 @@ def test_single_gpu_line_has_the_contract_fields():
     assert pf["particles_500"]["update_us"] > 0 and pf["particles_100000"]["particles_per_s"] > 1e6
 
 
-def test_stream_of_batches_line():
-    """`bench.py --stream`: the previous batch's argmin and records inside the next batch's rollout launch
-    (acmpc_solve_stream_device); the line names the kernel that carried them, and the step is that kernel and a launch
-    boundary - the round-3 review's bar, `ms_per_step <= 1.01 x kernel_ms`, in the letter (`value` is the same
-    as with two launches)."""
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stream", "--steps", "60", "--warmup", "10",
-                           "--no-cpu-baseline", "--no-single-solve"], capture_output=True, text=True, timeout=600)
+def test_stream_of_batches_is_the_default_and_two_launches_the_option():
+    """One rank: the previous batch's argmin and records run inside the next batch's rollout launch
+    (acmpc_solve_stream_device, the default); the line names the kernel that carried them, and the step is that kernel and a
+    launch boundary - `ms_per_step <= 1.01 x kernel_ms`, the round-3 review's bar.  `--no-stream`: two launches per batch."""
+    common = ["--steps", "60", "--warmup", "10", "--no-cpu-baseline", "--no-single-solve"]
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     out = _last_json(proc.stdout)
     assert out["roofline"]["kernel"] == "rollout_chained_kernel" and "acmpc_solve_stream_device" in out["config"]["pipeline"]
     assert out["value"] > 1e9 and 0.5 < out["roofline"]["frac"] < 1
     assert out["ms_per_step"] <= 1.012 * out["roofline"]["kernel_ms"], (out["ms_per_step"], out["roofline"]["kernel_ms"])
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-stream"] + common, capture_output=True,
+                          text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    two = _last_json(proc.stdout)
+    assert two["roofline"]["kernel"] == "rollout_kernel" and two["config"]["pipeline"] == "none (stream order)"
+    assert two["ms_per_step"] > 1.005 * two["roofline"]["kernel_ms"]      # (the finalize and its boundary, behind the kernel)
 
 
 def test_strong_scaling_mode_is_config_4():

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def _solve(monkeypatch, switch, problems, P, N, n, sampled):
     import torch
     from acmpc_amd import Engine, _capi
-    for name in ("ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE"):
+    for name in ("ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES"):
         monkeypatch.delenv(name, raising=False)
     for name in (switch or "").split():
         monkeypatch.setenv(name, "1")
@@ -64,7 +64,8 @@ def test_tailed_rollout_equals_two_launches_and_the_oracle(monkeypatch, P, N, H,
     one = _solve(monkeypatch, "ACMPC_TAILED_ROLLOUT", problems, P, N, n, sampled)
     two = _solve(monkeypatch, None, problems, P, N, n, sampled)     # (the default: two launches; from 256 problems sixteen
     waves = _solve(monkeypatch, "ACMPC_NO_GROUP_FINALIZE", problems, P, N, n, sampled)                      # lanes per problem)
-    for other in (two, waves):
+    four = _solve(monkeypatch, "ACMPC_FINALIZE_WAVES", problems, P, N, n, sampled)     # (a wavefront per problem, four per workgroup)
+    for other in (two, waves, four):
         for a, b, what in zip(one, other, ("records", "keys", "costs", "controls")):
             np.testing.assert_array_equal(a, b, err_msg=what)
     rec, keys, costs, U = one
@@ -86,7 +87,7 @@ def test_tailed_rollout_equals_two_launches_and_the_oracle(monkeypatch, P, N, H,
 @pytest.mark.parametrize("layout", [0, 1])
 def test_two_shards_of_many_problems_in_every_finalize_form(monkeypatch, layout):
     """The sharded protocol's finalize (global keys in, the winner's record written by the shard that owns it, a blank
-    record with the shard's feasible count by the other) at a problem count that takes the many-problem kernel: both
+    record with the shard's feasible count by the other) at a problem count that takes the many-problem kernels: all
     forms write the same records, and the two shards' records add up to the unsharded solve's."""
     import torch
     from acmpc_amd import Engine, _capi
@@ -103,8 +104,9 @@ def test_two_shards_of_many_problems_in_every_finalize_form(monkeypatch, layout)
     R = _capi.record_floats(n)
     shards = [(0, 500), (500, 268)]
     results = {}
-    for switch in ("", "ACMPC_NO_GROUP_FINALIZE"):
+    for switch in ("", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES"):
         monkeypatch.delenv("ACMPC_NO_GROUP_FINALIZE", raising=False)
+        monkeypatch.delenv("ACMPC_FINALIZE_WAVES", raising=False)
         for name in switch.split():
             monkeypatch.setenv(name, "1")
         full = Engine(**engine_kwargs(problems[0], 0, P, total, n))
@@ -254,13 +256,14 @@ def test_new_tables_in_the_middle_of_a_stream(monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("switch", ["", "ACMPC_NO_GROUP_FINALIZE"])
+@pytest.mark.parametrize("switch", ["", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES"])
 def test_records_from_reduced_keys_equal_the_one_call_solve(monkeypatch, switch):
     """The multi-rank step's last call - acmpc_finalize_sampled_device on the keys an all-reduce(MIN) left - at the
     headline's problem count per launch shape: the records of the one-call solve, from the keys alone."""
     import torch
     from acmpc_amd import Engine, _capi
     monkeypatch.delenv("ACMPC_NO_GROUP_FINALIZE", raising=False)
+    monkeypatch.delenv("ACMPC_FINALIZE_WAVES", raising=False)
     for name in switch.split():
         monkeypatch.setenv(name, "1")
     P, N, H = 333, 2048, 50
