@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    needle = sys.argv[2] if len(sys.argv) > 2 else "rollout_kernel"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "rollout_"   # (the dominant one: rows are sorted by total duration)
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
