@@ -55,7 +55,9 @@ def _solve(monkeypatch, switch, problems, P, N, n, sampled):
                                    (301, 2048, 20),     # two candidates per lane: 4 workgroups of 512; a last wavefront of
                                                         # the finalize with one problem for its four quarters
                                    (3, 65536 + 1024, 50),   # beyond the one-launch solve's 1 024 workgroups of 64
-                                   (520, 1000, 33)])    # a ragged last workgroup, one candidate per lane
+                                   (520, 1000, 33),     # a ragged last workgroup, one candidate per lane
+                                   (260, 1024, 80),     # 79 steps: more than one pass of a problem's lanes in the finalize
+                                   (257, 512, 130)])    # 129 steps: three passes of sixteen lanes x four, three of 64
 @pytest.mark.parametrize("sampled", [True, False])
 def test_tailed_rollout_equals_two_launches_and_the_oracle(monkeypatch, P, N, H, sampled):
     from acmpc_amd import _capi
@@ -146,8 +148,11 @@ def test_two_shards_of_many_problems_in_every_finalize_form(monkeypatch, layout)
                                            (301, 2048, 20, True),     # a ragged last finalize workgroup and a ragged last row
                                            (520, 1000, 33, False),    # winners read from the previous batch's matrix
                                            (3, 4096, 50, True),       # fewer problems than a finalize workgroup takes
-                                           (40, 2048, 80, True)])     # horizon 80: the finalize image would cost the rollout
+                                           (40, 2048, 80, True),      # horizon 80: the finalize image would cost the rollout
                                                                       # its occupancy - a launch of its own in front
+                                           (1, 64, 3, True),          # one workgroup in all, two steps
+                                           (5, 1000, 59, True),       # 58 steps: the longest horizon the one launch takes
+                                           (7, 4096, 61, False)])     # 60 steps: the first it does not
 @pytest.mark.parametrize("chained", [True, False])
 def test_a_stream_of_batches_equals_one_call_per_batch(monkeypatch, P, N, H, sampled, chained):
     """acmpc_solve_stream_device: batch k's argmin and records computed inside batch k + 1's rollout launch (or by the
