@@ -1261,7 +1261,8 @@ __global__ void __launch_bounds__(kFinalizeWaves * kWave) finalize_waves_kernel(
 // start when the grid has no rollout workgroup left to hand out, in the wave slots the rollout's last generation leaves
 // empty as it drains, and are done before it is.  Measured on the headline's batch (tools/chained_ab.py, launches
 // alternating with the plain kernel in one process; tools/finalize_ab.sh, interleaved bench runs): the kernel is as long
-// as the plain one (-4 .. +3 us), the step 9-15 us shorter than with two launches.  What did NOT work, same tools: the
+// as the plain one or up to 10 us longer (by the box: how ragged the rollout's tail is), the step 2-15 us shorter than
+// with two launches in every pair.  What did NOT work, same tools: the
 // sixteen-lane form on ONE wave per finalize workgroup in the same last rows, +11.5 us on the kernel (its six dependent
 // trips to memory outlast the tail: the step as long as with two launches); the same rows spread evenly through the grid
 // (one in seventeen), +25 us - every finalize workgroup then displaces a rollout workgroup for its ~40 us under a saturated
