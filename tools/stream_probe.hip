@@ -3,6 +3,7 @@
 // arithmetic?  Build & run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/stream_probe.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 
@@ -64,8 +65,8 @@ float time_us(F f, int iters = 30) {
   return t[t.size() / 2];
 }
 
-int main() {
-  const int P = 256, N = 4096, n = 49;
+int main(int argc, char** argv) {
+  const int P = argc > 1 ? atoi(argv[1]) : 256, N = 4096, n = 49;   // (4096: the headline's batch, 6.6 GB per matrix)
   const size_t floats = (size_t)P * n * 2 * N;
   float *U[2], *costs;
   for (int b = 0; b < 2; ++b) {
@@ -74,7 +75,7 @@ int main() {
   }
   hipMalloc(&costs, (size_t)P * N * 4);
   const double bytes = floats * 4.0;
-  for (int blocks : {1024, 2048, 4096, 8192}) {
+  for (int blocks : {2048, 8192, 32768}) {
     float us = time_us([&](int i) { flat_sum<<<blocks, 256>>>((const f32x4*)U[i & 1], costs, floats / 4); });
     printf("flat float4 sum   grid %5d x256 : %7.1f us  %.2f TB/s\n", blocks, us, bytes / us / 1e6);
   }
