@@ -46,6 +46,30 @@ __global__ void __launch_bounds__(256) pattern_sum(const float* __restrict__ U, 
   for (int j = 0; j < CPT; ++j) costs[(size_t)p * N + c0 + j] = acc[j];
 }
 
+// the rollout's pattern with its non-temporal loads, BLOCK threads x 4 adjacent candidates per lane, `work` dependent
+// multiply-adds per step and candidate standing in for the model (0: trivial arithmetic)
+template <int BLOCK, int UNROLL>
+__global__ void __launch_bounds__(BLOCK) pattern_nt(const float* __restrict__ U, float* __restrict__ costs, int N, int n, int work) {
+  const int p = blockIdx.y;
+  const int c0 = (blockIdx.x * BLOCK + threadIdx.x) * 4;
+  if (c0 >= N) return;
+  float acc[4] = {};
+#pragma unroll UNROLL
+  for (int i = 0; i < n; ++i) {
+    const float* row = U + ((size_t)p * n + i) * 2 * (size_t)N + c0;
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row));
+    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + N));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = a[j] * 0.5f + b[j];
+      for (int w = 0; w < work; ++w) x = x * 1.0001f + acc[j] * 0.25f;
+      acc[j] += x;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) costs[(size_t)p * N + c0 + j] = acc[j];
+}
+
 template <typename F>
 float time_us(F f, int iters = 30) {
   hipEvent_t a, b;
@@ -92,6 +116,16 @@ int main(int argc, char** argv) {
     printf("pattern CPT1 unroll49           : %7.1f us  %.2f TB/s\n", us, bytes / us / 1e6);
     us = time_us([&](int i) { pattern_sum<4, 49><<<dim3(N / 1024, P), 256>>>(U[i & 1], costs, N, n); });
     printf("pattern CPT4 unroll49           : %7.1f us  %.2f TB/s\n", us, bytes / us / 1e6);
+  }
+  for (int work : {0, 12}) {
+    float us = time_us([&](int i) { pattern_nt<256, 7><<<dim3(N / 1024, P), 256>>>(U[i & 1], costs, N, n, work); });
+    printf("nt pattern 256 x4, work %2d      : %7.1f us  %.2f TB/s\n", work, us, bytes / us / 1e6);
+    us = time_us([&](int i) { pattern_nt<512, 7><<<dim3(N / 2048, P), 512>>>(U[i & 1], costs, N, n, work); });
+    printf("nt pattern 512 x4, work %2d      : %7.1f us  %.2f TB/s\n", work, us, bytes / us / 1e6);
+    us = time_us([&](int i) { pattern_nt<1024, 7><<<dim3(N / 4096, P), 1024>>>(U[i & 1], costs, N, n, work); });
+    printf("nt pattern 1024 x4, work %2d     : %7.1f us  %.2f TB/s\n", work, us, bytes / us / 1e6);
+    us = time_us([&](int i) { pattern_nt<128, 7><<<dim3(N / 512, P), 128>>>(U[i & 1], costs, N, n, work); });
+    printf("nt pattern 128 x4, work %2d      : %7.1f us  %.2f TB/s\n", work, us, bytes / us / 1e6);
   }
   return 0;
 }
