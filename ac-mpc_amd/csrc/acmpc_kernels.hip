@@ -120,6 +120,15 @@ __device__ __forceinline__ void published() {
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
 
+// Candidate 2 of a sampled round is the LQ plan (SampleArgs::u_extra) - ONE candidate of the launch, in one workgroup.
+// The plan is read in place from pinned HOST memory (the tick's host computes it while the first round runs): only the
+// workgroup that holds global index 2 fetches it.  With every workgroup staging it the last round of a tick moved
+// 256 x 392 B over PCIe for one lane's sake - two microseconds of its fourteen.
+__device__ __forceinline__ bool holds_candidate_2(const RolloutArgs& a, const SampleArgs& smp) {
+  const int64_t first = a.index_offset + static_cast<int64_t>(blockIdx.x) * kWave;
+  return smp.u_extra != nullptr && first <= 2 && 2 < first + kWave;
+}
+
 // PACK = candidates per arithmetic state: 2 = pairs in v_pk_* instructions, 1 = plain float32 instructions.
 // Mode T with two candidates per lane needs 67 VGPRs as the compiler allocates it freely: seven waves per SIMD, where a
 // launch of 1 M candidates is eight - the eighth workgroup of every CU then runs alone after the others (a second
@@ -485,7 +494,7 @@ __device__ __forceinline__ void rollout_sampled_body(const RolloutArgs& a, const
   const float* __restrict__ x0 = a.x0 + p * 3;
   const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
   const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
-  const float* __restrict__ extra = (smp.u_extra != nullptr) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
+  const float* __restrict__ extra = holds_candidate_2(a, smp) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
   const float* __restrict__ knot_weight = sp.segments;
   float* s_wp = s_fused;
   float* s_xy = s_wp + n * kCoefT;
@@ -1514,7 +1523,7 @@ __global__ void __launch_bounds__(2 * kWave) rollout_sampled_pair_kernel(const R
     const SampleSpec sp = smp.spec;
     const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
     const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
-    const float* __restrict__ extra = (smp.u_extra != nullptr) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ extra = holds_candidate_2(a, smp) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
     const float* __restrict__ knot_weight = sp.segments;
     const bool chained = smp.prev_keys != nullptr;
     constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
@@ -1801,7 +1810,7 @@ __global__ void __launch_bounds__(kQuadWaves * kWave) rollout_sampled_quad_kerne
     // ---- controls: requests, its quarter of the draws, the uniform operands of the control waves into LDS, then chunk by chunk ----
     const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
     const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
-    const float* __restrict__ extra = (smp.u_extra != nullptr) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ extra = holds_candidate_2(a, smp) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
     const float* __restrict__ knot_weight = sp.segments;
     const bool chained = smp.prev_keys != nullptr;
     constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
@@ -2025,7 +2034,7 @@ __global__ void __launch_bounds__(3 * kWave) rollout_sampled_trio_kernel(const R
     const SampleSpec sp = smp.spec;
     const float* __restrict__ centre = smp.centre + static_cast<size_t>(p) * smp.centre_stride;
     const float* __restrict__ ref = (smp.u_ref != nullptr) ? smp.u_ref + static_cast<size_t>(p) * n * 2 : nullptr;
-    const float* __restrict__ extra = (smp.u_extra != nullptr) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
+    const float* __restrict__ extra = holds_candidate_2(a, smp) ? smp.u_extra + static_cast<size_t>(p) * n * 2 : nullptr;
     const float* __restrict__ knot_weight = sp.segments;
     const bool chained = smp.prev_keys != nullptr;
     constexpr int kPairs = (kStagedSteps + kWave - 1) / kWave;
