@@ -19,7 +19,7 @@ track = workloads.synthetic_track("silverstone")
 paths = [workloads.reference_path_from_centreline(workloads.local_centreline(track, (i * 2) % len(track["centre"])), 50)
          for i in range(1020)]
 for device in (True, False):
-    for check in ((10, 5) if device else (10,)):
+    for check in ((10, 5, 3, 2, 1) if device else (10,)):
         cfg = copy.deepcopy(workloads.RACING_CONTROL["silverstone"])
         cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
         cfg.update(device_prologue=device, speed_profile_check_every=check)
