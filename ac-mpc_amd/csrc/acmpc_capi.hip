@@ -147,7 +147,7 @@ struct acmpc_ctx {
   acmpc::LaunchOptions opt;
   struct Switches {
     bool no_verified_search = false, no_solo = false, no_fused_finalize = false, no_traced_finalize = false,
-         no_chained_rounds = false, no_chained_stream = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false,
+         no_chained_rounds = false, no_chained_stream = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false, tick_no_inline_path = false,
          tailed_rollout = false;
   } sw;
 
@@ -606,7 +606,7 @@ const char* const kOptionNames[] = {
     "ACMPC_SHAPE", "ACMPC_T_PACK", "ACMPC_NO_TILE", "ACMPC_TILE_ROWS", "ACMPC_TILE_TABLE", "ACMPC_NO_TRIO_ROUNDS",
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
-    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES",
+    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TICK_NO_INLINE_PATH", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES",
     "ACMPC_NO_CHAINED_STREAM"};
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
@@ -642,6 +642,7 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_NO_FUSED_SAMPLING") { w.no_fused_sampling = on; return true; }
   if (key == "ACMPC_TICK_GRAPH") { w.tick_graph = on; return true; }
   if (key == "ACMPC_TICK_NO_FLAG") { w.tick_no_flag = on; return true; }
+  if (key == "ACMPC_TICK_NO_INLINE_PATH") { w.tick_no_inline_path = on; return true; }
   if (key == "ACMPC_TAILED_ROLLOUT") { w.tailed_rollout = on; return true; }
   return false;
 }
@@ -1789,6 +1790,11 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   } else {
     pa.header_by_value = 1;
     pa.header_value = *h;
+    if (!from_map && H <= acmpc::kInlinePathPoints && !c->sw.tick_no_inline_path) {
+      pa.path_by_value = 1;
+      std::memcpy(pa.coords_value, coords, static_cast<size_t>(H) * 3 * sizeof(double));
+      if (centre != nullptr) std::memcpy(pa.centre_value, centre, static_cast<size_t>(n) * 2 * sizeof(float));
+    }
     int rc_rounds = ACMPC_OK;
     const hipError_t e = enqueue(s, &rc_rounds);
     if (rc_rounds != ACMPC_OK || e != hipSuccess) {

@@ -47,6 +47,11 @@ struct PrologueArgs {
   // replayed from a captured graph), carried in the kernel arguments themselves, which saves the read over the host link
   int header_by_value;
   TickHeader header_value;
+  // likewise the path and the previous plan of a directly launched tick, up to kInlinePathPoints points: the kernel
+  // arguments live in device memory, the pinned block is a trip over the host link in front of construct_waypoints
+  int path_by_value;
+  double coords_value[3 * 64];   // [H][3], H <= kInlinePathPoints
+  float centre_value[2 * 64];    // [n][2]
   const TickHeader* header;   // pinned host memory
   const double* coords;       // [H][3] (x, y, width), pinned host memory
   const float* centre_in;     // [n][2] pinned host memory (ignored when header->centre_is_reference)
@@ -74,6 +79,7 @@ struct PrologueArgs {
   int* index_out;             // pinned host memory
 };
 
+constexpr int kInlinePathPoints = 64;
 constexpr int kPrologueMaxSteps = admm::kPcrMaxN;  // LDS budget of the single-workgroup prologue (~390 n bytes) and the
                                                    // size up to which the tridiagonal solve is the parallel one
 

@@ -280,8 +280,8 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
       }
     } else {
       for (int r = lane; r < n; r += 64) {   // construct_waypoints: x, y = the first n points of the path
-        xr[r] = static_cast<double>(static_cast<float>(a.coords[3 * r]));
-        yr[r] = static_cast<double>(static_cast<float>(a.coords[3 * r + 1]));
+        xr[r] = static_cast<double>(static_cast<float>((a.path_by_value != 0) ? a.coords_value[3 * r] : a.coords[3 * r]));
+        yr[r] = static_cast<double>(static_cast<float>((a.path_by_value != 0) ? a.coords_value[3 * r + 1] : a.coords[3 * r + 1]));
       }
     }
     __syncthreads();
@@ -322,8 +322,13 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
 #pragma unroll
   for (int q = 0; q < kPerLane; ++q) {
     const int i = min(lane + 64 * q, n - 1);
-    centre_in_v[q] = (h.centre_is_reference != 0) ? 0.0f : a.centre_in[2 * i];
-    centre_in_k[q] = (h.centre_is_reference != 0) ? 0.0f : a.centre_in[2 * i + 1];
+    if (a.path_by_value != 0) {   // (i < kInlinePathPoints: the host checked the horizon)
+      centre_in_v[q] = (h.centre_is_reference != 0) ? 0.0f : a.centre_value[2 * min(i, kInlinePathPoints - 1)];
+      centre_in_k[q] = (h.centre_is_reference != 0) ? 0.0f : a.centre_value[2 * min(i, kInlinePathPoints - 1) + 1];
+    } else {
+      centre_in_v[q] = (h.centre_is_reference != 0) ? 0.0f : a.centre_in[2 * i];
+      centre_in_k[q] = (h.centre_is_reference != 0) ? 0.0f : a.centre_in[2 * i + 1];
+    }
     warm_v[q] = (a.warm_capacity >= n) ? state[2 + i] : 0.0;
   }
 #pragma unroll
@@ -343,6 +348,11 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
       }
     }
     if (lane == 0) a.index_out[0] = first;
+    team.sync();
+    coords = s_coords;
+  } else if (a.path_by_value != 0) {
+    // the caller's path out of the kernel arguments (device memory) instead of the pinned block (the host link)
+    for (int r = lane; r < 3 * H; r += 64) s_coords[r] = a.coords_value[r];
     team.sync();
     coords = s_coords;
   }
