@@ -147,7 +147,7 @@ struct acmpc_ctx {
   acmpc::LaunchOptions opt;
   struct Switches {
     bool no_verified_search = false, no_solo = false, no_fused_finalize = false, no_traced_finalize = false,
-         no_chained_rounds = false, no_chained_stream = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false, tick_no_inline_path = false,
+         no_chained_rounds = false, no_chained_stream = false, no_graph = false, no_fused_sampling = false, tick_graph = false, tick_no_flag = false, tick_no_inline_path = false, no_zero_copy = false,
          tailed_rollout = false;
   } sw;
 
@@ -591,7 +591,7 @@ int ensure_staging(acmpc_ctx* c) {
   const int rc_tail = ensure_tail_buffers(c);
   if (rc_tail != ACMPC_OK) return rc_tail;
   ACMPC_HIP(c, host_alloc_once(&c->h_keys, static_cast<size_t>(p.max_problems) * sizeof(int64_t)));
-  ACMPC_HIP(c, host_alloc_once(&c->h_io, static_cast<size_t>(p.max_problems) * (3 + acmpc_record_floats(p.max_steps)) * sizeof(float)));
+  ACMPC_HIP(c, host_alloc_once(&c->h_io, (static_cast<size_t>(p.max_problems) * (3 + acmpc_record_floats(p.max_steps)) + 4) * sizeof(float)));
   if (p.lq_candidate != 0 && c->h_lq == nullptr) {
     const size_t lq_bytes = static_cast<size_t>(p.max_problems) * p.max_steps * 2 * sizeof(float);
     ACMPC_HIP(c, host_alloc_once(&c->h_lq, lq_bytes));
@@ -606,7 +606,7 @@ const char* const kOptionNames[] = {
     "ACMPC_SHAPE", "ACMPC_T_PACK", "ACMPC_NO_TILE", "ACMPC_TILE_ROWS", "ACMPC_TILE_TABLE", "ACMPC_NO_TRIO_ROUNDS",
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
-    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TICK_NO_INLINE_PATH", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES",
+    "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TICK_NO_INLINE_PATH", "ACMPC_NO_ZERO_COPY", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES",
     "ACMPC_NO_CHAINED_STREAM"};
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
@@ -643,6 +643,7 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_TICK_GRAPH") { w.tick_graph = on; return true; }
   if (key == "ACMPC_TICK_NO_FLAG") { w.tick_no_flag = on; return true; }
   if (key == "ACMPC_TICK_NO_INLINE_PATH") { w.tick_no_inline_path = on; return true; }
+  if (key == "ACMPC_NO_ZERO_COPY") { w.no_zero_copy = on; return true; }
   if (key == "ACMPC_TAILED_ROLLOUT") { w.tailed_rollout = on; return true; }
   return false;
 }
@@ -1073,27 +1074,53 @@ int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_
   if (rc != ACMPC_OK) return rc;
   const size_t cand = static_cast<size_t>(P) * N;
   const size_t rec_bytes = static_cast<size_t>(P) * acmpc_record_floats(n) * sizeof(float);
-  // the small transfers go through page-locked staging: a copy from or to pageable memory is a synchronous staged copy of
-  // ~15 us whatever its size (measured: 1 kB down), two of which were a third of a 4 096-candidate solve
+  // Nothing small crosses the host link as a copy of its own (round 4): the start states are written into the handle's
+  // page-locked block and READ THERE by the kernels, keys and records are written there BY the kernels (page-locked host
+  // memory is device-addressable: what acmpc_control_tick does with its tick block) - each of those copies was a packet of
+  // ~4 us in the stream.  The control matrix is read in place too when the caller built it in page-locked memory
+  // (acmpc_host_alloc): the rollout then streams it over the host link while it computes, instead of behind a copy of the
+  // whole matrix; from pageable memory it is staged into device memory as before.  ACMPC_NO_ZERO_COPY=1: every transfer a copy.
   float* h_x0 = c->h_io;
-  float* h_records = c->h_io + static_cast<size_t>(P) * 3;
+  float* h_records = c->h_io + ((static_cast<size_t>(P) * 3 + 3) & ~static_cast<size_t>(3));   // (16-byte aligned)
   std::memcpy(h_x0, x0, static_cast<size_t>(P) * 3 * sizeof(float));
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, h_x0, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_U, U, cand * n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
-  if (use_solo(c, P, N, n, layout)) {
-    rc = solve_solo(c, c->d_x0, c->d_U, P, N, n, layout, costs != nullptr ? c->d_costs : nullptr, c->d_keys,
-                    records != nullptr ? c->d_records : nullptr, s);
+  const bool solo = use_solo(c, P, N, n, layout);
+  // (the one-launch solve: a few workgroups, latency is everything.  A batch of thousands of problems keeps its small
+  // copies - every workgroup fetching its start state over the host link would be thousands of requests for one packet)
+  const bool in_place = !c->sw.no_zero_copy && solo;
+  const float* d_x0 = c->d_x0;
+  const float* d_U = c->d_U;
+  int64_t* d_keys = c->d_keys;
+  float* d_records = records != nullptr ? c->d_records : nullptr;
+  if (in_place) {
+    d_x0 = h_x0;
+    d_keys = c->h_keys;
+    if (records != nullptr) d_records = h_records;
+  } else {
+    ACMPC_HIP(c, hipMemcpyAsync(c->d_x0, h_x0, static_cast<size_t>(P) * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  if (!c->sw.no_zero_copy) {
+    hipPointerAttribute_t where{};
+    if (hipPointerGetAttributes(&where, U) == hipSuccess && where.type == hipMemoryTypeHost && where.devicePointer != nullptr) {
+      d_U = static_cast<const float*>(where.devicePointer);
+    } else {
+      (void)hipGetLastError();   // (pageable memory is not an error here)
+    }
+  }
+  if (d_U == c->d_U) ACMPC_HIP(c, hipMemcpyAsync(c->d_U, U, cand * n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+  if (solo) {
+    rc = solve_solo(c, d_x0, d_U, P, N, n, layout, costs != nullptr ? c->d_costs : nullptr, d_keys, d_records, s);
   } else {
     acmpc::LaunchShape shape;
-    rc = rollout(c, c->d_x0, c->d_U, P, N, n, layout, 0, costs != nullptr ? c->d_costs : nullptr, s, &shape);
+    rc = rollout(c, d_x0, d_U, P, N, n, layout, 0, costs != nullptr ? c->d_costs : nullptr, s, &shape);
     if (rc != ACMPC_OK) return rc;
-    rc = finalize(c, nullptr, c->d_keys, c->d_x0, c->d_U, P, N, n, layout, 0, records != nullptr ? c->d_records : nullptr,
-                  shape.blocks_per_problem, s);
+    rc = finalize(c, nullptr, d_keys, d_x0, d_U, P, N, n, layout, 0, d_records, shape.blocks_per_problem, s);
   }
   if (rc != ACMPC_OK) return rc;
-  ACMPC_HIP(c, hipMemcpyAsync(c->h_keys, c->d_keys, static_cast<size_t>(P) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  if (!in_place) {
+    ACMPC_HIP(c, hipMemcpyAsync(c->h_keys, c->d_keys, static_cast<size_t>(P) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (records != nullptr) ACMPC_HIP(c, hipMemcpyAsync(h_records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
+  }
   if (costs != nullptr) ACMPC_HIP(c, hipMemcpyAsync(costs, c->d_costs, cand * sizeof(float), hipMemcpyDeviceToHost, s));
-  if (records != nullptr) ACMPC_HIP(c, hipMemcpyAsync(h_records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
   if (records != nullptr) std::memcpy(records, h_records, rec_bytes);
   if (best_idx != nullptr)
