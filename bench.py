@@ -244,7 +244,7 @@ def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50, p
     noise = (np.random.default_rng(5).standard_normal((N, n, 2)) * np.array(SAMPLE_SIGMA)).astype(np.float32)
     noise[0] = 0.0
     U = np.empty((1, N, n, 2), dtype=np.float32)
-    if pinned:   # the matrix built in page-locked memory (acmpc_host_alloc): one DMA up instead of the runtime's staging
+    if pinned:   # the matrix built in page-locked memory (acmpc_host_alloc): the rollout reads it in place over the host link
         U = _capi.pinned_empty((1, N, n, 2), np.float32)
     warm, wall, infeasible = None, np.empty(poses), 0
     for i in range(poses + 20):
@@ -271,7 +271,8 @@ def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50, p
             "solve_us_p50": float(np.percentile(wall, 50) * 1e6), "solve_us_p99": float(np.percentile(wall, 99) * 1e6),
             "traj_per_s_at_p50": N / float(np.percentile(wall, 50)), "winners_with_a_bound_violation": infeasible,
             "controls_in": "page-locked host memory (acmpc_host_alloc)" if pinned else "pageable host memory",
-            "note": "PCIe-inclusive (1.6 MB of controls up per solve): never `value`"}
+            "note": "PCIe-inclusive (1.6 MB of controls per solve: staged into device memory from pageable memory, read in place "
+                    "from page-locked memory): never `value`"}
 
 
 def particle_filter_block(workloads, iters=20):
