@@ -38,6 +38,15 @@ def timed(fn, iters=300):
 
 print("acmpc_solve pageable U   p50 %.1f us p99 %.1f" % tuple(timed(lambda: eng.solve(x0, U_page, layout=0, want_costs=False))))
 print("acmpc_solve pinned U     p50 %.1f us p99 %.1f" % tuple(timed(lambda: eng.solve(x0, U_pin, layout=0, want_costs=False))))
+
+
+def with_new_path(U):   # what a controller does per pose: new tables, then the solve (the upload rides in the solve)
+    eng.set_paths(batch.tables)
+    eng.solve(x0, U, layout=0, want_costs=False)
+
+
+print("set_paths + solve, pageable U   p50 %.1f us p99 %.1f" % tuple(timed(lambda: with_new_path(U_page))))
+print("set_paths + solve, pinned U     p50 %.1f us p99 %.1f" % tuple(timed(lambda: with_new_path(U_pin))))
 dev = torch.empty(U_page.shape, device="cuda")
 t_page, t_pin = torch.from_numpy(U_page), torch.from_numpy(U_pin)
 
