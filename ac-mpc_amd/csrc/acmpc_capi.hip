@@ -331,8 +331,15 @@ void stream_synchronised(acmpc_ctx* c, hipStream_t s) {
 // up to date on the launch stream before the graph runs.
 int upload_frames(acmpc_ctx* c, hipStream_t s) {
   if (!c->frames_dirty || c->h_nn_frames.empty() || c->d_nn_frames == nullptr) return ACMPC_OK;
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_frames, c->h_nn_frames.data(), c->h_nn_frames.size() * sizeof(float),
-                              hipMemcpyHostToDevice, s));
+  const size_t floats = c->h_nn_frames.size();
+  const void* src = c->h_nn_frames.data();
+  if (c->h_upload != nullptr && !c->upload_busy && floats <= kUploadFloats && !c->sw.no_zero_copy) {   // (as upload_tables)
+    std::memcpy(c->h_upload, src, floats * sizeof(float));
+    src = c->h_upload;
+    c->upload_busy = true;
+    c->upload_stream = s;
+  }
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_frames, src, floats * sizeof(float), hipMemcpyHostToDevice, s));
   c->frames_dirty = false;
   return ACMPC_OK;
 }
