@@ -919,12 +919,17 @@ int acmpc_pf_score(acmpc_pf* h, const float* states, int32_t P, const float* obs
   a.thr_rotation = h->prm.threshold_rotation;
   a.thr_offset = h->prm.threshold_offset;
   a.thr_error = h->prm.threshold_error;
-  a.minimum_offset = reinterpret_cast<double*>(h->d_down);
+  // the reference's particle counts (hundreds): the scoring kernel writes its results straight into the page-locked block
+  // the host reads them from (posted writes over the host link; page-locked memory is device-addressable) - no copy
+  // packet behind the kernel.  Large counts keep the copy: megabytes of 8-byte pieces are better moved as one DMA.
+  const bool in_place = P < 4096;
+  unsigned char* out = in_place ? h->h_down : h->d_down;
+  a.minimum_offset = reinterpret_cast<double*>(out);
   a.heading_offset = a.minimum_offset + P;
   a.error = a.heading_offset + P;
   a.score = a.error + P;
-  a.track_indices = reinterpret_cast<int32_t*>(h->d_down + 4 * pd);
-  a.valid = reinterpret_cast<uint8_t*>(h->d_down + 4 * pd + static_cast<size_t>(P) * 3 * sizeof(int32_t));
+  a.track_indices = reinterpret_cast<int32_t*>(out + 4 * pd);
+  a.valid = reinterpret_cast<uint8_t*>(out + 4 * pd + static_cast<size_t>(P) * 3 * sizeof(int32_t));
   (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
   PF_HIP(h, launch_nearest(h, a, P, s));
   if (P >= 4096) {
@@ -935,7 +940,7 @@ int acmpc_pf_score(acmpc_pf* h, const float* states, int32_t P, const float* obs
   }
   PF_HIP(h, hipGetLastError());
   const size_t down = 4 * pd + static_cast<size_t>(P) * (3 * sizeof(int32_t) + 1);
-  PF_HIP(h, hipMemcpyAsync(h->h_down, h->d_down, down, hipMemcpyDeviceToHost, s));
+  if (!in_place) PF_HIP(h, hipMemcpyAsync(h->h_down, h->d_down, down, hipMemcpyDeviceToHost, s));
   PF_HIP(h, hipStreamSynchronize(s));
   const unsigned char* dn = h->h_down;
   std::memcpy(minimum_offset, dn, pd);
