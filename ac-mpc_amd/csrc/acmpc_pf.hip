@@ -362,7 +362,7 @@ __global__ void pf_advance_kernel(float* states, const float* delta, const float
 // estimate (localiser.py:561-579).  One workgroup; float64 accumulation in a fixed order.
 __global__ void __launch_bounds__(kBlock) pf_estimate_kernel(const float* states, const float* scores, int P,
                                                              double* out /*[5]: x, y, yaw, max_dist, max_angle*/,
-                                                             const int* live = nullptr) {
+                                                             const int* live = nullptr, int* counts_out = nullptr) {
   __shared__ double s[4][kBlock];
   const int tid = threadIdx.x;
   if (live != nullptr) P = live[0];
@@ -413,6 +413,8 @@ __global__ void __launch_bounds__(kBlock) pf_estimate_kernel(const float* states
     __syncthreads();
   }
   if (tid == 0) {
+    if (counts_out != nullptr && live != nullptr)   // (the device-resident filter: its four counts beside the estimate)
+      for (int e = 0; e < 4; ++e) counts_out[e] = live[e];
     out[0] = est[0];
     out[1] = est[1];
     out[2] = est[2];
@@ -1178,11 +1180,11 @@ int acmpc_pf_filter_update(acmpc_pf* h, const float* obs_left, int32_t k_left, c
   PF_HIP(h, hipGetLastError());
   h->f_cur = 1 - h->f_cur;
   double* res = h->h_result;
+  // the estimate and the counts are written by the last kernel straight into the page-locked result block (posted writes
+  // over the host link): no copy packets behind the update
   hipLaunchKernelGGL(pf_estimate_kernel, dim3(1), dim3(kBlock), 0, s, h->f_states[h->f_cur], h->f_scores[h->f_cur], -1,
-                     h->d_out, h->f_counts);
+                     res, h->f_counts, reinterpret_cast<int*>(res + 8));
   PF_HIP(h, hipGetLastError());
-  PF_HIP(h, hipMemcpyAsync(res, h->d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
-  PF_HIP(h, hipMemcpyAsync(res + 8, h->f_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   PF_HIP(h, hipStreamSynchronize(s));
   const int* counts = reinterpret_cast<const int*>(res + 8);
   for (int i = 0; i < 5; ++i) result[i] = res[i];
