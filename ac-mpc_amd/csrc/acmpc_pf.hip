@@ -962,6 +962,22 @@ int acmpc_pf_advance(acmpc_pf* h, float* states, const float* delta, const float
   if (rc != ACMPC_OK) return rc;
   hipStream_t s = h->stream;
   const size_t pf = static_cast<size_t>(P) * sizeof(float);
+  if (P < 4096) {
+    // the reference's particle counts: every particle is read and written once by its own lane, so the kernel works IN
+    // the page-locked block (20 bytes per particle of the 45 it holds) - four copies from and to pageable memory, a
+    // synchronous staged copy of ~15 us each whatever its size, were most of this call
+    float* block = reinterpret_cast<float*>(h->h_down);
+    std::memcpy(block, states, 3 * pf);
+    std::memcpy(block + 3 * static_cast<size_t>(P), delta, pf);
+    std::memcpy(block + 4 * static_cast<size_t>(P), velocity, pf);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(pf_advance_kernel, dim3((P + 255) / 256), dim3(256), 0, s, block, block + 3 * static_cast<size_t>(P),
+                       block + 4 * static_cast<size_t>(P), P, static_cast<float>(h->prm.wheelbase), static_cast<float>(dt));
+    PF_HIP(h, hipGetLastError());
+    PF_HIP(h, hipStreamSynchronize(s));
+    std::memcpy(states, block, 3 * pf);
+    return ACMPC_OK;
+  }
   PF_HIP(h, hipMemcpyAsync(h->d_states, states, 3 * pf, hipMemcpyHostToDevice, s));
   PF_HIP(h, hipMemcpyAsync(h->d_aux, delta, pf, hipMemcpyHostToDevice, s));
   PF_HIP(h, hipMemcpyAsync(h->d_aux + P, velocity, pf, hipMemcpyHostToDevice, s));
