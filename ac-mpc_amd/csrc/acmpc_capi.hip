@@ -42,13 +42,6 @@ struct acmpc_ctx {
   int P_set = 0, n_set = 0;
   bool tables_dirty = false;
   bool frames_dirty = false;  // the verified search's frames of the current paths are not on the device yet
-  // small tables go up through a page-locked staging block (an async DMA packet) instead of straight from the pageable
-  // vectors (a synchronous staged copy of ~15 us whatever its size).  The block is free again once the stream it was
-  // copied on has been synchronised by the library (acmpc_solve does at its end): `upload_busy` says when it is not, and
-  // the upload then takes the pageable route
-  float* h_upload = nullptr;
-  hipStream_t upload_stream = nullptr;
-  bool upload_busy = false;
 
   // device state (created lazily)
   bool device_ready = false;
@@ -250,8 +243,6 @@ hipError_t host_alloc_once(T** slot, size_t bytes) {
   return hipHostMalloc(reinterpret_cast<void**>(slot), bytes, hipHostMallocDefault);
 }
 
-constexpr size_t kUploadFloats = 64 * 1024;   // the page-locked staging block for small table uploads (256 kB)
-
 int ensure_device(acmpc_ctx* c) {
   if (c->device_ready) return ACMPC_OK;
   c->touched_device = true;
@@ -279,51 +270,25 @@ int ensure_device(acmpc_ctx* c) {
     ACMPC_HIP(c, alloc_once(&c->d_nn_frames, static_cast<size_t>(p.max_problems) * sizeof(float) *
                                                  acmpc::verified_frame_floats(std::max(std::min(p.max_steps, kMaxVerifiedSteps),
                                                                                        acmpc::kVerifiedWindow))));
-  ACMPC_HIP(c, host_alloc_once(&c->h_upload, kUploadFloats * sizeof(float)));
   c->device_ready = true;
   return ACMPC_OK;
 }
 
 int upload_tables(acmpc_ctx* c, hipStream_t s) {
   if (c->P_set == 0) return fail(c, ACMPC_ESTATE, "acmpc_set_paths has not been called");
-  const bool frames = c->frames_dirty && !c->h_nn_frames.empty() && c->d_nn_frames != nullptr;
-  if (!frames && !c->tables_dirty) return ACMPC_OK;
-  const size_t frame_floats = frames ? c->h_nn_frames.size() : 0;
-  const size_t coef_floats = c->tables_dirty ? static_cast<size_t>(c->P_set) * c->n_set * c->coef_stride : 0;
-  // small and the staging block free: one memcpy into page-locked memory, then true async DMA (the vectors may change
-  // as soon as this returns, as with the pageable route, which stages before returning)
-  const bool staged = c->h_upload != nullptr && !c->upload_busy && frame_floats + coef_floats <= kUploadFloats &&
-                      !c->sw.no_zero_copy;
-  float* stage = c->h_upload;
-  if (frames) {
-    const void* src = c->h_nn_frames.data();
-    if (staged) {
-      std::memcpy(stage, src, frame_floats * sizeof(float));
-      src = stage;
-      stage += frame_floats;
-    }
-    ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_frames, src, frame_floats * sizeof(float), hipMemcpyHostToDevice, s));
+  // pageable source: hipMemcpyAsync stages it before returning, so the host vectors may change afterwards.  (Round 4 tried
+  // a page-locked staging block for small tables - a memcpy and a true asynchronous packet: 0.7 us of a 91 us
+  // set_paths + solve, not worth the bookkeeping of when the block is free again.)
+  if (c->frames_dirty && !c->h_nn_frames.empty() && c->d_nn_frames != nullptr) {
+    ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_frames, c->h_nn_frames.data(), c->h_nn_frames.size() * sizeof(float),
+                                hipMemcpyHostToDevice, s));
     c->frames_dirty = false;
   }
-  if (c->tables_dirty) {
-    const void* src = c->h_coef.data();
-    if (staged) {
-      std::memcpy(stage, src, coef_floats * sizeof(float));
-      src = stage;
-    }
-    ACMPC_HIP(c, hipMemcpyAsync(c->d_coef, src, coef_floats * sizeof(float), hipMemcpyHostToDevice, s));
-    c->tables_dirty = false;
-  }
-  if (staged) {
-    c->upload_busy = true;
-    c->upload_stream = s;
-  }
+  if (!c->tables_dirty) return ACMPC_OK;
+  const size_t bytes = static_cast<size_t>(c->P_set) * c->n_set * c->coef_stride * sizeof(float);
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_coef, c->h_coef.data(), bytes, hipMemcpyHostToDevice, s));
+  c->tables_dirty = false;
   return ACMPC_OK;
-}
-
-// the library has just synchronised `s`: a staged upload on it has landed
-void stream_synchronised(acmpc_ctx* c, hipStream_t s) {
-  if (c->upload_busy && c->upload_stream == s) c->upload_busy = false;
 }
 
 // The captured optimisation carries the coefficient table in its staging block but not the frames of mode T's
@@ -331,15 +296,8 @@ void stream_synchronised(acmpc_ctx* c, hipStream_t s) {
 // up to date on the launch stream before the graph runs.
 int upload_frames(acmpc_ctx* c, hipStream_t s) {
   if (!c->frames_dirty || c->h_nn_frames.empty() || c->d_nn_frames == nullptr) return ACMPC_OK;
-  const size_t floats = c->h_nn_frames.size();
-  const void* src = c->h_nn_frames.data();
-  if (c->h_upload != nullptr && !c->upload_busy && floats <= kUploadFloats && !c->sw.no_zero_copy) {   // (as upload_tables)
-    std::memcpy(c->h_upload, src, floats * sizeof(float));
-    src = c->h_upload;
-    c->upload_busy = true;
-    c->upload_stream = s;
-  }
-  ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_frames, src, floats * sizeof(float), hipMemcpyHostToDevice, s));
+  ACMPC_HIP(c, hipMemcpyAsync(c->d_nn_frames, c->h_nn_frames.data(), c->h_nn_frames.size() * sizeof(float),
+                              hipMemcpyHostToDevice, s));
   c->frames_dirty = false;
   return ACMPC_OK;
 }
@@ -452,7 +410,6 @@ int upload_segments(acmpc_ctx* c, int n, hipStream_t s) {
   c->knot_begin[0] = 0;
   ACMPC_HIP(c, hipMemcpyAsync(c->d_segments, seg.data(), seg.size() * sizeof(float), hipMemcpyHostToDevice, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));  // `seg` is a local
-  stream_synchronised(c, s);
   c->segments_n = n;
   return ACMPC_OK;
 }
@@ -816,7 +773,6 @@ void acmpc_destroy(acmpc_ctx* c) {
     (void)hipFree(c->d_nn_frames);
     if (c->h_keys != nullptr) (void)hipHostFree(c->h_keys);
     if (c->h_io != nullptr) (void)hipHostFree(c->h_io);
-    if (c->h_upload != nullptr) (void)hipHostFree(c->h_upload);
     if (c->h_lq != nullptr) (void)hipHostFree(c->h_lq);
     for (hipGraphExec_t g : c->opt_graph)
       if (g != nullptr) (void)hipGraphExecDestroy(g);
@@ -944,7 +900,6 @@ int acmpc_sync_tables(acmpc_ctx* c, void* stream) {
   rc = upload_tables(c, s);
   if (rc != ACMPC_OK) return rc;
   ACMPC_HIP(c, hipStreamSynchronize(s));
-  stream_synchronised(c, s);
   return ACMPC_OK;
 }
 
@@ -1169,7 +1124,6 @@ int acmpc_solve(acmpc_ctx* c, const float* x0, const float* U, int32_t P, int32_
   }
   if (costs != nullptr) ACMPC_HIP(c, hipMemcpyAsync(costs, c->d_costs, cand * sizeof(float), hipMemcpyDeviceToHost, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
-  stream_synchronised(c, s);
   if (records != nullptr) std::memcpy(records, h_records, rec_bytes);
   if (best_idx != nullptr)
     for (int p = 0; p < P; ++p) best_idx[p] = static_cast<int32_t>(acmpc_key_index(c->h_keys[p]));
@@ -1451,7 +1405,6 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
     if (rc != ACMPC_OK) return rc;
     ACMPC_HIP(c, hipMemcpyAsync(records, c->d_records, rec_bytes, hipMemcpyDeviceToHost, s));
     ACMPC_HIP(c, hipStreamSynchronize(s));
-    stream_synchronised(c, s);
     return ACMPC_OK;
   }
 
@@ -1552,7 +1505,6 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   if (rc != ACMPC_OK) return rc;
   ACMPC_HIP(c, hipGraphLaunch(c->opt_graph[slot], s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
-  stream_synchronised(c, s);
   std::memcpy(records, c->h_opt_records, rec_bytes);
   return ACMPC_OK;
 }
@@ -1604,13 +1556,11 @@ int upload_map(acmpc_ctx* c, hipStream_t s) {
     g = nullptr;
   }
   ACMPC_HIP(c, hipStreamSynchronize(s));   // nothing of an earlier tick still reads the old map
-  stream_synchronised(c, s);
   (void)hipFree(c->d_map);
   c->d_map = nullptr;
   ACMPC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_map), c->h_map.size() * sizeof(double)));
   ACMPC_HIP(c, hipMemcpyAsync(c->d_map, c->h_map.data(), c->h_map.size() * sizeof(double), hipMemcpyHostToDevice, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
-  stream_synchronised(c, s);
   c->map_dirty = false;
   return ACMPC_OK;
 }
@@ -1895,12 +1845,10 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
     std::atomic_thread_fence(std::memory_order_acquire);
     if (*flag != done_value) {   // no flag: wait the ordinary way, which also reports what went wrong
       ACMPC_HIP(c, hipStreamSynchronize(s));
-      stream_synchronised(c, s);
       if (*flag != done_value) return fail(c, ACMPC_EHIP, "the tick finished without its completion flag");
     }
   } else {
     ACMPC_HIP(c, hipStreamSynchronize(s));
-    stream_synchronised(c, s);
   }
   c->tick_last_n = n;
 
@@ -1988,7 +1936,6 @@ int acmpc_map_reference_path(acmpc_ctx* c, int32_t map_index, double pose_x, dou
   h->lateral_offset = lateral_offset;
   ACMPC_HIP(c, acmpc::launch_map_window(ma, s));
   ACMPC_HIP(c, hipStreamSynchronize(s));
-  stream_synchronised(c, s);
   std::memcpy(coords, c->h_tick_out + out.coords, static_cast<size_t>(horizon) * 3 * sizeof(double));
   if (first_index != nullptr) *first_index = reinterpret_cast<const int*>(c->h_tick_out + out.status)[2];
   return ACMPC_OK;
