@@ -11,7 +11,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libacmpc_hip.so")
 SOURCES = ("acmpc_kernels.hip", "acmpc_kernels_temporal.hip", "acmpc_capi.hip", "acmpc_prologue.hip", "acmpc_pf.hip",
            "acmpc_speed_profile.cpp", "acmpc_host_path.cpp")
-HEADERS = ("acmpc_kernels.h", "acmpc_device.h", "acmpc_frames.h", "acmpc_admm.h", "acmpc_prologue.h", "acmpc_lq.h",
+HEADERS = ("acmpc_kernels.h", "acmpc_device.h", "acmpc_frames.h", "acmpc_admm.h", "acmpc_prologue.h", "acmpc_lq.h", "acmpc_lq_box.h",
            os.path.join("..", "..", "include", "acmpc.h"))
 
 # -ffp-contract=off: no IMPLICIT fused multiply-add anywhere; the FMAs of mode T's specification are spelt out

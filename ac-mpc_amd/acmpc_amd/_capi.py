@@ -132,6 +132,9 @@ SIGNATURES = {
     "acmpc_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_char_p]),
     "acmpc_lq_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
+    "acmpc_lq_box_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acmpc_lq_box_stats": (C.c_int, [_CTX, C.c_void_p]),
     "acmpc_last_error": (C.c_char_p, [_CTX]),
     "acmpc_set_paths": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
     "acmpc_get_coefficients": (C.c_int, [_CTX, C.c_int32, _F32P, C.c_int32]),
@@ -294,6 +297,28 @@ def lq_plan(table: np.ndarray, x0, step_cost, r_term, final_cost, u_min, u_max):
     return plan if rc == OK else None
 
 
+def lq_box_plan(table: np.ndarray, x0, step_cost, r_term, final_cost, u_min, u_max, margin: float, w_bound: float,
+                iterations: int = 40, state: np.ndarray = None):
+    """The plan of `lq_candidate=2` for one path on the host (acmpc_lq_box_plan, csrc/acmpc_lq_box.h): the LQ plan refined
+    against the QP's box rows where it is not already the optimum.  `state`: the [1 + 8 n] iterate a previous call
+    returned (None: cold).  Returns dict(plan [n, 2] float32 or None, iterations, chosen, triggered, J, V, state)."""
+    lib = load_library()
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    n = table.shape[1]
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x0, step_cost, r_term, final_cost)]
+    box = [np.ascontiguousarray(a, dtype=np.float32) for a in (u_min, u_max)]
+    plan = np.empty((n, 2), dtype=np.float32)
+    iterate = np.zeros(1 + 8 * n) if state is None else np.array(state, dtype=np.float64)
+    info = np.zeros(5)
+    rc = lib.acmpc_lq_box_plan(table.ctypes.data, n, *(a.ctypes.data for a in args), *(b.ctypes.data for b in box),
+                               float(margin), float(w_bound), int(iterations), iterate.ctypes.data, plan.ctypes.data,
+                               info.ctypes.data)
+    if rc != OK:
+        return dict(plan=None, iterations=0, chosen=0, triggered=False, J=float("nan"), V=float("nan"), state=None)
+    return dict(plan=plan, iterations=int(info[0]), chosen=int(info[1]), triggered=bool(info[2]), J=float(info[3]),
+                V=float(info[4]), state=iterate if iterate[0] == n else None)
+
+
 class _TickBuffers:
     """Everything `Engine.control_tick` hands to the library for one horizon, allocated once: the inputs are copied
     into fixed arrays (taking an array's address through `.ctypes` costs more than copying 150 doubles), the outputs
@@ -359,13 +384,15 @@ class Engine:
     def __init__(self, *, mode: int, max_problems: int, max_candidates: int, max_steps: int, step_cost, r_term,
                  final_cost, u_min, u_max, margin: float, wheelbase: float, t_min: float = 0.01, dt: float = 0.05,
                  w_bound: float = 1.0e6, softmin_lambda: float = 1.0, device: int = -1, nn_window=None,
-                 centre_update: str = "argmin", lq_candidate: bool = False):
+                 centre_update: str = "argmin", lq_candidate=False):
         """`nn_window=(back, ahead)` restricts mode T's nearest-waypoint search to that many waypoints round the
         previous step's nearest index; None = the nearest of ALL waypoints at every step (localiser.py:282-289's
         semantics: the kernels search an 8-waypoint window whose winner a certificate accepts as the global one, and
         scan every waypoint where it does not - the same index either way, see csrc/acmpc_frames.h).
         `lq_candidate`: the last sampling round of `optimize` / `control_tick` also holds the LQ plan (the optimum of the
-        reference's control QP without its box rows, rolled forward and clipped: csrc/acmpc_lq.h) as candidate 2."""
+        reference's control QP without its box rows, rolled forward and clipped: csrc/acmpc_lq.h) as candidate 2;
+        `lq_candidate=2`: that plan refined against the QP WITH its box rows wherever a control sits on the input box or
+        a state row is violated (csrc/acmpc_lq_box.h)."""
         self._lib = load_library()
         p = Params()
         p.struct_size = C.sizeof(Params)
@@ -373,7 +400,7 @@ class Engine:
         p.max_problems, p.max_candidates, p.max_steps = max_problems, max_candidates, max_steps
         p.nn_back, p.nn_ahead = (-1, -1) if nn_window is None else (int(nn_window[0]), int(nn_window[1]))
         p.centre_update = {"argmin": 0, "softmin": 1}[centre_update]
-        p.lq_candidate = 1 if lq_candidate else 0
+        p.lq_candidate = int(lq_candidate)   # False / True / 2
         p.step_cost[:] = [float(v) for v in step_cost]
         p.r_term[:] = [float(v) for v in r_term]
         p.final_cost[:] = [float(v) for v in final_cost]
@@ -394,6 +421,12 @@ class Engine:
     def _check(self, rc: int):
         if rc != OK:
             raise EngineError(rc, (self._lib.acmpc_last_error(self._ctx) or b"").decode())
+
+    def lq_box_stats(self):
+        """What the last `lq_candidate=2` plan of this handle did: dict(iterations, chosen, triggered, J, V)."""
+        info = np.zeros(5)
+        self._check(self._lib.acmpc_lq_box_stats(self._ctx, info.ctypes.data))
+        return dict(iterations=int(info[0]), chosen=int(info[1]), triggered=bool(info[2]), J=float(info[3]), V=float(info[4]))
 
     def set_option(self, name: str, value=None):
         """One of the handle's A/B switches (tools/README.md; `name` as the environment spells it, e.g. "ACMPC_NO_SOLO").

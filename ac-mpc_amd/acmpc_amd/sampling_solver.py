@@ -11,10 +11,14 @@ one solve is a single host round trip.  The rounds, the candidate count and the 
 from optional config keys (`n_candidates`, `sampling_rounds`, `sampling_sigma`, `sampling_cold_rounds`,
 `sampling_cold_sigma`, `sampling_seed`, `w_bound`, `sampling_update`, `softmin_lambda`, `lq_candidate`).
 
-Round 4: the last round of every solve also holds one deterministic candidate, the LQ plan (`lq_candidate`, default on):
+Round 4: the last round of every solve also holds one deterministic candidate, the LQ plan (`lq_candidate`):
 the optimum of the reference's QP without its box rows - a backward Riccati pass over the linearised model
 (dynamics.py:65-103, control.py:26-79) - rolled forward with its feedback and clipped into the input box
 (csrc/acmpc_lq.h, on the host).  Where no bound is active it IS the QP optimum; the argmin keeps it only when it wins.
+Round 5 (`lq_candidate: 2`, the default): where a bound IS active - a control on the input box, a corridor or time row
+violated (control.py:47-70,130-144) - that plan is refined against the QP with its box rows by the OSQP splitting with
+a Riccati z-update (csrc/acmpc_lq_box.h, on the host, warm-started from tick to tick), and the first solve of a handle
+plans with a speed profile solved once on the host.
 
 `rollout_mode: "T"` (default "S") scores the candidates with the Cartesian rollout instead - BASELINE.json north_star's
 literal shape: kinematic bicycle (localisation/localiser.py:66-95) advanced by `rollout_dt` seconds per step (0.05),
@@ -85,8 +89,10 @@ class ControlSolver:
         self._w_bound = float(config.get("w_bound", 1.0e4))
         self._centre_update = config.get("sampling_update", "argmin")   # or "softmin" (MPPI-style weighted mean)
         self._lambda = float(config.get("softmin_lambda", 1.0))
-        # the LQ plan in the last round (Engine(lq_candidate=...)): on by default for the argmin update
-        self._lq_candidate = bool(config.get("lq_candidate", True)) and self._centre_update == "argmin"
+        # the deterministic candidate of the last round (Engine(lq_candidate=...)), argmin update only: 2 (default) = the LQ
+        # plan refined against the QP's box rows where one of them is active (csrc/acmpc_lq_box.h), 1 / True = the LQ plan
+        # alone (round 4), 0 / False = none
+        self._lq_candidate = int(config.get("lq_candidate", 2)) if self._centre_update == "argmin" else 0
         self._incumbent = None
         self._engine = None  # built on first solve: the input box follows the live velocity limits
         mode = str(config.get("rollout_mode", "S")).upper()

@@ -191,3 +191,44 @@ def family_path(kind: str, parameter: float, horizon: int, angle: float = 0.0, w
         return _turned(np.zeros(horizon), np.linspace(0.0, parameter, horizon), angle, width)
     raise ValueError("unknown path family %r" % kind)
 
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Racing-configuration paths on which the reference QP's BOX rows are active (round 5, tests/test_gpu_qp_gap.py,
+# tests/test_lq_box.py): the corridor e_y in +-(w/2 - margin) under the widths linspace(10, 6, H) the control process
+# hands over (/root/reference/src/acmpc/control/controller.py:256-267; control/solvers/control.py:57-60) and the input
+# box (control.py:130-139) - corners at or inside the steering limit kappa_max = tan(delta_max) / L, entered from a
+# straight, so that the QP's optimum prepares for them steps ahead.
+# ---------------------------------------------------------------------------------------------------------
+def curvature_path(kappa_of_s, length: float, horizon: int) -> np.ndarray:
+    """H x 3 path in the vehicle frame (from the origin, heading +y) with curvature `kappa_of_s(s)` over `length` metres,
+    widths linspace(10, 6, H)."""
+    s = np.linspace(0.0, length, 4001)
+    k = np.asarray(kappa_of_s(s), dtype=np.float64)
+    step = np.diff(s)
+    psi = np.pi / 2 + np.concatenate([[0.0], np.cumsum(0.5 * (k[1:] + k[:-1]) * step)])
+    x = np.concatenate([[0.0], np.cumsum(0.5 * (np.cos(psi[1:]) + np.cos(psi[:-1])) * step)])
+    y = np.concatenate([[0.0], np.cumsum(0.5 * (np.sin(psi[1:]) + np.sin(psi[:-1])) * step)])
+    at = np.linspace(0.0, length, horizon)
+    return np.column_stack([np.interp(at, s, x), np.interp(at, s, y), np.linspace(10.0, 6.0, horizon)])
+
+
+def corner_entry_path(radius: float, lead: float, horizon: int, arc_angle: float = 1.2 * np.pi, tail: float = 0.0) -> np.ndarray:
+    """`lead` metres straight ahead, then a left-hand arc of `radius` through `arc_angle`, then `tail` metres straight."""
+    arc = arc_angle * radius
+    return curvature_path(lambda s: np.where((s > lead) & (s <= lead + arc), 1.0 / radius, 0.0), lead + arc + tail, horizon)
+
+
+def s_bend_path(radius: float, lead: float, horizon: int, angle: float = 0.5 * np.pi, tail: float = 20.0) -> np.ndarray:
+    """`lead` metres straight, a left-hand arc of `radius` through `angle`, the same to the right, `tail` metres straight."""
+    arc = angle * radius
+    return curvature_path(lambda s: np.where(s <= lead, 0.0, np.where(s <= lead + arc, 1.0 / radius,
+                                                                      np.where(s <= lead + 2 * arc, -1.0 / radius, 0.0))),
+                          lead + 2 * arc + tail, horizon)
+
+
+def racing_widths(path: np.ndarray) -> np.ndarray:
+    """The same path with the corridor the control process gives it: widths linspace(10, 6, H) (controller.py:256-267)."""
+    out = np.array(path, dtype=np.float64)
+    out[:, 2] = np.linspace(10.0, 6.0, out.shape[0])
+    return out

@@ -21,6 +21,7 @@
 #include "acmpc_frames.h"
 #include "acmpc_kernels.h"
 #include "acmpc_lq.h"
+#include "acmpc_lq_box.h"
 #include "acmpc_prologue.h"
 
 namespace {
@@ -141,6 +142,12 @@ struct acmpc_ctx {
   double tick_prev_x0[3] = {0.0, 0.0, 0.0};   // ... and its start state (Frenet)
   std::vector<double> tick_lq_table;    // scratch: this tick's waypoints with the previous tick's speed profile
   int tick_prev_n = 0;                  // 0: nothing usable (first tick, or a tick that did not end with a finite plan)
+  // lq_candidate = 2 (csrc/acmpc_lq_box.h): the splitting's iterate per problem, its factorisation scratch, what the last
+  // plan did (acmpc_lq_box_stats) and the iteration cap (ACMPC_LQ_BOX_ITERATIONS)
+  std::vector<acmpc::lqbox::State> lq_box_state;
+  acmpc::lqbox::Workspace lq_box_ws;
+  acmpc::lqbox::Result lq_box_last;
+  int lq_box_iterations = 40;
 
   // A/B switches of the tests and the tools: read from the environment ONCE, by acmpc_create, or set with acmpc_set_option;
   // nothing on a launch path calls getenv
@@ -609,7 +616,7 @@ const char* const kOptionNames[] = {
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
     "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TICK_NO_INLINE_PATH", "ACMPC_NO_ZERO_COPY", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES",
-    "ACMPC_NO_CHAINED_STREAM"};
+    "ACMPC_NO_CHAINED_STREAM", "ACMPC_LQ_BOX_ITERATIONS"};
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   const std::string key(name);
@@ -647,6 +654,7 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_TICK_NO_INLINE_PATH") { w.tick_no_inline_path = on; return true; }
   if (key == "ACMPC_NO_ZERO_COPY") { w.no_zero_copy = on; return true; }
   if (key == "ACMPC_TAILED_ROLLOUT") { w.tailed_rollout = on; return true; }
+  if (key == "ACMPC_LQ_BOX_ITERATIONS") { c->lq_box_iterations = present ? std::max(0, std::atoi(value)) : 40; return true; }
   return false;
 }
 
@@ -664,6 +672,43 @@ int acmpc_lq_plan(const double* table, int32_t n, const double x0[3], const doub
       u_min == nullptr || u_max == nullptr || plan == nullptr || n < 1)
     return ACMPC_EINVAL;
   return acmpc::lq::plan(table, n, x0, step_cost, r_term, final_cost, u_min, u_max, plan) ? ACMPC_OK : ACMPC_ESTATE;
+}
+
+int acmpc_lq_box_plan(const double* table, int32_t n, const double x0[3], const double step_cost[3], const double r_term[2],
+                      const double final_cost[3], const float u_min[2], const float u_max[2], double margin, double w_bound,
+                      int32_t iterations, double* state, float* plan, double* info) {
+  if (table == nullptr || x0 == nullptr || step_cost == nullptr || r_term == nullptr || final_cost == nullptr ||
+      u_min == nullptr || u_max == nullptr || plan == nullptr || state == nullptr || info == nullptr || n < 1)
+    return ACMPC_EINVAL;
+  if (!acmpc::lq::plan(table, n, x0, step_cost, r_term, final_cost, u_min, u_max, plan)) return ACMPC_ESTATE;
+  acmpc::lqbox::State st;
+  const size_t m = static_cast<size_t>(n) * 2;
+  if (state[0] == static_cast<double>(n)) {   // a warm iterate: wx, wu, lx, lu behind the horizon it belongs to
+    st.n = n;
+    st.wx.assign(state + 1, state + 1 + m);
+    st.wu.assign(state + 1 + m, state + 1 + 2 * m);
+    st.lx.assign(state + 1 + 2 * m, state + 1 + 3 * m);
+    st.lu.assign(state + 1 + 3 * m, state + 1 + 4 * m);
+  }
+  acmpc::lqbox::Workspace ws;
+  const acmpc::lqbox::Result r = acmpc::lqbox::refine(table, n, x0, step_cost, r_term, final_cost, u_min, u_max, margin,
+                                                      w_bound, iterations, st, ws, plan);
+  state[0] = static_cast<double>(st.n);
+  if (st.n == n) {
+    std::copy(st.wx.begin(), st.wx.end(), state + 1);
+    std::copy(st.wu.begin(), st.wu.end(), state + 1 + m);
+    std::copy(st.lx.begin(), st.lx.end(), state + 1 + 2 * m);
+    std::copy(st.lu.begin(), st.lu.end(), state + 1 + 3 * m);
+  }
+  info[0] = r.iterations, info[1] = r.chosen, info[2] = r.triggered ? 1.0 : 0.0, info[3] = r.cost.J, info[4] = r.cost.V;
+  return ACMPC_OK;
+}
+
+int acmpc_lq_box_stats(const acmpc_ctx* c, double info[5]) {
+  if (c == nullptr || info == nullptr) return ACMPC_EINVAL;
+  const acmpc::lqbox::Result& r = c->lq_box_last;
+  info[0] = r.iterations, info[1] = r.chosen, info[2] = r.triggered ? 1.0 : 0.0, info[3] = r.cost.J, info[4] = r.cost.V;
+  return ACMPC_OK;
 }
 
 int64_t acmpc_pack_key(float cost, uint32_t index) { return acmpc::pack_key(cost, index); }
@@ -692,8 +737,8 @@ int acmpc_create(const acmpc_params* params, acmpc_ctx** out) {
     return fail(nullptr, ACMPC_EINVAL, "nearest-waypoint window: need nn_back >= 0 and at most 64 waypoints");
   if (params->centre_update != 0 && params->centre_update != 1)
     return fail(nullptr, ACMPC_EINVAL, "centre_update must be 0 (argmin) or 1 (softmin mean)");
-  if (params->lq_candidate != 0 && params->lq_candidate != 1)
-    return fail(nullptr, ACMPC_EINVAL, "lq_candidate must be 0 or 1");
+  if (params->lq_candidate < 0 || params->lq_candidate > 2)
+    return fail(nullptr, ACMPC_EINVAL, "lq_candidate must be 0, 1 (LQ plan) or 2 (LQ plan + box-constrained refinement)");
   if (params->max_steps > 1024)
     return fail(nullptr, ACMPC_EINVAL, "the waypoint table and the winner record are staged in LDS: max_steps <= 1024");
   if (params->max_problems > 65535)
@@ -1222,13 +1267,25 @@ bool use_traced_finalize(const acmpc_ctx* c, int P, int N, int n) {
 // (mode S: the Frenet state; mode T: the pose, moved into the Frenet frame of the first waypoint here).  Without a finite
 // plan (a singular step, a speed profile that was never solved) `out` gets the reference controls clipped into the box -
 // candidate 1 again, harmless - and false comes back.
-bool lq_plan_into(const acmpc_ctx* c, const double* table, int n, const double start[3], float* out,
-                  bool start_is_pose = false) {
+// With lq_candidate = 2 the plan is then refined against the QP's box rows (csrc/acmpc_lq_box.h; the iterate of problem
+// `problem` is kept in the handle between calls).
+bool lq_plan_into(acmpc_ctx* c, const double* table, int n, const double start[3], float* out,
+                  bool start_is_pose = false, int problem = 0) {
   double x0[3] = {start[0], start[1], start[2]};
   if (start_is_pose || c->prm.mode == ACMPC_MODE_TEMPORAL) acmpc::lq::frenet_start(table, n, start, x0);
   const float lo[2] = {c->w.ulo0, c->w.ulo1}, hi[2] = {c->w.uhi0, c->w.uhi1};
   const bool finite_start = std::isfinite(x0[0]) && std::isfinite(x0[1]) && std::isfinite(x0[2]);
-  if (finite_start && acmpc::lq::plan(table, n, x0, c->prm.step_cost, c->prm.r_term, c->prm.final_cost, lo, hi, out)) return true;
+  if (finite_start && acmpc::lq::plan(table, n, x0, c->prm.step_cost, c->prm.r_term, c->prm.final_cost, lo, hi, out)) {
+    if (c->prm.lq_candidate == 2) {
+      if (c->lq_box_state.size() <= static_cast<size_t>(problem)) c->lq_box_state.resize(static_cast<size_t>(problem) + 1);
+      c->lq_box_last = acmpc::lqbox::refine(table, n, x0, c->prm.step_cost, c->prm.r_term, c->prm.final_cost, lo, hi,
+                                            c->prm.margin, c->prm.w_bound, c->lq_box_iterations,
+                                            c->lq_box_state[static_cast<size_t>(problem)], c->lq_box_ws, out);
+    }
+    return true;
+  }
+  if (c->prm.lq_candidate == 2 && c->lq_box_state.size() > static_cast<size_t>(problem))
+    c->lq_box_state[static_cast<size_t>(problem)].reset();
   const double *kappa = table + 3 * static_cast<size_t>(n), *vel = table + 6 * static_cast<size_t>(n);
   for (int i = 0; i < n; ++i) {
     out[2 * i] = std::fmin(std::fmax(static_cast<float>(vel[i]), lo[0]), hi[0]);
@@ -1387,7 +1444,8 @@ int acmpc_optimize(acmpc_ctx* c, const float* x0, const float* centre, const flo
   if (has_extra) {
     for (int p = 0; p < P; ++p) {
       const double start[3] = {x0[3 * p], x0[3 * p + 1], x0[3 * p + 2]};
-      (void)lq_plan_into(c, c->h_tables.data() + static_cast<size_t>(p) * 7 * n, n, start, c->h_lq + static_cast<size_t>(p) * n * 2);
+      (void)lq_plan_into(c, c->h_tables.data() + static_cast<size_t>(p) * 7 * n, n, start, c->h_lq + static_cast<size_t>(p) * n * 2,
+                         false, p);
     }
   }
 
@@ -1696,13 +1754,29 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   // out of the map on the device (coords = NULL) the host does not have it: the plan is then the previous tick's problem's.
   const bool lq_on = c->prm.lq_candidate != 0;
   const double lq_offset = t->offset;
-  auto plan_previous = [c, n, H, coords, lq_offset]() -> bool {
-    if (c->tick_prev_n != n) return false;   // first tick, another horizon, or a previous tick without a finite plan
+  auto plan_previous = [c, n, H, coords, lq_offset, t]() -> bool {
+    // no previous tick to take a speed profile from (a handle's first tick, another horizon, a tick without a finite
+    // plan): with the path on the host the profile is solved HERE, once - the host statement of the prologue's QP
+    // (acmpc_velocity_ceiling + acmpc_speed_profile_qp, cold: a few hundred iterations of O(n), ~0.1 ms)
+    const bool have_previous = c->tick_prev_n == n;
+    if (!have_previous && coords == nullptr) return false;   // (the path is cut out of the map on the device: nothing to plan for)
     if (coords == nullptr) return lq_plan_into(c, c->tick_prev_table.data(), n, c->tick_prev_x0, c->h_lq);
     c->tick_lq_table.resize(static_cast<size_t>(7) * n);
     if (acmpc_waypoint_table(coords, H, kEps, c->tick_lq_table.data()) != ACMPC_OK) return false;
-    std::memcpy(c->tick_lq_table.data() + static_cast<size_t>(6) * n, c->tick_prev_table.data() + static_cast<size_t>(6) * n,
-                static_cast<size_t>(n) * sizeof(double));
+    if (!have_previous) {
+      std::vector<double> ceiling(static_cast<size_t>(n)), dual(static_cast<size_t>(2) * n);
+      double* profile = c->tick_lq_table.data() + static_cast<size_t>(6) * n;
+      int32_t iterations = 0;
+      if (acmpc_velocity_ceiling(c->tick_lq_table.data() + static_cast<size_t>(3) * n, n, t->ay_max, t->ki_min, t->v_min,
+                                 t->v_max, t->localised, t->has_end_velocity, t->end_velocity, ceiling.data()) != ACMPC_OK ||
+          acmpc_speed_profile_qp(ceiling.data(), c->tick_lq_table.data() + static_cast<size_t>(4) * n, n, t->a_min, t->a_max,
+                                 t->v_min, t->qp_max_iter, t->qp_check_every, t->qp_eps_abs, t->qp_eps_rel, profile,
+                                 dual.data(), 0, &iterations) != 0)
+        return false;
+    } else {
+      std::memcpy(c->tick_lq_table.data() + static_cast<size_t>(6) * n, c->tick_prev_table.data() + static_cast<size_t>(6) * n,
+                  static_cast<size_t>(n) * sizeof(double));
+    }
     const double pose[3] = {lq_offset, 0.0, M_PI / 2.0};
     return lq_plan_into(c, c->tick_lq_table.data(), n, pose, c->h_lq, true);
   };
@@ -1811,9 +1885,13 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   if (centre != nullptr) std::memcpy(c->h_tick + in.centre_in, centre, static_cast<size_t>(n) * 2 * sizeof(float));
   if (use_graph) {
     if (lq_on && !plan_previous()) {
-      // no plan for the replayed graph's candidate 2: it reads the centre sequence instead (candidate 0 again)
+      // no plan for the replayed graph's candidate 2, which always reads h_lq: it gets the centre sequence instead
+      // (candidate 0 again) or, without one, zeros - the sampler clips them into the input box like every candidate, so
+      // the slot holds a DEFINED sequence (never the stale plan of another path) that the argmin will not keep
       if (centre != nullptr && t->centre_is_reference == 0)
         std::memcpy(c->h_lq, centre, static_cast<size_t>(n) * 2 * sizeof(float));
+      else
+        std::memset(c->h_lq, 0, static_cast<size_t>(n) * 2 * sizeof(float));
     }
     ACMPC_HIP(c, hipGraphLaunch(c->tick_graph[slot], s));
   } else {

@@ -92,8 +92,17 @@ typedef struct acmpc_params {
                             paths of acmpc_set_paths and the x0 it is given; acmpc_control_tick, whose table is built on
                             the device, plans on the host meanwhile for this tick's path (acmpc_waypoint_table of `coords`)
                             and pose with the speed profile its PREVIOUS call solved (with coords = NULL - the path cut
-                            out of the map on the device - for the previous call's problem as it was); no plan in a
-                            handle's first tick.  The argmin keeps the plan only when it wins.  0 = no such candidate */
+                            out of the map on the device - for the previous call's problem as it was; none in a
+                            handle's first tick then).  A handle's first tick with `coords` solves the speed profile once
+                            on the host (acmpc_velocity_ceiling + acmpc_speed_profile_qp) to plan with.  The argmin keeps
+                            the plan only when it wins.
+                            2 = as 1, and where that plan is not already the QP's optimum - a control on the input box, or
+                            state rows (corridor control.py:57-60, t >= 0.01 control.py:134) violated beyond the solver's
+                            acceptance tolerance - it is refined against the QP WITH its box rows (csrc/acmpc_lq_box.h: the
+                            OSQP splitting with the model as a hard constraint of the Riccati z-update; host, float64,
+                            iterate kept between calls, at most ACMPC_LQ_BOX_ITERATIONS = 40 iterations per call) and the
+                            cheapest of {LQ plan, the two iterates} under J + w_bound V takes the slot.
+                            0 = no such candidate */
   /* real-valued fields are doubles so that Python floats cross the ABI exactly; the device gets float32 */
   double step_cost[3];   /* Q  = diag(step_cost)  on (e_y, e_psi, t)     control.py:126               */
   double r_term[2];      /* R  = diag(r_term)     on (v, kappa)          control.py:127               */
@@ -124,6 +133,19 @@ int acmpc_set_option(acmpc_ctx* ctx, const char* name, const char* value);
  * plan [n][2] float32 (v, kappa).  ACMPC_ESTATE when the problem has no finite plan.  No handle, no GPU work. */
 int acmpc_lq_plan(const double* table, int32_t n, const double x0[3], const double step_cost[3], const double r_term[2],
                   const double final_cost[3], const float u_min[2], const float u_max[2], float* plan);
+
+/* The plan of acmpc_params::lq_candidate = 2 for one path, on the host (csrc/acmpc_lq_box.h): arguments as acmpc_lq_plan,
+ * `margin` / `w_bound` as in acmpc_params, at most `iterations` splitting iterations.  `state` [1 + 8 n]: the iterate -
+ * state[0] = n marks a warm one (wx, wu, lx, lu [n][2] each behind it), anything else starts cold; written back (state[0]
+ * = 0 when the call kept none).  `info` [5]: iterations run (negative: a non-finite iterate), which plan took the slot
+ * (0 the LQ plan, 1 the box iterate, 2 the clipped dynamics iterate), whether the refinement was triggered, and the
+ * chosen plan's tracking cost J and summed squared state-row excess V (float64 rollout).  ACMPC_ESTATE when the
+ * problem has no finite LQ plan.  No handle, no GPU work. */
+int acmpc_lq_box_plan(const double* table, int32_t n, const double x0[3], const double step_cost[3], const double r_term[2],
+                      const double final_cost[3], const float u_min[2], const float u_max[2], double margin, double w_bound,
+                      int32_t iterations, double* state, float* plan, double* info);
+/* What the handle's last lq_candidate = 2 plan did: `info` [5] as acmpc_lq_box_plan's. */
+int acmpc_lq_box_stats(const acmpc_ctx* ctx, double info[5]);
 
 /* Message of the last failing call on `ctx` (or of the last failing acmpc_create when ctx is NULL). */
 const char* acmpc_last_error(const acmpc_ctx* ctx);

@@ -946,6 +946,212 @@ def lq_plan(table, x0, Q, R, QN, u_lo, u_hi):
     return out if np.isfinite(out).all() else None
 
 
+# --- the box-constrained LQ plan (csrc/acmpc_lq_box.h, round 5) ---------------------------------------------------------
+LQBOX_ALPHA = 1.6
+LQBOX_RHO_EY, LQBOX_RHO_T = 3.0e-3, 3.0e-2
+LQBOX_PER_TOL = (1.0e4, 1.0e5, 1.0e3, 1.0e6)   # 1 / tolerance of e_y [m], t [s], v [m/s], kappa [1/m]
+
+
+def _clip64(x, lo, hi):
+    # std::fmin(std::fmax(x, lo), hi) on doubles (NaN operands dropped, as IEEE maxNum / minNum)
+    return float(np.fmin(np.fmax(x, lo), hi))
+
+
+def lq_box_rollout_cost(table, x0, Q, R, QN, u_lo, u_hi, margin, plan):
+    """csrc/acmpc_lq_box.h rollout_cost(): what the kernels charge a plan, in float64 - tracking cost J, summed squared
+    excess V over the state box rows (control.py:57-60,134), the largest |entry| of the decision vector and whether a
+    control sits on the input box.  plan [n, 2] float32."""
+    table = np.asarray(table, dtype=np.float64)
+    n = table.shape[1]
+    kappa, ds, width, vel = table[ROW_KAPPA], table[ROW_DS], table[ROW_WIDTH], table[ROW_V]
+    Q, R, QN = ([float(x) for x in w] for w in (Q, R, QN))
+    lo, hi = np.asarray(u_lo, dtype=np.float32), np.asarray(u_hi, dtype=np.float32)
+    plan = np.asarray(plan, dtype=np.float32)
+    ey, ep, t = (float(x) for x in x0)
+    J = V = 0.0
+    biggest = max(abs(ey), abs(ep), abs(t))
+    saturated = False
+    margin = float(margin)
+    with np.errstate(all="ignore"):
+        for i in range(n):
+            d = float(ds[i]); ki = float(kappa[i]); vi = float(vel[i])
+            a = -(ki * ki) * d
+            g = -ki / (vi * d + EPS)
+            b = -1.0 / (vi * vi * d + EPS)
+            c = 1.0 / (vi * d + EPS)
+            v, k = plan[i, 0], plan[i, 1]
+            saturated = saturated or bool(v <= lo[0] or v >= hi[0] or k <= lo[1] or k >= hi[1])
+            dv, dk = float(v) - vi, float(k) - ki
+            J += 0.5 * ((((Q[0] * ey) * ey + (Q[1] * ep) * ep) + (Q[2] * t) * t) + ((R[0] * dv) * dv + (R[1] * dk) * dk))
+            ey, ep, t = ey + d * ep, (ep + a * ey) + d * dk, ((t + g * ey) + b * dv) + c
+            half = float(width[i]) / 2.0 - margin
+            over = float(np.fmax(np.fmax(-half - ey, ey - half), 0.0))
+            early = float(np.fmax(T_MIN - t, 0.0))
+            V += over * over + early * early
+            biggest = float(np.fmax(biggest, np.fmax(np.fmax(abs(ey), abs(ep)), np.fmax(abs(t), np.fmax(abs(float(v)), abs(float(k)))))))
+        J += 0.5 * (((QN[0] * ey) * ey + (QN[1] * ep) * ep) + (QN[2] * t) * t)
+    return dict(J=J, V=V, biggest=biggest, saturated=saturated)
+
+
+def lq_box_plan(table, x0, Q, R, QN, u_lo, u_hi, margin, w_bound, iterations, state=None):
+    """The box-constrained LQ plan (csrc/acmpc_lq_box.h, round 5): the reference's control QP WITH its box rows
+    (control/solvers/control.py:26-79,130-144) by the operator splitting of O'Donoghue, Stathopoulos & Boyd (2013) - the
+    linearised model (dynamics.py:65-103) stays a hard constraint of the z-update, which is one Riccati factorisation per
+    path and a backward vector pass + forward rollout per iteration; the w-update clips into the box rows.  Restated line
+    by line in the library's operation order (float64, no fused multiply-add): bit-identical to acmpc_lq_box_plan().
+    `state`: None (cold) or the dict a previous call returned under "state" (wx, wu, lx, lu [n, 2] each).
+    Returns dict(plan [n, 2] float32 or None, iterations, chosen (0 LQ plan, 1 w iterate, 2 clipped z iterate), triggered,
+    J, V, state)."""
+    table = np.asarray(table, dtype=np.float64)
+    n = table.shape[1]
+    kappa, ds, width, vel = table[ROW_KAPPA], table[ROW_DS], table[ROW_WIDTH], table[ROW_V]
+    lo32, hi32 = np.asarray(u_lo, dtype=np.float32), np.asarray(u_hi, dtype=np.float32)
+    plan = lq_plan(table, x0, Q, R, QN, lo32, hi32)
+    if plan is None:
+        return dict(plan=None, iterations=0, chosen=0, triggered=False, J=float("nan"), V=float("nan"), state=None)
+    Qf, Rf, QNf = ([float(x) for x in w] for w in (Q, R, QN))
+    margin = float(margin)
+    cost = lq_box_rollout_cost(table, x0, Qf, Rf, QNf, lo32, hi32, margin, plan)
+    accept = 1.0e-3 + 1.0e-3 * cost["biggest"]
+    triggered = bool(cost["saturated"] or cost["V"] > accept * accept or not (cost["V"] == cost["V"]))
+    out = dict(plan=plan, iterations=0, chosen=0, triggered=triggered, J=cost["J"], V=cost["V"], state=None)
+    if not triggered or iterations < 1:
+        return out
+    rho = (LQBOX_RHO_EY, LQBOX_RHO_T, Rf[0], Rf[1])
+    if not (rho[2] > 0.0) or not (rho[3] > 0.0):
+        return out
+    rows = np.zeros((n, 5))
+    fac = np.zeros((n, 18))
+    with np.errstate(all="ignore"):
+        # factor()
+        R0, R1 = Rf[0] + rho[2], Rf[1] + rho[3]
+        P00, P01, P02, P11, P12, P22 = QNf[0] + rho[0], 0.0, 0.0, QNf[1], 0.0, QNf[2] + rho[1]
+        for i in range(n - 1, -1, -1):
+            d = float(ds[i]); ki = float(kappa[i]); vi = float(vel[i])
+            a = -(ki * ki) * d
+            g = -ki / (vi * d + EPS)
+            b = -1.0 / (vi * vi * d + EPS)
+            c = 1.0 / (vi * d + EPS)
+            rows[i] = (d, a, g, b, c)
+            h0, h1, h2 = b * P02, b * P12, b * P22
+            m0, m1, m2 = d * P01, d * P11, d * P12
+            Quu00 = R0 + b * h2
+            Quu01 = d * h1
+            Quu11 = R1 + d * m1
+            S00, S01, S02 = (h0 + a * h1) + g * h2, d * h0 + h1, h2
+            S10, S11, S12 = (m0 + a * m1) + g * m2, d * m0 + m1, m2
+            det = Quu00 * Quu11 - Quu01 * Quu01
+            if not (det > 0.0) or not math.isfinite(det):
+                return out
+            inv = 1.0 / det
+            I00, I01, I11 = inv * Quu11, -(inv * Quu01), inv * Quu00
+            K00, K01, K02 = -(I00 * S00 + I01 * S10), -(I00 * S01 + I01 * S11), -(I00 * S02 + I01 * S12)
+            K10, K11, K12 = -(I01 * S00 + I11 * S10), -(I01 * S01 + I11 * S11), -(I01 * S02 + I11 * S12)
+            fac[i] = (K00, K01, K02, K10, K11, K12, I00, I01, I11, S00, S01, S02, S10, S11, S12, P02, P12, P22)
+            t00, t10, t20 = (P00 + a * P01) + g * P02, (P01 + a * P11) + g * P12, (P02 + a * P12) + g * P22
+            t01, t11, t21 = d * P00 + P01, d * P01 + P11, d * P02 + P12
+            t02, t12, t22 = P02, P12, P22
+            N00, N01, N02 = (t00 + a * t10) + g * t20, (t01 + a * t11) + g * t21, (t02 + a * t12) + g * t22
+            N11, N12, N22 = d * t01 + t11, d * t02 + t12, t22
+            q0 = Qf[0] + rho[0] if i >= 1 else Qf[0]
+            q2 = Qf[2] + rho[1] if i >= 1 else Qf[2]
+            n00 = (q0 + N00) + (S00 * K00 + S10 * K10)
+            n01 = N01 + (S00 * K01 + S10 * K11)
+            n02 = N02 + (S00 * K02 + S10 * K12)
+            n11 = (Qf[1] + N11) + (S01 * K01 + S11 * K11)
+            n12 = N12 + (S01 * K02 + S11 * K12)
+            n22 = (q2 + N22) + (S02 * K02 + S12 * K12)
+            P00, P01, P02, P11, P12, P22 = n00, n01, n02, n11, n12, n22
+        if not (math.isfinite(P00) and math.isfinite(P11) and math.isfinite(P22)):
+            return out
+        # iterate()
+        lo_v, lo_k, hi_v, hi_k = float(lo32[0]), float(lo32[1]), float(hi32[0]), float(hi32[1])
+        if state is not None and state["wx"].shape == (n, 2):
+            wx, wu, lx, lu = (np.array(state[key], dtype=np.float64) for key in ("wx", "wu", "lx", "lu"))
+        else:
+            wx, wu, lx, lu = (np.zeros((n, 2)) for _ in range(4))
+            for i in range(n):
+                half = float(width[i]) / 2.0 - margin
+                wx[i, 0] = _clip64(0.0, -half, half)
+                wx[i, 1] = float(np.fmax(0.0, T_MIN))
+                wu[i, 0] = _clip64(0.0, lo_v - float(vel[i]), hi_v - float(vel[i]))
+                wu[i, 1] = _clip64(0.0, lo_k - float(kappa[i]), hi_k - float(kappa[i]))
+        ks = np.zeros((n, 2))
+        zu = np.zeros((n, 2))
+        x0f = [float(x) for x in x0]
+        it = 0
+        failed = False
+        while it < iterations:
+            it += 1
+            p0 = -(rho[0] * (wx[n - 1, 0] - lx[n - 1, 0]))
+            p1 = 0.0
+            p2 = -(rho[1] * (wx[n - 1, 1] - lx[n - 1, 1]))
+            for i in range(n - 1, -1, -1):
+                d, a, g, b, c = (float(x) for x in rows[i])
+                F = [float(x) for x in fac[i]]
+                w0, w1, w2 = c * F[15] + p0, c * F[16] + p1, c * F[17] + p2
+                qu0 = -(rho[2] * (wu[i, 0] - lu[i, 0])) + b * w2
+                qu1 = -(rho[3] * (wu[i, 1] - lu[i, 1])) + d * w1
+                k0, k1 = -(F[6] * qu0 + F[7] * qu1), -(F[7] * qu0 + F[8] * qu1)
+                ks[i] = (k0, k1)
+                q0 = q2 = 0.0
+                if i >= 1:
+                    q0 = -(rho[0] * (wx[i - 1, 0] - lx[i - 1, 0]))
+                    q2 = -(rho[1] * (wx[i - 1, 1] - lx[i - 1, 1]))
+                n0 = (q0 + ((w0 + a * w1) + g * w2)) + (F[9] * k0 + F[12] * k1)
+                n1 = (d * w0 + w1) + (F[10] * k0 + F[13] * k1)
+                n2 = (q2 + w2) + (F[11] * k0 + F[14] * k1)
+                p0, p1, p2 = float(n0), float(n1), float(n2)
+            ey, ep, t = x0f
+            gap = move = 0.0
+            finite = True
+            for i in range(n):
+                d, a, g, b, c = (float(x) for x in rows[i])
+                F = [float(x) for x in fac[i]]
+                dv = ((F[0] * ey + F[1] * ep) + F[2] * t) + float(ks[i, 0])
+                dk = ((F[3] * ey + F[4] * ep) + F[5] * t) + float(ks[i, 1])
+                ey, ep, t = ey + d * ep, (ep + a * ey) + d * dk, ((t + g * ey) + b * dv) + c
+                zu[i] = (dv, dk)
+                half = float(width[i]) / 2.0 - margin
+                z = (ey, t, dv, dk)
+                blo = (-half, T_MIN, lo_v - float(vel[i]), lo_k - float(kappa[i]))
+                bhi = (half, math.inf, hi_v - float(vel[i]), hi_k - float(kappa[i]))
+                for q, (w_arr, l_arr, col) in enumerate(((wx, lx, 0), (wx, lx, 1), (wu, lu, 0), (wu, lu, 1))):
+                    w_old, l_old = float(w_arr[i, col]), float(l_arr[i, col])
+                    relaxed = LQBOX_ALPHA * z[q] + (1.0 - LQBOX_ALPHA) * w_old
+                    nxt = _clip64(relaxed + l_old, blo[q], bhi[q])
+                    l_new = (l_old + relaxed) - nxt
+                    l_arr[i, col] = l_new
+                    finite = finite and math.isfinite(relaxed) and math.isfinite(l_new)
+                    gap = float(np.fmax(gap, abs(z[q] - nxt) * LQBOX_PER_TOL[q]))
+                    move = float(np.fmax(move, abs(nxt - w_old) * LQBOX_PER_TOL[q]))
+                    w_arr[i, col] = nxt
+            if not finite:
+                failed = True
+                break
+            if gap <= 1.0 and move <= 1.0:
+                break
+        if failed:
+            out["iterations"] = -it
+            return out
+        out["iterations"] = it
+        out["state"] = dict(wx=wx, wu=wu, lx=lx, lu=lu)
+        best = cost["J"] + float(w_bound) * cost["V"]
+        for which, du in ((1, wu), (2, zu)):
+            trial = np.zeros((n, 2), dtype=np.float32)
+            for i in range(n):
+                trial[i, 0] = np.fmin(np.fmax(np.float32(float(vel[i]) + float(du[i, 0])), lo32[0]), hi32[0])
+                trial[i, 1] = np.fmin(np.fmax(np.float32(float(kappa[i]) + float(du[i, 1])), lo32[1]), hi32[1])
+            if not np.isfinite(trial).all():
+                continue
+            tc = lq_box_rollout_cost(table, x0, Qf, Rf, QNf, lo32, hi32, margin, trial)
+            total = tc["J"] + float(w_bound) * tc["V"]
+            if total < best:
+                best = total
+                out.update(plan=trial, chosen=which, J=tc["J"], V=tc["V"])
+    return out
+
+
 def frenet_start(table, pose):
     """Frenet start state of a pose w.r.t. the path's first waypoint (t2s, dynamics.py:23-40) as csrc/acmpc_lq.h computes it
     for mode T handles: libm cos / sin / fmod on float64 scalars."""

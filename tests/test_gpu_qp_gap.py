@@ -30,21 +30,22 @@ COLD_MAX, WARM_MAX, WARM_MEDIAN_MAX = 0.02, 0.015, 0.002
 # round 4: the last round of a warm solve holds the LQ plan (csrc/acmpc_lq.h) - the QP's optimum wherever no box row is
 # active - so the excess over the optimum's TRACKING cost has a bound on every quantile, the worst case included
 # (measured: median 0.000, p90 0.007, worst 0.011 for the plan alone)
-TRACKING_MEDIAN_MAX, TRACKING_P90_MAX, TRACKING_WORST_MAX = 0.05, 0.3, 1.0
+# round 5: thresholds at <= 5x what was measured (they were ~90x: a 50-fold regression passed)
+TRACKING_MEDIAN_MAX, TRACKING_P90_MAX, TRACKING_WORST_MAX = 0.001, 0.03, 0.05
 
 
-def _qp_optimum(mpc, cfg):
+def _qp_optimum(mpc, cfg, offset=0.0, max_iter=6000):
     """The reference's QP for the controller's current path, solved by the oracle's restated OSQP at the tightest of
     1e-5 / 1e-4 / 1e-3 that converges (one nearly straight scenario is feasible only to ~1e-4: the reference pins t_0 = 0
     while boxing t >= 0.01, control.py:134 vs :67, and the solver's tolerance has to absorb what is left of that)."""
     n = cfg["horizon"] - 1
     path = mpc.reference_path
-    x0 = mpc.model.t2s(path.get_state(0), np.array([0.0, 0.0, np.pi / 2]))
+    x0 = mpc.model.t2s(path.get_state(0), np.array([offset, 0.0, np.pi / 2]))
     qp = orc.control_qp(x0, path.table, cfg, mpc.model)
     n_eq = 3 * (n + 1)   # drop x_0's box rows (see above)
     keep = np.r_[0:n_eq, n_eq + 3:len(qp["l"])]
     for eps in (1e-5, 1e-4, 1e-3):
-        ref = orc.osqp_restated(qp["P_diag"], qp["q"], qp["A"][keep], qp["l"][keep], qp["u"][keep], max_iter=6000,
+        ref = orc.osqp_restated(qp["P_diag"], qp["q"], qp["A"][keep], qp["l"][keep], qp["u"][keep], max_iter=max_iter,
                                 eps_abs=eps, eps_rel=eps, adaptive_rho=True)
         if ref.info.status == "solved":
             break
@@ -118,3 +119,132 @@ def test_shipped_schedule_against_the_qp_optimum():
     assert np.median(of_tracking) <= TRACKING_MEDIAN_MAX, of_tracking
     assert np.percentile(of_tracking, 90) <= TRACKING_P90_MAX, of_tracking
     assert of_tracking.max() <= TRACKING_WORST_MAX, of_tracking
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: the racing configuration, where the QP's box rows are ACTIVE.  The 28 scenarios above drive a 100 m wide road:
+# no corridor row binds and the LQ plan is the optimum.  The control process hands over widths linspace(10, 6, H)
+# (/root/reference/src/acmpc/control/controller.py:256-267) at the per-track weights of configs/<track>.yaml:67-81, horizon
+# 50; then the corridor e_y in +-(w/2 - margin) (control/solvers/control.py:57-60) and the input box (control.py:130-139)
+# are what make the problem a QP.
+# ---------------------------------------------------------------------------------------------------------------------
+def _racing_scenarios():
+    """(name, track, H x 3 path, offset, extra) - extra: dict(build_v_max=..) builds the model with that speed limit."""
+    from acmpc_amd import workloads as wl
+    H = 50
+    out = []
+    # (a) input saturation: the reference script's hairpins under the racing corridor ...
+    for r in (9.0, 10.0, 12.0, 15.0):
+        out.append(("hairpin(%g)" % r, "monza", wl.racing_widths(wl.family_path("hairpin", r, H)), 0.0, {}))
+    out.append(("hairpin(15) entered at 30 deg", "monza", wl.racing_widths(wl.family_path("hairpin", 15.0, H, angle=-np.pi / 6)), 0.0, {}))
+    # ... and corners at or inside the steering limit (kappa_max = tan(0.30) / 2.65 = 0.1167: r_min 8.57 m) entered from a
+    # straight - the optimum prepares steps ahead; the clipped LQ plan's excess here is 2x - 15x, or it leaves the corridor
+    for track, r, lead in (("monza", 8.0, 30.0), ("monza", 7.5, 60.0), ("monza", 9.0, 15.0), ("spa", 8.0, 30.0), ("spa", 7.5, 15.0),
+                           ("nordschleife", 8.0, 30.0), ("nordschleife", 7.5, 60.0), ("silverstone", 8.0, 15.0),
+                           ("silverstone", 7.5, 30.0)):
+        out.append(("straight %g m + corner r %g" % (lead, r), track, wl.corner_entry_path(r, lead, H), 0.0, {}))
+    for track, r in (("monza", 8.0), ("spa", 10.0), ("nordschleife", 8.0)):
+        out.append(("s-bend r %g" % r, track, wl.s_bend_path(r, 20.0, H), 0.0, {}))
+    # (b) corridor: from 2 / 3 / 3.8 m off the centre line (the corridor is +-4.03 m at the car, +-2.03 m at the horizon)
+    for off in (-3.8, -3.0, -2.0, 2.0, 3.0, 3.8):
+        out.append(("straight 150 m from %+g m" % off, "silverstone" if off < 0 else "nordschleife",
+                    wl.racing_widths(wl.family_path("straight", 150.0, H)), off, {}))
+    for track, r, off in (("monza", 8.0, -2.0), ("monza", 8.0, 2.0), ("spa", 10.0, 2.0), ("nordschleife", 8.0, -2.0),
+                          ("silverstone", 10.0, -2.0)):
+        out.append(("straight 30 m + corner r %g from %+g m" % (r, off), track, wl.corner_entry_path(r, 30.0, H), off, {}))
+    # (c) speed box: the model built with v_max = 20 m/s (input box 20.1) under a live reference speed of 28 - the speed
+    # profile, hence u_ref, lies above the box along the straights
+    for kind, parameter in (("straight", 150.0), ("hairpin", 40.0)):
+        out.append(("%s(%g), speed box 20 under a 28 m/s profile" % (kind, parameter), "monza",
+                    wl.racing_widths(wl.family_path(kind, parameter, H)), 1.0, {"build_v_max": 20.0}))
+    return out
+
+
+# measured (round 5, gpurun_out/qp_gap_racing.json): see the assertions' messages; thresholds <= 5x measured
+RACING_EXCESS_MEDIAN_MAX, RACING_EXCESS_P90_MAX, RACING_EXCESS_WORST_MAX = 0.005, 0.03, 0.06
+RACING_VIOLATION_WORST_MAX = 1.0e-6     # sum of squared state-row excess of the returned plan [m^2 / s^2]
+
+
+def test_racing_configuration_with_active_box_rows():
+    """Per scenario: a fresh controller (cold solve, then four warm ones of the same pose, the live v_max rewritten
+    before every solve as the control process does, controller.py:241-243); the returned plan's tracking cost against
+    the restated-OSQP optimum's, and the plan's OWN summed squared box-row excess - the reference returns a feasible
+    dec.x or keeps the previous plan (spatial_mpc.py:193-217)."""
+    import time
+    from acmpc_amd.mpc import build_mpc
+    from test_support import RACING
+    rows = []
+    for name, track, path_in, offset, extra in _racing_scenarios():
+        cfg = copy.deepcopy(RACING[track])
+        live_v_max = float(cfg["unlocalised_max_speed"])
+        if "build_v_max" in extra:
+            cfg["speed_profile_constraints"]["v_max"] = extra["build_v_max"]
+        mpc = build_mpc(cfg, PlaceholderVehicle())
+        assert mpc._control_solver._lq_candidate == 2      # the shipped default
+        failures, plans, stats, took, problem = 0, [], [], [], None
+        for solve in range(5):
+            mpc.speed_profile_constraints["v_max"] = live_v_max
+            start = time.perf_counter()
+            mpc.get_control(path_in, offset=offset)
+            took.append(time.perf_counter() - start)
+            failures += mpc.infeasibility_counter > 0
+            stats.append(mpc._control_solver._engine.lq_box_stats())
+            if mpc.infeasibility_counter == 0 and solve in (0, 4):
+                if problem is None:
+                    problem = _qp_optimum(mpc, cfg, offset, max_iter=20000)
+                plans.append(_plan_objective(mpc, cfg, problem))
+        assert failures == 0 and len(plans) == 2, "%s/%s: %d of 5 solves rejected" % (track, name, failures)
+        tracking = problem["j_qp"] + problem["constant"]
+        rows.append({"scenario": "%s: %s" % (track, name), "tracking_cost_qp": tracking, "qp_eps": problem["eps"],
+                     "cold_excess": (plans[0][0] - problem["j_qp"]) / tracking, "cold_violation": plans[0][1],
+                     "warm_4_excess": (plans[1][0] - problem["j_qp"]) / tracking, "warm_4_violation": plans[1][1],
+                     "box_iterations": [s["iterations"] for s in stats], "box_chosen": [s["chosen"] for s in stats],
+                     "box_triggered": [int(s["triggered"]) for s in stats], "solve_us": [round(1e6 * t, 1) for t in took]})
+    print("\n%-58s %9s %9s %9s %9s %9s  %s" % ("scenario", "track qp", "cold ex", "cold V", "warm4 ex", "warm4 V", "box iterations"))
+    for r in rows:
+        print("%-58s %9.4f %9.4f %9.1e %9.4f %9.1e  %s" % (r["scenario"], r["tracking_cost_qp"], r["cold_excess"],
+                                                         r["cold_violation"], r["warm_4_excess"], r["warm_4_violation"],
+                                                         r["box_iterations"]))
+    excess = np.array([r["warm_4_excess"] for r in rows])
+    violation = np.array([r["warm_4_violation"] for r in rows])
+    cold = np.array([r["cold_excess"] for r in rows])
+    summary = {"warm_4_excess": {"median": float(np.median(excess)), "p90": float(np.percentile(excess, 90)),
+                                 "max": float(excess.max()), "min": float(excess.min())},
+               "cold_excess": {"median": float(np.median(cold)), "p90": float(np.percentile(cold, 90)), "max": float(cold.max())},
+               "warm_4_violation_max": float(violation.max()),
+               "cold_violation_max": float(max(r["cold_violation"] for r in rows)),
+               "triggered_scenarios": int(sum(any(r["box_triggered"]) for r in rows)), "scenarios": len(rows)}
+    print(json.dumps(summary))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "qp_gap_racing.json"), "w") as handle:
+            json.dump({"summary": summary, "rows": rows}, handle, indent=1)
+    assert summary["triggered_scenarios"] >= 15, summary     # the family does exercise the box rows
+    # a plan that rolls out feasibly cannot beat the QP's optimum by more than the restated solver's own slack (~1 %)
+    assert excess.min() > -0.03 and cold.min() > -0.03, summary
+    assert np.median(excess) <= RACING_EXCESS_MEDIAN_MAX, summary
+    assert np.percentile(excess, 90) <= RACING_EXCESS_P90_MAX, summary
+    assert excess.max() <= RACING_EXCESS_WORST_MAX, summary
+    assert violation.max() <= RACING_VIOLATION_WORST_MAX, summary
+
+
+def test_an_infeasible_corridor_keeps_the_previous_plan():
+    """A hairpin of radius 10 m entered at 30 degrees under the racing corridor has no feasible plan (the restated OSQP
+    does not converge; every plan leaves the corridor by metres).  The reference then keeps its previous plan and counts
+    the failure (spatial_mpc.py:212-217) - so does the controller, whatever candidate the box refinement offered."""
+    from acmpc_amd import workloads as wl
+    from acmpc_amd.mpc import build_mpc
+    from test_support import RACING
+    cfg = copy.deepcopy(RACING["monza"])
+    mpc = build_mpc(cfg, PlaceholderVehicle())
+    H = cfg["horizon"]
+    mpc.speed_profile_constraints["v_max"] = 28.0
+    mpc.get_control(wl.racing_widths(wl.family_path("hairpin", 40.0, H)), offset=0.5)
+    assert mpc.infeasibility_counter == 0
+    kept = mpc.projected_control.copy()
+    for attempt in range(3):
+        mpc.get_control(wl.racing_widths(wl.family_path("hairpin", 10.0, H, angle=-np.pi / 6)), offset=0.0)
+        assert mpc.infeasibility_counter == attempt + 1
+        np.testing.assert_array_equal(mpc.projected_control, kept)
+    mpc.get_control(wl.racing_widths(wl.family_path("hairpin", 40.0, H)), offset=0.5)
+    assert mpc.infeasibility_counter == 0

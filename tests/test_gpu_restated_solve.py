@@ -72,8 +72,9 @@ def _tick(H, cons, N, rounds, offset, seed):
 def test_the_tick_equals_the_restated_solve(mode, window):
     """Three consecutive ticks of acmpc_control_tick (16 384 candidates x 2 rounds, the controller's shape): each record
     is the restated solve on the tables the device prologue built, warm-started from the tick before, with the LQ plan for
-    this tick's waypoints and pose and the PREVIOUS tick's speed profile as the last round's candidate 2 (none in the first)."""
-    from acmpc_amd import Engine
+    this tick's waypoints and pose and the PREVIOUS tick's speed profile as the last round's candidate 2 - in the first
+    tick (round 5) the profile the host solves once for it: acmpc_velocity_ceiling + acmpc_speed_profile_qp, cold."""
+    from acmpc_amd import Engine, _capi
     from acmpc_amd.mpc import waypoint_table
     H, N, rounds = 50, 16384, 2
     n = H - 1
@@ -95,13 +96,19 @@ def test_the_tick_equals_the_restated_solve(mode, window):
         out = eng.control_tick(t, coords, centre)
         assert out["info"][4] == 0 and out["info"][7] == 0
         x0, u_ref, coef = eng.tick_device_tables(n)
-        plan = None
-        if previous is not None:   # this tick's waypoints, the previous tick's speed profile, this tick's pose
-            table = waypoint_table(coords, 1e-12)
+        # this tick's waypoints and pose; the previous tick's speed profile, or the one the host solves for a first tick
+        table = waypoint_table(coords, 1e-12)
+        if previous is not None:
             table[6] = previous[6]
-            frenet = orc.frenet_start(table, np.array([offset, 0.0, np.pi / 2]))
-            plan = orc.lq_plan(table, frenet, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi)
-            assert plan is not None
+        else:
+            ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
+                                             cons["end_velocity"])
+            table[6], _, status, _ = _capi.speed_profile_qp(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"],
+                                                            max_iter=4000, check_every=10)
+            assert status == "solved"
+        frenet = orc.frenet_start(table, np.array([offset, 0.0, np.pi / 2]))
+        plan = orc.lq_plan(table, frenet, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi)
+        assert plan is not None
         want = orc.optimize_restated(mode, x0, coef, u_ref if centre is None else centre, u_ref, N, rounds, (0.5, 1e-3), 0.5,
                                      900 + j, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi, 1.0e6, 0.05, window,
                                      extra=plan)
