@@ -160,9 +160,12 @@ def _racing_scenarios():
     return out
 
 
-# measured (round 5, gpurun_out/qp_gap_racing.json): see the assertions' messages; thresholds <= 5x measured
-RACING_EXCESS_MEDIAN_MAX, RACING_EXCESS_P90_MAX, RACING_EXCESS_WORST_MAX = 0.005, 0.03, 0.06
-RACING_VIOLATION_WORST_MAX = 1.0e-6     # sum of squared state-row excess of the returned plan [m^2 / s^2]
+# measured (round 5, 30 scenarios, 19 of them with the refinement triggered): warm-4 excess median 7.6e-5, p90 0.0065, worst
+# 0.0113 (the restated OSQP's own slack at 1e-5: its equality rows are met to the tolerance, a plan's exactly), least -0.0032;
+# cold (first solve of a fresh controller) median 1.8e-5, p90 0.0065, worst 0.0113; the returned plan's summed squared
+# state-row excess at most 1.5e-7 (the t >= 0.01 row of x_1 at 32 m/s, control.py:134 vs :67).  Thresholds <= 5x measured
+RACING_EXCESS_MEDIAN_MAX, RACING_EXCESS_P90_MAX, RACING_EXCESS_WORST_MAX = 0.0004, 0.03, 0.055
+RACING_VIOLATION_WORST_MAX = 7.5e-7     # sum of squared state-row excess of the returned plan [m^2 / s^2]
 
 
 def test_racing_configuration_with_active_box_rows():
