@@ -32,6 +32,18 @@ struct Track {
   int m;
 };
 
+// the map's points binned into square cells (see grid_nearest below)
+struct GridIndex {
+  const int* start;     // [nx * ny + 1]: cell c holds entries [start[c], start[c + 1]) of the three arrays below
+  const double* x;      // the points in cell order (row-major cells, ascending point index inside a cell) ...
+  const double* y;
+  const int* index;     // ... and the index each has in the polyline
+};
+struct GridGeometry {
+  double x0, y0, cell;
+  int nx, ny;
+};
+
 struct ScoreArgs {
   const float* states;     // [P][3]
   const float* obs;        // [K_left + K_right][2], vehicle frame (x right, y forward)
@@ -49,6 +61,10 @@ struct ScoreArgs {
   // nearest points found by pf_nearest_kernel (the grid search) - the scoring kernel then skips its own scan
   const int32_t* given_index;   // [P][3] or nullptr
   const double* given_d2;       // [P][3]
+  // or found by the scoring workgroup itself through the grid (pf_score_kernel<1>: a wavefront per polyline)
+  int own_grid_search;
+  GridIndex grid[3];
+  GridGeometry geometry;
 };
 
 constexpr int kWaves = kBlock / 64;
@@ -87,12 +103,6 @@ __device__ __forceinline__ double wave_sum(double v) {
 // distance is below margin^2.  Same float64 distance expression, ties to the lower index: the answer is the
 // exhaustive scan's, bit for bit.  A particle whose search is not settled after kMaxRings rings (far from the track,
 // or outside the box) is scanned exhaustively by its whole wavefront.
-struct GridIndex {
-  const int* start;     // [nx * ny + 1]: cell c holds entries [start[c], start[c + 1]) of the three arrays below
-  const double* x;      // the points in cell order (row-major cells, ascending point index inside a cell) ...
-  const double* y;
-  const int* index;     // ... and the index each has in the polyline
-};
 struct GridArgs {
   const float* states;   // [P][3]
   const int* live;       // or nullptr
@@ -105,92 +115,148 @@ struct GridArgs {
 };
 constexpr int kMaxRings = 4;
 
-// One lane per (particle, polyline): the search is a chain of dependent loads, and three short chains side by side
-// finish sooner than one long one.
+// (distance^2, index) minimum over the LANES consecutive lanes that share a query (LANES a power of two), every one
+// of them ends with the result
+template <int LANES>
+__device__ __forceinline__ void group_argmin(double& d, int& i) {
+#pragma unroll
+  for (int mask = LANES / 2; mask >= 1; mask >>= 1) {
+    const double od = __shfl_xor(d, mask, 64);
+    const int oi = __shfl_xor(i, mask, 64);
+    take_smaller(d, i, od, oi);
+  }
+}
+
+// One run of the cell-ordered arrays - the points of a row of cells - against the query, LANES lanes side by side, two
+// points per lane and trip: consecutive lanes read consecutive points, so a trip is a handful of cache lines, where a lane
+// walking its own run (rounds 2-4: one lane per query) touched a line per lane and array - the search was bound by the
+// number of LINES its gathers asked the vector cache for, not by their bytes (round 5, profiles/r05_pf_sq_counters.json).
+template <int LANES>
+__device__ __forceinline__ void scan_run(const double* __restrict__ gx, const double* __restrict__ gy,
+                                         const int* __restrict__ gi, int j0, int j1, int sub, double px, double py,
+                                         double& best, int& best_i) {
+  for (int j = j0 + sub; j < j1; j += 2 * LANES) {
+    const int k = min(j + LANES, j1 - 1);   // past the run: its last point again (harmless: same distance, same index)
+    const double ax = gx[j], ay = gy[j], bx = gx[k], by = gy[k];
+    const int ai = gi[j], bi = gi[k];
+    const double adx = px - ax, ady = py - ay, bdx = px - bx, bdy = py - by;
+    take_smaller(best, best_i, adx * adx + ady * ady, ai);
+    take_smaller(best, best_i, bdx * bdx + bdy * bdy, bi);
+  }
+}
+
+// The nearest point of one polyline to (px, py) through the grid, by the LANES lanes of a group together (`sub` = the
+// lane's place in its group; every argument but `sub` is the same for all of them).  The block of 3 x 3 cells round the
+// query first - its three rows requested together - then 5 x 5 ... (2 kMaxRings + 1)^2, each block scanned whole; after a
+// block every point not yet seen is at least `margin` = the distance to the nearest side of the block that has cells
+// beyond it away, so the search stops as soon as the best squared distance is below margin^2.  Returns whether it settled;
+// (best, best_i) are the group's result then.  Same float64 distance expression as the exhaustive scan, ties to the lower
+// index: its answer, bit for bit.  (The single cell of rounds 2-4 is no longer tried first: the left and right limits
+// lie 4.75 m from the centre line, more than half a cell - two queries in three never settled there.)
+template <int LANES>
+__device__ __forceinline__ bool grid_nearest(double px, double py, const GridGeometry& g, const int* __restrict__ start,
+                                             const double* __restrict__ gx, const double* __restrict__ gy,
+                                             const int* __restrict__ gi, int sub, double& best, int& best_i) {
+  const int ix = min(max(static_cast<int>(floor((px - g.x0) / g.cell)), 0), g.nx - 1);
+  const int iy = min(max(static_cast<int>(floor((py - g.y0) / g.cell)), 0), g.ny - 1);
+  for (int r = 1; r <= kMaxRings; ++r) {
+    const int x_lo = max(ix - r, 0), x_hi = min(ix + r, g.nx - 1);
+    const int y_lo = max(iy - r, 0), y_hi = min(iy + r, g.ny - 1);
+    best = INFINITY;
+    best_i = 0x7fffffff;
+    if (r == 1) {   // three rows at most: their six run bounds in flight together, then their points
+      int j0[3], j1[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int cy = iy - 1 + k;
+        const bool inside = cy >= 0 && cy < g.ny;
+        const int row = inside ? cy * g.nx : 0;
+        j0[k] = start[row + x_lo];
+        j1[k] = inside ? start[row + x_hi + 1] : j0[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) scan_run<LANES>(gx, gy, gi, j0[k], j1[k], sub, px, py, best, best_i);
+    } else {
+      for (int cy = y_lo; cy <= y_hi; ++cy)
+        scan_run<LANES>(gx, gy, gi, start[cy * g.nx + x_lo], start[cy * g.nx + x_hi + 1], sub, px, py, best, best_i);
+    }
+    group_argmin<LANES>(best, best_i);
+    // distance to the nearest side of the block that has cells beyond it
+    double margin = INFINITY;
+    if (ix - r > 0) margin = fmin(margin, px - (g.x0 + (ix - r) * g.cell));
+    if (ix + r < g.nx - 1) margin = fmin(margin, (g.x0 + (ix + r + 1) * g.cell) - px);
+    if (iy - r > 0) margin = fmin(margin, py - (g.y0 + (iy - r) * g.cell));
+    if (iy + r < g.ny - 1) margin = fmin(margin, (g.y0 + (iy + r + 1) * g.cell) - py);
+    // (1 - 1e-9: the comparison must hold for the exact values; strictly below, so that a point outside the block at
+    // exactly the same distance, which could carry a lower index, is still looked at)
+    if (margin > 0.0 && best < margin * margin * (1.0 - 1e-9)) return true;
+    if (margin == INFINITY) return true;   // the block covers the whole box
+  }
+  return false;
+}
+
+// The exhaustive scan of one polyline by a whole wavefront (what the grid search falls back to: a query far from the
+// track, outside the box, non-finite); every lane ends with the result.
+__device__ __forceinline__ void wave_scan(const Track& track, double qx, double qy, int lane, double& d, int& i) {
+  d = INFINITY;
+  i = 0x7fffffff;
+  for (int m = lane; m < track.m; m += 64) {
+    const double dx = qx - track.xy[2 * m], dy = qy - track.xy[2 * m + 1];
+    const double dd = dx * dx + dy * dy;
+    if (dd < d) {   // ascending m per lane: the first minimum stays
+      d = dd;
+      i = m;
+    }
+  }
+  wave_argmin(d, i);
+}
+
+// Sixteen lanes per (particle, polyline) query, four queries per wavefront at a time, kQueriesPerWave per wavefront.
+constexpr int kGroupLanes = 16;
+constexpr int kQueriesPerWave = 16;
+
 __global__ void __launch_bounds__(64) pf_nearest_kernel(const GridArgs a, const int P_arg) {
   const int lane = threadIdx.x;
   const int P = (a.live != nullptr) ? a.live[0] : P_arg;
-  const int first = blockIdx.x * 64;
+  const int first = blockIdx.x * kQueriesPerWave;
   if (first >= 3 * P) return;   // wave-uniform
-  const int query = first + lane;
-  const bool active = query < 3 * P;
-  const int p = active ? query / 3 : P - 1;
-  const int t = active ? query - 3 * p : 0;
-  const double px = a.states[3 * p], py = a.states[3 * p + 1];
-  const int ix = min(max(static_cast<int>(floor((px - a.x0) / a.cell)), 0), a.nx - 1);
-  const int iy = min(max(static_cast<int>(floor((py - a.y0) / a.cell)), 0), a.ny - 1);
-  const int* __restrict__ start = (t == 0) ? a.grid[0].start : (t == 1) ? a.grid[1].start : a.grid[2].start;
-  const double* __restrict__ gx = (t == 0) ? a.grid[0].x : (t == 1) ? a.grid[1].x : a.grid[2].x;
-  const double* __restrict__ gy = (t == 0) ? a.grid[0].y : (t == 1) ? a.grid[1].y : a.grid[2].y;
-  const int* __restrict__ gi = (t == 0) ? a.grid[0].index : (t == 1) ? a.grid[1].index : a.grid[2].index;
-  double best = INFINITY;
-  int best_i = 0x7fffffff;
-  bool settled = false;
-  for (int r = 0; r <= kMaxRings && !settled; ++r) {
-    // the whole block of (2r + 1)^2 cells again (a second ring is rare): a row of cells is ONE run of the cell-ordered
-    // arrays, walked eight points at a time so that the loads of a batch are in flight together - a lane has nothing
-    // else to hide a load behind
-    const int x_lo = max(ix - r, 0), x_hi = min(ix + r, a.nx - 1);
-    const int y_lo = max(iy - r, 0), y_hi = min(iy + r, a.ny - 1);
-    best = INFINITY;
-    best_i = 0x7fffffff;
-    for (int cy = y_lo; cy <= y_hi; ++cy) {
-      const int j0 = start[cy * a.nx + x_lo], j1 = start[cy * a.nx + x_hi + 1];
-      for (int j = j0; j < j1; j += 8) {
-        double bx[8], by[8];
-        int bi[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int jj = min(j + k, j1 - 1);   // past the run: its last point again (harmless: same distance, same index)
-          bx[k] = gx[jj];
-          by[k] = gy[jj];
-          bi[k] = gi[jj];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const double dx = px - bx[k], dy = py - by[k];
-          take_smaller(best, best_i, dx * dx + dy * dy, bi[k]);
-        }
+  const int group = lane / kGroupLanes, sub = lane % kGroupLanes;
+  const GridGeometry geo{a.x0, a.y0, a.cell, a.nx, a.ny};
+#pragma unroll 1
+  for (int round = 0; round < kQueriesPerWave / (64 / kGroupLanes); ++round) {
+    const int base = first + round * (64 / kGroupLanes);
+    if (base >= 3 * P) break;   // wave-uniform
+    const int query = base + group;
+    const bool active = query < 3 * P;
+    const int p = active ? query / 3 : P - 1;
+    const int t = active ? query - 3 * p : 0;
+    const double px = a.states[3 * p], py = a.states[3 * p + 1];
+    const int* __restrict__ start = (t == 0) ? a.grid[0].start : (t == 1) ? a.grid[1].start : a.grid[2].start;
+    const double* __restrict__ gx = (t == 0) ? a.grid[0].x : (t == 1) ? a.grid[1].x : a.grid[2].x;
+    const double* __restrict__ gy = (t == 0) ? a.grid[0].y : (t == 1) ? a.grid[1].y : a.grid[2].y;
+    const int* __restrict__ gi = (t == 0) ? a.grid[0].index : (t == 1) ? a.grid[1].index : a.grid[2].index;
+    double best;
+    int best_i;
+    const bool settled = grid_nearest<kGroupLanes>(px, py, geo, start, gx, gy, gi, sub, best, best_i);
+    // the rest: all 64 lanes scan the polyline side by side for each unsettled query of the wave
+    unsigned long long pending = __ballot(!settled && sub == 0);
+    while (pending != 0ull) {
+      const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(pending)) - 1);
+      pending &= pending - 1ull;
+      const double qx = __shfl(px, src, 64), qy = __shfl(py, src, 64);
+      const int qt = __builtin_amdgcn_readlane(t, src);
+      double d;
+      int i;
+      wave_scan(a.track[qt], qx, qy, lane, d, i);
+      if (lane == src) {
+        best = d;
+        best_i = i;
       }
     }
-    // distance to the nearest side of the block that has cells beyond it
-    double margin = INFINITY;
-    if (ix - r > 0) margin = fmin(margin, px - (a.x0 + (ix - r) * a.cell));
-    if (ix + r < a.nx - 1) margin = fmin(margin, (a.x0 + (ix + r + 1) * a.cell) - px);
-    if (iy - r > 0) margin = fmin(margin, py - (a.y0 + (iy - r) * a.cell));
-    if (iy + r < a.ny - 1) margin = fmin(margin, (a.y0 + (iy + r + 1) * a.cell) - py);
-    // (1 - 1e-9: the comparison must hold for the exact values; strictly below, so that a point outside the block at
-    // exactly the same distance, which could carry a lower index, is still looked at)
-    settled = margin > 0.0 && best < margin * margin * (1.0 - 1e-9);
-    if (margin == INFINITY) settled = true;   // the block covers the whole box
-  }
-  // the rest: all 64 lanes scan the polyline side by side for each unsettled query of the wave
-  unsigned long long pending = __ballot(!settled);
-  while (pending != 0ull) {
-    const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(pending)) - 1);
-    pending &= pending - 1ull;
-    const double qx = __shfl(px, src, 64), qy = __shfl(py, src, 64);
-    const int qt = __builtin_amdgcn_readlane(t, src);
-    const Track track = a.track[qt];
-    double d = INFINITY;
-    int i = 0x7fffffff;
-    for (int m = lane; m < track.m; m += 64) {
-      const double dx = qx - track.xy[2 * m], dy = qy - track.xy[2 * m + 1];
-      const double dd = dx * dx + dy * dy;
-      if (dd < d) {   // ascending m per lane: the first minimum stays
-        d = dd;
-        i = m;
-      }
+    if (active && sub == 0) {
+      a.index_out[3 * p + t] = best_i;
+      a.d2_out[3 * p + t] = best;
     }
-    wave_argmin(d, i);
-    if (lane == src) {
-      best = d;
-      best_i = i;
-    }
-  }
-  if (active) {
-    a.index_out[3 * p + t] = best_i;
-    a.d2_out[3 * p + t] = best;
   }
 }
 
@@ -223,8 +289,25 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
   // three nearest-neighbour queries (localiser.py:282-289): first minimum of the float64 squared distance - found
   // already by the grid search, or scanned here
   const Track tracks[3] = {a.centre, a.left, a.right};
-  const bool given = a.given_index != nullptr;   // wave-uniform
-  if (given) {
+  const bool own_search = PB == 1 && a.own_grid_search != 0;   // wave-uniform
+  if (own_search) {
+    // the reference's particle counts (hundreds): a wavefront per polyline, its 64 lanes across the points of the cells
+    // round the particle - ~150 points per polyline instead of all 11 600 (rounds 1-4 scanned the whole map here: 35 us
+    // for 500 particles, every workgroup reading 556 kB through the L2)
+    if (wave < 3) {
+      double best;
+      int best_i;
+      if (!grid_nearest<64>(px[0], py[0], a.geometry, a.grid[wave].start, a.grid[wave].x, a.grid[wave].y,
+                            a.grid[wave].index, lane, best, best_i))
+        wave_scan(tracks[wave], px[0], py[0], lane, best, best_i);
+      if (lane < kWaves) {
+        s_d[wave][0][lane] = (lane == 0) ? best : INFINITY;
+        s_i[wave][0][lane] = (lane == 0) ? best_i : 0x7fffffff;
+      }
+    }
+  }
+  const bool given = a.given_index != nullptr || own_search;   // wave-uniform
+  if (given && !own_search) {
     for (int e = tid; e < 3 * PB * kWaves; e += kBlock) {
       const int w = e % kWaves, q = (e / kWaves) % PB, t = e / (kWaves * PB);
       const int p = min(p0 + q, P - 1);
@@ -737,15 +820,22 @@ void build_grid(acmpc_pf* h) {
   }
 }
 
-// (below kGridParticles the scan is faster: a few hundred particles cannot hide the grid search's dependent loads,
-// while the scan spreads every particle over a whole workgroup)
+// from kGridParticles up the grid search is a launch of its own in front of the scoring (sixteen lanes per query); below,
+// the scoring workgroup of a particle searches the grid itself, a wavefront per polyline
 constexpr int kGridParticles = 4096;
 bool use_grid(const acmpc_pf* h, int P) {
   return h->grid_nx > 0 && P >= kGridParticles && !h->no_grid;
 }
 
-// the grid search in front of a scoring launch; fills `a.given_*`
+// the grid search in front of a scoring launch (fills `a.given_*`) - or, below kGridParticles, inside it
 hipError_t launch_nearest(acmpc_pf* h, ScoreArgs& a, int P, hipStream_t s) {
+  a.own_grid_search = 0;
+  if (h->grid_nx > 0 && !h->no_grid && P < kGridParticles) {
+    a.own_grid_search = 1;
+    for (int t = 0; t < 3; ++t) a.grid[t] = GridIndex{h->d_grid_start[t], h->d_grid_x[t], h->d_grid_y[t], h->d_grid_index[t]};
+    a.geometry = GridGeometry{h->grid_x0, h->grid_y0, h->grid_cell, h->grid_nx, h->grid_ny};
+    return hipSuccess;
+  }
   if (!use_grid(h, P)) return hipSuccess;
   GridArgs g{};
   g.states = a.states;
@@ -761,7 +851,7 @@ hipError_t launch_nearest(acmpc_pf* h, ScoreArgs& a, int P, hipStream_t s) {
   g.ny = h->grid_ny;
   g.index_out = h->d_near_index;
   g.d2_out = h->d_near_d2;
-  hipLaunchKernelGGL(pf_nearest_kernel, dim3((3 * P + 63) / 64), dim3(64), 0, s, g, P);
+  hipLaunchKernelGGL(pf_nearest_kernel, dim3((3 * P + kQueriesPerWave - 1) / kQueriesPerWave), dim3(64), 0, s, g, P);
   a.given_index = h->d_near_index;
   a.given_d2 = h->d_near_d2;
   return hipGetLastError();
