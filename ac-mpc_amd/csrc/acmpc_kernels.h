@@ -18,6 +18,10 @@ struct RolloutArgs {
   int P, N, n;
   int64_t index_offset;   // global index of local candidate 0
   Weights w;
+  // mode T, set by the launcher for a launch that is ONE generation of waves (every workgroup resident from the start):
+  // a wave lowers its own issue priority as it moves through the horizon, so that the waves of a SIMD finish together
+  // instead of oldest first
+  int even_progress = 0;
 };
 
 struct FinalizeArgs {

@@ -129,6 +129,31 @@ __device__ __forceinline__ bool holds_candidate_2(const RolloutArgs& a, const Sa
   return smp.u_extra != nullptr && first <= 2 && 2 < first + kWave;
 }
 
+// Phase stamps of the mode T rollout for tools/modeT_stamps.py (a scratch build of the library with -DACMPC_T_STAMPS,
+// tools/ab_build.sh): lane 0 of every wave stamps the 100 MHz wall clock at entry, after the tables are staged, after the
+// step loop and at its end, and leaves its place on the chip (XCC_ID, HW_ID) beside them.  Nothing in the library.
+#ifdef ACMPC_T_STAMPS
+constexpr int kStampWaves = 1 << 17;
+__device__ unsigned long long g_t_stamps[kStampWaves * 6];
+#define ACMPC_T_STAMP(slot)                                                                                      \
+  do {                                                                                                           \
+    if constexpr (MODE == 1) {                                                                                   \
+      const unsigned wave_ = (blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / kWave) + (threadIdx.x / kWave);   \
+      if ((threadIdx.x & (kWave - 1)) == 0 && wave_ < kStampWaves) {                                             \
+        g_t_stamps[wave_ * 6 + (slot)] = wall_clock64();                                                         \
+        if ((slot) == 0) {                                                                                       \
+          g_t_stamps[wave_ * 6 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   /* HW_ID */         \
+          g_t_stamps[wave_ * 6 + 5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   /* XCC_ID */        \
+        }                                                                                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+  } while (0)
+#else
+#define ACMPC_T_STAMP(slot) \
+  do {                      \
+  } while (0)
+#endif
+
 // PACK = candidates per arithmetic state: 2 = pairs in v_pk_* instructions, 1 = plain float32 instructions.
 // Mode T with two candidates per lane needs 67 VGPRs as the compiler allocates it freely: seven waves per SIMD, where a
 // launch of 1 M candidates is eight - the eighth workgroup of every CU then runs alone after the others (a second
@@ -154,6 +179,7 @@ __device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned cha
   const float* __restrict__ coef = a.coef + static_cast<size_t>(p) * n * kStride;
   const float* __restrict__ x0 = a.x0 + p * 3;
 
+  ACMPC_T_STAMP(0);
   float* s_xy = s_wp + n * kCoefT;  // the nearest-waypoint search's key table: (a, b, c) per waypoint (search_entry)
   float* s_frames = s_xy + ((kKeyStride * n + 3) & ~3);  // frames of the verified search (exhaustive semantics), when given
   if constexpr (MODE == 1) {
@@ -164,6 +190,7 @@ __device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned cha
     }
     __syncthreads();
   }
+  ACMPC_T_STAMP(1);
 
   float cost[CPT];
   bool feas[CPT];
@@ -230,6 +257,21 @@ __device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned cha
       }
       with_search_kind(w, n, [&](auto kind) {
         for (int i = 0; i < n; ++i) {
+          // A launch of ONE generation (a.even_progress, set by the launcher): the hardware issues from the oldest wave
+          // first, so the eight waves of a SIMD finish one after the other - the first after half the launch, the last
+          // alone, with nothing to hide its latencies behind - and the launch ends a quarter later than the SIMD's
+          // instructions take.  A wave that is ahead yields instead: priority 3 in the first quarter of the horizon down to
+          // 0 in the last; the waves stay within a quarter of each other and leave together (1 M candidates, one box:
+          // resident share of the launch 0.57-0.73 -> 0.89, 110 -> 98 us; tools/modeT_stamps.py).  With several
+          // generations the staggered ends are what overlaps a new workgroup's staging with its neighbours' arithmetic:
+          // there the flag stays off (16.8 M: 1 % slower with it).
+          if (a.even_progress != 0 && (i & 3) == 0) {
+            const int quarter = (4 * i) / n;
+            if (quarter == 0) __builtin_amdgcn_s_setprio(3);
+            else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
+            else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+          }
           float v[CPT], k[CPT];
           load_controls<LAYOUT, CPT>(a.U, p, a.N, n, i, c_run, v, k);
           if constexpr (decltype(kind)::value == kSearchVerified) {
@@ -280,6 +322,7 @@ __device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned cha
     }
   }
 
+  ACMPC_T_STAMP(2);
   // (cost, index) argmin: thread -> wave (shuffles) -> workgroup (LDS) -> one partial per workgroup
   int64_t key = kKeyMax;
   int nfeas = 0;
@@ -320,6 +363,7 @@ __device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned cha
       a.partial_feas[slot] = nfeas;
     }
   }
+  ACMPC_T_STAMP(3);
 }
 
 template <int MODE, int LAYOUT, int CPT, int BLOCK, int PACK = (CPT >= 2 ? 2 : 1), int WAVES = 1>
@@ -2810,15 +2854,27 @@ hipError_t launch_rollout_tile_rows_plain(const LaunchShape& shape, const Rollou
   return launch_rollout_tile_rows<kTileRowsMaxSteps, 4, false>(shape, args, s, e0, e1);
 }
 
+#ifdef ACMPC_T_STAMPS
+}  // namespace acmpc
+extern "C" int acmpc_debug_t_stamps(unsigned long long* out, int waves) {
+  return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(acmpc::g_t_stamps), static_cast<size_t>(waves) * 6 * sizeof(unsigned long long)));
+}
+namespace acmpc {
+#endif
 hipError_t launch_rollout_temporal_plain(const LaunchShape& shape, const RolloutArgs& args, hipStream_t s,
                                          hipEvent_t e0, hipEvent_t e1) {
   if (shape.block == 64 && shape.cpt == 1) return launch_rollout_t<1, 1, 1, 64, 1>(shape, args, s, e0, e1);
   if (shape.block == 256 && shape.cpt == 1) return launch_rollout_t<1, 1, 1, 256, 1>(shape, args, s, e0, e1);
   if (shape.block == 256 && shape.cpt == 2) {
-    // two candidates per lane: 67 VGPRs, or 63 when capped at eight waves per SIMD (see rollout_kernel)
-    const bool window_of_eight = args.w.nn_ahead >= 0 && args.w.nn_back + args.w.nn_ahead + 1 == 8;
-    return window_of_eight ? launch_rollout_t<1, 1, 2, 256, 1>(shape, args, s, e0, e1)
-                           : launch_rollout_t<1, 1, 2, 256, 1, 8>(shape, args, s, e0, e1);
+    // two candidates per lane, the allocation capped for eight waves per SIMD (62 VGPRs either way since round 4's key
+    // table).  Round 5: ONE instantiation for every search.  The uncapped one the 8-waypoint window used to take
+    // (next_free_sgpr 74 against 72, otherwise the same resources) was dealt badly by the dispatcher in every launch
+    // looked at: of 2 048 workgroups - eight per compute unit, all of which fit - 12 to 60 were held back until a first
+    // workgroup had finished, 65 us into a 130 us launch, beside compute units that ran seven all along; this one starts
+    // all 8 192 waves within 1.6 us, eight per SIMD (tools/modeT_stamps.py).
+    RolloutArgs one = args;
+    one.even_progress = static_cast<long long>(args.P) * shape.blocks_per_problem * (shape.block / kWave) <= 8 * 1024 ? 1 : 0;
+    return launch_rollout_t<1, 1, 2, 256, 1, 8>(shape, one, s, e0, e1);
   }
   if (shape.block == 256 && shape.cpt == 4) return launch_rollout_t<1, 1, 4, 256, 1>(shape, args, s, e0, e1);
   return hipErrorInvalidConfiguration;

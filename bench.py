@@ -301,50 +301,104 @@ def particle_filter_block(workloads, iters=20):
             t.append(time.perf_counter() - t0)
         us = float(np.median(t) * 1e6)
         entry = {"update_us": us, "particles_per_s": P / (us * 1e-6)}
-        if P < 4096:
-            # below 4 096 particles every query scans its whole polyline (a workgroup per particle): particle x map-point
-            # distance evaluations, 5 float64 flops + a compare each; from 4 096 up the grid search looks at ~150 points
-            pairs = P * 3 * len(centre)
-            entry.update(nearest_point_search="exhaustive scan", distance_evaluations_per_s=pairs / (us * 1e-6),
-                         fp64_TFLOPs=pairs * 5 / (us * 1e-6) / 1e12)
-        else:
-            entry.update(nearest_point_search="uniform grid, exact (certified rings, wave-wide scan for the rest)")
+        # the three nearest points per particle through the uniform grid (exact: certified blocks of cells, a wave-wide scan
+        # for what they do not settle): inside the scoring workgroup below 4 096 particles (a wavefront per polyline), as a
+        # launch of its own in front of the scoring above (sixteen lanes per query)
+        entry.update(nearest_point_search="uniform grid, exact; " + ("inside the scoring launch" if P < 4096 else
+                                                                      "pf_nearest_kernel in front of the scoring launch"))
         out["particles_%d" % P] = entry
     scorer.close()
-    # What bounds the kernels: kernel durations from the committed rocprofv3 summary of
-    # tools/bench_pf.py (profiles/*_pf_kernel_stats.json, tools/profile_pf.sh), the work they do, and the roofs it is held
-    # against: the float64 vector rate (78.6 TFLOP/s: half the guide's 157.3 TFLOP/s float32 vector peak) and the L2's
-    # bandwidth for rows every workgroup shares (guide: 16.8-18.8 TB/s).  Both kernels are latency-bound: a few hundred
-    # workgroups of dependent loads - the fractions say how far.
+    # What bounds the kernels: kernel durations from the committed rocprofv3 summary of tools/bench_pf.py
+    # (profiles/*_pf_kernel_stats.json, tools/profile_pf.sh) and - round 5 - the counters of the same command
+    # (profiles/*_pf_sq_counters.json, tools/pmc_pf.sh): the cache LINES the kernel's vector loads ask the per-CU vector
+    # caches for (TCP_TOTAL_CACHE_ACCESSES) against what 256 of them serve - a 64-byte line per clock each at the ~2.1 GHz
+    # the chip holds, 34.4 TB/s, the guide's L2 -> L1 figure.  Round 4's searches (one lane per query walking its own cells)
+    # asked for 16 lines per load instruction and sat at 0.59 of that rate; round 5's (consecutive lanes on consecutive
+    # points) ask for a third of the lines and are bound by the length of a query's chain of dependent loads.
     stats, stats_path = newest_profile("pf_kernel_stats.json")
+    counters, counters_path = newest_profile("pf_sq_counters.json")
+    line_rate = 256 * 64 * 2.1e9
     if stats is not None:
-        m = len(centre)
-        map_bytes = 3 * m * 2 * 8                                     # three polylines of float64 (x, y)
-        bounds = {"source": stats_path, "measured_in_this_run": False, "fp64_vector_peak_TFLOPs": 78.6,
-                  "l2_shared_rows_peak_TBps": 17.8}
-        small = stats["sizes"].get("500", {}).get("pf_score_kernel<1>")
-        if small is not None:
-            t = small["average_us"] * 1e-6
-            pairs = 500 * 3 * m
-            bounds["pf_score_kernel<1>_at_500"] = {
-                "kernel_us": small["average_us"], "distance_evaluations_per_s": pairs / t,
-                "fp64_TFLOPs": pairs * 5 / t / 1e12, "frac_of_fp64_vector_peak": pairs * 5 / t / 78.6e12,
-                "l2_bytes": 500 * map_bytes, "l2_TBps": 500 * map_bytes / t / 1e12,
-                "frac_of_l2_bandwidth": 500 * map_bytes / t / 17.8e12,
-                "note": "one workgroup per particle scans the whole %d kB map out of the L2" % (map_bytes // 1000)}
-        big = stats["sizes"].get("100000", {}).get("pf_nearest_kernel")
-        if big is not None:
-            t = big["average_us"] * 1e-6
-            gathered = 100000 * 3 * 150 * 16                          # ~150 map points of 16 bytes per (particle, polyline) query
-            bounds["pf_nearest_kernel_at_100000"] = {
-                "kernel_us": big["average_us"], "queries_per_s": 300000 / t, "bytes_gathered": gathered,
-                "l2_TBps": gathered / t / 1e12, "frac_of_l2_bandwidth": gathered / t / 17.8e12,
-                "note": "uniform-grid search: ~150 points of its cells per (particle, polyline) query, dependent loads ring by ring"}
-            score = stats["sizes"]["100000"].get("pf_score_kernel<8>")
-            if score is not None:
-                bounds["pf_score_kernel<8>_at_100000"] = {"kernel_us": score["average_us"]}
+        bounds = {"source": stats_path, "counters_source": counters_path, "measured_in_this_run": False,
+                  "vector_cache_line_rate_TBps": line_rate / 1e12}
+        runs = (counters or {}).get("runs", {})
+        newest = [run for label, run in sorted(runs.items()) if label.endswith("new")]
+        for label, size, kernel in (("pf_score_kernel<1>_at_500", "500", "pf_score_kernel<1>"),
+                                    ("pf_nearest_kernel_at_100000", "100000", "pf_nearest_kernel"),
+                                    ("pf_score_kernel<8>_at_100000", "100000", "pf_score_kernel<8>")):
+            timed = stats["sizes"].get(size, {}).get(kernel)
+            if timed is None:
+                continue
+            entry = {"kernel_us": timed["average_us"]}
+            counted = newest[-1]["sizes"].get(size, {}).get(kernel) if newest else None
+            if counted is not None and "derived" in counted and "vector_cache_line_accesses" in counted["derived"]:
+                d = counted["derived"]
+                lines = d["vector_cache_line_accesses"]
+                entry.update(vector_cache_line_accesses=lines,
+                             line_accesses_per_read_instruction=d["vector_cache_line_accesses_per_read_instruction"],
+                             l2_hit_rate=d["l2_hit_rate"],
+                             share_of_wave_cycles_waiting=d["share_of_wave_cycles"]["waiting_on_memory_or_barrier (SQ_WAIT_ANY)"],
+                             share_of_wave_cycles_issue_stalled=d["share_of_wave_cycles"][
+                                 "issue_stalled (SQ_WAIT_INST_ANY: the vector-memory queue is full)"],
+                             frac_of_vector_cache_line_rate=lines * 64 / (timed["average_us"] * 1e-6) / line_rate)
+            if kernel == "pf_nearest_kernel":
+                entry["queries_per_s"] = 300000 / (timed["average_us"] * 1e-6)
+            bounds[label] = entry
         out["kernel_bounds"] = bounds
     return out
+
+
+SECONDARY_SCALARS = ("mode_T_window_2_5_frac_1M", "mode_T_window_2_5_frac_16M", "mode_T_exhaustive_frac_1M",
+                     "mode_T_exhaustive_frac_16M", "mode_T_window_1_2_frac_1M", "mode_T_valu_frac_window_2_5_1M",
+                     "mode_T_valu_frac_window_2_5_16M", "mode_T_valu_frac_exhaustive_1M", "mode_T_valu_frac_exhaustive_16M",
+                     "mode_T_window_2_5_us_1M", "mode_T_exhaustive_us_1M", "mode_S_candidate_major_frac_1M",
+                     "sampled_fused_16M_traj_per_s", "single_solve_us_p50", "config3_single_us_p50", "config4_share_us_p50",
+                     "config5_us_p50", "config5_us_p99", "config5_pinned_us_p50", "config5_pinned_us_p99", "tick_ms_p50",
+                     "tick_ms_p99", "tick_infeasible_solves", "tick_mode_T_ms_p50", "tick_mode_T_ms_p99",
+                     "tick_mode_T_window_2_5_ms_p50", "pf_update_us_500", "pf_update_us_100000")
+
+
+def secondary_scalars(out):
+    """Scalar copies of the secondary results, for `roofline` (see main)."""
+    second = out["secondary_kernels"]
+
+    def frac(name, key="frac_of_hbm_roofline"):
+        return second.get(name, {}).get(key)
+
+    def valu(name):
+        return second.get(name, {}).get("roofline_valu", {}).get("frac")
+
+    pf = out.get("particle_filter", {})
+    scalars = {
+        "mode_T_window_2_5_frac_1M": frac("mode_T_window_2_5"), "mode_T_window_2_5_frac_16M": frac("mode_T_window_2_5_16M"),
+        "mode_T_exhaustive_frac_1M": frac("mode_T_exhaustive_search"),
+        "mode_T_exhaustive_frac_16M": frac("mode_T_exhaustive_search_16M"),
+        "mode_T_window_1_2_frac_1M": frac("mode_T_window_1_2"),
+        "mode_T_valu_frac_window_2_5_1M": valu("mode_T_window_2_5"), "mode_T_valu_frac_window_2_5_16M": valu("mode_T_window_2_5_16M"),
+        "mode_T_valu_frac_exhaustive_1M": valu("mode_T_exhaustive_search"),
+        "mode_T_valu_frac_exhaustive_16M": valu("mode_T_exhaustive_search_16M"),
+        "mode_T_window_2_5_us_1M": frac("mode_T_window_2_5", "kernel_us"),
+        "mode_T_exhaustive_us_1M": frac("mode_T_exhaustive_search", "kernel_us"),
+        "mode_S_candidate_major_frac_1M": frac("mode_S_candidate_major"),
+        "sampled_fused_16M_traj_per_s": frac("sampled_fused_16M", "candidate_trajectories_per_s"),
+        "single_solve_us_p50": out.get("single_solve", {}).get("device_resident_us_p50"),
+        "config3_single_us_p50": out.get("config3_single", {}).get("device_resident_us_p50"),
+        "config4_share_us_p50": out.get("config4_share", {}).get("device_resident_us_p50"),
+        "config5_us_p50": out.get("config5_host_pointer", {}).get("solve_us_p50"),
+        "config5_us_p99": out.get("config5_host_pointer", {}).get("solve_us_p99"),
+        "config5_pinned_us_p50": out.get("config5_host_pointer", {}).get("pinned", {}).get("solve_us_p50"),
+        "config5_pinned_us_p99": out.get("config5_host_pointer", {}).get("pinned", {}).get("solve_us_p99"),
+        "tick_ms_p50": out.get("closed_loop_replay", {}).get("solve_ms_p50"),
+        "tick_ms_p99": out.get("closed_loop_replay", {}).get("solve_ms_p99"),
+        "tick_infeasible_solves": out.get("closed_loop_replay", {}).get("infeasible_solves"),
+        "tick_mode_T_ms_p50": out.get("closed_loop_replay_mode_T", {}).get("solve_ms_p50"),
+        "tick_mode_T_ms_p99": out.get("closed_loop_replay_mode_T", {}).get("solve_ms_p99"),
+        "tick_mode_T_window_2_5_ms_p50": out.get("closed_loop_replay_mode_T_window_2_5", {}).get("solve_ms_p50"),
+        "pf_update_us_500": pf.get("particles_500", {}).get("update_us"),
+        "pf_update_us_100000": pf.get("particles_100000", {}).get("update_us"),
+    }
+    assert set(scalars) == set(SECONDARY_SCALARS)
+    return scalars
 
 
 def latest_traffic(algorithmic_bytes, kernel_name):
@@ -1022,6 +1076,11 @@ def main():
             out["config5_host_pointer"] = config5_host_pointer(workloads, Engine, device)
             out["config5_host_pointer"]["pinned"] = config5_host_pointer(workloads, Engine, device, poses=3000, pinned=True)
             out["particle_filter"] = particle_filter_block(workloads)
+        if "secondary_kernels" in out:
+            # The driver's record keeps `roofline`'s scalar keys verbatim and only the NAMES of the nested blocks: the figures
+            # the review reads - north_star's literal kernel, the one-solve configurations, the tick, the particle filter -
+            # are copied here as scalars (the blocks they come from stay in the line).
+            out["roofline"].update(secondary_scalars(out))
         if world == 1 and not args.no_cpu_baseline:
             gpu_costs = last.costs[:32].cpu().numpy()  # costs of the last step = controls[(steps-1) % buffers]
             out["cpu_baseline"] = cpu_baseline(batch, mode, controls[(args.steps - 1) % args.buffers], args.layout, N,

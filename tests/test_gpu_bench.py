@@ -69,6 +69,17 @@ def test_single_gpu_line_has_the_contract_fields():
     assert "10000 consecutive poses" in five["workload"] and 0 < five["solve_us_p50"] <= five["solve_us_p99"]
     pf = out["particle_filter"]
     assert pf["particles_500"]["update_us"] > 0 and pf["particles_100000"]["particles_per_s"] > 1e6
+    # the driver keeps `roofline`'s scalar keys and only the names of the nested blocks: every secondary figure the review
+    # reads is there as a scalar too, and equals the block it was copied from
+    sys.path.insert(0, ROOT)
+    import bench
+    for key in bench.SECONDARY_SCALARS:
+        assert key in roof and isinstance(roof[key], (int, float)) and not isinstance(roof[key], bool), key
+    assert roof["mode_T_window_2_5_frac_1M"] == second["mode_T_window_2_5"]["frac_of_hbm_roofline"]
+    assert roof["mode_T_exhaustive_frac_16M"] == second["mode_T_exhaustive_search_16M"]["frac_of_hbm_roofline"]
+    assert roof["tick_ms_p50"] == out["closed_loop_replay"]["solve_ms_p50"] and roof["tick_infeasible_solves"] == 0
+    assert roof["config5_us_p50"] == five["solve_us_p50"] and roof["pf_update_us_500"] == pf["particles_500"]["update_us"]
+    assert roof["config3_single_us_p50"] == out["config3_single"]["device_resident_us_p50"]
 
 
 def test_stream_of_batches_is_the_default_and_two_launches_the_option():

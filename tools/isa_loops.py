@@ -23,6 +23,11 @@ def loops(path, needle):
         t = l.strip().split()
         if len(t) == 2 and t[0].startswith("s_cbranch") and t[1] in where and where[t[1]] < i:
             found.append((where[t[1]], i, t[1]))
+    # (a backward branch between the flow blocks of a scalar if-chain - s_setprio by quarter of the horizon - is not a loop
+    # of the arithmetic: ranges without a vector instruction do not count)
+    def has_valu(f):
+        return any(l.strip().startswith("v_") for l in body[f[0]:f[1] + 1])
+    found = [f for f in found if has_valu(f)]
     inner = [f for f in found if not any(o is not f and f[0] <= o[0] and o[1] <= f[1] for o in found)]
     out = []
     for lo, hi, label in inner:

@@ -23,7 +23,7 @@ from isa_loops import loops  # noqa: E402
 
 # entry -> (source, kernel name substring, how to recognise the loop: (opcode, count) pairs that must match)
 ENTRIES = {
-    "window_2_5": ("acmpc_kernels_temporal.hip", "rollout_kernelILi1ELi1ELi2ELi256ELi1ELi1E", {"ds_read_b128": 16}),
+    "window_2_5": ("acmpc_kernels_temporal.hip", "rollout_kernelILi1ELi1ELi2ELi256ELi1ELi8E", {"ds_read_b128": 16}),
     "window_1_2": ("acmpc_kernels_temporal.hip", "rollout_kernelILi1ELi1ELi2ELi256ELi1ELi8E", {"ds_read_b128": 10}),
     "exhaustive": ("acmpc_kernels_temporal.hip", "rollout_kernelILi1ELi1ELi2ELi256ELi1ELi8E", {"ds_read_b128": 20}),
     # the fused sample + rollout round: its step loop comes in several unrolled pieces of one mix; the largest stands for it
