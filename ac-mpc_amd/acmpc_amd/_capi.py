@@ -135,6 +135,9 @@ SIGNATURES = {
     "acmpc_lq_box_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acmpc_lq_box_stats": (C.c_int, [_CTX, C.c_void_p]),
+    "acmpc_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "acmpc_rccl_comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "acmpc_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
     "acmpc_last_error": (C.c_char_p, [_CTX]),
     "acmpc_set_paths": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
     "acmpc_get_coefficients": (C.c_int, [_CTX, C.c_int32, _F32P, C.c_int32]),
@@ -295,6 +298,38 @@ def lq_plan(table: np.ndarray, x0, step_cost, r_term, final_cost, u_min, u_max):
     rc = lib.acmpc_lq_plan(table.ctypes.data, n, *(a.ctypes.data for a in args), *(b.ctypes.data for b in box),
                            plan.ctypes.data)
     return plan if rc == OK else None
+
+
+RCCL_UNIQUE_ID_BYTES = 128
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId of the RCCL `Engine.reduce_across_ranks` resolves (acmpc_rccl_unique_id): call on ONE rank, hand the
+    128 bytes to the others."""
+    buffer = C.create_string_buffer(RCCL_UNIQUE_ID_BYTES)
+    rc = load_library().acmpc_rccl_unique_id(buffer)
+    if rc != OK:
+        raise EngineError(rc, "acmpc_rccl_unique_id: no RCCL in the process and librccl.so.1 not loadable"
+                          if rc == ESTATE else "acmpc_rccl_unique_id: ncclGetUniqueId failed")
+    return buffer.raw
+
+
+def rccl_comm_create(unique_id: bytes, n_ranks: int, rank: int, device: int = -1) -> int:
+    """ncclCommInitRank (acmpc_rccl_comm_create): collective over the `n_ranks` ranks that hold `unique_id`; returns the
+    communicator as an integer handle for `Engine.reduce_across_ranks` / `rccl_comm_destroy`."""
+    if len(unique_id) != RCCL_UNIQUE_ID_BYTES:
+        raise EngineError(EINVAL, "an ncclUniqueId is %d bytes" % RCCL_UNIQUE_ID_BYTES)
+    comm = C.c_void_p()
+    rc = load_library().acmpc_rccl_comm_create(C.create_string_buffer(unique_id, RCCL_UNIQUE_ID_BYTES), int(n_ranks), int(rank),
+                                               int(device), C.byref(comm))
+    if rc != OK:
+        raise EngineError(rc, "acmpc_rccl_comm_create(n_ranks=%d, rank=%d) failed" % (n_ranks, rank))
+    return comm.value
+
+
+def rccl_comm_destroy(comm: int) -> None:
+    if comm:
+        load_library().acmpc_rccl_comm_destroy(C.c_void_p(comm))
 
 
 def lq_box_plan(table: np.ndarray, x0, step_cost, r_term, final_cost, u_min, u_max, margin: float, w_bound: float,

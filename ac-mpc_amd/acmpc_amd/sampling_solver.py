@@ -9,7 +9,8 @@ A few refinement rounds (sample around the incumbent, shrink the spread) take th
 optimum.  Candidates are generated on the device too (Philox counters, smooth perturbations - `acmpc_optimize`), so
 one solve is a single host round trip.  The rounds, the candidate count and the spread are build parameters read
 from optional config keys (`n_candidates`, `sampling_rounds`, `sampling_sigma`, `sampling_cold_rounds`,
-`sampling_cold_sigma`, `sampling_seed`, `w_bound`, `sampling_update`, `softmin_lambda`, `lq_candidate`).
+`sampling_cold_sigma`, `sampling_seed`, `w_bound`, `sampling_update`, `softmin_lambda`, `lq_candidate`,
+`conformant_sync`).
 
 Round 4: the last round of every solve also holds one deterministic candidate, the LQ plan (`lq_candidate`):
 the optimum of the reference's QP without its box rows - a backward Riccati pass over the linearised model
@@ -93,6 +94,7 @@ class ControlSolver:
         # plan refined against the QP's box rows where one of them is active (csrc/acmpc_lq_box.h), 1 / True = the LQ plan
         # alone (round 4), 0 / False = none
         self._lq_candidate = int(config.get("lq_candidate", 2)) if self._centre_update == "argmin" else 0
+        self._conformant_sync = bool(config.get("conformant_sync", False))
         self._incumbent = None
         self._engine = None  # built on first solve: the input box follows the live velocity limits
         mode = str(config.get("rollout_mode", "S")).upper()
@@ -132,6 +134,8 @@ class ControlSolver:
                 wheelbase=self._dynamics_model.length, w_bound=self._w_bound, centre_update=self._centre_update,
                 softmin_lambda=self._lambda, dt=self._dt, nn_window=self._nn_window if self.temporal else None,
                 lq_candidate=self._lq_candidate)
+            if self._conformant_sync:   # (control config key `conformant_sync`: include/acmpc.h, acmpc_set_option)
+                self._engine.set_option("ACMPC_CONFORMANT_SYNC", "1")
             if getattr(self, "_map", None) is not None:
                 self._engine.bind_map(*self._map)
         return self._engine

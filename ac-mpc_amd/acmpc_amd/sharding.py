@@ -97,6 +97,15 @@ class ShardedRollout:
         self.costs = torch.empty(n_problems, n_local, dtype=torch.float32, device=device) if want_costs else None
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.sampler = None
+        self.rccl_comm = 0     # use_library_collective()
+
+    def use_library_collective(self, rccl_comm: int):
+        """Carry the step's one collective - the all-reduce(MIN) of the packed keys - through the library's own entry point,
+        `acmpc_reduce_across_ranks` on `rccl_comm` (an ncclComm_t as an integer: `LibraryCommunicator` below, or the
+        host's own), enqueued on the step's stream, instead of torch.distributed.  The rank then takes the multi-rank path
+        (rollout -> keys -> reduce -> finalize) even when it is the only one: a one-rank communicator is a valid one."""
+        self.rccl_comm = int(rccl_comm)
+        self.distributed = True
 
     def use_sampler(self, centre: torch.Tensor, u_ref: Optional[torch.Tensor], sigma, seed: int, round_: int = 0):
         """Declare that the control matrices handed to rollout()/select() were produced by `sample()` with these
@@ -125,7 +134,7 @@ class ShardedRollout:
         if self.sampler is not None:
             sp = self.sampler
             if self.distributed:
-                self._all_reduce(self.keys, dist.ReduceOp.MIN)   # the only collective
+                self._reduce_keys(stream)   # the only collective
             centre = sp["centre"]
             stride = centre.shape[-2] * 2 if centre.dim() == 3 else centre.shape[-1]
             self.engine.finalize_sampled_device(self.keys.data_ptr() if self.distributed else 0, x0.data_ptr(),
@@ -136,10 +145,11 @@ class ShardedRollout:
                                                 stream)
             return self.records
         if self.distributed:
-            self._all_reduce(self.keys, dist.ReduceOp.MIN)
+            self._reduce_keys(stream)
             self.engine.finalize_device(self.keys.data_ptr(), x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n,
                                         self.layout, self.offset, self.records.data_ptr(), stream)
-            self._all_reduce(self.records, dist.ReduceOp.SUM)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                self._all_reduce(self.records, dist.ReduceOp.SUM)
         else:
             self.engine.finalize_device(0, x0.data_ptr(), U.data_ptr(), self.P, self.N, self.n, self.layout,
                                         self.offset, self.records.data_ptr(), stream)
@@ -230,6 +240,12 @@ class ShardedRollout:
             dist.all_gather(parts, mine, group=self.group)
         return combine_softmin(parts, self.n)
 
+    def _reduce_keys(self, stream: int):
+        if self.rccl_comm:
+            self.engine.reduce_across_ranks(self.rccl_comm, self.keys.data_ptr(), self.P, stream)
+        else:
+            self._all_reduce(self.keys, dist.ReduceOp.MIN)
+
     def _all_reduce(self, tensor: torch.Tensor, op):
         if self.host_collectives:
             staged = tensor.cpu()              # synchronises with the stream that produced `tensor`
@@ -237,6 +253,35 @@ class ShardedRollout:
             tensor.copy_(staged)
         else:
             dist.all_reduce(tensor, op=op, group=self.group)
+
+
+class LibraryCommunicator:
+    """An RCCL communicator made by the library itself (acmpc_rccl_unique_id / acmpc_rccl_comm_create: the copy of RCCL that
+    `acmpc_reduce_across_ranks` resolves), one rank per GPU.  Rank 0 draws the ncclUniqueId; with more than one rank it
+    travels through the torch.distributed group that is already up (any backend - it is 128 bytes of host memory).
+    `ShardedRollout.use_library_collective(communicator.handle)` then routes the step's all-reduce through the C ABI."""
+
+    def __init__(self, device_index: int, group: Optional[dist.ProcessGroup] = None):
+        from . import _capi
+        self._capi = _capi
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if multi else 1
+        self.rank = dist.get_rank(group) if multi else 0
+        unique = [_capi.rccl_unique_id() if self.rank == 0 else None]
+        if multi:
+            dist.broadcast_object_list(unique, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.handle = _capi.rccl_comm_create(unique[0], self.world, self.rank, device_index)
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._capi.rccl_comm_destroy(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PipelinedRollout:

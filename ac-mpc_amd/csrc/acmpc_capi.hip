@@ -616,7 +616,8 @@ const char* const kOptionNames[] = {
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
     "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TICK_NO_INLINE_PATH", "ACMPC_NO_ZERO_COPY", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES",
-    "ACMPC_NO_CHAINED_STREAM", "ACMPC_LQ_BOX_ITERATIONS"};
+    "ACMPC_NO_CHAINED_STREAM", "ACMPC_LQ_BOX_ITERATIONS",
+    "ACMPC_CONFORMANT_SYNC"};   // (last: it sets several of the switches above, and wins over them when both are in the environment)
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   const std::string key(name);
@@ -654,6 +655,17 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_TICK_NO_INLINE_PATH") { w.tick_no_inline_path = on; return true; }
   if (key == "ACMPC_NO_ZERO_COPY") { w.no_zero_copy = on; return true; }
   if (key == "ACMPC_TAILED_ROLLOUT") { w.tailed_rollout = on; return true; }
+  if (key == "ACMPC_CONFORMANT_SYNC") {
+    // ONE switch for the forms that stay inside the HSA memory model and HIP's barrier rule (include/acmpc.h): every solve,
+    // round and batch as separate launches, nothing published between workgroups of one launch, no wave of a workgroup
+    // ending while the others still meet at a barrier, completion by hipStreamSynchronize.  Sets (or, off, clears) the
+    // switches that select them - the one-launch solve, the in-launch finalize (with it the traced finalize, the chained
+    // rounds and the multi-wave rounds, which need it), the chained stream, the tick's completion flag - and the tailed
+    // rollout off.  The same bits either way (tests/test_gpu_conformant.py); INTEGRATION.md section 6 has what it costs.
+    w.no_solo = w.no_fused_finalize = w.no_chained_stream = w.tick_no_flag = on;
+    if (on) w.tailed_rollout = false;
+    return true;
+  }
   if (key == "ACMPC_LQ_BOX_ITERATIONS") { c->lq_box_iterations = present ? std::max(0, std::atoi(value)) : 40; return true; }
   return false;
 }
@@ -2082,9 +2094,16 @@ namespace {
 using AllReduceFn = ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
 using ErrorStringFn = const char* (*)(ncclResult_t);
 
+using UniqueIdFn = ncclResult_t (*)(ncclUniqueId*);
+using CommInitRankFn = ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int);
+using CommDestroyFn = ncclResult_t (*)(ncclComm_t);
+
 struct Rccl {
   AllReduceFn all_reduce = nullptr;
   ErrorStringFn error_string = nullptr;
+  UniqueIdFn unique_id = nullptr;
+  CommInitRankFn comm_init_rank = nullptr;
+  CommDestroyFn comm_destroy = nullptr;
 };
 
 // the RCCL that is already in the process owns the caller's communicator; only without one open the system's
@@ -2100,8 +2119,11 @@ const Rccl& rccl() {
       if (handle != nullptr) sym = dlsym(handle, "ncclAllReduce");
     }
     r.all_reduce = reinterpret_cast<AllReduceFn>(sym);
-    void* err = (handle != nullptr) ? dlsym(handle, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
-    r.error_string = reinterpret_cast<ErrorStringFn>(err);
+    auto also = [handle](const char* name) { return (handle != nullptr) ? dlsym(handle, name) : dlsym(RTLD_DEFAULT, name); };
+    r.error_string = reinterpret_cast<ErrorStringFn>(also("ncclGetErrorString"));
+    r.unique_id = reinterpret_cast<UniqueIdFn>(also("ncclGetUniqueId"));
+    r.comm_init_rank = reinterpret_cast<CommInitRankFn>(also("ncclCommInitRank"));
+    r.comm_destroy = reinterpret_cast<CommDestroyFn>(also("ncclCommDestroy"));
     return r;
   }();
   return api;
@@ -2109,6 +2131,40 @@ const Rccl& rccl() {
 
 }  // namespace
 }  // extern "C++"
+
+// A communicator for acmpc_reduce_across_ranks from the SAME copy of RCCL that call resolves (a process can hold two - the
+// system's and the one PyTorch bundles - and a communicator only works with the copy that made it).
+int acmpc_rccl_unique_id(void* id_out) {
+  if (id_out == nullptr) return ACMPC_EINVAL;
+  const Rccl& api = rccl();
+  if (api.unique_id == nullptr) return ACMPC_ESTATE;
+  static_assert(sizeof(ncclUniqueId) == ACMPC_RCCL_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+  return api.unique_id(static_cast<ncclUniqueId*>(id_out)) == ncclSuccess ? ACMPC_OK : ACMPC_EHIP;
+}
+
+int acmpc_rccl_comm_create(const void* id, int32_t n_ranks, int32_t rank, int32_t device, void** comm_out) {
+  if (id == nullptr || comm_out == nullptr || n_ranks < 1 || rank < 0 || rank >= n_ranks) return ACMPC_EINVAL;
+  *comm_out = nullptr;
+  const Rccl& api = rccl();
+  if (api.comm_init_rank == nullptr) return ACMPC_ESTATE;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) {
+    (void)hipGetLastError();
+    return ACMPC_ENODEVICE;
+  }
+  ncclUniqueId by_value;
+  std::memcpy(&by_value, id, sizeof by_value);
+  ncclComm_t comm = nullptr;
+  if (api.comm_init_rank(&comm, n_ranks, by_value, rank) != ncclSuccess) return ACMPC_EHIP;
+  *comm_out = comm;
+  return ACMPC_OK;
+}
+
+int acmpc_rccl_comm_destroy(void* comm) {
+  if (comm == nullptr) return ACMPC_OK;
+  const Rccl& api = rccl();
+  if (api.comm_destroy == nullptr) return ACMPC_ESTATE;
+  return api.comm_destroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? ACMPC_OK : ACMPC_EHIP;
+}
 
 int acmpc_reduce_across_ranks(acmpc_ctx* c, void* rccl_comm, int64_t* d_keys, int32_t P, void* stream) {
   if (c == nullptr) return ACMPC_EINVAL;

@@ -57,6 +57,12 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the multi-rank path with the "
                          "collective payloads staged through the CPU (ranks may then share one GPU)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "capi"],
+                    help="who carries the step's one all-reduce(MIN) of the packed keys: torch = torch.distributed (RCCL "
+                         "through PyTorch; nothing to exchange on one rank); capi = the library's own entry point, "
+                         "acmpc_reduce_across_ranks, on a communicator it makes itself (acmpc_rccl_unique_id on rank 0, shared "
+                         "through the torch.distributed group, acmpc_rccl_comm_create on every rank) - also with ONE rank, "
+                         "where it forces the multi-rank step (rollout, keys, reduce, finalize) through a one-rank communicator")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="(diagnostic) attach no events to the rollout launches; roofline fields become null")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -746,7 +752,8 @@ def sampled_fused_at_scale(workloads, Engine, track, H, device, P=1024, N=16384,
     return block
 
 
-def sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_rank, device, backend, solves=200):
+def sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_rank, device, backend, solves=200,
+                          library_comm=None):
     """The second half of BASELINE.json's metric at N > 1 GPUs: BASELINE configs[3] as ONE sharded solve - 262 144
     candidates x horizon 80 in total, 262 144 / N per rank - one call at a time: this rank's rollout, the all-reduce(MIN)
     of the packed key over the ranks, the winner's record on every rank; barrier before, drained after, max over the
@@ -766,6 +773,8 @@ def sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_
                          U.data_ptr(), stream)
     slot = ShardedRollout(engine, 1, N, n, 1, index_offset=rank * N, device=device, host_collectives=backend == "gloo")
     slot.use_sampler(u_ref, u_ref, SAMPLE_SIGMA, 1000, 0)
+    if library_comm is not None:
+        slot.use_library_collective(library_comm.handle)
     warm = 10
     lat = np.empty(warm + solves)
     for i in range(lat.shape[0]):
@@ -849,7 +858,20 @@ def main():
                       "world_size": dist.get_world_size(), "local_ranks": seen}
 
     from acmpc_amd import Engine, workloads
-    from acmpc_amd.sharding import PipelinedRollout, ShardedRollout
+    from acmpc_amd.sharding import LibraryCommunicator, PipelinedRollout, ShardedRollout
+
+    library_comm = None
+    if args.collective == "capi":
+        if args.pipeline:
+            raise SystemExit("bench: --collective capi runs the collective on the launch stream (no --pipeline)")
+        if args.backend != "nccl":
+            raise SystemExit("bench: --collective capi is RCCL on device memory: one rank per GPU, --backend nccl")
+        library_comm = LibraryCommunicator(local_rank)   # collective: every rank joins here
+        collective = dict(collective or {"world_size": 1, "local_ranks": [local_rank]},
+                          backend="rccl (the library's own communicator: acmpc_rccl_comm_create)",
+                          entry="acmpc_reduce_across_ranks")
+    elif collective is not None:
+        collective["entry"] = "torch.distributed.all_reduce"
 
     mode = 0 if args.mode == "S" else 1
     P, N, H = args.poses, args.candidates, args.horizon
@@ -894,6 +916,8 @@ def main():
                                            host_collectives=args.backend == "gloo")
                 if args.layout == 1:
                     self.slot.use_sampler(u_ref, u_ref, SAMPLE_SIGMA, seeds[0], 0)
+                if library_comm is not None:
+                    self.slot.use_library_collective(library_comm.handle)
 
                 # one rank, nothing to exchange between rollout and argmin: the batches are a STREAM - batch i's argmin and
                 # records run in the last rows of batch i + 1's rollout launch, the last batch's behind drain()
@@ -995,7 +1019,7 @@ def main():
         # (every rank: it contains collectives; after the timed region, so it cannot disturb the headline)
         try:
             sharded_solve = sharded_solve_latency(workloads, Engine, ShardedRollout, world, rank, local_rank, device,
-                                                  args.backend)
+                                                  args.backend, library_comm=library_comm)
         except Exception as error:   # (the same on every rank, or the collectives above would not have returned)
             sharded_solve = {"error": "%s: %s" % (type(error).__name__, error)}
     if rank == 0:
@@ -1091,6 +1115,8 @@ def main():
                 out["cpu_baseline"]["numpy_all_cores"] = numpy_all_cores_baseline(
                     batch, controls[(args.steps - 1) % args.buffers], args.layout, N, n)
         print(json.dumps(out), flush=True)
+    if library_comm is not None:
+        library_comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

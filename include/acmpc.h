@@ -127,6 +127,15 @@ void acmpc_destroy(acmpc_ctx* ctx);
  * environment spells it; value NULL, "" or - for the on / off ones - "0" restores the default).  No launch path reads the
  * environment.  ACMPC_EINVAL for an unknown name. */
 int acmpc_set_option(acmpc_ctx* ctx, const char* name, const char* value);
+/* One of them is for deployment rather than for A/B runs: "ACMPC_CONFORMANT_SYNC" = "1".  The default forms of the latency
+ * paths lean on what gfx950 does rather than on what HIP and the HSA memory model promise (csrc/acmpc_kernels.hip, top):
+ * values cross workgroups inside a launch as relaxed agent-scope atomics ordered by s_waitcnt vmcnt(0), waves of a
+ * workgroup end while the others still meet at s_barrier, and acmpc_control_tick learns of completion from a flag the
+ * last kernel writes into page-locked memory.  With the option on, every solve / round / batch is separate launches
+ * ordered by the stream (rollout, then finalize), rounds run on one wave per workgroup, and completion is
+ * hipStreamSynchronize - the same bits (tests/test_gpu_conformant.py), a few microseconds more per call
+ * (INTEGRATION.md section 6).  Equivalent to ACMPC_NO_SOLO + ACMPC_NO_FUSED_FINALIZE + ACMPC_NO_CHAINED_STREAM +
+ * ACMPC_TICK_NO_FLAG (and no ACMPC_TAILED_ROLLOUT). */
 
 /* The LQ plan of acmpc_params::lq_candidate for one path, on the host (csrc/acmpc_lq.h): table [7][n] float64 in the
  * reference's row order, x0 = (e_y, e_psi, t), weights as in acmpc_params, the input box as the kernels hold it;
@@ -292,6 +301,16 @@ int acmpc_solve_stream_flush(acmpc_ctx* ctx, void* stream);
  * in the process if there is one (the one that owns `rccl_comm`), else `librccl.so.1` (or $ACMPC_RCCL_LIBRARY);
  * the library itself does not link RCCL.  ACMPC_ESTATE when no RCCL can be found, ACMPC_EHIP when RCCL fails. */
 int acmpc_reduce_across_ranks(acmpc_ctx* ctx, void* rccl_comm, int64_t* d_keys, int32_t P, void* stream);
+/* A communicator for it out of the same copy of RCCL (a process may hold two - the system's and the one PyTorch bundles -
+ * and a communicator only works with the copy that made it): acmpc_rccl_unique_id on ONE rank (ncclGetUniqueId; 128
+ * bytes, handed to the others by whatever channel the host has - bench.py uses the torch.distributed store),
+ * acmpc_rccl_comm_create on EVERY rank (ncclCommInitRank: collective, returns when all `n_ranks` have called it; `device`
+ * >= 0 is made current first, one rank per GPU), acmpc_rccl_comm_destroy at the end.  ACMPC_ESTATE when no RCCL can be
+ * found, ACMPC_EHIP when RCCL fails, ACMPC_ENODEVICE for a device that cannot be selected.  No handle. */
+#define ACMPC_RCCL_UNIQUE_ID_BYTES 128
+int acmpc_rccl_unique_id(void* id_out);
+int acmpc_rccl_comm_create(const void* id, int32_t n_ranks, int32_t rank, int32_t device, void** comm_out);
+int acmpc_rccl_comm_destroy(void* comm);
 
 /* Replaces: ControlSolver.solve (control.py:15-24) end to end on the device - `rounds` rounds of
  * sample -> rollout + cost -> argmin, each round sampling round the previous winner with the spread shrunk by

@@ -171,3 +171,22 @@ def test_unpack_decision_temporal_on_the_host():
     np.testing.assert_array_equal(steer_rates, (projected[1, 1:] - projected[1, :-1]) / dt)
     with pytest.raises(ValueError):
         _capi.unpack_decision_temporal(z[:-1], n, dt, wheelbase)
+
+
+def test_rccl_communicator_helpers_refuse_bad_arguments():
+    """acmpc_rccl_unique_id / acmpc_rccl_comm_create / acmpc_rccl_comm_destroy (the communicator bench.py --collective capi
+    makes for acmpc_reduce_across_ranks): the refusals that need neither a GPU nor RCCL."""
+    import ctypes as C
+    from acmpc_amd import _capi
+    lib = _capi.load_library()
+    assert lib.acmpc_rccl_unique_id(None) == _capi.EINVAL
+    comm = C.c_void_p(123)
+    identifier = C.create_string_buffer(_capi.RCCL_UNIQUE_ID_BYTES)
+    for n_ranks, rank in ((0, 0), (2, 2), (2, -1)):
+        assert lib.acmpc_rccl_comm_create(identifier, n_ranks, rank, -1, C.byref(comm)) == _capi.EINVAL
+    assert lib.acmpc_rccl_comm_create(None, 1, 0, -1, C.byref(comm)) == _capi.EINVAL
+    assert lib.acmpc_rccl_comm_create(identifier, 1, 0, -1, None) == _capi.EINVAL
+    assert lib.acmpc_rccl_comm_destroy(None) == _capi.OK          # nothing to destroy
+    with pytest.raises(_capi.EngineError) as refused:
+        _capi.rccl_comm_create(b"too short", 1, 0)
+    assert refused.value.code == _capi.EINVAL

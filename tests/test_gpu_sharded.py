@@ -553,6 +553,53 @@ def test_reduce_across_ranks_with_a_caller_owned_rccl_communicator():
 
 
 
+def test_the_library_makes_its_own_communicator_and_bench_can_use_it():
+    """`LibraryCommunicator` (acmpc_rccl_unique_id / acmpc_rccl_comm_create: the RCCL acmpc_reduce_across_ranks resolves) with
+    the one rank a single GPU allows, `ShardedRollout.use_library_collective`: the step then takes the multi-rank path -
+    rollout, keys, all-reduce(MIN) through the C ABI, finalize - and returns the plain step's records; and
+    `bench.py --collective capi` runs its timed steps that way and says so in its line."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from acmpc_amd import Engine, _capi
+    from acmpc_amd.sharding import LibraryCommunicator, ShardedRollout
+    P, H, N = 5, 50, 2048
+    n = H - 1
+    problems = [make_problem(orc, "monza", H, 4, seed=930 + p) for p in range(P)]
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    x0 = torch.tensor(np.stack([p["x0"] for p in problems]), device=dev)
+    u_ref = torch.tensor(np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]),
+                         dtype=torch.float32, device=dev).contiguous()
+    records = []
+    comm = LibraryCommunicator(0)
+    assert comm.world == 1 and comm.handle
+    for library in (False, True):
+        eng = Engine(**engine_kwargs(problems[0], 0, P, N, n))
+        eng.set_paths(np.stack([p["table"] for p in problems]))
+        slot = ShardedRollout(eng, P, N, n, 1, index_offset=0, device=dev)
+        slot.use_sampler(u_ref, u_ref, (2.0, 0.01), 31, 0)
+        if library:
+            slot.use_library_collective(comm.handle)
+            assert slot.distributed
+        U = torch.empty(P, n, 2, N, device=dev)
+        slot.sample(U, s)
+        slot.step(x0, U, s)
+        torch.cuda.synchronize()
+        records.append(slot.records.cpu().numpy().copy())
+        eng.close()
+    comm.close()
+    np.testing.assert_array_equal(records[0], records[1])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--collective", "capi", "--poses", "64", "--steps", "10",
+                           "--warmup", "3", "--no-cpu-baseline", "--no-single-solve"], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["collective"]["entry"] == "acmpc_reduce_across_ranks" and line["collective"]["world_size"] == 1
+    assert line["value"] > 1e8 and line["roofline"]["kernel"] == "rollout_kernel"     # (no stream form: the reduce sits between)
+
+
 def test_sharded_optimizer_two_ranks_equal_the_unsharded_solve():
     """The multi-GPU closed-loop solve rehearsed with two ranks on the one card (gloo carries the key all-reduce):
     `tests/sharded_optimizer_ranks.py` under torch.distributed.run; both modes, three rounds."""
