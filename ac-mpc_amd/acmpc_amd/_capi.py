@@ -138,6 +138,7 @@ SIGNATURES = {
     "acmpc_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "acmpc_rccl_comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "acmpc_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "acmpc_rollout_start_clocks": (C.c_int, [_CTX, C.c_void_p, C.c_int32, _I32P]),
     "acmpc_last_error": (C.c_char_p, [_CTX]),
     "acmpc_set_paths": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
     "acmpc_get_coefficients": (C.c_int, [_CTX, C.c_int32, _F32P, C.c_int32]),
@@ -651,6 +652,15 @@ class Engine:
         if rc < 0:
             self._check(rc)
         return v, y, ("solved" if rc == 0 else "maximum iterations reached"), iters.value
+
+    def rollout_start_clocks(self, capacity: int = 1 << 20) -> np.ndarray:
+        """Start times [us, from the earliest] of the workgroups of the last rollout launch - needs
+        `set_option("ACMPC_START_CLOCKS", "1")` before it (acmpc_rollout_start_clocks).  Empty without a stamped launch."""
+        raw = np.zeros(capacity, dtype=np.uint64)
+        count = C.c_int32(0)
+        self._check(self._lib.acmpc_rollout_start_clocks(self._ctx, raw.ctypes.data, capacity, C.byref(count)))
+        ticks = raw[:count.value].astype(np.int64)
+        return (ticks - ticks.min()) / 100.0 if count.value else np.zeros(0)
 
     def profile_enable(self, capacity: int):
         """Attach event pairs to the next `capacity` rollout launches (no extra packets on the stream)."""

@@ -144,6 +144,11 @@ struct acmpc_ctx {
   int tick_prev_n = 0;                  // 0: nothing usable (first tick, or a tick that did not end with a finite plan)
   // lq_candidate = 2 (csrc/acmpc_lq_box.h): the splitting's iterate per problem, its factorisation scratch, what the last
   // plan did (acmpc_lq_box_stats) and the iteration cap (ACMPC_LQ_BOX_ITERATIONS)
+  // ACMPC_START_CLOCKS: the rollout launches leave every workgroup's start time here (acmpc_rollout_start_clocks)
+  bool want_start_clocks = false;
+  unsigned long long* d_start_clock = nullptr;
+  size_t start_clock_slots = 0;
+  int start_clock_count = 0;
   std::vector<acmpc::lqbox::State> lq_box_state;
   acmpc::lqbox::Workspace lq_box_ws;
   acmpc::lqbox::Result lq_box_last;
@@ -352,6 +357,19 @@ int rollout(acmpc_ctx* c, const float* d_x0, const float* d_U, int P, int N, int
     e0 = c->prof_start[c->prof_used];
     e1 = c->prof_stop[c->prof_used];
     ++c->prof_used;
+  }
+  c->start_clock_count = 0;
+  if (c->want_start_clocks && !shape.tile) {
+    const size_t slots = static_cast<size_t>(P) * shape.blocks_per_problem;
+    if (slots > c->start_clock_slots) {
+      if (c->d_start_clock != nullptr) (void)hipFree(c->d_start_clock);
+      c->d_start_clock = nullptr;
+      c->start_clock_slots = 0;
+      ACMPC_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_start_clock), slots * sizeof(unsigned long long)));
+      c->start_clock_slots = slots;
+    }
+    a.start_clock = c->d_start_clock;
+    c->start_clock_count = static_cast<int>(slots);
   }
   ACMPC_HIP(c, acmpc::launch_rollout(c->prm.mode, layout, shape, a, s, e0, e1));
   *shape_out = shape;
@@ -616,7 +634,7 @@ const char* const kOptionNames[] = {
     "ACMPC_NO_QUAD_ROUNDS", "ACMPC_NO_PAIR_ROUNDS", "ACMPC_SOLO_REGISTERS", "ACMPC_SOLO_SPLIT", "ACMPC_NO_VERIFIED_SEARCH",
     "ACMPC_NO_SOLO", "ACMPC_NO_FUSED_FINALIZE", "ACMPC_NO_TRACED_FINALIZE", "ACMPC_NO_CHAINED_ROUNDS", "ACMPC_NO_GRAPH",
     "ACMPC_NO_FUSED_SAMPLING", "ACMPC_TICK_GRAPH", "ACMPC_TICK_NO_FLAG", "ACMPC_TICK_NO_INLINE_PATH", "ACMPC_NO_ZERO_COPY", "ACMPC_TAILED_ROLLOUT", "ACMPC_NO_GROUP_FINALIZE", "ACMPC_FINALIZE_WAVES",
-    "ACMPC_NO_CHAINED_STREAM", "ACMPC_LQ_BOX_ITERATIONS",
+    "ACMPC_NO_CHAINED_STREAM", "ACMPC_LQ_BOX_ITERATIONS", "ACMPC_START_CLOCKS",
     "ACMPC_CONFORMANT_SYNC"};   // (last: it sets several of the switches above, and wins over them when both are in the environment)
 
 bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
@@ -655,6 +673,7 @@ bool apply_option(acmpc_ctx* c, const char* name, const char* value) {
   if (key == "ACMPC_TICK_NO_INLINE_PATH") { w.tick_no_inline_path = on; return true; }
   if (key == "ACMPC_NO_ZERO_COPY") { w.no_zero_copy = on; return true; }
   if (key == "ACMPC_TAILED_ROLLOUT") { w.tailed_rollout = on; return true; }
+  if (key == "ACMPC_START_CLOCKS") { c->want_start_clocks = on; return true; }
   if (key == "ACMPC_CONFORMANT_SYNC") {
     // ONE switch for the forms that stay inside the HSA memory model and HIP's barrier rule (include/acmpc.h): every solve,
     // round and batch as separate launches, nothing published between workgroups of one launch, no wave of a workgroup
@@ -814,6 +833,7 @@ void acmpc_destroy(acmpc_ctx* c) {
   if (c->touched_device) {  // also after a failed bring-up: whatever was allocated before the failure is freed
     if (c->prm.device >= 0) (void)hipSetDevice(c->prm.device);
     (void)hipFree(c->d_coef);
+    (void)hipFree(c->d_start_clock);
     (void)hipFree(c->d_partial_keys);
     (void)hipFree(c->d_partial_feas);
     (void)hipFree(c->d_soft_partial);
@@ -2179,6 +2199,17 @@ int acmpc_reduce_across_ranks(acmpc_ctx* c, void* rccl_comm, int64_t* d_keys, in
     msg += (api.error_string != nullptr) ? api.error_string(rc) : "error";
     return fail(c, ACMPC_EHIP, msg.c_str());
   }
+  return ACMPC_OK;
+}
+
+int acmpc_rollout_start_clocks(acmpc_ctx* c, uint64_t* out, int32_t capacity, int32_t* count) {
+  if (c == nullptr) return ACMPC_EINVAL;
+  if (out == nullptr || count == nullptr) return fail(c, ACMPC_EINVAL, "null output");
+  *count = c->start_clock_count;
+  if (c->start_clock_count == 0) return ACMPC_OK;
+  if (capacity < c->start_clock_count) return fail(c, ACMPC_ECAPACITY, "start clocks: capacity below the launch's workgroups");
+  ACMPC_HIP(c, hipDeviceSynchronize());
+  ACMPC_HIP(c, hipMemcpy(out, c->d_start_clock, static_cast<size_t>(c->start_clock_count) * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return ACMPC_OK;
 }
 

@@ -22,6 +22,9 @@ struct RolloutArgs {
   // a wave lowers its own issue priority as it moves through the horizon, so that the waves of a SIMD finish together
   // instead of oldest first
   int even_progress = 0;
+  // diagnostic (acmpc_set_option ACMPC_START_CLOCKS): when not null, every workgroup leaves the 100 MHz wall clock of its
+  // first instruction at [p * blocks_per_problem + block] - what shows a launch whose workgroups did not all start together
+  unsigned long long* start_clock = nullptr;
 };
 
 struct FinalizeArgs {

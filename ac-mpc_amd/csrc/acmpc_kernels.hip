@@ -180,6 +180,8 @@ __device__ __forceinline__ void rollout_block(const RolloutArgs& a, unsigned cha
   const float* __restrict__ x0 = a.x0 + p * 3;
 
   ACMPC_T_STAMP(0);
+  if (a.start_clock != nullptr && threadIdx.x == 0)   // (wave-uniform: a scalar compare when the diagnostic is off)
+    a.start_clock[static_cast<size_t>(p) * gridDim.x + blockIdx.x] = wall_clock64();
   float* s_xy = s_wp + n * kCoefT;  // the nearest-waypoint search's key table: (a, b, c) per waypoint (search_entry)
   float* s_frames = s_xy + ((kKeyStride * n + 3) & ~3);  // frames of the verified search (exhaustive semantics), when given
   if constexpr (MODE == 1) {

@@ -445,6 +445,14 @@ int acmpc_speed_profile_qp(const double* v_hi, const double* ds, int32_t n, doub
                            int32_t max_iter, int32_t check_every, double eps_abs, double eps_rel, double* v, double* y,
                            int32_t warm_start, int32_t* iterations);
 
+/* Diagnostic: with acmpc_set_option(ctx, "ACMPC_START_CLOCKS", "1") every workgroup of a rollout launch
+ * (acmpc_rollout_device and the calls built on it; not the candidate-major tile kernels) leaves the 100 MHz wall clock of
+ * its first instruction on the device; this copies the LAST launch's out (after a device synchronise): `count` = its
+ * workgroups, P x blocks per problem, problem-major.  A launch that fits the chip in one generation should start all of
+ * them within a couple of microseconds; workgroups that start tens of microseconds late are what a dispatcher that
+ * over-subscribes some compute units looks like.  *count = 0: no stamped launch yet. */
+int acmpc_rollout_start_clocks(acmpc_ctx* ctx, uint64_t* out, int32_t capacity, int32_t* count);
+
 /* Measurement hooks.  After acmpc_profile_enable(ctx, K) the next K rollout launches of this handle carry a HIP
  * event pair attached to the dispatch itself (hipExtLaunchKernel: the kernel's own begin/end timestamps on the
  * stream it is launched on, no marker packets between launches); acmpc_profile_collect waits for them, writes the

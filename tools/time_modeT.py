@@ -34,14 +34,20 @@ for name, window in (("exhaustive", None), ("window_2_5", (2, 5)), ("window_1_2"
     x0 = torch.tensor(batch.pose0, device=device)
     U = torch.empty((P, n, 2, N), device=device)
     eng.sample_device(u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, 1, 0, bench.SAMPLE_SIGMA, 77, 0, U.data_ptr(), stream)
-    for _ in range(3):
+    for _ in range(max(3, 4096 // P)):   # (a small launch is over before the clocks have come up from idle: warm up for ~2 ms)
         eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, costs.data_ptr(), 0, stream)
+    eng.set_option("ACMPC_START_CLOCKS", "1")
     eng.profile_enable(20)
+    late = []
     for _ in range(20):
         eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, costs.data_ptr(), 0, stream)
+        starts = eng.rollout_start_clocks()     # (synchronises: the launches of this loop do not queue up behind each other)
+        late.append(int((starts > 10.0).sum()))
     torch.cuda.synchronize()
-    ms = float(np.median(eng.profile_collect()))
+    times = eng.profile_collect()
+    ms = float(np.median(times))
     byts = P * N * (8 * n + 4)
-    print("%-12s %8.1f us  %.3f of the HBM roofline  (checksum %.6e)" % (name, ms * 1e3, byts / (ms * 1e-3) / 1e9 / 8000.0,
-                                                                     float(costs.double().sum())), flush=True)
+    print("%-12s %8.1f us  %.3f of the HBM roofline  (min %.1f max %.1f us; workgroups started > 10 us late per launch: median %d, "
+          "max %d of %d; checksum %.6e)" % (name, ms * 1e3, byts / (ms * 1e-3) / 1e9 / 8000.0, times.min() * 1e3, times.max() * 1e3,
+                                           int(np.median(late)), max(late), len(starts), float(costs.double().sum())), flush=True)
     eng.close()
