@@ -417,6 +417,10 @@ int finalize(acmpc_ctx* c, const int64_t* d_keys_in, int64_t* d_keys_out, const 
 // raised-cosine blend between kSampleKnots knots spread evenly over the n steps
 int upload_segments(acmpc_ctx* c, int n, hipStream_t s) {
   if (c->segments_n == n) return ACMPC_OK;
+  // a pending batch of acmpc_solve_stream_device re-draws its winners with the knot table of ITS horizon, in place in
+  // d_segments: it must have run before the table is rewritten for another (acmpc_solve_stream_device flushes it itself)
+  if (c->stream_pending)
+    return fail(c, ACMPC_ESTATE, "a batch of acmpc_solve_stream_device with another horizon is pending: acmpc_solve_stream_flush first");
   std::vector<float> seg(static_cast<size_t>(n) * 2);
   const double width = static_cast<double>(n - 1) / (acmpc::kSampleKnots - 1);
   for (int i = 0; i < n; ++i) {
@@ -1070,7 +1074,8 @@ int acmpc_solve_stream_device(acmpc_ctx* c, const float* d_x0, const float* d_U,
   if (rc != ACMPC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the pending finalize reads the tables its batch was rolled with: new ones go up behind it
-  if (c->stream_pending && (c->tables_dirty || c->frames_dirty)) {
+  // (and the sampler's knot table of its horizon: upload_segments rewrites it in place for another)
+  if (c->stream_pending && (c->tables_dirty || c->frames_dirty || (d_centre != nullptr && c->segments_n != n))) {
     rc = acmpc_solve_stream_flush(c, stream);
     if (rc != ACMPC_OK) return rc;
   }

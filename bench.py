@@ -357,7 +357,8 @@ def particle_filter_block(workloads, iters=20):
 SECONDARY_SCALARS = ("mode_T_window_2_5_frac_1M", "mode_T_window_2_5_frac_16M", "mode_T_exhaustive_frac_1M",
                      "mode_T_exhaustive_frac_16M", "mode_T_window_1_2_frac_1M", "mode_T_valu_frac_window_2_5_1M",
                      "mode_T_valu_frac_window_2_5_16M", "mode_T_valu_frac_exhaustive_1M", "mode_T_valu_frac_exhaustive_16M",
-                     "mode_T_window_2_5_us_1M", "mode_T_exhaustive_us_1M", "mode_S_candidate_major_frac_1M",
+                     "mode_T_window_2_5_us_1M", "mode_T_exhaustive_us_1M", "mode_T_window_2_5_late_workgroups_1M",
+                     "mode_T_exhaustive_late_workgroups_1M", "mode_S_candidate_major_frac_1M",
                      "sampled_fused_16M_traj_per_s", "single_solve_us_p50", "config3_single_us_p50", "config4_share_us_p50",
                      "config5_us_p50", "config5_us_p99", "config5_pinned_us_p50", "config5_pinned_us_p99", "tick_ms_p50",
                      "tick_ms_p99", "tick_infeasible_solves", "tick_mode_T_ms_p50", "tick_mode_T_ms_p99",
@@ -385,6 +386,8 @@ def secondary_scalars(out):
         "mode_T_valu_frac_exhaustive_16M": valu("mode_T_exhaustive_search_16M"),
         "mode_T_window_2_5_us_1M": frac("mode_T_window_2_5", "kernel_us"),
         "mode_T_exhaustive_us_1M": frac("mode_T_exhaustive_search", "kernel_us"),
+        "mode_T_window_2_5_late_workgroups_1M": frac("mode_T_window_2_5", "workgroups_started_more_than_10us_late"),
+        "mode_T_exhaustive_late_workgroups_1M": frac("mode_T_exhaustive_search", "workgroups_started_more_than_10us_late"),
         "mode_S_candidate_major_frac_1M": frac("mode_S_candidate_major"),
         "sampled_fused_16M_traj_per_s": frac("sampled_fused_16M", "candidate_trajectories_per_s"),
         "single_solve_us_p50": out.get("single_solve", {}).get("device_resident_us_p50"),
@@ -711,6 +714,20 @@ def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
             roofs = valu_roofline(counted_valu("mode_T", entry), P * N, n, ms * 1e-3, mix_entry=entry)
             if roofs is not None:
                 out[name]["roofline_valu"], out[name]["roofline_lds"] = roofs
+            if P * N <= 128 * 8 * 1024:
+                # one generation of waves (two candidates per lane, eight waves on each of 1 024 SIMDs): every workgroup fits
+                # from the start, so all of them should START within a couple of microseconds - the library's own check that
+                # the dispatcher dealt them evenly (acmpc_rollout_start_clocks; round 4's launch of the 8-waypoint window had
+                # 12-60 workgroups wait 65 us for a compute unit while others ran seven: DESIGN 4.1).  Untimed extra launches.
+                eng.profile_enable(0)
+                eng.set_option("ACMPC_START_CLOCKS", "1")
+                late = []
+                for _ in range(5):
+                    eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, layout, 0, costs.data_ptr(), 0, stream)
+                    starts = eng.rollout_start_clocks()
+                    late.append(int((starts > 10.0).sum()))
+                out[name]["workgroups"] = int(len(starts))
+                out[name]["workgroups_started_more_than_10us_late"] = max(late)
         eng.close()
         del U, costs
     return out

@@ -170,7 +170,11 @@ int acmpc_set_paths(acmpc_ctx* ctx, const double* tables, int32_t P, int32_t n);
  * acmpc_get_coefficients and acmpc_tick_read_device_tables hand out) instead of paths: for callers that keep their
  * tables packed, and for the tests, which feed a tick's own device-built table to the two-call path so that
  * `acmpc_control_tick == acmpc_set_paths + acmpc_optimize` holds bit for bit whatever the last float32 bit of a host
- * cos / sin was.  The float64 tables of an earlier acmpc_set_paths of the same shape stay (the LQ plan reads them). */
+ * cos / sin was.  CONTRACT for handles with lq_candidate != 0: the LQ plan (candidate 2 of the last round) is computed from
+ * float64 paths, which this call does not carry - the float64 tables of an earlier acmpc_set_paths of the SAME shape (P, n)
+ * stay and are taken to describe the same paths as `coef` (the caller's responsibility: the packed table is meant to be
+ * that acmpc_set_paths' own, re-packed); with no such tables, or after a call with another shape, acmpc_optimize runs
+ * without the plan (candidate 2 is then an ordinary sample).  Call acmpc_set_paths again to plan for new paths. */
 int acmpc_set_coefficients(acmpc_ctx* ctx, const float* coef, int32_t P, int32_t n);
 
 /* Copies the packed float32 table of problem `problem` (n rows of ACMPC_COEF_STRIDE_* floats) to `out`.

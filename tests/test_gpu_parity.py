@@ -514,3 +514,37 @@ def test_bad_device_ordinal_and_closed_handle_are_errors():
     good = _engine([prob], 0, 16, 19)
     assert good.solve(prob["x0"][None], prob["U"][None])["owner"][0] == 1.0
 
+
+
+@pytest.mark.parametrize("window", [None, (2, 5)])
+def test_a_one_generation_mode_t_launch_starts_its_workgroups_together(window):
+    """1 M candidates = 2 048 workgroups = eight waves on every SIMD: all of them fit from the first microsecond.  Round 4's
+    launch of the 8-waypoint window (an instantiation of its own) had 12 to 60 of them wait 65 us - half the launch - for a
+    compute unit while others ran seven (tools/modeT_stamps.py, profiles/r05_mode_T_timeline.json); the launcher now takes ONE
+    instantiation for every search, which the dispatcher deals evenly.  The library's own diagnostic
+    (ACMPC_START_CLOCKS / acmpc_rollout_start_clocks) holds it there."""
+    import torch
+    from acmpc_amd import Engine, workloads
+    P, N, H = 256, 4096, 50
+    n = H - 1
+    batch = workloads.problem_batch("monza", P, H, seed=0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = Engine(**workloads.engine_kwargs(batch, 1, N, device=0, nn_window=window))
+    eng.set_paths(batch.tables)
+    eng.sync_tables(stream)
+    u_ref = torch.tensor(np.stack([batch.tables[:, 6, :], batch.tables[:, 3, :]], axis=2), dtype=torch.float32, device=dev).contiguous()
+    x0 = torch.tensor(batch.pose0, device=dev)
+    U = torch.empty((P, n, 2, N), device=dev)
+    costs = torch.empty(P, N, device=dev)
+    eng.sample_device(u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, 1, 0, (2.0, 0.01), 77, 0, U.data_ptr(), stream)
+    assert eng.rollout_start_clocks().size == 0          # nothing stamped without the option
+    eng.set_option("ACMPC_START_CLOCKS", "1")
+    late = []
+    for _ in range(6):
+        eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, 1, 0, costs.data_ptr(), 0, stream)
+        starts = eng.rollout_start_clocks()
+        assert starts.shape == (2048,) and starts.min() == 0.0
+        late.append(int((starts > 10.0).sum()))
+    eng.close()
+    assert max(late[1:]) <= 4, late        # (the first launch of a handle also loads the code object)

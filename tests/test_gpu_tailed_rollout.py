@@ -297,3 +297,54 @@ def test_records_from_reduced_keys_equal_the_one_call_solve(monkeypatch, switch)
     index = keys.cpu().numpy() & 0xffffffff
     assert (index == 1).sum() < P and len(np.unique(index)) > 10     # (not all the reference controls: real winners)
     eng.close()
+
+
+def test_a_pending_batch_keeps_the_knot_table_of_its_own_horizon():
+    """(advisor, round 4) The pending finalize of a stream re-draws its winners with the sampler's knot table, which lives
+    in ONE device buffer rewritten in place when the horizon changes.  With a batch pending, acmpc_sample_device for another
+    horizon is refused, and acmpc_solve_stream_device for another horizon runs the pending finalize FIRST: the first batch's
+    records are the ones a plain solve of it gives."""
+    import torch
+    from acmpc_amd import Engine, _capi
+    P, N = 6, 2048
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    sigma = (2.0, 0.01)
+
+    def inputs(H, seed):
+        problems = [make_problem(orc, "monza", H, 4, seed=seed + p) for p in range(P)]
+        tables = np.stack([p["table"] for p in problems])
+        x0 = torch.tensor(np.stack([p["x0"] for p in problems]), device=dev)
+        u_ref = torch.tensor(np.stack([np.stack([p["table"][orc.ROW_V], p["table"][orc.ROW_KAPPA]], axis=1) for p in problems]),
+                             dtype=torch.float32, device=dev).contiguous()
+        return problems, tables, x0, u_ref
+
+    long_, short = inputs(50, 300), inputs(30, 400)
+    eng = Engine(**engine_kwargs(long_[0][0], 0, P, N, 49))
+    want = {}
+    for name, (problems, tables, x0, u_ref), n in (("long", long_, 49), ("short", short, 29)):
+        eng.set_paths(tables)
+        U = torch.empty(P, n, 2, N, device=dev)
+        eng.sample_device(u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, 1, 0, sigma, 11, 0, U.data_ptr(), s)
+        rec = torch.zeros(P, _capi.record_floats(n), device=dev)
+        eng.solve_sampled_device(x0.data_ptr(), U.data_ptr(), u_ref.data_ptr(), 2 * n, u_ref.data_ptr(), P, N, n, 1, sigma, 11, 0, 0, 0,
+                                 rec.data_ptr(), s)
+        torch.cuda.synchronize()
+        want[name] = (U, rec.cpu().numpy().copy())
+    # the stream: the long-horizon batch pending, then everything about the short one
+    eng.set_paths(long_[1])
+    rec_long = torch.zeros(P, _capi.record_floats(49), device=dev)
+    eng.solve_stream_device(long_[2].data_ptr(), want["long"][0].data_ptr(), long_[3].data_ptr(), 98, long_[3].data_ptr(), P, N, 49, 1,
+                            sigma, 11, 0, 0, 0, rec_long.data_ptr(), s)
+    eng.set_paths(short[1])
+    scratch = torch.empty(P, 29, 2, N, device=dev)
+    with pytest.raises(_capi.EngineError, match="pending"):
+        eng.sample_device(short[3].data_ptr(), 58, short[3].data_ptr(), P, N, 29, 1, 0, sigma, 11, 0, scratch.data_ptr(), s)
+    rec_short = torch.zeros(P, _capi.record_floats(29), device=dev)
+    eng.solve_stream_device(short[2].data_ptr(), want["short"][0].data_ptr(), short[3].data_ptr(), 58, short[3].data_ptr(), P, N, 29, 1,
+                            sigma, 11, 0, 0, 0, rec_short.data_ptr(), s)
+    eng.solve_stream_flush(s)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rec_long.cpu().numpy(), want["long"][1])
+    np.testing.assert_array_equal(rec_short.cpu().numpy(), want["short"][1])
+    eng.close()
