@@ -41,7 +41,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Phase stamps for tools/solo_probe.hip (a standalone build of this file with -DACMPC_STAMPS); nothing in the library.
+// Phase stamps for tools/archive/solo_probe.hip (a standalone build of this file with -DACMPC_STAMPS); nothing in the library.
 #ifdef ACMPC_STAMPS
 __device__ unsigned long long g_stamps[4096 * 16];
 #define ACMPC_STAMP(slot)                                                                                         \
@@ -1314,8 +1314,8 @@ __global__ void __launch_bounds__(kFinalizeWaves * kWave) finalize_waves_kernel(
 // grid are rows of finalize workgroups - four wavefronts, a problem each, a lane per step (finalize_group<..., 64>: one
 // pass, every operand requested before the keys are reduced, two trips to memory).  Rows are dispatched in order, so these
 // start when the grid has no rollout workgroup left to hand out, in the wave slots the rollout's last generation leaves
-// empty as it drains, and are done before it is.  Measured on the headline's batch (tools/chained_ab.py, launches
-// alternating with the plain kernel in one process; tools/finalize_ab.sh, interleaved bench runs): the kernel is as long
+// empty as it drains, and are done before it is.  Measured on the headline's batch (tools/archive/chained_ab.py, launches
+// alternating with the plain kernel in one process; tools/archive/finalize_ab.sh, interleaved bench runs): the kernel is as long
 // as the plain one or up to 10 us longer (by the box: how ragged the rollout's tail is), the step 2-15 us shorter than
 // with two launches in every pair.  What did NOT work, same tools: the
 // sixteen-lane form on ONE wave per finalize workgroup in the same last rows, +11.5 us on the kernel (its six dependent

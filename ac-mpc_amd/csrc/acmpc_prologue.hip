@@ -28,7 +28,7 @@
 
 namespace acmpc {
 
-// Phase stamps of the prologue for tools/prologue_probe.py (an A/B build with -DACMPC_STAMPS); nothing in the library.
+// Phase stamps of the prologue for tools/archive/prologue_probe.py (an A/B build with -DACMPC_STAMPS); nothing in the library.
 #ifdef ACMPC_STAMPS
 __device__ unsigned long long g_prologue_stamps[16];
 #define ACMPC_PSTAMP(slot)                                                    \

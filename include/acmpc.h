@@ -201,7 +201,7 @@ int acmpc_solve(acmpc_ctx* ctx, const float* x0, const float* U, int32_t P, int3
 /* Page-locked host memory for acmpc_solve's control matrix.  A matrix in ordinary (pageable) memory is staged into
  * device memory by a copy in front of the rollout (~40 us for the 1.6 MB of 4 096 candidates x horizon 50); one built in
  * memory these calls return is READ IN PLACE by the rollout, which streams it over the host link while it computes - a
- * 4 096-candidate solve 58 us instead of 74 (measured through the Python wrapper, tools/time_host_solve.py).  Start states,
+ * 4 096-candidate solve 58 us instead of 74 (measured through the Python wrapper, tools/archive/time_host_solve.py).  Start states,
  * keys and records of a one-launch solve never travel as copies of their own either way: the kernels read and write them
  * in the handle's page-locked block.  acmpc_host_alloc initialises the HIP runtime: call it in the process that solves
  * (after the fork of controller.py:94-100), never before.  The closed loop does not need it: acmpc_control_tick samples
