@@ -27,3 +27,15 @@ $ROOT/tools/pmc_sampled.sh $TAG > $ROOT/gpurun_out/pmc_sampled_run.log 2>&1
 tail -1 $ROOT/gpurun_out/pmc_sampled_run.log
 $ROOT/tools/profile_pf.sh $TAG > $ROOT/gpurun_out/profile_pf_run.log 2>&1
 echo "particle filter traces done"
+# round 5: the particle filter's counters (the tree's kernels, and round 4's beside them when tools/_ab_old/ is there), the
+# mode T launch wave by wave, what the conformant forms cost
+rm -rf $ROOT/gpurun_out/pmc_${TAG}new_pf_* $ROOT/gpurun_out/pmc_${TAG}old_pf_* $ROOT/gpurun_out/pf_${TAG}new_* $ROOT/gpurun_out/pf_${TAG}old_*
+$ROOT/tools/pmc_pf.sh ${TAG}new > $ROOT/gpurun_out/pmc_pf_run.log 2>&1
+if [ -f $ROOT/tools/_ab_old/acmpc_pf.hip ]; then $ROOT/tools/pmc_pf.sh ${TAG}old $($ROOT/tools/ab_old_pf.sh | tail -1) >> $ROOT/gpurun_out/pmc_pf_run.log 2>&1; fi
+echo "particle filter counters done"
+STAMP_REPEATS=2 $ROOT/tools/modeT_stamps_ab.sh 256 ${TAG}= > /dev/null 2>&1
+for k in 1 2 3; do python3 $ROOT/tools/time_modeT.py 256; done > $ROOT/gpurun_out/time_modeT_${TAG}.log 2>&1
+python3 $ROOT/tools/time_modeT.py 4096 >> $ROOT/gpurun_out/time_modeT_${TAG}.log 2>&1
+echo "mode T timeline done"
+$ROOT/tools/conformant_cost.sh $ROOT/gpurun_out/conformant_cost_${TAG}.json > /dev/null 2>&1
+echo "conformant cost done"
