@@ -960,6 +960,8 @@ def main():
         pipe.bind_stream(torch.cuda.current_stream())
 
     streamed = bool(getattr(pipe, "streamed", False))
+    # (the handle read these at create: with either, acmpc_solve_stream_device runs the pending finalize as its own launch)
+    separate_finalize = any(os.environ.get(name, "0") not in ("", "0") for name in ("ACMPC_CONFORMANT_SYNC", "ACMPC_NO_CHAINED_STREAM"))
 
     def barrier():
         if world > 1:
@@ -1074,13 +1076,14 @@ def main():
                              "(acmpc_solve_stream_device)" if streamed else "none (stream order)"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "rollout_chained_kernel" if streamed else "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "bound": "hbm", "kernel": "rollout_chained_kernel" if (streamed and not separate_finalize) else "rollout_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms,
             },
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
         }
-        traffic = latest_traffic(algorithmic_bytes, "rollout_chained_kernel<%d" % args.layout if streamed else
+        traffic = latest_traffic(algorithmic_bytes, "rollout_chained_kernel<%d" % args.layout if (streamed and not separate_finalize) else
                                  "rollout_kernel<%d, %d" % (mode, args.layout))
         if traffic is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic

@@ -24,6 +24,7 @@ for form in ("default", "on"):
         "config3_single_us_p50 (65 536 x 49)": pick(lambda r: r["config3_single"]["device_resident_us_p50"]),
         "tick_ms_p50 (get_control_at, mode S)": pick(lambda r: r["closed_loop_replay"]["solve_ms_p50"]),
         "tick_mode_T_ms_p50": pick(lambda r: r["closed_loop_replay_mode_T"]["solve_ms_p50"]),
+        "tick_mode_T_window_2_5_ms_p50": pick(lambda r: r["closed_loop_replay_mode_T_window_2_5"]["solve_ms_p50"]),
         "headline ms_per_step": pick(lambda r: r["ms_per_step"]),
         "headline kernel_ms": pick(lambda r: r["roofline"]["kernel_ms"]),
         "headline kernel": runs[0]["roofline"]["kernel"],
