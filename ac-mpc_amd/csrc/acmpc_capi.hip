@@ -141,6 +141,7 @@ struct acmpc_ctx {
   std::vector<double> tick_prev_table;  // what the previous acmpc_control_tick solved: its 7 x n table ...
   double tick_prev_x0[3] = {0.0, 0.0, 0.0};   // ... and its start state (Frenet)
   std::vector<double> tick_lq_table;    // scratch: this tick's waypoints with the previous tick's speed profile
+  std::vector<double> tick_host_coords; // scratch: the H x 3 path of a map window, cut on the host for the plan
   int tick_prev_n = 0;                  // 0: nothing usable (first tick, or a tick that did not end with a finite plan)
   // lq_candidate = 2 (csrc/acmpc_lq_box.h): the splitting's iterate per problem, its factorisation scratch, what the last
   // plan did (acmpc_lq_box_stats) and the iteration cap (ACMPC_LQ_BOX_ITERATIONS)
@@ -1791,12 +1792,29 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   // out of the map on the device (coords = NULL) the host does not have it: the plan is then the previous tick's problem's.
   const bool lq_on = c->prm.lq_candidate != 0;
   const double lq_offset = t->offset;
-  auto plan_previous = [c, n, H, coords, lq_offset, t]() -> bool {
+  // With the path cut out of the map on the device the host cuts the same window itself (round 5) when it knows where it
+  // starts - `map_index` given; for a pose, whose nearest map point the device searches, the plan stays the previous tick's
+  // problem's: a scan of the map on the host would outlast the rounds it has to hide behind.
+  const bool host_window = lq_on && from_map && t->map_index >= 0;
+  const int window_M = ma.M, window_count = ma.count, window_points = ma.points;
+  auto plan_previous = [c, n, H, given = coords, lq_offset, t, host_window, window_M, window_count, window_points]() -> bool {
+    const double* coords = given;
+    if (host_window) {   // (here, not in front of the launches: this runs while the prologue and the first round do)
+      c->tick_host_coords.resize(static_cast<size_t>(H) * 3);
+      const int first = ((t->map_index % window_M) + window_M) % window_M;
+      const acmpc::MapFrame frame = acmpc::map_frame(c->h_map.data(), window_M, first);
+      for (int r = 0; r < H; ++r) {
+        double row[3];
+        acmpc::map_path_row(c->h_map.data(), window_M, first, window_count, window_points, H, r, t->lateral_offset, frame, row);
+        for (int e = 0; e < 3; ++e) c->tick_host_coords[static_cast<size_t>(3) * r + e] = row[e];
+      }
+      coords = c->tick_host_coords.data();
+    }
     // no previous tick to take a speed profile from (a handle's first tick, another horizon, a tick without a finite
     // plan): with the path on the host the profile is solved HERE, once - the host statement of the prologue's QP
     // (acmpc_velocity_ceiling + acmpc_speed_profile_qp, cold: a few hundred iterations of O(n), ~0.1 ms)
     const bool have_previous = c->tick_prev_n == n;
-    if (!have_previous && coords == nullptr) return false;   // (the path is cut out of the map on the device: nothing to plan for)
+    if (!have_previous && coords == nullptr) return false;   // (no path on the host: nothing to plan for)
     if (coords == nullptr) return lq_plan_into(c, c->tick_prev_table.data(), n, c->tick_prev_x0, c->h_lq);
     c->tick_lq_table.resize(static_cast<size_t>(7) * n);
     if (acmpc_waypoint_table(coords, H, kEps, c->tick_lq_table.data()) != ACMPC_OK) return false;

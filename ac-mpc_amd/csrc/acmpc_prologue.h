@@ -79,6 +79,47 @@ struct PrologueArgs {
   int* index_out;             // pinned host memory
 };
 
+// Row r of the H x 3 reference path for the window of `count` map points that starts at map point `first`: the window moved
+// into the vehicle frame (car at the window's first point heading +y), resampled to `points` samples the way np.interp does,
+// every (points / H)-th kept, rounded to float32 where perception's shared memory does, widths linspace(10, 6, H)
+// (workloads.local_centreline + ControlProcess._reference_path, controller.py:256-267).  ONE statement for the device - the
+// window kernel's and the prologue's lanes - and the host, which cuts the same window for the plan of the last round's
+// candidate 2 while the device builds the tick's tables (round 5; the two libm's atan2 / cos / sin may differ in the last
+// float64 bit, which the float32 rounding of the positions absorbs but for a tie).
+struct MapFrame {
+  double x0, y0, c, sn;
+};
+__host__ __device__ inline MapFrame map_frame(const double* centre, int M, int first) {
+  const double* w0 = centre + 2 * first;
+  const double* w1 = centre + 2 * ((first + 1) % M);
+  const double heading = atan2(w1[1] - w0[1], w1[0] - w0[0]);
+  const double rot = 3.14159265358979323846 / 2.0 - heading;
+  return MapFrame{w0[0], w0[1], cos(rot), sin(rot)};
+}
+__host__ __device__ inline void map_path_row(const double* centre, int M, int first, int count, int points, int H, int r,
+                                             double lateral_offset, const MapFrame& f, double (&row)[3]) {
+  const int stride = points / H;
+  const double step = static_cast<double>(count - 1) / static_cast<double>(points - 1);  // np.linspace's step
+  const int q = r * stride;                                   // sample of the resampled centre line kept for row r
+  const double t = (q == points - 1) ? static_cast<double>(count - 1) : static_cast<double>(q) * step;
+  int j = static_cast<int>(t);                                // np.interp: the bracket [j, j + 1] with xp = arange
+  if (j > count - 2) j = count - 2;
+  double local[2][2];
+  for (int e = 0; e < 2; ++e) {
+    const double* wp = centre + 2 * ((first + j + e) % M);
+    const double dx = wp[0] - f.x0, dy = wp[1] - f.y0;
+    local[e][0] = (dx * f.c + dy * (-f.sn)) - lateral_offset;   // (window - window[0]) @ [[c, s], [-s, c]]
+    local[e][1] = dx * f.sn + dy * f.c;
+  }
+  const double frac = t - static_cast<double>(j);
+  const bool last = t >= static_cast<double>(count - 1);
+  const double x = last ? local[1][0] : (local[1][0] - local[0][0]) * frac + local[0][0];
+  const double y = last ? local[1][1] : (local[1][1] - local[0][1]) * frac + local[0][1];
+  row[0] = static_cast<double>(static_cast<float>(x));         // perception publishes float32
+  row[1] = static_cast<double>(static_cast<float>(y));
+  row[2] = (r == H - 1) ? 6.0 : 10.0 + static_cast<double>(r) * ((6.0 - 10.0) / static_cast<double>(H - 1));
+}
+
 constexpr int kInlinePathPoints = 64;
 constexpr int kPrologueMaxSteps = admm::kPcrMaxN;  // LDS budget of the single-workgroup prologue (~390 n bytes) and the
                                                    // size up to which the tridiagonal solve is the parallel one

@@ -69,41 +69,6 @@ struct WaveTeam {
 
 }  // namespace
 
-// Row r of the H x 3 reference path for the window that starts at map point `first` (see map_window_kernel)
-struct MapFrame {
-  double x0, y0, c, sn;
-};
-__device__ __forceinline__ MapFrame map_frame(const double* centre, int M, int first) {
-  const double* w0 = centre + 2 * first;
-  const double* w1 = centre + 2 * ((first + 1) % M);
-  const double heading = atan2(w1[1] - w0[1], w1[0] - w0[0]);
-  const double rot = kPi / 2.0 - heading;
-  return MapFrame{w0[0], w0[1], cos(rot), sin(rot)};
-}
-__device__ __forceinline__ void map_path_row(const double* centre, int M, int first, int count, int points, int H, int r,
-                                             double lateral_offset, const MapFrame& f, double (&row)[3]) {
-  const int stride = points / H;
-  const double step = static_cast<double>(count - 1) / static_cast<double>(points - 1);  // np.linspace's step
-  const int q = r * stride;                                   // sample of the resampled centre line kept for row r
-  const double t = (q == points - 1) ? static_cast<double>(count - 1) : static_cast<double>(q) * step;
-  int j = static_cast<int>(t);                                // np.interp: the bracket [j, j + 1] with xp = arange
-  if (j > count - 2) j = count - 2;
-  double local[2][2];
-  for (int e = 0; e < 2; ++e) {
-    const double* wp = centre + 2 * ((first + j + e) % M);
-    const double dx = wp[0] - f.x0, dy = wp[1] - f.y0;
-    local[e][0] = (dx * f.c + dy * (-f.sn)) - lateral_offset;   // (window - window[0]) @ [[c, s], [-s, c]]
-    local[e][1] = dx * f.sn + dy * f.c;
-  }
-  const double frac = t - static_cast<double>(j);
-  const bool last = t >= static_cast<double>(count - 1);
-  const double x = last ? local[1][0] : (local[1][0] - local[0][0]) * frac + local[0][0];
-  const double y = last ? local[1][1] : (local[1][1] - local[0][1]) * frac + local[0][1];
-  row[0] = static_cast<double>(static_cast<float>(x));         // perception publishes float32
-  row[1] = static_cast<double>(static_cast<float>(y));
-  row[2] = (r == H - 1) ? 6.0 : 10.0 + static_cast<double>(r) * ((6.0 - 10.0) / static_cast<double>(H - 1));
-}
-
 // ---- mode T with the exhaustive nearest-waypoint search: the frames of its verified window search (acmpc_frames.h, the
 // arithmetic acmpc_set_paths runs on the host), one or two windows per lane.  xr / yr: the n float32 waypoint positions the
 // rollout sees, widened (LDS); gap_doubles: 4 n + 1 doubles of LDS scratch.  One wavefront: a workgroup of its own in the
