@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
   __shared__ double s_d[3][PB][kWaves];
   __shared__ int s_i[3][PB][kWaves];
   __shared__ double s_sum[PB][kWaves];
+  __shared__ float s_frame[PB][4];   // cos, sin of the placement angle and the particle's position, per particle
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int p0 = blockIdx.x * PB;
@@ -305,6 +306,16 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
         s_i[wave][0][lane] = (lane == 0) ? best_i : 0x7fffffff;
       }
     }
+  }
+  // the placement of the observation in each particle's frame needs cos / sin of ITS angle: once per particle (round 5;
+  // every thread used to evaluate both for every particle of the workgroup - a fifth of the kernel's instructions at PB = 8)
+  if (tid < PB) {
+    const int p = min(p0 + tid, P - 1);
+    const float angle = -a.states[3 * p + 2] + 1.57079632679489661923f;
+    s_frame[tid][0] = cosf(angle);
+    s_frame[tid][1] = sinf(angle);
+    s_frame[tid][2] = a.states[3 * p];
+    s_frame[tid][3] = a.states[3 * p + 1];
   }
   const bool given = a.given_index != nullptr || own_search;   // wave-uniform
   if (given && !own_search) {
@@ -365,10 +376,7 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
   const int K = a.k_left + a.k_right;
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
-    const int p = min(p0 + q, P - 1);
-    const float phi32 = a.states[3 * p + 2], px32 = a.states[3 * p], py32 = a.states[3 * p + 1];
-    const float angle = -phi32 + 1.57079632679489661923f;
-    const float ca = cosf(angle), sa = sinf(angle);
+    const float ca = s_frame[q][0], sa = s_frame[q][1], px32 = s_frame[q][2], py32 = s_frame[q][3];
     double sum = 0.0;
     for (int k = tid; k < K; k += kBlock) {
       const float ox = a.obs[2 * k], oy = a.obs[2 * k + 1];

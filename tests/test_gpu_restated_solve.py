@@ -127,6 +127,68 @@ def test_the_tick_equals_the_restated_solve(mode, window):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_the_tick_with_the_box_constrained_plan_equals_the_restated_solve(mode):
+    """`lq_candidate = 2` (the controller's default, round 5) on a path where the QP's box rows are active - a corner of
+    radius 8 m after 30 m of straight under the racing corridor: the last round's candidate 2 is the plan of
+    csrc/acmpc_lq_box.h, warm-started from tick to tick.  Four consecutive ticks equal `oracle.optimize_restated` with
+    `oracle.lq_box_plan` (the host solver's line-by-line restatement, iterate chained the same way) as that candidate,
+    exactly - and the refinement did run (acmpc_lq_box_stats)."""
+    from acmpc_amd import Engine, _capi
+    from acmpc_amd import workloads as wl
+    from acmpc_amd.mpc import waypoint_table
+    H, N, rounds = 50, 16384, 2
+    n = H - 1
+    cfg = RACING["monza"]
+    cons = dict(cfg["speed_profile_constraints"], v_max=28.0)
+    lim = orc.vehicle_limits(2.65, 1.94, 0.30, cons["v_min"], cons["v_max"])
+    lo, hi = orc.input_box(lim)
+    w_bound = 1.0e4
+    eng = Engine(mode=mode, max_problems=1, max_candidates=N, max_steps=n, step_cost=cfg["step_cost"], r_term=cfg["r_term"],
+                 final_cost=cfg["final_cost"], u_min=lo, u_max=hi, margin=lim.margin, wheelbase=lim.length, nn_window=None,
+                 lq_candidate=2, w_bound=w_bound)
+    base = wl.corner_entry_path(8.0, 30.0, H)
+    centre, previous, state, ran = None, None, None, []
+    for j in range(4):
+        coords = np.array(base)
+        coords[:, 1] -= (0.0, 0.0, 0.25, 0.5)[j]          # the car moves on along the straight
+        offset = (0.0, 0.0, 0.04, 0.08)[j]
+        t = _tick(H, cons, N, rounds, offset, 40 + j)
+        t.centre_is_reference = 1 if centre is None else 0
+        out = eng.control_tick(t, coords, centre)
+        assert out["info"][4] == 0 and out["info"][7] == 0
+        stats = eng.lq_box_stats()
+        x0, u_ref, coef = eng.tick_device_tables(n)
+        table = waypoint_table(coords, 1e-12)
+        if previous is not None:
+            table[6] = previous[6]
+        else:
+            ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
+                                             cons["end_velocity"])
+            table[6], _, status, _ = _capi.speed_profile_qp(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"],
+                                                            max_iter=4000, check_every=10)
+            assert status == "solved"
+        frenet = orc.frenet_start(table, np.array([offset, 0.0, np.pi / 2]))
+        restated = orc.lq_box_plan(table, frenet, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi, lim.margin, w_bound,
+                                   40, state)
+        state = restated["state"]
+        assert restated["plan"] is not None
+        assert (stats["iterations"], stats["chosen"], stats["triggered"]) == (restated["iterations"], restated["chosen"],
+                                                                               restated["triggered"]), (j, stats, restated)
+        ran.append(stats["iterations"])
+        want = orc.optimize_restated(mode, x0, coef, u_ref if centre is None else centre, u_ref, N, rounds, (0.5, 1e-3), 0.5,
+                                     40 + j, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi, w_bound, 0.05, None,
+                                     extra=restated["plan"])
+        rec = out["record"]
+        got = dict(cost=rec[0], violation=rec[1], n_feasible=rec[2], u=rec[4:4 + 2 * n].reshape(n, 2),
+                   x=rec[4 + 2 * n:].reshape(n + 1, 3))
+        _record_equals(got, want, n)
+        centre = got["u"].copy()
+        previous = out["table"].copy()
+    assert ran[0] >= 10 and all(k >= 1 for k in ran), ran       # cold: tens of iterations; warm: it confirms or continues
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["solve_monza_H50_S", "solve_monza_H50_T", "solve_monza_H50_T_window"])
 def test_optimize_reproduces_the_frozen_solves(name):
     """The records frozen in tests/golden/composition.npz (tests/golden/gen_composition.py: the oracle's restated solve at
