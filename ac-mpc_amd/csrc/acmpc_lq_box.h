@@ -38,7 +38,8 @@ constexpr double kTMin = 0.01;        // control.py:134
 constexpr double kAlpha = 1.6;        // over-relaxation (OSQP's default)
 constexpr double kRhoEy = 3.0e-3;     // step sizes of the state classes (the input classes use r_term)
 constexpr double kRhoT = 3.0e-2;
-// the iteration stops when every boxed component's z and w agree AND w has stopped moving, per class:
+// the iteration stops when every boxed component's z and w agree AND w has stopped moving (or both have stopped moving
+// apart: an infeasible row), per class:
 // e_y 1e-4 m, t 1e-5 s, v 1e-3 m/s, kappa 1e-6 1/m
 constexpr double kPerTolEy = 1.0e4, kPerTolT = 1.0e5, kPerTolV = 1.0e3, kPerTolK = 1.0e6;   // 1 / tolerance
 
@@ -106,8 +107,8 @@ inline bool factor(const double* table, int n, const double Q[3], const double R
   ws.rows.resize(static_cast<size_t>(n) * 5);
   ws.fac.resize(static_cast<size_t>(n) * 18);
   ws.ks.resize(static_cast<size_t>(n) * 2);
-  ws.zx.resize(static_cast<size_t>(n) * 2);
-  ws.zu.resize(static_cast<size_t>(n) * 2);
+  ws.zx.assign(static_cast<size_t>(n) * 2, 0.0);
+  ws.zu.assign(static_cast<size_t>(n) * 2, 0.0);
   ws.trial.resize(static_cast<size_t>(n) * 2);
   const double R0 = R[0] + rho[2], R1 = R[1] + rho[3];
   double P00 = QN[0] + rho[0], P01 = 0.0, P02 = 0.0, P11 = QN[1], P12 = 0.0, P22 = QN[2] + rho[1];
@@ -206,7 +207,7 @@ inline int iterate(const double* table, int n, const double x0[3], const float u
     }
     // forward rollout of the policy (the z iterate), then the box projection and the dual step, component by component
     double ey = x0[0], ep = x0[1], t = x0[2];
-    double gap = 0.0, move = 0.0;   // largest tolerance-scaled |z - w| and |w+ - w|
+    double gap = 0.0, move = 0.0, drift = 0.0;   // largest tolerance-scaled |z - w|, |w+ - w| and |z+ - z|
     bool finite = true;
     for (int i = 0; i < n; ++i) {
       const double* row = ws.rows.data() + static_cast<size_t>(i) * 5;
@@ -218,6 +219,8 @@ inline int iterate(const double* table, int n, const double x0[3], const float u
       const double ep_n = (ep + a * ey) + d * dk;
       const double t_n = ((t + g * ey) + b * dv) + c;
       ey = ey_n, ep = ep_n, t = t_n;
+      drift = std::fmax(drift, std::fmax(std::fmax(std::fabs(ey - ws.zx[2 * i]) * kPerTolEy, std::fabs(t - ws.zx[2 * i + 1]) * kPerTolT),
+                                        std::fmax(std::fabs(dv - ws.zu[2 * i]) * kPerTolV, std::fabs(dk - ws.zu[2 * i + 1]) * kPerTolK)));
       ws.zu[2 * i] = dv, ws.zu[2 * i + 1] = dk;
       ws.zx[2 * i] = ey, ws.zx[2 * i + 1] = t;
       const double half = width[i] / 2.0 - margin;
@@ -241,7 +244,11 @@ inline int iterate(const double* table, int n, const double x0[3], const float u
       st.reset();
       return -it;
     }
-    if (gap <= 1.0 && move <= 1.0) break;
+    // converged: the two iterates agree and the box iterate has stopped moving; or - box rows that NO plan can meet (the
+    // reference pins t_0 = 0 while boxing t >= 0.01, control.py:134 vs :67: at 84 m/s on 3 m steps t_1 = 0.004) - both
+    // iterates have stopped moving a gap apart: nothing more to gain either (from the second iteration on: the first has
+    // no previous dynamics iterate to compare with)
+    if (move <= 1.0 && (gap <= 1.0 || (it >= 2 && drift <= 1.0))) break;
   }
   return it;
 }

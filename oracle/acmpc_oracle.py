@@ -1078,6 +1078,7 @@ def lq_box_plan(table, x0, Q, R, QN, u_lo, u_hi, margin, w_bound, iterations, st
                 wu[i, 1] = _clip64(0.0, lo_k - float(kappa[i]), hi_k - float(kappa[i]))
         ks = np.zeros((n, 2))
         zu = np.zeros((n, 2))
+        zx = np.zeros((n, 2))
         x0f = [float(x) for x in x0]
         it = 0
         failed = False
@@ -1103,7 +1104,7 @@ def lq_box_plan(table, x0, Q, R, QN, u_lo, u_hi, margin, w_bound, iterations, st
                 n2 = (q2 + w2) + (F[11] * k0 + F[14] * k1)
                 p0, p1, p2 = float(n0), float(n1), float(n2)
             ey, ep, t = x0f
-            gap = move = 0.0
+            gap = move = drift = 0.0
             finite = True
             for i in range(n):
                 d, a, g, b, c = (float(x) for x in rows[i])
@@ -1111,7 +1112,10 @@ def lq_box_plan(table, x0, Q, R, QN, u_lo, u_hi, margin, w_bound, iterations, st
                 dv = ((F[0] * ey + F[1] * ep) + F[2] * t) + float(ks[i, 0])
                 dk = ((F[3] * ey + F[4] * ep) + F[5] * t) + float(ks[i, 1])
                 ey, ep, t = ey + d * ep, (ep + a * ey) + d * dk, ((t + g * ey) + b * dv) + c
+                drift = float(np.fmax(drift, np.fmax(np.fmax(abs(ey - float(zx[i, 0])) * LQBOX_PER_TOL[0], abs(t - float(zx[i, 1])) * LQBOX_PER_TOL[1]),
+                                                     np.fmax(abs(dv - float(zu[i, 0])) * LQBOX_PER_TOL[2], abs(dk - float(zu[i, 1])) * LQBOX_PER_TOL[3]))))
                 zu[i] = (dv, dk)
+                zx[i] = (ey, t)
                 half = float(width[i]) / 2.0 - margin
                 z = (ey, t, dv, dk)
                 blo = (-half, T_MIN, lo_v - float(vel[i]), lo_k - float(kappa[i]))
@@ -1129,7 +1133,7 @@ def lq_box_plan(table, x0, Q, R, QN, u_lo, u_hi, margin, w_bound, iterations, st
             if not finite:
                 failed = True
                 break
-            if gap <= 1.0 and move <= 1.0:
+            if move <= 1.0 and (gap <= 1.0 or (it >= 2 and drift <= 1.0)):
                 break
         if failed:
             out["iterations"] = -it
