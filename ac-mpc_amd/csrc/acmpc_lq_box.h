@@ -38,6 +38,7 @@ constexpr double kTMin = 0.01;        // control.py:134
 constexpr double kAlpha = 1.6;        // over-relaxation (OSQP's default)
 constexpr double kRhoEy = 3.0e-3;     // step sizes of the state classes (the input classes use r_term)
 constexpr double kRhoT = 3.0e-2;
+constexpr int kWarmIterations = 8;    // per call from a kept iterate (a cold start takes the caller's cap)
 // the iteration stops when every boxed component's z and w agree AND w has stopped moving (or both have stopped moving
 // apart: an infeasible row), per class:
 // e_y 1e-4 m, t 1e-5 s, v 1e-3 m/s, kappa 1e-6 1/m
@@ -276,7 +277,10 @@ inline Result refine(const double* table, int n, const double x0[3], const doubl
     st.reset();
     return res;
   }
-  res.iterations = iterate(table, n, x0, u_lo, u_hi, margin, rho, iterations, st, ws);
+  // a warm iterate continues for at most kWarmIterations per call: what fits behind the prologue and the first round of a
+  // tick (8 x 1.8 us + the factorisation and the rollouts, ~20 us); one that needs more takes it over the next ticks
+  const int budget = (st.n == n && iterations > kWarmIterations) ? kWarmIterations : iterations;
+  res.iterations = iterate(table, n, x0, u_lo, u_hi, margin, rho, budget, st, ws);
   if (res.iterations < 0) return res;
   const double* kappa = table + 3 * static_cast<size_t>(n);
   const double* vel = table + 6 * static_cast<size_t>(n);

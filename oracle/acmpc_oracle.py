@@ -949,6 +949,7 @@ def lq_plan(table, x0, Q, R, QN, u_lo, u_hi):
 # --- the box-constrained LQ plan (csrc/acmpc_lq_box.h, round 5) ---------------------------------------------------------
 LQBOX_ALPHA = 1.6
 LQBOX_RHO_EY, LQBOX_RHO_T = 3.0e-3, 3.0e-2
+LQBOX_WARM_ITERATIONS = 8
 LQBOX_PER_TOL = (1.0e4, 1.0e5, 1.0e3, 1.0e6)   # 1 / tolerance of e_y [m], t [s], v [m/s], kappa [1/m]
 
 
@@ -1068,6 +1069,7 @@ def lq_box_plan(table, x0, Q, R, QN, u_lo, u_hi, margin, w_bound, iterations, st
         lo_v, lo_k, hi_v, hi_k = float(lo32[0]), float(lo32[1]), float(hi32[0]), float(hi32[1])
         if state is not None and state["wx"].shape == (n, 2):
             wx, wu, lx, lu = (np.array(state[key], dtype=np.float64) for key in ("wx", "wu", "lx", "lu"))
+            iterations = min(iterations, LQBOX_WARM_ITERATIONS)   # a kept iterate continues for at most this many per call
         else:
             wx, wu, lx, lu = (np.zeros((n, 2)) for _ in range(4))
             for i in range(n):
