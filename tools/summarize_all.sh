@@ -5,7 +5,7 @@ set -eu
 TAG=${1:-r04}; AGE=${2:-10}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT/gpurun_out"
-for d in prof_$TAG allk_$TAG trace_f_* pmc_${TAG}_T_*_a pmc_${TAG}_T_*_b pmc_${TAG}_sampled_a pmc_${TAG}_sampled_b pf_${TAG}_500 pf_${TAG}_100000; do
+for d in prof_$TAG allk_$TAG trace_f_* pmc_${TAG}_T_*_a pmc_${TAG}_T_*_b pmc_${TAG}_sampled_a pmc_${TAG}_sampled_b pf_${TAG}_500 pf_${TAG}_100000 pmc_${TAG}new_pf_* pmc_${TAG}old_pf_* pf_${TAG}new_* pf_${TAG}old_*; do
   [ -d "$d" ] && find "$d" -type f -mmin +$AGE -delete
 done
 cd "$ROOT"
@@ -15,6 +15,8 @@ python3 tools/summarize_sq_counters.py $TAG sampled > /dev/null
 python3 tools/summarize_pf_profile.py $TAG > /dev/null
 python3 tools/summarize_tick_trace.py $TAG mode_S_h50=f_S50 mode_S_h25=f_S25 mode_S_h100=f_S100 mode_S_h50_pair=f_S50_pair \
   mode_T_h50=f_T50 mode_T_h50_one=f_T50_one mode_T_h50_window_2_5=f_T50_w25 > /dev/null
+python3 tools/summarize_pf_counters.py $TAG > /dev/null
+python3 tools/summarize_round5.py $TAG
 cp "$(ls -t gpurun_out/allk_$TAG/runc/*_kernel_stats.csv | head -1)" profiles/${TAG}_all_kernels_stats.csv
 python3 - "$TAG" <<'PY'
 import json, sys
