@@ -160,7 +160,7 @@ def _racing_scenarios():
     return out
 
 
-# measured (round 5, 30 scenarios, 19 of them with the refinement triggered): warm-4 excess median 7.6e-5, p90 0.0065, worst
+# measured (round 5, 30 scenarios, 19 of them with the refinement triggered): warm-4 excess median 1.1e-4, p90 0.0065, worst
 # 0.0113 (the restated OSQP's own slack at 1e-5: its equality rows are met to the tolerance, a plan's exactly), least -0.0032;
 # cold (first solve of a fresh controller) median 1.8e-5, p90 0.0065, worst 0.0113; the returned plan's summed squared
 # state-row excess at most 1.5e-7 (the t >= 0.01 row of x_1 at 32 m/s, control.py:134 vs :67).  Thresholds <= 5x measured
