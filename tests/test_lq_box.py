@@ -162,3 +162,39 @@ def test_never_worse_than_the_lq_plan():
             assert np.all(out["plan"] >= p["lo"].astype(np.float32)) and np.all(out["plan"] <= p["hi"].astype(np.float32))
         triggered += out["triggered"]
     assert triggered >= 10, triggered
+
+
+def test_degenerate_paths_are_refused_or_survived():
+    """Paths the solver cannot factor - a zero step, a zero reference speed, a non-finite waypoint, a horizon of one step - come
+    back as "no plan" (the round then runs without the candidate) or as a finite plan inside the input box: no exception,
+    no non-finite control, no endless loop."""
+    from acmpc_amd import _capi
+    track, coords, offset = _cases()["corner entry r 8, monza"]
+    p = _problem(track, coords, offset)
+    cfg = p["cfg"]
+    base = p["table"]
+
+    def run(table, x0=p["x0"], iterations=40):
+        out = _capi.lq_box_plan(table, x0, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], p["lo"], p["hi"], p["limits"].margin,
+                                W_BOUND, iterations)
+        if out["plan"] is not None:
+            assert np.isfinite(out["plan"]).all()
+            assert np.all(out["plan"] >= p["lo"].astype(np.float32)) and np.all(out["plan"] <= p["hi"].astype(np.float32))
+            assert 0 <= abs(out["iterations"]) <= 40
+        return out
+
+    for row, value in ((orc.ROW_DS, 0.0), (orc.ROW_V, 0.0), (orc.ROW_KAPPA, np.nan), (orc.ROW_DS, np.inf), (orc.ROW_WIDTH, np.nan),
+                       (orc.ROW_WIDTH, 0.5)):          # (a corridor narrower than the car: the e_y box is empty)
+        table = np.array(base)
+        table[row, 20] = value
+        lib, restated = run(table), orc.lq_box_plan(table, p["x0"], cfg["step_cost"], cfg["r_term"], cfg["final_cost"], p["lo"], p["hi"],
+                                                    p["limits"].margin, W_BOUND, 40)
+        assert (lib["plan"] is None) == (restated["plan"] is None), (row, value)
+        if lib["plan"] is not None:
+            np.testing.assert_array_equal(lib["plan"], restated["plan"])
+            assert lib["iterations"] == restated["iterations"] and lib["chosen"] == restated["chosen"]
+    run(base, x0=np.array([np.nan, 0.0, 0.0]))
+    run(base, x0=np.array([1e30, 0.0, 0.0]))
+    run(np.ascontiguousarray(base[:, :1]))              # one step
+    run(base, iterations=0)                             # the refinement switched off: the LQ plan
+    assert run(base, iterations=0)["iterations"] == 0
