@@ -137,7 +137,7 @@ def test_key_minimum_is_the_oracles_argmin_on_arbitrary_bit_patterns():
     from hypothesis import given, settings, strategies as st
     from acmpc_amd import _capi
 
-    @settings(max_examples=300, deadline=None)
+    @settings(max_examples=300, deadline=None, derandomize=True)
     @given(st.lists(st.integers(min_value=0, max_value=2**32 - 1), min_size=1, max_size=40))
     def check(bits):
         costs = np.array(bits, dtype=np.uint32).view(np.float32)

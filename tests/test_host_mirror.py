@@ -320,14 +320,16 @@ def test_native_waypoint_table_equals_numpy_on_arbitrary_paths():
     the library's waypoint table equals the NumPy statement: positions, spacings and widths exactly, headings to the
     last bit or two (libm's atan2 vs NumPy's), curvature accordingly - where the 1e-12-regularised division by a
     vanishing spacing amplifies that bit, only relative to its own huge magnitude."""
-    from hypothesis import given, settings, strategies as st
+    from hypothesis import example, given, settings, strategies as st
     from hypothesis.extra import numpy as hnp
     from acmpc_amd.mpc import waypoint_table, waypoint_table_numpy
 
     finite = st.floats(min_value=-1e4, max_value=1e4, allow_nan=False, allow_infinity=False, width=64)
 
-    @settings(max_examples=200, deadline=None)
+    @settings(max_examples=200, deadline=None, derandomize=True)   # (the same 200 paths in every run: no flaky suite)
     @given(hnp.arrays(np.float64, st.tuples(st.integers(3, 40), st.just(3)), elements=finite))
+    @example(np.array([[-8145.796875, -8145.796875, -8145.796875], [-1.5, 4149.13455, -8145.796875],
+                       [-8145.796875, -8145.796875, -8145.796875], [0.0, -8145.796875, -8145.796875]]))
     def check(coords):
         got, want = waypoint_table(coords), waypoint_table_numpy(coords)
         assert got.shape == want.shape == (7, coords.shape[0] - 1)
@@ -335,7 +337,15 @@ def test_native_waypoint_table_equals_numpy_on_arbitrary_paths():
             np.testing.assert_array_equal(got[row], want[row])
         # headings: libm's atan2 here, NumPy's own (on some CPUs vectorised, 1 ulp apart) there
         np.testing.assert_allclose(got[2], want[2], rtol=1e-14, atol=1e-15)
-        np.testing.assert_allclose(got[3], want[3], rtol=1e-9, atol=1e-3 * np.abs(want[3]).max() if np.abs(want[3]).max() > 1e9 else 1e-9)
+        # curvature = wrapped heading change / spacing.  A path that doubles back EXACTLY turns by +pi or by -pi - which of the
+        # two the wrap gives hangs on that last bit of atan2 - so such steps are compared by magnitude (found by this very
+        # test in round 5: [-8145.8, -8145.8] -> [-1.5, 4149.1] -> back)
+        turn = np.abs(want[3] - 1e-12) * (want[4] + 1e-12)
+        reversal = np.abs(turn - np.pi) < 1e-9
+        reversal[0] = reversal[0] or reversal[1]          # (kappa[0] is a copy of kappa[1])
+        atol = 1e-3 * np.abs(want[3]).max() if np.abs(want[3]).max() > 1e9 else 1e-9
+        np.testing.assert_allclose(got[3][~reversal], want[3][~reversal], rtol=1e-9, atol=atol)
+        np.testing.assert_allclose(np.abs(got[3][reversal]), np.abs(want[3][reversal]), rtol=1e-9, atol=atol)
         assert got[3, 0] == got[3, 1]
 
     check()
