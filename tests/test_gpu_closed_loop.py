@@ -58,3 +58,28 @@ def test_controller_keeps_the_car_on_the_track(shifted_warm_start):
     assert lateral[100:].mean() < 0.8, "does not converge to the centreline: %.2f m" % lateral[100:].mean()
     assert 8.0 <= min(speeds[50:]) and max(speeds) <= 30.1
     assert (progress[-1] - progress[0]) % len(centre) > 400                              # > 200 m travelled
+
+
+def test_corners_that_bind_the_box_rows_in_closed_loop():
+    """The controller in closed loop round a stadium whose half circles are at (radius 9 m) or inside (8.2 m) the steering
+    limit (kappa_max = tan(0.30) / 2.65: 8.57 m), under the racing corridor - where the reference's problem is a QP because
+    of its box rows (control.py:47-70,130-144) - with the kinematic bicycle of localiser.py:66-95 as the plant
+    (tools/closed_loop_corner.py).  Radius 9: no solve rejected, the car stays within 2.5 m of the centre line (corridor
+    4.03 m), the box-constrained refinement runs in a good share of the ticks without lengthening them.  Radius 8.2 - a
+    corner the car cannot follow, solves are rejected whatever the candidate (the reference would keep its previous plan
+    as well): the refined candidate (lq_candidate 2) loses fewer solves than the clipped LQ plan alone (lq_candidate 1),
+    and sampling alone (0) loses the track."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import closed_loop_corner as loop
+    nine = loop.run(9.0, 2, "monza", 2, verbose=False)
+    assert nine["rejected_solves"] == 0 and nine["lateral_max_m"] < 2.5, nine
+    assert nine["refinement_triggered_share"] > 0.2 and nine["iterations_max"] <= 40, nine
+    assert nine["solve_us_p50_when_triggered"] < 1.25 * nine["solve_us_p50"] + 5.0, nine     # hidden behind the GPU's work
+    tight_refined = loop.run(8.2, 2, "monza", 2, verbose=False)
+    tight_clipped = loop.run(8.2, 2, "monza", 1, verbose=False)
+    tight_sampled = loop.run(8.2, 1, "monza", 0, verbose=False)
+    assert tight_refined["lateral_max_m"] < 2.5 and tight_clipped["lateral_max_m"] < 3.0, (tight_refined, tight_clipped)
+    assert tight_refined["rejected_solves"] < 0.7 * tight_clipped["rejected_solves"], (tight_refined, tight_clipped)
+    assert tight_sampled["lateral_max_m"] > 4.03 or tight_sampled["rejected_solves"] > tight_clipped["rejected_solves"], tight_sampled
