@@ -38,7 +38,10 @@ constexpr double kTMin = 0.01;        // control.py:134
 constexpr double kAlpha = 1.6;        // over-relaxation (OSQP's default)
 constexpr double kRhoEy = 3.0e-3;     // step sizes of the state classes (the input classes use r_term)
 constexpr double kRhoT = 3.0e-2;
-constexpr int kWarmIterations = 8;    // per call from a kept iterate (a cold start takes the caller's cap)
+#ifndef ACMPC_LQ_BOX_WARM
+#define ACMPC_LQ_BOX_WARM 12
+#endif
+constexpr int kWarmIterations = ACMPC_LQ_BOX_WARM;    // per call from a kept iterate (a cold start takes the caller's cap)
 // the iteration stops when every boxed component's z and w agree AND w has stopped moving (or both have stopped moving
 // apart: an infeasible row), per class:
 // e_y 1e-4 m, t 1e-5 s, v 1e-3 m/s, kappa 1e-6 1/m
@@ -278,7 +281,8 @@ inline Result refine(const double* table, int n, const double x0[3], const doubl
     return res;
   }
   // a warm iterate continues for at most kWarmIterations per call: what fits behind the prologue and the first round of a
-  // tick (8 x 1.8 us + the factorisation and the rollouts, ~20 us); one that needs more takes it over the next ticks
+  // tick (12 x 1.8 us + the factorisation and the rollouts, ~28 us: closed loop round a 9 m corner, same box, 8 / 12 / 16 / 40 per call:
+  // tick p50 52.2 / 52.5 / 56.1 / 81 us; solves lost in an 8.2 m corner 218 / 179 / 171 / 160 of 1 790); one that needs more takes it over the next ticks
   const int budget = (st.n == n && iterations > kWarmIterations) ? kWarmIterations : iterations;
   res.iterations = iterate(table, n, x0, u_lo, u_hi, margin, rho, budget, st, ws);
   if (res.iterations < 0) return res;

@@ -102,7 +102,7 @@ typedef struct acmpc_params {
                             state rows (corridor control.py:57-60, t >= 0.01 control.py:134) violated beyond the solver's
                             acceptance tolerance - it is refined against the QP WITH its box rows (csrc/acmpc_lq_box.h: the
                             OSQP splitting with the model as a hard constraint of the Riccati z-update; host, float64,
-                            iterate kept between calls; at most ACMPC_LQ_BOX_ITERATIONS = 40 iterations per call from a cold start, 8 from a kept iterate) and the
+                            iterate kept between calls; at most ACMPC_LQ_BOX_ITERATIONS = 40 iterations per call from a cold start, 12 from a kept iterate) and the
                             cheapest of {LQ plan, the two iterates} under J + w_bound V takes the slot.
                             0 = no such candidate */
   /* real-valued fields are doubles so that Python floats cross the ABI exactly; the device gets float32 */
@@ -146,7 +146,7 @@ int acmpc_lq_plan(const double* table, int32_t n, const double x0[3], const doub
                   const double final_cost[3], const float u_min[2], const float u_max[2], float* plan);
 
 /* The plan of acmpc_params::lq_candidate = 2 for one path, on the host (csrc/acmpc_lq_box.h): arguments as acmpc_lq_plan,
- * `margin` / `w_bound` as in acmpc_params, at most `iterations` splitting iterations (8 when that is more and the iterate
+ * `margin` / `w_bound` as in acmpc_params, at most `iterations` splitting iterations (12 when that is more and the iterate
  * handed in is a warm one).  `state` [1 + 8 n]: the iterate -
  * state[0] = n marks a warm one (wx, wu, lx, lu [n][2] each behind it), anything else starts cold; written back (state[0]
  * = 0 when the call kept none).  `info` [5]: iterations run (negative: a non-finite iterate), which plan took the slot

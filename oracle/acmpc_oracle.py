@@ -949,7 +949,7 @@ def lq_plan(table, x0, Q, R, QN, u_lo, u_hi):
 # --- the box-constrained LQ plan (csrc/acmpc_lq_box.h, round 5) ---------------------------------------------------------
 LQBOX_ALPHA = 1.6
 LQBOX_RHO_EY, LQBOX_RHO_T = 3.0e-3, 3.0e-2
-LQBOX_WARM_ITERATIONS = 8
+LQBOX_WARM_ITERATIONS = 12
 LQBOX_PER_TOL = (1.0e4, 1.0e5, 1.0e3, 1.0e6)   # 1 / tolerance of e_y [m], t [s], v [m/s], kappa [1/m]
 
 
