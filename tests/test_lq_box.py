@@ -115,6 +115,37 @@ def _qp_tracking_optimum(p):
     return orc.qp_objective(qp["P_diag"], qp["q"], ref.x) + 0.5 * float(np.sum(qp["q"][weighted] ** 2 / qp["P_diag"][weighted]))
 
 
+@pytest.mark.parametrize("name", ["corner entry r 8, monza", "corner entry r 7.5 after 60 m, nordschleife", "s-bend r 8, spa",
+                                  "hairpin r 9 (input box only), monza"])
+def test_the_optimum_the_plan_is_measured_against_is_a_kkt_point(name):
+    """`oracle.osqp_restated` restates a published algorithm and is pinned by nothing of the reference's (no OSQP here), so
+    the optimum the bounds of this file and of tests/test_gpu_qp_gap.py are quoted against is certified solver-independently:
+    at 1e-7 its primal-dual pair satisfies the KKT conditions of the reference's QP - rows met, stationary, multipliers of the
+    right sign and only on rows that are active - which for a convex QP makes it THE optimum; and the looser solve the bounds
+    use (1e-5) has the same objective to 1e-4."""
+    track, coords, offset = _cases()[name]
+    p = _problem(track, coords, offset)
+    n = H - 1
+    qp = orc.control_qp(p["x0"], p["table"], p["cfg"], p["limits"])
+    n_eq = 3 * (n + 1)
+    keep = np.r_[0:n_eq, n_eq + 3:len(qp["l"])]
+    A, l, u = qp["A"][keep], qp["l"][keep], qp["u"][keep]
+    tight = orc.osqp_restated(qp["P_diag"], qp["q"], A, l, u, max_iter=100000, eps_abs=1e-7, eps_rel=1e-7, adaptive_rho=True)
+    assert tight.info.status == "solved"
+    x, y = tight.x, tight.y
+    Ax = A @ x
+    assert np.max(l - Ax) <= 1e-5 and np.max(Ax - u) <= 1e-5
+    np.testing.assert_allclose(qp["P_diag"] * x + qp["q"] + A.T @ y, 0.0, atol=1e-6)
+    box = np.isfinite(u) & np.isfinite(l) & (u > l)
+    assert np.max(np.maximum(y, 0.0)[np.isfinite(u)] * (u - Ax)[np.isfinite(u)], initial=0.0) <= 1e-5     # y > 0: at its upper bound
+    assert np.max(np.maximum(-y, 0.0)[np.isfinite(l)] * (Ax - l)[np.isfinite(l)], initial=0.0) <= 1e-5    # y < 0: at its lower bound
+    assert not (y[~np.isfinite(u)] > 1e-9).any() and not (y[~np.isfinite(l)] < -1e-9).any()
+    assert box.any() and (np.abs(y[box]) > 1e-3).any()          # and box rows ARE active in these cases
+    loose = orc.osqp_restated(qp["P_diag"], qp["q"], A, l, u, max_iter=20000, eps_abs=1e-5, eps_rel=1e-5, adaptive_rho=True)
+    f_tight, f_loose = (orc.qp_objective(qp["P_diag"], qp["q"], r.x) for r in (tight, loose))
+    assert abs(f_tight - f_loose) <= 1e-4 * abs(f_tight)
+
+
 @pytest.mark.parametrize("name,lq_excess_at_least", [("corner entry r 8, monza", 1.0),
                                                      ("corner entry r 7.5 after 60 m, nordschleife", 5.0),
                                                      ("s-bend r 8, spa", 0.0),
