@@ -65,6 +65,7 @@ struct ScoreArgs {
   int own_grid_search;
   GridIndex grid[3];
   GridGeometry geometry;
+  float inv_left_m, inv_right_m;   // 1.0f / left.m, 1.0f / right.m (pf_score_given_kernel: mod_u16)
 };
 
 constexpr int kWaves = kBlock / 64;
@@ -437,6 +438,179 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
   }
 }
 
+// x mod m for 0 <= x < 65 536 and m >= 1 (the reference's uint16 index arithmetic, :388-392) without the integer division
+// the compiler emits for `%`: the quotient from a float32 product (inv_m = 1.0f / m), off by one at most, then put right.
+__device__ __forceinline__ int mod_u16(int x, int m, float inv_m) {
+  const int q = static_cast<int>(static_cast<float>(x) * inv_m);
+  int r = x - q * m;
+  r = (r < 0) ? r + m : r;
+  return (r >= m) ? r - m : r;
+}
+
+// v of lane (l ^ MASK): the vector pipe's own lane permutations where it has one for the mask (inside a quad, across the
+// halves of a row of 16), the LDS crossbar otherwise
+template <int MASK>
+__device__ __forceinline__ double from_lane_xor(double v) {
+  if constexpr (MASK == 1 || MASK == 2 || MASK == 8) {
+    constexpr int ctrl = (MASK == 1) ? 0xB1 : (MASK == 2) ? 0x4E : 0x128;   // quad_perm [1,0,3,2] / [2,3,0,1] / row_ror:8
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), ctrl, 0xf, 0xf, false);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+  } else {
+    return __shfl_xor(v, MASK, 64);
+  }
+}
+
+// ((wave_sum(s[0]) + wave_sum(s[1])) + wave_sum(s[2])) + wave_sum(s[3]), bit for bit, in ten exchanges instead of twenty-
+// four.  wave_sum's tree adds lane l ^ 32, then l ^ 16, ... l ^ 1; after the first stage both halves of the wave hold the
+// same 32 partial sums (a + b = b + a), so two sums share a vector from there - and after the second stage four.  Every
+// sum is still reduced by exactly wave_sum's tree.
+__device__ __forceinline__ double wave_sum_of_four(const double (&s)[4], int lane) {
+  double t[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) t[w] = s[w] + from_lane_xor<32>(s[w]);
+  double a = (lane < 32) ? t[0] : t[1], b = (lane < 32) ? t[2] : t[3];
+  a += from_lane_xor<16>(a);
+  b += from_lane_xor<16>(b);
+  double c = (lane & 16) ? b : a;   // lanes 0-15: s[0]'s partial sums, 16-31: s[2]'s, 32-47: s[1]'s, 48-63: s[3]'s
+  c += from_lane_xor<8>(c);
+  c += from_lane_xor<4>(c);
+  c += from_lane_xor<2>(c);
+  c += from_lane_xor<1>(c);
+  auto of_lane = [&](int l) {
+    const long long bits = __double_as_longlong(c);
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(bits), l), hi = __builtin_amdgcn_readlane(static_cast<int>(bits >> 32), l);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+  };
+  return ((of_lane(0) + of_lane(32)) + of_lane(16)) + of_lane(48);
+}
+
+// The scoring of particles whose nearest points are GIVEN (pf_nearest_kernel ran in front: 4 096 particles and more), one
+// WAVEFRONT for PW particles and no workgroup at all: lane l (< PW) holds particle l's frame and nearest points and
+// evaluates its score at the end; in between the 64 lanes place the observation in one particle's frame after the other
+// (wave-uniform frame: read out of lane l's registers) and sum the distances.  pf_score_kernel<8> spent its time waiting -
+// two barriers and four dependent trips to memory per workgroup of 3 us of work, 1 150 instructions per wave (profiles/
+// r05_pf_sq_counters.json) - and evaluated the eight tails (atan2, exp, float64 divisions) on eight lanes of one wave.
+// Same bits: pf_score_kernel's thread `tid` sums the observation points k = tid, tid + 256, ...; its wave w reduces them
+// with wave_sum and the four sums are added in the order of the waves.  Here lane l does the same for each of the four
+// slots w (k = 64 w + l, + 256, ...), each slot is reduced by the same tree, and they are added in the same order.
+// ONE_TRIP: at most 256 observation points (the reference's downsampled observation: 200), a point per lane and slot.
+// NO_WRAP: nearest index + offset stays below 65 536 and below twice the polyline's length on both sides (launch_score
+// checks the lengths), so the uint16 wrap never happens and the modulo is one conditional subtraction.
+template <int PW, bool ONE_TRIP, bool NO_WRAP>
+__global__ void __launch_bounds__(64) pf_score_given_kernel(const ScoreArgs a, const int P_arg) {
+  static_assert(PW >= 1 && PW <= 64, "a lane per particle");
+  static_assert(kWaves == 4, "wave_sum_of_four");
+  const int lane = threadIdx.x;
+  const int p0 = blockIdx.x * PW;
+  const int P = (a.live != nullptr) ? a.live[0] : P_arg;
+  if (p0 >= P) return;   // wave-uniform
+  // phase 0: lane l's own particle (lanes beyond the count repeat the last one and write nothing)
+  const int p_own = min(p0 + min(lane, PW - 1), P - 1);
+  const float sx = a.states[3 * p_own], sy = a.states[3 * p_own + 1], sphi = a.states[3 * p_own + 2];
+  const float angle = -sphi + 1.57079632679489661923f;
+  const float ca_own = cosf(angle), sa_own = sinf(angle);
+  int i_centre = a.given_index[3 * p_own], i_left = a.given_index[3 * p_own + 1], i_right = a.given_index[3 * p_own + 2];
+  const double dc = a.given_d2[3 * p_own];
+  i_centre = (i_centre == 0x7fffffff) ? 0 : i_centre;   // a non-finite position is nearest to nothing: point 0, like np.argmin
+  i_left = (i_left == 0x7fffffff) ? 0 : i_left;
+  i_right = (i_right == 0x7fffffff) ? 0 : i_right;
+
+  // phase 1: the observation against the map limits ahead of each particle's nearest points (:330-410), float32 placement
+  // as the reference's, float64 from the subtraction of the map on
+  const int K = a.k_left + a.k_right;
+  // what observation point k contributes for every particle alike
+  struct Slot {
+    float ox, oy;
+    int off;        // np.linspace(closest, closest + count, count, dtype=uint16): closest + i, except the last entry = closest + count
+    bool is_left, live;
+  };
+  auto slot_of = [&](int k_raw) {
+    Slot t;
+    t.live = k_raw < K;
+    const int k = min(k_raw, K - 1);   // (a lane past the end evaluates the last point and adds nothing)
+    t.ox = a.obs[2 * k];
+    t.oy = a.obs[2 * k + 1];
+    t.is_left = k < a.k_left;
+    const int i = t.is_left ? k : k - a.k_left;
+    const int count = t.is_left ? a.k_left : a.k_right;
+    t.off = (count > 1 && i == count - 1) ? count : i;
+    return t;
+  };
+  auto distance = [&](const Slot& t, float ca, float sa, float px32, float py32, int near_left, int near_right) {
+    const double wx = (ca * t.ox + sa * t.oy) + px32;   // transpose of [[cos, -sin], [sin, cos]] (:355-364)
+    const double wy = (-sa * t.ox + ca * t.oy) + py32;
+    const double* __restrict__ xy = t.is_left ? a.left.xy : a.right.xy;
+    const int m = t.is_left ? a.left.m : a.right.m;
+    const int ahead = (t.is_left ? near_left : near_right) + t.off;
+    int idx;
+    if constexpr (NO_WRAP) {
+      idx = (ahead >= m) ? ahead - m : ahead;
+    } else {
+      idx = mod_u16(ahead & 0xffff, m, t.is_left ? a.inv_left_m : a.inv_right_m);
+    }
+    const double dx = wx - xy[2 * idx], dy = wy - xy[2 * idx + 1];
+    return sqrt(dx * dx + dy * dy);
+  };
+  Slot slots[kWaves];
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) slots[w] = slot_of(64 * w + lane);
+  double total_own = 0.0;
+  const int count_here = min(PW, P - p0);
+#pragma unroll 1
+  for (int q = 0; q < count_here; ++q) {
+    const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca_own), q));
+    const float sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sa_own), q));
+    const float px32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), q));
+    const float py32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), q));
+    const int near_left = __builtin_amdgcn_readlane(i_left, q), near_right = __builtin_amdgcn_readlane(i_right, q);
+    double sum[kWaves];
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const double d = distance(slots[w], ca, sa, px32, py32, near_left, near_right);
+      sum[w] = slots[w].live ? d : 0.0;
+    }
+    if constexpr (!ONE_TRIP) {
+      for (int base = kBlock; base < K; base += kBlock) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+          const Slot t = slot_of(base + 64 * w + lane);
+          const double d = distance(t, ca, sa, px32, py32, near_left, near_right);
+          sum[w] += t.live ? d : 0.0;
+        }
+      }
+    }
+    const double total = wave_sum_of_four(sum, lane);
+    total_own = (lane == q) ? total : total_own;
+  }
+
+  // phase 2: lane l finishes particle l (heading of the centre line at the nearest point, score, validity)
+  if (lane < count_here) {
+    const int p = p0 + lane;
+    const double error = total_own / static_cast<double>(K);
+    const double phi = sphi;
+    // heading of the centreline at the nearest point, indices mod (len - 1) (:291-318)
+    const int m1 = a.centre.m - 1;
+    const int here = i_centre % m1, next = (i_centre + 1) % m1;
+    const double track_heading = atan2(a.centre.xy[2 * next + 1] - a.centre.xy[2 * here + 1],
+                                       a.centre.xy[2 * next] - a.centre.xy[2 * here]);
+    const double raw = track_heading - phi + kPi;
+    const double heading = fabs(raw - floor(raw / (2 * kPi)) * (2 * kPi) - kPi);
+    const double offset = sqrt(dc);
+    const double z = (error - a.mean) / a.sigma;
+    const double score = exp(-z * z / 2.0) / sqrt(2.0 * kPi) / a.sigma / a.scale;
+    a.track_indices[3 * p] = i_centre;
+    a.track_indices[3 * p + 1] = i_left;
+    a.track_indices[3 * p + 2] = i_right;
+    a.minimum_offset[p] = offset;
+    a.heading_offset[p] = heading;
+    a.error[p] = error;
+    a.score[p] = score;
+    a.valid[p] = (heading < a.thr_rotation && offset < a.thr_offset && error < a.thr_error) ? 1 : 0;
+  }
+}
+
 // states += x_dot * dt, x_dot = (v cos phi, v sin phi, v tan delta / L) in float32 as the reference computes it
 // (localiser.py:66-95: float32 state array, per-particle delta and v)
 __global__ void pf_advance_kernel(float* states, const float* delta, const float* velocity, int P, float wheelbase,
@@ -707,6 +881,7 @@ thread_local std::string g_pf_create_error;
 struct acmpc_pf {
   acmpc_pf_params prm{};
   bool no_grid = false;   // ACMPC_PF_NO_GRID (A/B switch of the tests): read from the environment once, by acmpc_pf_create
+  bool workgroup_score = false;   // ACMPC_PF_WORKGROUP_SCORE (likewise): pf_score_kernel<8> behind the grid search, as in rounds 2-5
   std::vector<double> h_track[3];
   double scale = 1.0;
   bool device_ready = false;
@@ -865,6 +1040,35 @@ hipError_t launch_nearest(acmpc_pf* h, ScoreArgs& a, int P, hipStream_t s) {
   return hipGetLastError();
 }
 
+// the scoring launch behind launch_nearest: given nearest points -> a wavefront per 16 particles (4 where that would leave
+// the chip short of waves); none given -> the workgroup kernels, which find them (PB = 1: through the grid)
+void launch_score(const acmpc_pf* h, const ScoreArgs& a, int P, hipStream_t s) {
+  if (a.given_index != nullptr && !h->workgroup_score) {
+    ScoreArgs b = a;
+    b.inv_left_m = 1.0f / static_cast<float>(a.left.m);
+    b.inv_right_m = 1.0f / static_cast<float>(a.right.m);
+    const int K = a.k_left + a.k_right;
+    const bool one_trip = K <= kBlock;
+    // the indices ahead of a nearest point: nearest + offset <= (m - 1) + max(k_left, k_right)
+    const bool no_wrap = std::max(a.left.m, a.right.m) + K <= 65536 && K <= std::min(a.left.m, a.right.m);
+    const dim3 wide((P + 15) / 16), narrow((P + 3) / 4);
+    if (P >= 65536) {
+      if (one_trip && no_wrap) hipLaunchKernelGGL((pf_score_given_kernel<16, true, true>), wide, dim3(64), 0, s, b, P);
+      else if (one_trip) hipLaunchKernelGGL((pf_score_given_kernel<16, true, false>), wide, dim3(64), 0, s, b, P);
+      else hipLaunchKernelGGL((pf_score_given_kernel<16, false, false>), wide, dim3(64), 0, s, b, P);
+    } else {
+      if (one_trip && no_wrap) hipLaunchKernelGGL((pf_score_given_kernel<4, true, true>), narrow, dim3(64), 0, s, b, P);
+      else if (one_trip) hipLaunchKernelGGL((pf_score_given_kernel<4, true, false>), narrow, dim3(64), 0, s, b, P);
+      else hipLaunchKernelGGL((pf_score_given_kernel<4, false, false>), narrow, dim3(64), 0, s, b, P);
+    }
+  } else if (P >= kGridParticles) {
+    constexpr int PB = 8;
+    hipLaunchKernelGGL(pf_score_kernel<PB>, dim3((P + PB - 1) / PB), dim3(kBlock), 0, s, a, P);
+  } else {
+    hipLaunchKernelGGL(pf_score_kernel<1>, dim3(P), dim3(kBlock), 0, s, a, P);
+  }
+}
+
 int pf_ensure_device(acmpc_pf* h) {
   if (h->device_ready) return ACMPC_OK;
   int count = 0;
@@ -928,6 +1132,8 @@ int acmpc_pf_create(const acmpc_pf_params* params, const double* centre, int32_t
   {
     const char* value = std::getenv("ACMPC_PF_NO_GRID");
     h->no_grid = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
+    value = std::getenv("ACMPC_PF_WORKGROUP_SCORE");
+    h->workgroup_score = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
   }
   h->h_track[0].assign(centre, centre + 2 * static_cast<size_t>(m_centre));
   h->h_track[1].assign(left, left + 2 * static_cast<size_t>(m_left));
@@ -1032,12 +1238,7 @@ int acmpc_pf_score(acmpc_pf* h, const float* states, int32_t P, const float* obs
   a.valid = reinterpret_cast<uint8_t*>(out + 4 * pd + static_cast<size_t>(P) * 3 * sizeof(int32_t));
   (void)hipGetLastError();  // a stale error of an earlier call must not be read as this launch's
   PF_HIP(h, launch_nearest(h, a, P, s));
-  if (P >= 4096) {
-    constexpr int PB = 8;
-    hipLaunchKernelGGL(pf_score_kernel<PB>, dim3((P + PB - 1) / PB), dim3(kBlock), 0, s, a, P);
-  } else {
-    hipLaunchKernelGGL(pf_score_kernel<1>, dim3(P), dim3(kBlock), 0, s, a, P);
-  }
+  launch_score(h, a, P, s);
   PF_HIP(h, hipGetLastError());
   const size_t down = 4 * pd + static_cast<size_t>(P) * (3 * sizeof(int32_t) + 1);
   if (!in_place) PF_HIP(h, hipMemcpyAsync(h->h_down, h->d_down, down, hipMemcpyDeviceToHost, s));
@@ -1276,14 +1477,9 @@ int acmpc_pf_filter_update(acmpc_pf* h, const float* obs_left, int32_t k_left, c
   a.live = h->f_counts;   // the particle count is on the device
   (void)hipGetLastError();
   {
-    constexpr int PB = 8;
     const int P = h->prm.max_particles;   // workgroups beyond the live count return at once
     PF_HIP(h, launch_nearest(h, a, P, s));
-    if (P >= 4096) {
-      hipLaunchKernelGGL(pf_score_kernel<PB>, dim3((P + PB - 1) / PB), dim3(kBlock), 0, s, a, P);
-    } else {
-      hipLaunchKernelGGL(pf_score_kernel<1>, dim3(P), dim3(kBlock), 0, s, a, P);
-    }
+    launch_score(h, a, P, s);
   }
   PF_HIP(h, hipGetLastError());
   hipLaunchKernelGGL(pf_publish_scores_kernel, dim3((h->prm.max_particles + 255) / 256), dim3(256), 0, s, a.score,

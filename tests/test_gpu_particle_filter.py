@@ -56,11 +56,14 @@ def test_scoring_matches_the_oracle_on_other_inputs(golden):
     np.testing.assert_array_equal(out["valid_mask"], want["valid"])
 
 
-@pytest.mark.parametrize("P", [4096, 9001])
-def test_grid_search_equals_the_exhaustive_scan(golden, P, monkeypatch):
+@pytest.mark.parametrize("P,points", [(4096, (90, 70)), (9001, (90, 70)), (70001, (90, 70)), (4099, (300, 333)), (66000, (257, 1))])
+def test_grid_search_equals_the_exhaustive_scan(golden, P, points, monkeypatch):
     """The nearest map points come from a grid search (pf_nearest_kernel) - the exhaustive scan's answer, bit for bit:
     particles on the track, metres off it, far outside the map's box, exactly on cell borders of the grid, duplicates,
-    and a non-finite one; both launch shapes of the scoring kernel."""
+    and a non-finite one.  Behind the grid search the scoring runs on a wavefront per 4 or 16 particles
+    (pf_score_given_kernel; 70 001: the sixteen-particle form with a ragged last wave) - the same bits as the workgroup
+    kernel that scans for itself, and as the workgroup kernel behind the grid search (ACMPC_PF_WORKGROUP_SCORE); with more
+    than 256 observation points a lane sums several per slot, as a thread of the workgroup kernel does."""
     g = golden
     centre = g["pf/centre"]
     rng = np.random.default_rng(17)
@@ -75,13 +78,17 @@ def test_grid_search_equals_the_exhaustive_scan(golden, P, monkeypatch):
     xy[120:125] = centre[100]                                                         # on a map point, five times
     states = np.concatenate([xy, rng.uniform(-np.pi, np.pi, (P, 1))], axis=1).astype(np.float32)
     states[125, 0] = np.nan
-    left = np.stack([-4.5 + rng.normal(0, 0.2, 90), np.linspace(0, 60, 90)], axis=1).astype(np.float32)
-    right = np.stack([4.5 + rng.normal(0, 0.2, 70), np.linspace(0, 45, 70)], axis=1).astype(np.float32)
+    n_left, n_right = points
+    left = np.stack([-4.5 + rng.normal(0, 0.2, n_left), np.linspace(0, 60, n_left)], axis=1).astype(np.float32)
+    right = np.stack([4.5 + rng.normal(0, 0.2, n_right), np.linspace(0, 45, n_right)], axis=1).astype(np.float32)
     grid = _scorer(g, n_particles=P).update_particles(states, [left, right])
+    monkeypatch.setenv("ACMPC_PF_WORKGROUP_SCORE", "1")
+    workgroup = _scorer(g, n_particles=P).update_particles(states, [left, right])
     monkeypatch.setenv("ACMPC_PF_NO_GRID", "1")
     scan = _scorer(g, n_particles=P).update_particles(states, [left, right])
     for key in ("track_indices", "minimum_offset", "heading_offset", "observation_error", "score", "valid_mask"):
         np.testing.assert_array_equal(grid[key], scan[key], err_msg=key)
+        np.testing.assert_array_equal(grid[key], workgroup[key], err_msg=key)
     # and the brute-force statement itself on the finite ones
     some = np.r_[0:125, 126:600]   # (all but the non-finite one of the special cases, and a few hundred ordinary ones)
     d2 = ((states[some, None, :2].astype(np.float64) - centre[None]) ** 2).sum(-1)
