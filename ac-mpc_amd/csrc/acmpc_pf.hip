@@ -454,8 +454,9 @@ __device__ __forceinline__ double from_lane_xor(double v) {
   if constexpr (MASK == 1 || MASK == 2 || MASK == 8) {
     constexpr int ctrl = (MASK == 1) ? 0xB1 : (MASK == 2) ? 0x4E : 0x128;   // quad_perm [1,0,3,2] / [2,3,0,1] / row_ror:8
     const long long bits = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), ctrl, 0xf, 0xf, false);
+    // (every lane has a source under these controls: `old` is never kept, and passing the value itself saves its zeroing)
+    const int lo = __builtin_amdgcn_update_dpp(static_cast<int>(bits), static_cast<int>(bits), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(static_cast<int>(bits >> 32), static_cast<int>(bits >> 32), ctrl, 0xf, 0xf, false);
     return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
   } else {
     return __shfl_xor(v, MASK, 64);
@@ -498,9 +499,9 @@ __device__ __forceinline__ double wave_sum_of_four(const double (&s)[4], int lan
 // ONE_TRIP: at most 256 observation points (the reference's downsampled observation: 200), a point per lane and slot.
 // NO_WRAP: nearest index + offset stays below 65 536 and below twice the polyline's length on both sides (launch_score
 // checks the lengths), so the uint16 wrap never happens and the modulo is one conditional subtraction.
-template <int PW, bool ONE_TRIP, bool NO_WRAP>
-__global__ void __launch_bounds__(64) pf_score_given_kernel(const ScoreArgs a, const int P_arg) {
-  static_assert(PW >= 1 && PW <= 64, "a lane per particle");
+// PW (1 ... 64, wave-uniform): particles per wave - launch_score picks it so that the launch is whole generations of waves.
+template <bool ONE_TRIP, bool NO_WRAP>
+__global__ void __launch_bounds__(64) pf_score_given_kernel(const ScoreArgs a, const int P_arg, const int PW) {
   static_assert(kWaves == 4, "wave_sum_of_four");
   const int lane = threadIdx.x;
   const int p0 = blockIdx.x * PW;
@@ -538,9 +539,8 @@ __global__ void __launch_bounds__(64) pf_score_given_kernel(const ScoreArgs a, c
     t.off = (count > 1 && i == count - 1) ? count : i;
     return t;
   };
-  auto distance = [&](const Slot& t, float ca, float sa, float px32, float py32, int near_left, int near_right) {
-    const double wx = (ca * t.ox + sa * t.oy) + px32;   // transpose of [[cos, -sin], [sin, cos]] (:355-364)
-    const double wy = (-sa * t.ox + ca * t.oy) + py32;
+  // in two halves, so that a particle's four map points are requested together and not one after the other's arrival
+  auto map_point = [&](const Slot& t, int near_left, int near_right) {
     const double* __restrict__ xy = t.is_left ? a.left.xy : a.right.xy;
     const int m = t.is_left ? a.left.m : a.right.m;
     const int ahead = (t.is_left ? near_left : near_right) + t.off;
@@ -550,7 +550,12 @@ __global__ void __launch_bounds__(64) pf_score_given_kernel(const ScoreArgs a, c
     } else {
       idx = mod_u16(ahead & 0xffff, m, t.is_left ? a.inv_left_m : a.inv_right_m);
     }
-    const double dx = wx - xy[2 * idx], dy = wy - xy[2 * idx + 1];
+    return *reinterpret_cast<const double2*>(xy + 2 * idx);   // (x, y): 16-byte aligned
+  };
+  auto distance = [&](const Slot& t, float ca, float sa, float px32, float py32, double2 at) {
+    const double wx = (ca * t.ox + sa * t.oy) + px32;   // transpose of [[cos, -sin], [sin, cos]] (:355-364)
+    const double wy = (-sa * t.ox + ca * t.oy) + py32;
+    const double dx = wx - at.x, dy = wy - at.y;
     return sqrt(dx * dx + dy * dy);
   };
   Slot slots[kWaves];
@@ -566,18 +571,28 @@ __global__ void __launch_bounds__(64) pf_score_given_kernel(const ScoreArgs a, c
     const float py32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), q));
     const int near_left = __builtin_amdgcn_readlane(i_left, q), near_right = __builtin_amdgcn_readlane(i_right, q);
     double sum[kWaves];
+    double2 at[kWaves];
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) at[w] = map_point(slots[w], near_left, near_right);
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise reuses one register quad and serialises the four loads)
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) {
-      const double d = distance(slots[w], ca, sa, px32, py32, near_left, near_right);
+      const double d = distance(slots[w], ca, sa, px32, py32, at[w]);
       sum[w] = slots[w].live ? d : 0.0;
     }
     if constexpr (!ONE_TRIP) {
       for (int base = kBlock; base < K; base += kBlock) {
+        Slot t[kWaves];
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
-          const Slot t = slot_of(base + 64 * w + lane);
-          const double d = distance(t, ca, sa, px32, py32, near_left, near_right);
-          sum[w] += t.live ? d : 0.0;
+          t[w] = slot_of(base + 64 * w + lane);
+          at[w] = map_point(t[w], near_left, near_right);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+          const double d = distance(t[w], ca, sa, px32, py32, at[w]);
+          sum[w] += t[w].live ? d : 0.0;
         }
       }
     }
@@ -882,6 +897,7 @@ struct acmpc_pf {
   acmpc_pf_params prm{};
   bool no_grid = false;   // ACMPC_PF_NO_GRID (A/B switch of the tests): read from the environment once, by acmpc_pf_create
   bool workgroup_score = false;   // ACMPC_PF_WORKGROUP_SCORE (likewise): pf_score_kernel<8> behind the grid search, as in rounds 2-5
+  int given_wave_slots[3] = {0, 0, 0};   // waves of pf_score_given_kernel's three forms the device holds at once (ensure_device)
   std::vector<double> h_track[3];
   double scale = 1.0;
   bool device_ready = false;
@@ -1051,16 +1067,16 @@ void launch_score(const acmpc_pf* h, const ScoreArgs& a, int P, hipStream_t s) {
     const bool one_trip = K <= kBlock;
     // the indices ahead of a nearest point: nearest + offset <= (m - 1) + max(k_left, k_right)
     const bool no_wrap = std::max(a.left.m, a.right.m) + K <= 65536 && K <= std::min(a.left.m, a.right.m);
-    const dim3 wide((P + 15) / 16), narrow((P + 3) / 4);
-    if (P >= 65536) {
-      if (one_trip && no_wrap) hipLaunchKernelGGL((pf_score_given_kernel<16, true, true>), wide, dim3(64), 0, s, b, P);
-      else if (one_trip) hipLaunchKernelGGL((pf_score_given_kernel<16, true, false>), wide, dim3(64), 0, s, b, P);
-      else hipLaunchKernelGGL((pf_score_given_kernel<16, false, false>), wide, dim3(64), 0, s, b, P);
-    } else {
-      if (one_trip && no_wrap) hipLaunchKernelGGL((pf_score_given_kernel<4, true, true>), narrow, dim3(64), 0, s, b, P);
-      else if (one_trip) hipLaunchKernelGGL((pf_score_given_kernel<4, true, false>), narrow, dim3(64), 0, s, b, P);
-      else hipLaunchKernelGGL((pf_score_given_kernel<4, false, false>), narrow, dim3(64), 0, s, b, P);
-    }
+    const int form = one_trip ? (no_wrap ? 0 : 1) : 2;
+    // particles per wave: the launch as whole generations of resident waves (a handful of waves left over for a second
+    // generation would double the kernel's time), at least 4 per wave, at most 32
+    const int slots = std::max(h->given_wave_slots[form], 1);
+    const int generations = (P + 32 * slots - 1) / (32 * slots);
+    const int pw = std::min(std::max((P + slots * generations - 1) / (slots * generations), 4), 32);
+    const dim3 grid((P + pw - 1) / pw);
+    if (form == 0) hipLaunchKernelGGL((pf_score_given_kernel<true, true>), grid, dim3(64), 0, s, b, P, pw);
+    else if (form == 1) hipLaunchKernelGGL((pf_score_given_kernel<true, false>), grid, dim3(64), 0, s, b, P, pw);
+    else hipLaunchKernelGGL((pf_score_given_kernel<false, false>), grid, dim3(64), 0, s, b, P, pw);
   } else if (P >= kGridParticles) {
     constexpr int PB = 8;
     hipLaunchKernelGGL(pf_score_kernel<PB>, dim3((P + PB - 1) / PB), dim3(kBlock), 0, s, a, P);
@@ -1107,6 +1123,16 @@ int pf_ensure_device(acmpc_pf* h) {
   PF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_down), down));
   PF_HIP(h, hipMalloc(&h->d_aux, P * 2 * sizeof(float)));
   PF_HIP(h, hipMalloc(&h->d_out, 8 * sizeof(double)));
+  {
+    // how many waves of the wave-per-particles scoring kernel the device holds at once (launch_score sizes its waves by it)
+    int device = 0, units = 0, per_unit[3] = {0, 0, 0};
+    PF_HIP(h, hipGetDevice(&device));
+    PF_HIP(h, hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device));
+    PF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit[0], pf_score_given_kernel<true, true>, 64, 0));
+    PF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit[1], pf_score_given_kernel<true, false>, 64, 0));
+    PF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit[2], pf_score_given_kernel<false, false>, 64, 0));
+    for (int f = 0; f < 3; ++f) h->given_wave_slots[f] = units * per_unit[f];
+  }
   h->device_ready = true;
   return ACMPC_OK;
 }

@@ -331,7 +331,8 @@ def particle_filter_block(workloads, iters=20):
         newest = [run for label, run in sorted(runs.items()) if label.endswith("new")]
         for label, size, kernel in (("pf_score_kernel<1>_at_500", "500", "pf_score_kernel<1>"),
                                     ("pf_nearest_kernel_at_100000", "100000", "pf_nearest_kernel"),
-                                    ("pf_score_kernel<8>_at_100000", "100000", "pf_score_kernel<8>")):
+                                    ("pf_score_kernel<8>_at_100000", "100000", "pf_score_kernel<8>"),
+                                    ("pf_score_given_kernel_at_100000", "100000", "pf_score_given_kernel")):
             timed = stats["sizes"].get(size, {}).get(kernel)
             if timed is None:
                 continue
@@ -349,6 +350,12 @@ def particle_filter_block(workloads, iters=20):
                              frac_of_vector_cache_line_rate=lines * 64 / (timed["average_us"] * 1e-6) / line_rate)
             if kernel == "pf_nearest_kernel":
                 entry["queries_per_s"] = 300000 / (timed["average_us"] * 1e-6)
+            if counted is not None and "derived" in counted and "valu_instructions_per_wave" in counted["derived"] \
+                    and "waves" in counted["derived"]:
+                # instruction issue: a wave64 vector instruction holds its SIMD's issue port for four clocks
+                issue = counted["derived"]["valu_instructions_per_wave"] * counted["derived"]["waves"] * 4 / (1024 * 2.1e9)
+                entry["vector_issue_floor_us"] = issue * 1e6
+                entry["frac_of_vector_issue_rate"] = issue / (timed["average_us"] * 1e-6)
             bounds[label] = entry
         out["kernel_bounds"] = bounds
     return out

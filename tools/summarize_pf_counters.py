@@ -11,7 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
-SHORT = {"pf_nearest_kernel": "pf_nearest_kernel", "pf_score_kernel<1>": "pf_score_kernel<1>", "pf_score_kernel<8>": "pf_score_kernel<8>"}
+SHORT = {"pf_nearest_kernel": "pf_nearest_kernel", "pf_score_kernel<1>": "pf_score_kernel<1>", "pf_score_kernel<8>": "pf_score_kernel<8>",
+         "pf_score_given_kernel": "pf_score_given_kernel"}
 
 
 def short(name):
@@ -49,6 +50,7 @@ def one(label, P):
                                          "issuing (SQ_ACTIVE_INST_ANY)": m["SQ_ACTIVE_INST_ANY"] / wc},
                 "vector_memory_reads_per_wave": m["SQ_INSTS_VMEM_RD"] / m["SQ_WAVES"],
                 "valu_instructions_per_wave": m["SQ_INSTS_VALU"] / m["SQ_WAVES"],
+                "waves": m["SQ_WAVES"],
             }
             if "TCC_HIT_sum" in m:
                 lines = m.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0)

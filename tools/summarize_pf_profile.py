@@ -21,7 +21,7 @@ for P in (500, 100000):
     with open(found[0], newline="") as handle:
         for row in csv.DictReader(handle):
             name = row["Name"]
-            for short in ("pf_score_kernel<1>", "pf_score_kernel<8>", "pf_nearest_kernel", "pf_advance_kernel", "pf_estimate_kernel"):
+            for short in ("pf_score_kernel<1>", "pf_score_kernel<8>", "pf_score_given_kernel", "pf_nearest_kernel", "pf_advance_kernel", "pf_estimate_kernel"):
                 if short in name:
                     kernels[short] = {"calls": int(row["Calls"]), "average_us": float(row["AverageNs"]) / 1e3,
                                       "min_us": float(row["MinNs"]) / 1e3}
