@@ -83,3 +83,17 @@ def test_corners_that_bind_the_box_rows_in_closed_loop():
     assert tight_refined["lateral_max_m"] < 2.5 and tight_clipped["lateral_max_m"] < 3.0, (tight_refined, tight_clipped)
     assert tight_refined["rejected_solves"] < 0.7 * tight_clipped["rejected_solves"], (tight_refined, tight_clipped)
     assert tight_sampled["lateral_max_m"] > 4.03 or tight_sampled["rejected_solves"] > tight_clipped["rejected_solves"], tight_sampled
+
+
+@pytest.mark.parametrize("track", ["spa", "nordschleife", "silverstone"])
+def test_the_binding_corner_under_the_other_weight_sets(track):
+    """The same stadium (radius 9 m) with the other circuits' weights and speed limits (configs/<track>.yaml:67-81 - the cost
+    matrices differ by orders of magnitude between them): no solve rejected, the car inside the corridor, the refinement
+    at work in a good share of the ticks and within its cap."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import closed_loop_corner as loop
+    lap = loop.run(9.0, 1, track, 2, verbose=False)
+    assert lap["rejected_solves"] == 0 and lap["lateral_max_m"] < 3.2, lap        # corridor half-width 4.03 m
+    assert lap["refinement_triggered_share"] > 0.2 and lap["iterations_max"] <= 40, lap
