@@ -43,6 +43,16 @@ struct GridGeometry {
   double x0, y0, cell;
   int nx, ny;
 };
+// ... and, for the first ring of a search, the points of the 3 x 3 block of cells round every cell as ONE run (each point is
+// in nine blocks: 6 MB for the 35 k-point map), all three polylines in one set of arrays: a query reads two bounds and one
+// run instead of six bounds and three runs, and needs no choice of pointers by polyline
+struct GridBlocks {
+  const int* start;     // [3 * cells + 1]: block (t, c) holds entries [start[t * cells + c], start[t * cells + c + 1])
+  const double* x;      // rows of the block in order, cells of a row in order, ascending point index inside a cell
+  const double* y;
+  const int* index;
+  int cells;            // nx * ny
+};
 
 struct ScoreArgs {
   const float* states;     // [P][3]
@@ -65,6 +75,7 @@ struct ScoreArgs {
   int own_grid_search;
   GridIndex grid[3];
   GridGeometry geometry;
+  GridBlocks blocks;
   float inv_left_m, inv_right_m;   // 1.0f / left.m, 1.0f / right.m (pf_score_given_kernel: mod_u16)
 };
 
@@ -109,6 +120,7 @@ struct GridArgs {
   const int* live;       // or nullptr
   Track track[3];
   GridIndex grid[3];
+  GridBlocks blocks;
   double x0, y0, cell;
   int nx, ny;
   int32_t* index_out;    // [P][3]
@@ -155,31 +167,27 @@ __device__ __forceinline__ void scan_run(const double* __restrict__ gx, const do
 // index: its answer, bit for bit.  (The single cell of rounds 2-4 is no longer tried first: the left and right limits
 // lie 4.75 m from the centre line, more than half a cell - two queries in three never settled there.)
 template <int LANES>
-__device__ __forceinline__ bool grid_nearest(double px, double py, const GridGeometry& g, const int* __restrict__ start,
-                                             const double* __restrict__ gx, const double* __restrict__ gy,
-                                             const int* __restrict__ gi, int sub, double& best, int& best_i) {
-  const int ix = min(max(static_cast<int>(floor((px - g.x0) / g.cell)), 0), g.nx - 1);
-  const int iy = min(max(static_cast<int>(floor((py - g.y0) / g.cell)), 0), g.ny - 1);
+__device__ __forceinline__ bool grid_nearest(double px, double py, const GridGeometry& g, const GridBlocks& blocks,
+                                             const GridIndex (&grids)[3], int t, int sub, double& best, int& best_i) {
+  // (any cell will do for a correct answer - the margins below are measured from the particle itself - so the particle's
+  // cell comes from a product with 1 / cell here, where the host bins the map's points with the division)
+  const double inv_cell = 1.0 / g.cell;   // wave-uniform: scalar registers
+  const int ix = min(max(static_cast<int>(floor((px - g.x0) * inv_cell)), 0), g.nx - 1);
+  const int iy = min(max(static_cast<int>(floor((py - g.y0) * inv_cell)), 0), g.ny - 1);
   for (int r = 1; r <= kMaxRings; ++r) {
-    const int x_lo = max(ix - r, 0), x_hi = min(ix + r, g.nx - 1);
-    const int y_lo = max(iy - r, 0), y_hi = min(iy + r, g.ny - 1);
     best = INFINITY;
     best_i = 0x7fffffff;
-    if (r == 1) {   // three rows at most: their six run bounds in flight together, then their points
-      int j0[3], j1[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int cy = iy - 1 + k;
-        const bool inside = cy >= 0 && cy < g.ny;
-        const int row = inside ? cy * g.nx : 0;
-        j0[k] = start[row + x_lo];
-        j1[k] = inside ? start[row + x_hi + 1] : j0[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) scan_run<LANES>(gx, gy, gi, j0[k], j1[k], sub, px, py, best, best_i);
+    if (r == 1 && blocks.start != nullptr) {   // the 3 x 3 block: one run
+      const int c = t * blocks.cells + iy * g.nx + ix;
+      scan_run<LANES>(blocks.x, blocks.y, blocks.index, blocks.start[c], blocks.start[c + 1], sub, px, py, best, best_i);
     } else {
+      // (rare from the second ring on: the polyline's own arrays are chosen here, not in front of the search)
+      const GridIndex& gr = (t == 0) ? grids[0] : (t == 1) ? grids[1] : grids[2];
+      const int x_lo = max(ix - r, 0), x_hi = min(ix + r, g.nx - 1);
+      const int y_lo = max(iy - r, 0), y_hi = min(iy + r, g.ny - 1);
       for (int cy = y_lo; cy <= y_hi; ++cy)
-        scan_run<LANES>(gx, gy, gi, start[cy * g.nx + x_lo], start[cy * g.nx + x_hi + 1], sub, px, py, best, best_i);
+        scan_run<LANES>(gr.x, gr.y, gr.index, gr.start[cy * g.nx + x_lo], gr.start[cy * g.nx + x_hi + 1], sub, px, py, best,
+                        best_i);
     }
     group_argmin<LANES>(best, best_i);
     // distance to the nearest side of the block that has cells beyond it
@@ -212,9 +220,15 @@ __device__ __forceinline__ void wave_scan(const Track& track, double qx, double 
   wave_argmin(d, i);
 }
 
-// Sixteen lanes per (particle, polyline) query, four queries per wavefront at a time, kQueriesPerWave per wavefront.
-constexpr int kGroupLanes = 16;
+// kGroupLanes lanes per (particle, polyline) query, 64 / kGroupLanes queries per wavefront at a time, kQueriesPerWave per
+// wavefront.  (A/B builds: ACMPC_HIPCC_EXTRA=-DACMPC_PF_GROUP_LANES=8)
+#ifndef ACMPC_PF_GROUP_LANES
+#define ACMPC_PF_GROUP_LANES 16
+#endif
+constexpr int kGroupLanes = ACMPC_PF_GROUP_LANES;
 constexpr int kQueriesPerWave = 16;
+static_assert(kGroupLanes == 4 || kGroupLanes == 8 || kGroupLanes == 16 || kGroupLanes == 32, "a power of two, several groups per wave");
+static_assert(kQueriesPerWave % (64 / kGroupLanes) == 0, "whole rounds");
 
 __global__ void __launch_bounds__(64) pf_nearest_kernel(const GridArgs a, const int P_arg) {
   const int lane = threadIdx.x;
@@ -232,13 +246,9 @@ __global__ void __launch_bounds__(64) pf_nearest_kernel(const GridArgs a, const 
     const int p = active ? query / 3 : P - 1;
     const int t = active ? query - 3 * p : 0;
     const double px = a.states[3 * p], py = a.states[3 * p + 1];
-    const int* __restrict__ start = (t == 0) ? a.grid[0].start : (t == 1) ? a.grid[1].start : a.grid[2].start;
-    const double* __restrict__ gx = (t == 0) ? a.grid[0].x : (t == 1) ? a.grid[1].x : a.grid[2].x;
-    const double* __restrict__ gy = (t == 0) ? a.grid[0].y : (t == 1) ? a.grid[1].y : a.grid[2].y;
-    const int* __restrict__ gi = (t == 0) ? a.grid[0].index : (t == 1) ? a.grid[1].index : a.grid[2].index;
     double best;
     int best_i;
-    const bool settled = grid_nearest<kGroupLanes>(px, py, geo, start, gx, gy, gi, sub, best, best_i);
+    const bool settled = grid_nearest<kGroupLanes>(px, py, geo, a.blocks, a.grid, t, sub, best, best_i);
     // the rest: all 64 lanes scan the polyline side by side for each unsettled query of the wave
     unsigned long long pending = __ballot(!settled && sub == 0);
     while (pending != 0ull) {
@@ -299,8 +309,8 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
     if (wave < 3) {
       double best;
       int best_i;
-      if (!grid_nearest<64>(px[0], py[0], a.geometry, a.grid[wave].start, a.grid[wave].x, a.grid[wave].y,
-                            a.grid[wave].index, lane, best, best_i))
+      const int which = __builtin_amdgcn_readfirstlane(wave);
+      if (!grid_nearest<64>(px[0], py[0], a.geometry, a.blocks, a.grid, which, lane, best, best_i))
         wave_scan(tracks[wave], px[0], py[0], lane, best, best_i);
       if (lane < kWaves) {
         s_d[wave][0][lane] = (lane == 0) ? best : INFINITY;
@@ -911,6 +921,14 @@ struct acmpc_pf {
   int* d_grid_index[3] = {nullptr, nullptr, nullptr};
   double* d_grid_x[3] = {nullptr, nullptr, nullptr};
   double* d_grid_y[3] = {nullptr, nullptr, nullptr};
+  // the 3 x 3 blocks as single runs (GridBlocks), all three polylines in one set of arrays
+  bool no_blocks = false;   // ACMPC_PF_NO_BLOCKS (A/B switch): the first ring row by row from the cell-ordered arrays
+  std::vector<int> h_block_start, h_block_index;
+  std::vector<double> h_block_x, h_block_y;
+  int* d_block_start = nullptr;
+  int* d_block_index = nullptr;
+  double* d_block_x = nullptr;
+  double* d_block_y = nullptr;
   int32_t* d_near_index = nullptr;   // [max_particles][3]
   double* d_near_d2 = nullptr;       // [max_particles][3]
   hipStream_t stream = nullptr;
@@ -1017,6 +1035,31 @@ void build_grid(acmpc_pf* h) {
       h->h_grid_y[t][j] = h->h_track[t][2 * m + 1];
     }
   }
+  // the 3 x 3 block round every cell as one run: its rows in order, each row a run of the cell-ordered arrays
+  h->h_block_start.assign(3 * cells + 1, 0);
+  h->h_block_index.clear();
+  h->h_block_x.clear();
+  h->h_block_y.clear();
+  for (int t = 0; t < 3; ++t) {
+    const std::vector<int>& start = h->h_grid_start[t];
+    for (int iy = 0; iy < h->grid_ny; ++iy)
+      for (int ix = 0; ix < h->grid_nx; ++ix) {
+        h->h_block_start[t * cells + static_cast<size_t>(iy) * h->grid_nx + ix] = static_cast<int>(h->h_block_index.size());
+        const int x_lo = std::max(ix - 1, 0), x_hi = std::min(ix + 1, h->grid_nx - 1);
+        for (int cy = std::max(iy - 1, 0); cy <= std::min(iy + 1, h->grid_ny - 1); ++cy) {
+          const int j0 = start[static_cast<size_t>(cy) * h->grid_nx + x_lo], j1 = start[static_cast<size_t>(cy) * h->grid_nx + x_hi + 1];
+          h->h_block_index.insert(h->h_block_index.end(), h->h_grid_index[t].begin() + j0, h->h_grid_index[t].begin() + j1);
+          h->h_block_x.insert(h->h_block_x.end(), h->h_grid_x[t].begin() + j0, h->h_grid_x[t].begin() + j1);
+          h->h_block_y.insert(h->h_block_y.end(), h->h_grid_y[t].begin() + j0, h->h_grid_y[t].begin() + j1);
+        }
+      }
+  }
+  h->h_block_start[3 * cells] = static_cast<int>(h->h_block_index.size());
+  if (h->h_block_index.empty()) {   // (nothing to allocate for: one unused entry)
+    h->h_block_index.assign(1, 0);
+    h->h_block_x.assign(1, 0.0);
+    h->h_block_y.assign(1, 0.0);
+  }
 }
 
 // from kGridParticles up the grid search is a launch of its own in front of the scoring (sixteen lanes per query); below,
@@ -1026,6 +1069,11 @@ bool use_grid(const acmpc_pf* h, int P) {
   return h->grid_nx > 0 && P >= kGridParticles && !h->no_grid;
 }
 
+GridBlocks blocks_of(const acmpc_pf* h) {
+  if (h->no_blocks) return GridBlocks{nullptr, nullptr, nullptr, nullptr, 0};
+  return GridBlocks{h->d_block_start, h->d_block_x, h->d_block_y, h->d_block_index, h->grid_nx * h->grid_ny};
+}
+
 // the grid search in front of a scoring launch (fills `a.given_*`) - or, below kGridParticles, inside it
 hipError_t launch_nearest(acmpc_pf* h, ScoreArgs& a, int P, hipStream_t s) {
   a.own_grid_search = 0;
@@ -1033,6 +1081,7 @@ hipError_t launch_nearest(acmpc_pf* h, ScoreArgs& a, int P, hipStream_t s) {
     a.own_grid_search = 1;
     for (int t = 0; t < 3; ++t) a.grid[t] = GridIndex{h->d_grid_start[t], h->d_grid_x[t], h->d_grid_y[t], h->d_grid_index[t]};
     a.geometry = GridGeometry{h->grid_x0, h->grid_y0, h->grid_cell, h->grid_nx, h->grid_ny};
+    a.blocks = blocks_of(h);
     return hipSuccess;
   }
   if (!use_grid(h, P)) return hipSuccess;
@@ -1043,6 +1092,7 @@ hipError_t launch_nearest(acmpc_pf* h, ScoreArgs& a, int P, hipStream_t s) {
   g.track[1] = a.left;
   g.track[2] = a.right;
   for (int t = 0; t < 3; ++t) g.grid[t] = GridIndex{h->d_grid_start[t], h->d_grid_x[t], h->d_grid_y[t], h->d_grid_index[t]};
+  g.blocks = blocks_of(h);
   g.x0 = h->grid_x0;
   g.y0 = h->grid_y0;
   g.cell = h->grid_cell;
@@ -1112,6 +1162,15 @@ int pf_ensure_device(acmpc_pf* h) {
       PF_HIP(h, hipMalloc(&h->d_grid_y[t], kept * sizeof(double)));
       PF_HIP(h, hipMemcpy(h->d_grid_y[t], h->h_grid_y[t].data(), kept * sizeof(double), hipMemcpyHostToDevice));
     }
+    PF_HIP(h, hipMalloc(&h->d_block_start, h->h_block_start.size() * sizeof(int)));
+    PF_HIP(h, hipMemcpy(h->d_block_start, h->h_block_start.data(), h->h_block_start.size() * sizeof(int), hipMemcpyHostToDevice));
+    const size_t in_blocks = h->h_block_index.size();
+    PF_HIP(h, hipMalloc(&h->d_block_index, in_blocks * sizeof(int)));
+    PF_HIP(h, hipMemcpy(h->d_block_index, h->h_block_index.data(), in_blocks * sizeof(int), hipMemcpyHostToDevice));
+    PF_HIP(h, hipMalloc(&h->d_block_x, in_blocks * sizeof(double)));
+    PF_HIP(h, hipMemcpy(h->d_block_x, h->h_block_x.data(), in_blocks * sizeof(double), hipMemcpyHostToDevice));
+    PF_HIP(h, hipMalloc(&h->d_block_y, in_blocks * sizeof(double)));
+    PF_HIP(h, hipMemcpy(h->d_block_y, h->h_block_y.data(), in_blocks * sizeof(double), hipMemcpyHostToDevice));
     PF_HIP(h, hipMalloc(&h->d_near_index, P * 3 * sizeof(int32_t)));
     PF_HIP(h, hipMalloc(&h->d_near_d2, P * 3 * sizeof(double)));
   }
@@ -1160,6 +1219,8 @@ int acmpc_pf_create(const acmpc_pf_params* params, const double* centre, int32_t
     h->no_grid = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
     value = std::getenv("ACMPC_PF_WORKGROUP_SCORE");
     h->workgroup_score = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
+    value = std::getenv("ACMPC_PF_NO_BLOCKS");
+    h->no_blocks = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
   }
   h->h_track[0].assign(centre, centre + 2 * static_cast<size_t>(m_centre));
   h->h_track[1].assign(left, left + 2 * static_cast<size_t>(m_left));
@@ -1188,6 +1249,10 @@ void acmpc_pf_destroy(acmpc_pf* h) {
       (void)hipFree(h->d_grid_x[t]);
       (void)hipFree(h->d_grid_y[t]);
     }
+    (void)hipFree(h->d_block_start);
+    (void)hipFree(h->d_block_index);
+    (void)hipFree(h->d_block_x);
+    (void)hipFree(h->d_block_y);
     (void)hipFree(h->d_near_index);
     (void)hipFree(h->d_near_d2);
     (void)hipFree(h->d_states);

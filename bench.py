@@ -729,12 +729,15 @@ def secondary_kernels(workloads, Engine, track, H, N, device, iters=20):
                 eng.profile_enable(0)
                 eng.set_option("ACMPC_START_CLOCKS", "1")
                 late = []
-                for _ in range(5):
+                for _ in range(6):
                     eng.rollout_device(x0.data_ptr(), U.data_ptr(), P, N, n, layout, 0, costs.data_ptr(), 0, stream)
                     starts = eng.rollout_start_clocks()
                     late.append(int((starts > 10.0).sum()))
+                # (the first launch after the option is set allocates and clears the stamp buffer in front of the kernel:
+                # not counted, as in tests/test_gpu_parity.py)
                 out[name]["workgroups"] = int(len(starts))
-                out[name]["workgroups_started_more_than_10us_late"] = max(late)
+                out[name]["workgroups_started_more_than_10us_late"] = max(late[1:])
+                out[name]["workgroups_started_more_than_10us_late_per_launch"] = late
         eng.close()
         del U, costs
     return out
