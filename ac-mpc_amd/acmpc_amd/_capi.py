@@ -82,7 +82,7 @@ class Tick(C.Structure):
         ("centre_is_reference", C.c_int32),
         ("qp_max_iter", C.c_int32),
         ("qp_check_every", C.c_int32),
-        ("reserved", C.c_int32),
+        ("qp_method", C.c_int32),
         ("offset", C.c_double),
         ("v_min", C.c_double),
         ("v_max", C.c_double),
@@ -194,6 +194,8 @@ SIGNATURES = {
     "acmpc_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "acmpc_speed_profile_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
                                          C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, _I32P]),
+    "acmpc_speed_profile_exact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                            C.c_void_p, C.c_void_p]),
     "acmpc_pf_create": (C.c_int, [C.POINTER(PfParams), _F64P, C.c_int32, _F64P, C.c_int32, _F64P, C.c_int32,
                                   C.POINTER(_CTX)]),
     "acmpc_pf_destroy": (None, [_CTX]),
@@ -819,6 +821,20 @@ def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: floa
     if rc < 0:
         raise EngineError(rc, "acmpc_speed_profile_qp: bad arguments")
     return v, y, ("solved" if rc == 0 else "maximum iterations reached"), iters.value
+
+
+def speed_profile_exact(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: float, v_min: float):
+    """The speed-profile QP's exact optimum in two sweeps (acmpc_speed_profile_exact): (v, y = 0), or None where the
+    problem is infeasible or not of the shape the sweeps solve - `speed_profile_qp` is for those."""
+    v_hi = np.ascontiguousarray(v_hi, dtype=np.float64)
+    ds = np.ascontiguousarray(ds, dtype=np.float64)
+    n = v_hi.shape[0]
+    v, y = np.zeros(n), np.zeros(2 * n - 1)
+    rc = load_library().acmpc_speed_profile_exact(v_hi.ctypes.data, ds.ctypes.data, n, float(a_min), float(a_max),
+                                                  float(v_min), v.ctypes.data, y.ctypes.data)
+    if rc < 0:
+        raise EngineError(rc, "acmpc_speed_profile_exact: bad arguments")
+    return (v, y) if rc == 0 else None
 
 
 def philox4x32(counter, key) -> np.ndarray:

@@ -77,6 +77,7 @@ class SpatialMPC:
             "max_iterations": MAX_SOLVER_ITERATIONS,
             "constraints": self.speed_profile_constraints,
             "check_every": int(config.get("speed_profile_check_every", 5)),
+            "method": str(config.get("speed_profile_method", "exact")),
         }
         self._speed_profile_solver = SpeedProfileSolver(profile_config)
         self._localised_speed_profile_solver = LocalisedSpeedProfileSolver(profile_config)
@@ -86,14 +87,17 @@ class SpatialMPC:
         # halves the prologue against OSQP's customary 10-25 at the same 1e-3 tolerances)
         self._device_prologue = bool(config.get("device_prologue", True))
         self._qp_check_every = int(config.get("speed_profile_check_every", 5))
+        # `speed_profile_method`: "exact" (default) = the QP's optimum in two sweeps, the OSQP-style splitting only for a
+        # problem the sweeps do not solve (infeasible: the reference's status then); "admm" = always the splitting
+        self._speed_profile_method = profile_config["method"]
 
     # -- speed profiles -----------------------------------------------------------------------------------
     def compute_map_speed_profile(self, reference_path: ReferencePath, ay_max: float, a_min: float) -> ReferencePath:
         """Whole-lap profile at race start (spatial_mpc.py:60-87): own solver sized to the lap."""
         constraints = copy.deepcopy(self.speed_profile_constraints)
         constraints.update(a_min=a_min, ay_max=ay_max)
-        solver = SpeedProfileSolver({"control_horizon": len(reference_path),
-                                     "max_iterations": MAX_SOLVER_ITERATIONS_MAP, "constraints": constraints})
+        solver = SpeedProfileSolver({"control_horizon": len(reference_path), "max_iterations": MAX_SOLVER_ITERATIONS_MAP,
+                                     "constraints": constraints, "method": self._speed_profile_method})
         return self._compute_speed_profile(solver, reference_path)
 
     def compute_speed_profile(self, reference_path: ReferencePath, is_localised: bool = False,
@@ -180,7 +184,9 @@ class SpatialMPC:
             raise ValueError("reference_path must be %d x 3" % self.MPC_horizon)
         out, status, _ = self._control_solver.solve_tick(coords, float(offset), self.speed_profile_constraints,
                                                          is_localised, qp_max_iter=MAX_SOLVER_ITERATIONS,
-                                                         qp_check_every=self._qp_check_every, **from_map)
+                                                         qp_check_every=self._qp_check_every,
+                                                         qp_method=0 if self._speed_profile_method == "exact" else 1,
+                                                         **from_map)
         self.reference_coordinates = out["coords"]
         path = ReferencePath.adopt(out["table"])   # a view of this tick's own snapshot
         if out["info"][4] == 0.0:

@@ -166,7 +166,7 @@ class ControlSolver:
 
     def solve_tick(self, coords, offset: float, constraints: Dict, is_localised: bool,
                    qp_max_iter: int = 4000, qp_check_every: int = 10, map_index: int = -1, pose=(0.0, 0.0),
-                   lateral_offset: float = 0.0, centreline_points: int = 500):
+                   lateral_offset: float = 0.0, centreline_points: int = 500, qp_method: int = 0):
         """One whole tick of `SpatialMPC.get_control` as a single call into the library (`acmpc_control_tick`):
         waypoints, speed profile, Frenet start state, linearisation and the sampling rounds all run on the device
         inside one captured hipGraph.  `coords` is the H x 3 reference path (float64, C-contiguous), `constraints` the
@@ -187,7 +187,7 @@ class ControlSolver:
         # (a ctypes field store costs ~0.15 us and there are twenty: the struct is only rewritten when an input changed)
         inputs = (is_localised, end_velocity, offset, constraints["v_min"], constraints["v_max"], constraints["a_min"],
                   constraints["a_max"], constraints["ay_max"], constraints["ki_min"], qp_max_iter, qp_check_every,
-                  map_index, centreline_points, pose[0], pose[1], lateral_offset)
+                  map_index, centreline_points, pose[0], pose[1], lateral_offset, qp_method)
         if inputs != getattr(self, "_tick_inputs", None):
             self._tick_inputs = inputs
             tick.localised = 1 if is_localised else 0
@@ -198,6 +198,7 @@ class ControlSolver:
             tick.a_min, tick.a_max = constraints["a_min"], constraints["a_max"]
             tick.ay_max, tick.ki_min = constraints["ay_max"], constraints["ki_min"]
             tick.qp_max_iter, tick.qp_check_every = qp_max_iter, qp_check_every
+            tick.qp_method = qp_method
             tick.map_index, tick.centreline_points = map_index, centreline_points
             tick.pose_x, tick.pose_y, tick.lateral_offset = pose[0], pose[1], lateral_offset
         warm = self._incumbent is not None and self._incumbent.shape == (n, 2)

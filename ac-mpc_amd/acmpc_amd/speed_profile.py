@@ -5,9 +5,12 @@ The problem is the reference's:  min 1/2 |v|^2 - v_hi'v  subject to
     a_min <= (v[i+1] - v[i]) / (2 ds[i]) <= a_max        (speed_profile.py:47-51)
     v_min <= v <= v_hi                                    (speed_profile.py:45)
 with v_hi the curvature-limited ceiling sqrt(ay_max / |kappa|) clipped to [v_min, v_max] plus 2 m/s, and the
-last entry forced to the end velocity (speed_profile.py:26-43).  It is solved on the host by the library's native
-tridiagonal ADMM (`acmpc_speed_profile_qp`, O(n) per iteration - also for the 10^4-waypoint lap profile) instead of
-the `osqp` package.  `constraints` is held by reference: the control process rewrites its "v_max"
+last entry forced to the end velocity (speed_profile.py:26-43).  It is solved on the host by the library instead of the
+`osqp` package: EXACTLY, in two sweeps, wherever the problem is feasible (`acmpc_speed_profile_exact`: the objective is
+1/2 |v - v_hi|^2 and v_hi is the upper bound, so the optimum is the pointwise largest feasible profile - config key
+`method: "exact"`, the default), and by the native tridiagonal ADMM that restates OSQP's iteration
+(`acmpc_speed_profile_qp`, O(n) per iteration - also for the 10^4-waypoint lap profile) otherwise or with
+`method: "admm"`.  The tick's device prologue makes the same choice with the same arithmetic (acmpc_tick.qp_method).  `constraints` is held by reference: the control process rewrites its "v_max"
 every tick (controller.py:241-243) and the next solve must see it.
 """
 from __future__ import annotations
@@ -27,6 +30,9 @@ class SpeedProfileSolver:
         self._max_iterations = config["max_iterations"]
         self._constraints = config["constraints"]
         self._check_every = int(config.get("check_every", 10))   # the stopping test runs every this many iterations
+        self._method = str(config.get("method", "exact"))
+        if self._method not in ("exact", "admm"):
+            raise ValueError("speed profile method must be 'exact' or 'admm', not %r" % (self._method,))
         self._eps = 1e-12
         self._warm = None
 
@@ -68,6 +74,11 @@ class SpeedProfileSolver:
         """Result shaped like osqp's: `.x`, `.y`, `.info.status` ("solved" on success), `.info.iter`."""
         c = self._constraints
         ceiling = self.velocity_ceiling(reference_path, end_velocity)
+        if self._method == "exact":
+            swept = _capi.speed_profile_exact(ceiling, reference_path.distances, c["a_min"], c["a_max"], c["v_min"])
+            if swept is not None:
+                self._warm = swept          # (what the device keeps as its iterate too: the optimum, no multipliers)
+                return SimpleNamespace(x=swept[0], y=swept[1], info=SimpleNamespace(status="solved", iter=0))
         warm = self._warm if self._warm is not None and self._warm[0].shape == ceiling.shape else None
         x, y, status, iters = _capi.speed_profile_qp(ceiling, reference_path.distances, c["a_min"], c["a_max"],
                                                      c["v_min"], max_iter=self._max_iterations, warm=warm,

@@ -1824,9 +1824,12 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
       int32_t iterations = 0;
       if (acmpc_velocity_ceiling(c->tick_lq_table.data() + static_cast<size_t>(3) * n, n, t->ay_max, t->ki_min, t->v_min,
                                  t->v_max, t->localised, t->has_end_velocity, t->end_velocity, ceiling.data()) != ACMPC_OK ||
-          acmpc_speed_profile_qp(ceiling.data(), c->tick_lq_table.data() + static_cast<size_t>(4) * n, n, t->a_min, t->a_max,
-                                 t->v_min, t->qp_max_iter, t->qp_check_every, t->qp_eps_abs, t->qp_eps_rel, profile,
-                                 dual.data(), 0, &iterations) != 0)
+          ((t->qp_method != 0 ||
+            acmpc_speed_profile_exact(ceiling.data(), c->tick_lq_table.data() + static_cast<size_t>(4) * n, n, t->a_min,
+                                      t->a_max, t->v_min, profile, dual.data()) != 0) &&
+           acmpc_speed_profile_qp(ceiling.data(), c->tick_lq_table.data() + static_cast<size_t>(4) * n, n, t->a_min, t->a_max,
+                                  t->v_min, t->qp_max_iter, t->qp_check_every, t->qp_eps_abs, t->qp_eps_rel, profile,
+                                  dual.data(), 0, &iterations) != 0))
         return false;
     } else {
       std::memcpy(c->tick_lq_table.data() + static_cast<size_t>(6) * n, c->tick_prev_table.data() + static_cast<size_t>(6) * n,
@@ -1929,6 +1932,7 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
   h->centre_is_reference = t->centre_is_reference;
   h->qp_max_iter = t->qp_max_iter;
   h->qp_check_every = t->qp_check_every;
+  h->qp_method = t->qp_method;
   h->seed_lo = static_cast<uint32_t>(t->seed);
   h->seed_hi = static_cast<uint32_t>(t->seed >> 32);
   h->use_map = from_map ? 1 : 0;

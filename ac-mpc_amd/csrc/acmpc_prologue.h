@@ -22,6 +22,8 @@ struct TickHeader {
   int32_t centre_is_reference;            // sample round the reference controls (no previous plan)
   int32_t qp_max_iter, qp_check_every;
   uint32_t seed_lo, seed_hi;              // Philox key of this solve (read by the rollout kernels through seed_ptr)
+  int32_t qp_method;                      // 0: the speed profile's exact optimum in two sweeps first (acmpc_admm.h); 1: always the splitting
+  int32_t reserved;
   // reference path taken from the bound map instead of from `coords` (acmpc_bind_map)
   int32_t use_map;                        // != 0: the window kernel in front of the prologue produces the H x 3 path
   int32_t map_index;                      // first waypoint of the window, or < 0: the map point nearest to the pose

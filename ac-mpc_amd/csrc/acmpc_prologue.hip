@@ -382,7 +382,10 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   const admm::Settings settings{h.a_min, h.a_max, h.v_min, h.qp_max_iter, h.qp_check_every > 0 ? h.qp_check_every : 10,
                                 h.qp_eps_abs, h.qp_eps_rel};
   int iterations = 0;
-  const int status = admm::solve(team, ws, v_hi, tds, n, settings, qv, qy, warm ? 1 : 0, &iterations);
+  // the QP's exact optimum in two sweeps where it has that shape (every tick of a feasible profile: no iteration count to
+  // depend on the approach of a braking zone); the splitting - with the iterate kept from the last tick it ran - otherwise
+  const bool swept = h.qp_method == 0 && admm::exact_profile(team, ws, v_hi, tds, n, settings, qv, qy);
+  const int status = swept ? 0 : admm::solve(team, ws, v_hi, tds, n, settings, qv, qy, warm ? 1 : 0, &iterations);
   ACMPC_PSTAMP(4);
   if (status == 0 && a.warm_capacity >= n) {  // keep the iterate only when solved, as the host solver object does
     for (int i = lane; i < n; i += 64) state[2 + i] = qv[i];

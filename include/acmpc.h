@@ -349,7 +349,9 @@ typedef struct acmpc_tick {
   int32_t centre_is_reference; /* != 0: sample round the reference controls (`centre` is ignored, may be NULL)  */
   int32_t qp_max_iter;         /* speed-profile QP: iteration cap (the reference passes 4000, spatial_mpc.py:17) */
   int32_t qp_check_every;      /* stopping test every this many iterations (<= 0: 10)                           */
-  int32_t reserved;
+  int32_t qp_method;           /* speed-profile QP: 0 = its exact optimum in two sweeps (acmpc_speed_profile_exact), the
+                                  splitting below only where that does not apply (an infeasible or misshapen problem);
+                                  1 = always the OSQP splitting (acmpc_speed_profile_qp), warm-started between ticks    */
   double offset;               /* lateral displacement of the car: pose (offset, 0, pi/2), spatial_mpc.py:187   */
   double v_min, v_max, a_min, a_max, ay_max, ki_min, end_velocity; /* speed_profile_constraints, read every tick */
   double sigma[2];             /* first round's spread of (v, kappa); round r uses sigma * shrink^r             */
@@ -451,6 +453,16 @@ void acmpc_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t
 int acmpc_speed_profile_qp(const double* v_hi, const double* ds, int32_t n, double a_min, double a_max, double v_min,
                            int32_t max_iter, int32_t check_every, double eps_abs, double eps_rel, double* v, double* y,
                            int32_t warm_start, int32_t* iterations);
+
+/* The same QP solved EXACTLY, without iterating (csrc/acmpc_admm.h exact_profile): its objective is 1/2 |v - v_hi|^2 up to a
+ * constant and v_hi is also the upper bound, so the optimum is the pointwise largest feasible profile - v_hi cut down by a
+ * forward sweep (a_max) and a backward sweep (a_min).  Returns 0 with v [n] = the optimum and y [2n - 1] = 0; 1 when the
+ * problem is not of that shape (a_min > 0, a_max < 0, a spacing that is not positive and finite, a non-finite ceiling) or
+ * infeasible (some v below v_min): solve it with acmpc_speed_profile_qp then, whose status is the reference's for such a
+ * problem; ACMPC_EINVAL on bad arguments.  acmpc_control_tick's prologue does exactly this on the device (qp_method 0).
+ * No GPU work. */
+int acmpc_speed_profile_exact(const double* v_hi, const double* ds, int32_t n, double a_min, double a_max, double v_min,
+                              double* v, double* y);
 
 /* Diagnostic: with acmpc_set_option(ctx, "ACMPC_START_CLOCKS", "1") every workgroup of a rollout launch
  * (acmpc_rollout_device and the calls built on it; not the candidate-major tile kernels) leaves the 100 MHz wall clock of

@@ -73,7 +73,8 @@ def test_the_tick_equals_the_restated_solve(mode, window):
     """Three consecutive ticks of acmpc_control_tick (16 384 candidates x 2 rounds, the controller's shape): each record
     is the restated solve on the tables the device prologue built, warm-started from the tick before, with the LQ plan for
     this tick's waypoints and pose and the PREVIOUS tick's speed profile as the last round's candidate 2 - in the first
-    tick (round 5) the profile the host solves once for it: acmpc_velocity_ceiling + acmpc_speed_profile_qp, cold."""
+    tick (round 5) the profile the host solves once for it: acmpc_velocity_ceiling + the QP's exact optimum in two sweeps
+    (acmpc_speed_profile_exact, restated by the oracle)."""
     from acmpc_amd import Engine, _capi
     from acmpc_amd.mpc import waypoint_table
     H, N, rounds = 50, 16384, 2
@@ -103,9 +104,7 @@ def test_the_tick_equals_the_restated_solve(mode, window):
         else:
             ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
                                              cons["end_velocity"])
-            table[6], _, status, _ = _capi.speed_profile_qp(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"],
-                                                            max_iter=4000, check_every=10)
-            assert status == "solved"
+            table[6] = orc.speed_profile_exact(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"])   # (feasible here)
         frenet = orc.frenet_start(table, np.array([offset, 0.0, np.pi / 2]))
         plan = orc.lq_plan(table, frenet, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi)
         assert plan is not None
@@ -165,9 +164,7 @@ def test_the_tick_with_the_box_constrained_plan_equals_the_restated_solve(mode):
         else:
             ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
                                              cons["end_velocity"])
-            table[6], _, status, _ = _capi.speed_profile_qp(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"],
-                                                            max_iter=4000, check_every=10)
-            assert status == "solved"
+            table[6] = orc.speed_profile_exact(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"])   # (feasible here)
         frenet = orc.frenet_start(table, np.array([offset, 0.0, np.pi / 2]))
         restated = orc.lq_box_plan(table, frenet, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi, lim.margin, w_bound,
                                    40, state)

@@ -29,13 +29,15 @@ def _engine(n, n_candidates=1024, v_max=28.0, v_min=8.0, track="monza"):
                   margin=lim.margin, wheelbase=lim.length), lim, (lo, hi)
 
 
-def _tick(H, cons, n_candidates=1024, rounds=2, offset=0.0, localised=False, seed=5, qp_max_iter=4000, check_every=10):
+def _tick(H, cons, n_candidates=1024, rounds=2, offset=0.0, localised=False, seed=5, qp_max_iter=4000, check_every=10,
+          qp_method=0):
     from acmpc_amd import _capi
     t = _capi.Tick()
     t.struct_size = _capi.C.sizeof(_capi.Tick)
     t.horizon, t.localised, t.has_end_velocity = H, int(localised), 1
     t.n_candidates, t.rounds, t.centre_is_reference = n_candidates, rounds, 1
     t.qp_max_iter, t.qp_check_every = qp_max_iter, check_every
+    t.qp_method = qp_method     # 0 = the QP's exact optimum in two sweeps (the default), 1 = always the OSQP-style splitting
     t.offset = offset
     t.v_min, t.v_max, t.a_min, t.a_max = cons["v_min"], cons["v_max"], cons["a_min"], cons["a_max"]
     t.ay_max, t.ki_min, t.end_velocity = cons["ay_max"], cons["ki_min"], cons["end_velocity"]
@@ -79,11 +81,14 @@ def test_device_admm_is_bit_identical_to_the_host_solver(n):
     eng.close()
 
 
+@pytest.mark.parametrize("qp_method", [0, 1])
 @pytest.mark.parametrize("case", CASES)
-def test_prologue_against_the_reference_vectors(golden, case):
+def test_prologue_against_the_reference_vectors(golden, case, qp_method):
     """What the prologue kernel leaves for the rollout, against the reference: the waypoint table (G1), the Frenet
     start state (G2), the linearisation + corridor rows (G3, through the oracle's packing) and the QP's ceiling (G6,
-    through the profile the QP returns)."""
+    through the profile the QP returns) - the QP solved exactly by the two sweeps (qp_method 0, the default: the host's
+    sweeps on the reference's own ceiling, no iteration) and by the splitting that restates OSQP (1: the host solver's
+    profile and iteration count)."""
     from acmpc_amd import _capi
     coords = golden[case + "/coords"]
     H = coords.shape[0]
@@ -92,14 +97,21 @@ def test_prologue_against_the_reference_vectors(golden, case):
     cons = dict(RACING[track]["speed_profile_constraints"])     # as the vectors were made: v_max = 84
     offset = float(golden[case + "/offset"])
     eng, lim, (lo, hi) = _engine(n, v_max=cons["v_max"], v_min=cons["v_min"], track=track)
-    out = eng.control_tick(_tick(H, cons, offset=offset), np.ascontiguousarray(coords, dtype=np.float64), None)
+    tick = _tick(H, cons, offset=offset)
+    tick.qp_method = qp_method
+    out = eng.control_tick(tick, np.ascontiguousarray(coords, dtype=np.float64), None)
     table = out["table"]
     # G1: construct_waypoints (the device's atan2 may differ from libm's in the last float64 bit)
     np.testing.assert_allclose(table[:6], golden[case + "/table_no_v"][:6], rtol=0, atol=1e-12)
     # the speed profile: the host solver on the reference's own ceiling (G6), same warm state (none), same settings
     v_hi = golden[case + "/sp0_v_hi"]
-    host_v, _, status, iters = _capi.speed_profile_qp(v_hi, table[4], cons["a_min"], cons["a_max"], cons["v_min"])
-    assert status == "solved" and out["info"][4] == 0.0 and int(out["info"][5]) == iters
+    swept = _capi.speed_profile_exact(v_hi, table[4], cons["a_min"], cons["a_max"], cons["v_min"]) if qp_method == 0 else None
+    if swept is not None:
+        host_v, iters = swept[0], 0
+        assert out["info"][4] == 0.0 and int(out["info"][5]) == 0
+    else:
+        host_v, _, status, iters = _capi.speed_profile_qp(v_hi, table[4], cons["a_min"], cons["a_max"], cons["v_min"])
+        assert status == "solved" and out["info"][4] == 0.0 and int(out["info"][5]) == iters
     np.testing.assert_allclose(table[6], host_v, rtol=0, atol=1e-9)
     # G2: t2s of the pose (offset, 0, pi/2); G3: linearise + corridor rows, as float32 (1 ulp: the tolerance stated
     # for the device's float64 transcendentals)
@@ -208,24 +220,54 @@ def test_tick_forms_agree(monkeypatch):
 
 
 def test_warm_state_lives_on_the_device_per_solver():
-    """Second tick of the same solver warm-starts from the first (10 iterations instead of ~100); the localised
-    solver has its own state; an iteration cap the solve cannot meet leaves the velocities at zero, as the reference
-    keeps the path's (spatial_mpc.py:119-122)."""
+    """The splitting (qp_method 1): the second tick of the same solver warm-starts from the first (10 iterations instead
+    of ~100); the localised solver has its own state; an iteration cap the solve cannot meet leaves the velocities at zero,
+    as the reference keeps the path's (spatial_mpc.py:119-122)."""
     coords = np.stack([np.zeros(50), np.linspace(0, 120, 50), np.linspace(10, 6, 50)], axis=1)
     coords[:, 0] = 5.0 / (1 + np.exp(-0.1 * (coords[:, 1] - 60)))
     cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=28.0)
     eng, _, _ = _engine(49)
-    first = eng.control_tick(_tick(50, cons), coords, None)["info"]
-    second = eng.control_tick(_tick(50, cons), coords, None)["info"]
+    first = eng.control_tick(_tick(50, cons, qp_method=1), coords, None)["info"]
+    second = eng.control_tick(_tick(50, cons, qp_method=1), coords, None)["info"]
     assert first[4] == 0 and second[4] == 0 and first[5] > 10 and second[5] == 10
-    loc = eng.control_tick(_tick(50, cons, localised=True), coords, None)
+    loc = eng.control_tick(_tick(50, cons, localised=True, qp_method=1), coords, None)
     assert loc["info"][4] == 0 and loc["info"][5] >= 10
     np.testing.assert_allclose(loc["table"][6], 28.0, atol=0.2)      # ceiling = v_max everywhere, no end velocity
-    capped = eng.control_tick(_tick(50, cons, qp_max_iter=7), coords, None)
+    capped = eng.control_tick(_tick(50, cons, qp_max_iter=7, qp_method=1), coords, None)
     assert capped["info"][4] == 1 and capped["info"][5] == 7
     assert np.all(capped["table"][6] == 0.0)
-    again = eng.control_tick(_tick(50, cons), coords, None)["info"]   # the failed solve did not disturb the state
+    again = eng.control_tick(_tick(50, cons, qp_method=1), coords, None)["info"]   # the failed solve did not disturb the state
     assert again[4] == 0 and again[5] == 10
+    eng.close()
+
+
+def test_the_exact_profile_is_the_default_and_hands_infeasible_problems_to_the_splitting():
+    """qp_method 0: every tick's profile is the QP's optimum from the two sweeps - no iterations, whatever the tick before
+    was, equal to the host's sweeps bit for bit and within the splitting's tolerance of what that returns; the localised
+    solver's is its ceiling cut down from the end; a problem without a feasible profile (the end velocity below v_min)
+    goes to the splitting, whose verdict - and zero velocities - the tick reports as before."""
+    from acmpc_amd import _capi
+    coords = np.stack([np.zeros(50), np.linspace(0, 120, 50), np.linspace(10, 6, 50)], axis=1)
+    coords[:, 0] = 5.0 / (1 + np.exp(-0.1 * (coords[:, 1] - 60)))
+    cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=28.0)
+    eng, _, _ = _engine(49)
+    split = eng.control_tick(_tick(50, cons, qp_method=1), coords, None)
+    for _ in range(2):
+        out = eng.control_tick(_tick(50, cons), coords, None)
+        assert out["info"][4] == 0 and out["info"][5] == 0
+        table = out["table"]
+        ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
+                                         cons["end_velocity"])
+        swept = _capi.speed_profile_exact(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"])
+        np.testing.assert_array_equal(table[6], swept[0])
+        assert np.abs(table[6] - split["table"][6]).max() < 1.0
+    loc = eng.control_tick(_tick(50, cons, localised=True), coords, None)
+    assert loc["info"][4] == 0 and loc["info"][5] == 0 and np.all(loc["table"][6] == 28.0)
+    hopeless = dict(cons, v_min=20.0)                                   # end velocity 14 < v_min: no feasible profile
+    out = eng.control_tick(_tick(50, hopeless, qp_max_iter=60), coords, None)
+    assert out["info"][4] == 1 and out["info"][5] == 60 and np.all(out["table"][6] == 0.0)
+    out = eng.control_tick(_tick(50, cons), coords, None)               # and the next feasible tick is exact again
+    assert out["info"][4] == 0 and out["info"][5] == 0
     eng.close()
 
 
