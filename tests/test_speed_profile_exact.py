@@ -10,7 +10,7 @@ import acmpc_oracle as orc
 from test_support import RACING
 
 KEYS = ["monza_H50_chicane_90", "monza_H50_hairpin_10", "spa_H50_chicane_70", "nordschleife_H80_chicane_70",
-        "silverstone_H50_chicane_90"]
+        "silverstone_H50_chicane_70", "monza_H50_straight_146.667", "monza_H20_hairpin_10"]
 
 
 def _golden_problem(golden, key, tag):
@@ -55,6 +55,34 @@ def test_the_sweeps_give_the_optimum_of_the_reference_assembled_qp(golden, golde
     # these problems (3 % of 84 m/s), on either side of it - rows are met to the tolerance only
     loose, _, status, iters = _capi.speed_profile_qp(v_hi, np.append(ds, 1.0), a_min, a_max, v_min, max_iter=4000)
     assert status == "solved" and iters > 0 and np.abs(loose - v).max() < 3.0
+
+
+def test_every_golden_problem(golden, golden_cases):
+    """All 52 x 2 problems the reference assembled (both solvers): the library's sweeps equal the restatement bit for bit,
+    meet every row of the reference's A, l, u, and sit on the ceiling wherever no rate row holds them off it."""
+    from acmpc_amd import _capi
+    solved = 0
+    for key in golden_cases:
+        for tag in ("sp0_", "sp1_"):
+            A, l, u, q, n, ds = _golden_problem(golden, key, tag)
+            v_hi = u[n - 1:]
+            a_min, a_max, v_min = float(l[0]), float(u[0]), float(l[n - 1])
+            swept = _capi.speed_profile_exact(v_hi, np.append(ds, 1.0), a_min, a_max, v_min)
+            want = orc.speed_profile_exact(v_hi, np.append(ds, 1.0), a_min, a_max, v_min)
+            assert (swept is None) == (want is None), (key, tag)
+            if swept is None:
+                continue
+            solved += 1
+            v = swept[0]
+            np.testing.assert_array_equal(v, want, err_msg=key + tag)
+            Av = A @ v
+            assert (Av >= l - 1e-9).all() and (Av <= u + 1e-9).all(), (key, tag)
+            rate = Av[:n - 1]
+            free = np.ones(n, dtype=bool)          # points no active rate row touches must be ON the ceiling
+            free[1:] &= ~(rate >= a_max - 1e-9)
+            free[:-1] &= ~(rate <= a_min + 1e-9)
+            np.testing.assert_array_equal(v[free], v_hi[free])
+    assert solved >= len(golden_cases)             # (most problems of the fixture are feasible)
 
 
 def test_no_feasible_profile_lies_above_the_swept_one():
