@@ -271,6 +271,32 @@ def test_the_exact_profile_is_the_default_and_hands_infeasible_problems_to_the_s
     eng.close()
 
 
+def test_the_controller_takes_the_speed_profile_method_from_its_config():
+    """`speed_profile_method` of the control config: "exact" (default) and "admm" drive the same laps - no solve rejected,
+    reference speeds within the splitting's own tolerance band of each other - and are not the same numbers; the host
+    statements of the prologue (`device_prologue: false`) follow the key the same way."""
+    from acmpc_amd import workloads
+    from acmpc_amd.mpc import build_mpc
+    circuit = workloads.synthetic_track("monza")
+    profiles = {}
+    for method, device in (("exact", True), ("exact", False), ("admm", True)):
+        cfg = copy.deepcopy(workloads.RACING_CONTROL["monza"])
+        cfg["speed_profile_constraints"]["v_max"] = float(cfg["unlocalised_max_speed"])
+        cfg.update(speed_profile_method=method, device_prologue=device, n_candidates=4096)
+        mpc = build_mpc(cfg, PlaceholderVehicle())
+        seen = []
+        for i in range(25):
+            centre = workloads.local_centreline(circuit, (i * 40) % len(circuit["centre"]), lateral_offset=0.2)
+            mpc.get_control(workloads.reference_path_from_centreline(centre, cfg["horizon"]), offset=0.2)
+            assert mpc.infeasibility_counter == 0
+            seen.append(mpc.speed_profile.copy())
+        profiles[(method, device)] = np.array(seen)
+    # (the device's atan2 may differ from libm's in the last bit of a heading: 1e-12 on the curvature behind a ceiling)
+    np.testing.assert_allclose(profiles[("exact", True)], profiles[("exact", False)], rtol=0, atol=1e-8)
+    gap = np.abs(profiles[("exact", True)] - profiles[("admm", True)])
+    assert 1e-6 < gap.max() < 3.0, gap.max()
+
+
 @pytest.mark.parametrize("track", ["monza", "silverstone"])
 def test_get_control_with_the_device_prologue_matches_the_host_prologue(track):
     """The drop-in controller with the prologue on the device against the same controller with the host statements
