@@ -824,8 +824,8 @@ def speed_profile_qp(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: floa
 
 
 def speed_profile_exact(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: float, v_min: float):
-    """The speed-profile QP's exact optimum in two sweeps (acmpc_speed_profile_exact): (v, y = 0), or None where the
-    problem is infeasible or not of the shape the sweeps solve - `speed_profile_qp` is for those."""
+    """The speed-profile QP's exact optimum in two passes (acmpc_speed_profile_exact): (v, y = 0), or None where the
+    problem is infeasible or not of the shape the passes solve - `speed_profile_qp` is for those."""
     v_hi = np.ascontiguousarray(v_hi, dtype=np.float64)
     ds = np.ascontiguousarray(ds, dtype=np.float64)
     n = v_hi.shape[0]

@@ -87,8 +87,8 @@ class SpatialMPC:
         # halves the prologue against OSQP's customary 10-25 at the same 1e-3 tolerances)
         self._device_prologue = bool(config.get("device_prologue", True))
         self._qp_check_every = int(config.get("speed_profile_check_every", 5))
-        # `speed_profile_method`: "exact" (default) = the QP's optimum in two sweeps, the OSQP-style splitting only for a
-        # problem the sweeps do not solve (infeasible: the reference's status then); "admm" = always the splitting
+        # `speed_profile_method`: "exact" (default) = the QP's optimum in two passes, the OSQP-style splitting only for a
+        # problem the passes do not solve (infeasible: the reference's status then); "admm" = always the splitting
         self._speed_profile_method = profile_config["method"]
 
     # -- speed profiles -----------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ The problem is the reference's:  min 1/2 |v|^2 - v_hi'v  subject to
     v_min <= v <= v_hi                                    (speed_profile.py:45)
 with v_hi the curvature-limited ceiling sqrt(ay_max / |kappa|) clipped to [v_min, v_max] plus 2 m/s, and the
 last entry forced to the end velocity (speed_profile.py:26-43).  It is solved on the host by the library instead of the
-`osqp` package: EXACTLY, in two sweeps, wherever the problem is feasible (`acmpc_speed_profile_exact`: the objective is
+`osqp` package: EXACTLY, in two passes, wherever the problem is feasible (`acmpc_speed_profile_exact`: the objective is
 1/2 |v - v_hi|^2 and v_hi is the upper bound, so the optimum is the pointwise largest feasible profile - config key
 `method: "exact"`, the default), and by the native tridiagonal ADMM that restates OSQP's iteration
 (`acmpc_speed_profile_qp`, O(n) per iteration - also for the 10^4-waypoint lap profile) otherwise or with

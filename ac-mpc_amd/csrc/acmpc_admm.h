@@ -411,39 +411,110 @@ ACMPC_HD void refactor(const Team& team, const Workspace& w, int n, double rho, 
   team.sync();
 }
 
-// The QP's EXACT optimum in two sweeps, when it has the shape every configuration of the reference gives it.
+// The QP's EXACT optimum without iterating, when it has the shape every configuration of the reference gives it.
 //     min 1/2 |v|^2 - v_hi'v = 1/2 |v - v_hi|^2 + const   s.t.   v_min <= v <= v_hi,   a_min <= (v[i+1] - v[i]) / (2 ds[i]) <= a_max
 // The ceiling the objective pulls v towards is the box's own upper bound, so no feasible v exceeds it; and the feasible set
 // is closed under the pointwise maximum (every row is a bound, or of the form v[j] <= v[k] + c), so it has a pointwise
 // LARGEST element v*, which is then nearer to v_hi than any other feasible v in every coordinate: the optimum.  With
-// a_min <= 0 <= a_max, v* is v_hi cut down by one forward sweep (v[i+1] <= v[i] + 2 ds[i] a_max: no faster out of a slow
-// point than a_max allows) and one backward sweep (v[i] <= v[i+1] - 2 ds[i] a_min: no faster into one than braking
-// allows) - the tightest bounds a chain of difference rows implies; a path that goes forward and comes back only adds
-// non-negative terms.  The QP is feasible exactly when v* >= v_min everywhere.  OSQP - and its restatement below - get to
-// within their tolerance of this point in 5 iterations from the previous tick's iterate on a steady path and in 100 - 400
-// where the car approaches a braking zone (the closed loop's p90 tick was 170 us, p99 300 us for it; round 5).
+// a_min <= 0 <= a_max, v* is v_hi cut down by a forward pass (v[i+1] <= v[i] + 2 ds[i] a_max: no faster out of a slow
+// point than a_max allows) and a backward pass (v[i] <= v[i+1] - 2 ds[i] a_min: no faster into one than braking allows) -
+// the tightest bounds a chain of difference rows implies; a path that goes forward and comes back only adds non-negative
+// terms.  The QP is feasible exactly when v* >= v_min everywhere.  OSQP - and its restatement below - get to within their
+// tolerance of this point in 5 iterations from the previous tick's iterate on a steady path and in 100 - 400 where the
+// car approaches a braking zone (the closed loop's p90 tick was 170 us, p99 300 us for it; round 5).
+//
+// Each pass is v[i] = min over j of (v_hi[j] + the gaps between j and i), a prefix "minimum of sums" - evaluated as a scan
+// with doubling distances (Hillis - Steele), which is the SPECIFICATION of the roundings on both sides:
+//     forward    v[i] = v_hi[i],  G[i] = u[i - 1] = (2 ds[i - 1]) a_max  (G[0] = 0)
+//                for d = 1, 2, 4, ... < n, every i >= d at once:   v[i] = min(v[i], v[i - d] + G[i]),   G[i] = G[i] + G[i - d]
+//     backward   the same towards lower indices with b[i] = (-2 ds[i]) a_min, from the forward pass's result
+// (G[i] is the sum of the d gaps that end at i; elements without a partner at distance d keep their values.)  On the
+// device a wavefront holds an element per lane and a pass is six exchanges (n <= 64; through the workspace for more);
+// as two serial sweeps - 2 n dependent steps - the same profile took a lone wavefront 5.3 us at n = 49.
 // Returns true with v = the optimum and y = 0 (no dual iterate: nothing iterates), on every worker alike; false - v and y
 // untouched or partly written - when the problem is not of this shape (a_min > 0, a_max < 0, a non-finite or non-positive
 // spacing, a non-finite ceiling) or infeasible: the caller then runs the splitting, whose status is the reference's own
-// for such a problem.  One worker sweeps (two chains of n fused multiply-adds and minima); the same float64 operations
-// in the same order on the host and on the device.
+// for such a problem.  `scratch`: 4 n doubles (not needed by a 64-wide team with n <= 64).  v must not overlap v_hi or ds.
 template <class Team>
 ACMPC_HD bool exact_profile(const Team& team, const Workspace& w, const double* v_hi, const double* ds, int n,
-                            const Settings& s, double* v, double* y) {
+                            const Settings& s, double* v, double* y, double* scratch) {
   if (!(s.a_max >= 0.0) || !(s.a_min <= 0.0)) return false;   // (the same on every worker)
-  if (team.rank() == 0) {
-    double run = v_hi[0];
-    v[0] = run;
-    for (int i = 0; i + 1 < n; ++i) {
-      const double reach = fma_(2.0 * ds[i], s.a_max, run);
-      run = v_hi[i + 1] < reach ? v_hi[i + 1] : reach;
-      v[i + 1] = run;
+  const double inf = __builtin_huge_val();
+  bool done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (Team::size == 64) {
+    if (n <= 64) {   // an element per lane, in registers
+      const int i = team.rank();
+      const bool mine = i < n;
+      double val = mine ? v_hi[i] : inf;
+      double gap = (mine && i > 0) ? (2.0 * ds[i - 1]) * s.a_max : 0.0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double other = __shfl_up(val, d, 64), other_gap = __shfl_up(gap, d, 64);
+        if (i >= d && d < n) {
+          const double cand = other + gap;
+          val = cand < val ? cand : val;
+          gap = gap + other_gap;
+        }
+      }
+      gap = (i + 1 < n) ? (-2.0 * ds[i]) * s.a_min : 0.0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double other = __shfl_down(val, d, 64), other_gap = __shfl_down(gap, d, 64);
+        if (i + d < n) {
+          const double cand = other + gap;
+          val = cand < val ? cand : val;
+          gap = gap + other_gap;
+        }
+      }
+      if (mine) v[i] = val;
+      done = true;
     }
-    for (int i = n - 2; i >= 0; --i) {
-      const double reach = fma_(-2.0 * ds[i], s.a_min, run);
-      run = v[i] < reach ? v[i] : reach;
-      v[i] = run;
+  }
+#endif
+  if (!done) {   // arrays in the workspace, two buffers per pass; every worker takes the elements rank, rank + size, ...
+    double* cur_v = scratch;
+    double* cur_g = scratch + n;
+    double* nxt_v = scratch + 2 * n;
+    double* nxt_g = scratch + 3 * n;
+    for (int i = team.rank(); i < n; i += Team::size) {
+      cur_v[i] = v_hi[i];
+      cur_g[i] = i > 0 ? (2.0 * ds[i - 1]) * s.a_max : 0.0;
     }
+    team.sync();
+    for (int d = 1; d < n; d <<= 1) {
+      for (int i = team.rank(); i < n; i += Team::size) {
+        double val = cur_v[i], gap = cur_g[i];
+        if (i >= d) {
+          const double cand = cur_v[i - d] + gap;
+          val = cand < val ? cand : val;
+          gap = gap + cur_g[i - d];
+        }
+        nxt_v[i] = val;
+        nxt_g[i] = gap;
+      }
+      team.sync();
+      double* t = cur_v; cur_v = nxt_v; nxt_v = t;
+      t = cur_g; cur_g = nxt_g; nxt_g = t;
+    }
+    for (int i = team.rank(); i < n; i += Team::size) cur_g[i] = i + 1 < n ? (-2.0 * ds[i]) * s.a_min : 0.0;
+    team.sync();
+    for (int d = 1; d < n; d <<= 1) {
+      for (int i = team.rank(); i < n; i += Team::size) {
+        double val = cur_v[i], gap = cur_g[i];
+        if (i + d < n) {
+          const double cand = cur_v[i + d] + gap;
+          val = cand < val ? cand : val;
+          gap = gap + cur_g[i + d];
+        }
+        nxt_v[i] = val;
+        nxt_g[i] = gap;
+      }
+      team.sync();
+      double* t = cur_v; cur_v = nxt_v; nxt_v = t;
+      t = cur_g; cur_g = nxt_g; nxt_g = t;
+    }
+    for (int i = team.rank(); i < n; i += Team::size) v[i] = cur_v[i];
   }
   team.sync();
   double bad = 0.0;

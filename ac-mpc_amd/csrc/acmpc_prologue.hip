@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(64) prologue_kernel(const PrologueArgs a) {
   int iterations = 0;
   // the QP's exact optimum in two sweeps where it has that shape (every tick of a feasible profile: no iteration count to
   // depend on the approach of a braking zone); the splitting - with the iterate kept from the last tick it ran - otherwise
-  const bool swept = h.qp_method == 0 && admm::exact_profile(team, ws, v_hi, tds, n, settings, qv, qy);
+  const bool swept = h.qp_method == 0 && admm::exact_profile(team, ws, v_hi, tds, n, settings, qv, qy, ws.ex[0]);
   const int status = swept ? 0 : admm::solve(team, ws, v_hi, tds, n, settings, qv, qy, warm ? 1 : 0, &iterations);
   ACMPC_PSTAMP(4);
   if (status == 0 && a.warm_capacity >= n) {  // keep the iterate only when solved, as the host solver object does

@@ -22,13 +22,14 @@ extern "C" int acmpc_speed_profile_qp(const double* v_hi, const double* ds, int3
   return status;
 }
 
-// The same QP's exact optimum in two sweeps (acmpc_admm.h: exact_profile) - what the tick's prologue tries first.
+// The same QP's exact optimum in two passes (acmpc_admm.h: exact_profile) - what the tick's prologue tries first.
 extern "C" int acmpc_speed_profile_exact(const double* v_hi, const double* ds, int32_t n, double a_min, double a_max,
                                          double v_min, double* v, double* y) {
   if (v_hi == nullptr || ds == nullptr || v == nullptr || y == nullptr || n < 2) return ACMPC_EINVAL;
   double red[8];
   acmpc::admm::Workspace w{};   // (only its reduction scratch is used)
   w.red = red;
+  std::vector<double> scratch(static_cast<size_t>(4) * n);
   const acmpc::admm::Settings s{a_min, a_max, v_min, 0, 1, 0.0, 0.0};
-  return acmpc::admm::exact_profile(acmpc::admm::HostTeam{}, w, v_hi, ds, n, s, v, y) ? 0 : 1;
+  return acmpc::admm::exact_profile(acmpc::admm::HostTeam{}, w, v_hi, ds, n, s, v, y, scratch.data()) ? 0 : 1;
 }

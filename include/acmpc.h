@@ -349,7 +349,7 @@ typedef struct acmpc_tick {
   int32_t centre_is_reference; /* != 0: sample round the reference controls (`centre` is ignored, may be NULL)  */
   int32_t qp_max_iter;         /* speed-profile QP: iteration cap (the reference passes 4000, spatial_mpc.py:17) */
   int32_t qp_check_every;      /* stopping test every this many iterations (<= 0: 10)                           */
-  int32_t qp_method;           /* speed-profile QP: 0 = its exact optimum in two sweeps (acmpc_speed_profile_exact), the
+  int32_t qp_method;           /* speed-profile QP: 0 = its exact optimum in two passes (acmpc_speed_profile_exact), the
                                   splitting below only where that does not apply (an infeasible or misshapen problem);
                                   1 = always the OSQP splitting (acmpc_speed_profile_qp), warm-started between ticks    */
   double offset;               /* lateral displacement of the car: pose (offset, 0, pi/2), spatial_mpc.py:187   */

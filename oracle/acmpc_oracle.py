@@ -221,38 +221,41 @@ def speed_profile_qp(table: np.ndarray, constraints: Dict, end_velocity: Optiona
 def speed_profile_exact(v_hi: np.ndarray, ds: np.ndarray, a_min: float, a_max: float, v_min: float) -> Optional[np.ndarray]:
     """The exact optimum of `speed_profile_qp` (control/solvers/speed_profile.py:26-59) without a solver - restatement of
     csrc/acmpc_admm.h exact_profile, float64 operation for operation.  The objective is 1/2 |v - v_hi|^2 + const and v_hi is
-    the box's upper bound, so the optimum is the pointwise largest feasible profile: v_hi cut down by a forward sweep
-    (v[i+1] <= v[i] + 2 ds[i] a_max) and a backward sweep (v[i] <= v[i+1] - 2 ds[i] a_min).  None where the sweeps do not
-    apply (a_min > 0, a_max < 0, bad spacing, non-finite ceiling) or the problem is infeasible (some v below v_min)."""
+    the box's upper bound, so the optimum is the pointwise largest feasible profile: v_hi cut down by a forward pass
+    (v[i+1] <= v[i] + 2 ds[i] a_max) and a backward pass (v[i] <= v[i+1] - 2 ds[i] a_min), each the prefix minimum of
+    "ceiling + gaps in between" evaluated as a scan with doubling distances - the order of the roundings is part of the
+    specification.  None where the passes do not apply (a_min > 0, a_max < 0, bad spacing, non-finite ceiling) or the
+    problem is infeasible (some v below v_min)."""
     v_hi = np.asarray(v_hi, dtype=np.float64)
     ds = np.asarray(ds, dtype=np.float64)
     n = v_hi.shape[0]
     if not (a_max >= 0.0) or not (a_min <= 0.0):
         return None
-    v = np.empty(n)
-    run = v_hi[0]
-    v[0] = run
-    for i in range(n - 1):
-        reach = _fma64(2.0 * ds[i], a_max, run)
-        run = v_hi[i + 1] if v_hi[i + 1] < reach else reach
-        v[i + 1] = run
-    for i in range(n - 2, -1, -1):
-        reach = _fma64(-2.0 * ds[i], a_min, run)
-        run = v[i] if v[i] < reach else reach
-        v[i] = run
-    if not (np.all(v >= v_min) and np.all(v <= v_hi)) or not np.all((ds[:n - 1] > 0.0) & np.isfinite(ds[:n - 1])):
-        return None
+    with np.errstate(invalid="ignore", over="ignore"):
+        v = v_hi.copy()
+        gap = np.zeros(n)
+        gap[1:] = (2.0 * ds[:n - 1]) * a_max
+        d = 1
+        while d < n:
+            cand = v[:-d] + gap[d:]
+            new_v, new_gap = v.copy(), gap.copy()
+            new_v[d:] = np.where(cand < v[d:], cand, v[d:])
+            new_gap[d:] = gap[d:] + gap[:-d]
+            v, gap = new_v, new_gap
+            d *= 2
+        gap = np.zeros(n)
+        gap[:n - 1] = (-2.0 * ds[:n - 1]) * a_min
+        d = 1
+        while d < n:
+            cand = v[d:] + gap[:-d]
+            new_v, new_gap = v.copy(), gap.copy()
+            new_v[:-d] = np.where(cand < v[:-d], cand, v[:-d])
+            new_gap[:-d] = gap[:-d] + gap[d:]
+            v, gap = new_v, new_gap
+            d *= 2
+        if not (np.all(v >= v_min) and np.all(v <= v_hi)) or not np.all((ds[:n - 1] > 0.0) & np.isfinite(ds[:n - 1])):
+            return None
     return v
-
-
-def _fma64(a: float, b: float, c: float) -> float:
-    """a * b + c with one rounding, as the library's fused multiply-add (Python 3.10 has no math.fma): exact rational
-    arithmetic, rounded once by the conversion back (non-finite operands: the plain expression, which is what IEEE gives)."""
-    from fractions import Fraction
-    a, b, c = float(a), float(b), float(c)
-    if not (math.isfinite(a) and math.isfinite(b) and math.isfinite(c)):
-        return a * b + c
-    return float(Fraction(a) * Fraction(b) + Fraction(c))
 
 
 def osqp_restated(P_diag, q, A, l, u, max_iter=4000, rho=0.1, sigma=1e-6, alpha=1.6,
