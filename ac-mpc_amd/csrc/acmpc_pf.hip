@@ -872,6 +872,252 @@ __global__ void __launch_bounds__(kScanBlock) pf_resample_kernel(const FilterArg
   }
 }
 
+// ---- the same update for many particles (capacity >= kWideFilter): pf_resample_kernel and pf_estimate_kernel are ONE
+// workgroup each, which is what the reference's hundreds of particles want (8 us) and what 100 000 do not (607 + 214 us: a
+// thread walks ~100 particles of its own, a cache line apart from its neighbour's).  Here every step is a launch over tiles
+// of kScanBlock particles, a particle per thread:
+//   tiles    per tile: how many valid particles, the sum of their integer weights
+//   plan     one workgroup: exclusive prefix sums of the tiles' counts and weights; reset or not; the new counts
+//   scatter  per tile: the kept particles' places (stable: tile offset + rank inside the tile) and their inclusive weight sums
+//   emit     a thread per output particle: kept ones copied in order, new ones drawn (same draws, same binary search)
+// The integers - ranks, prefix sums, picks - are those of the one-workgroup kernel exactly; so are the particles.
+constexpr int kWideFilter = 8192;
+
+struct WideScratch {
+  unsigned long long* tile_count;    // [tiles]      valid particles per tile, then (plan) their exclusive prefix sums
+  unsigned long long* tile_weight;   // [tiles]      likewise the integer weights
+  unsigned long long* meta;          // [6]: n before the update, n_valid, total weight, uniform (0 / 1), reset (0 / 1), n_new
+};
+
+__global__ void __launch_bounds__(kScanBlock) pf_resample_tiles_kernel(const FilterArgs a, const WideScratch w) {
+  __shared__ unsigned long long s_scan[kScanBlock];
+  const int n = a.counts[0];
+  const int p = blockIdx.x * kScanBlock + threadIdx.x;
+  const bool keep = p < n && a.valid[p] != 0;
+  unsigned long long count = 0ull, weight = 0ull;
+  (void)block_exclusive_scan(keep ? 1ull : 0ull, s_scan, &count);
+  (void)block_exclusive_scan(keep ? weight_of(a.score[p]) : 0ull, s_scan, &weight);
+  if (threadIdx.x == 0) {
+    w.tile_count[blockIdx.x] = count;
+    w.tile_weight[blockIdx.x] = weight;
+  }
+}
+
+// (tiles <= kScanBlock: capacities up to 2^20 particles; beyond, the one-workgroup kernels serve)
+__global__ void __launch_bounds__(kScanBlock) pf_resample_plan_kernel(const FilterArgs a, const WideScratch w, const int tiles) {
+  __shared__ unsigned long long s_scan[kScanBlock];
+  const int tid = threadIdx.x;
+  const unsigned long long count = tid < tiles ? w.tile_count[tid] : 0ull;
+  const unsigned long long weight = tid < tiles ? w.tile_weight[tid] : 0ull;
+  unsigned long long n_valid = 0ull, total = 0ull;
+  const unsigned long long count_before = block_exclusive_scan(count, s_scan, &n_valid);
+  const unsigned long long weight_before = block_exclusive_scan(weight, s_scan, &total);
+  if (tid < tiles) {
+    w.tile_count[tid] = count_before;
+    w.tile_weight[tid] = weight_before;
+  }
+  if (tid == 0) {
+    const bool reset = static_cast<int>(n_valid) < a.minimum_particles;
+    const bool uniform = total == 0ull;   // all scores zero / NaN: uniform weights (localiser.py:523-526)
+    const int n_new = reset ? 0 : max(0, min(a.n_desired, a.capacity) - static_cast<int>(n_valid));
+    w.meta[0] = static_cast<unsigned long long>(a.counts[0]);
+    w.meta[1] = n_valid;
+    w.meta[2] = uniform ? n_valid : total;
+    w.meta[3] = uniform ? 1ull : 0ull;
+    w.meta[4] = reset ? 1ull : 0ull;
+    w.meta[5] = static_cast<unsigned long long>(n_new);
+    a.counts[0] = reset ? a.capacity : static_cast<int>(n_valid) + n_new;
+    a.counts[1] = static_cast<int>(n_valid);
+    a.counts[2] = reset ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(kScanBlock) pf_resample_scatter_kernel(const FilterArgs a, const WideScratch w) {
+  __shared__ unsigned long long s_scan[kScanBlock];
+  if (w.meta[4] != 0ull) return;   // reset: nothing is kept
+  const int n = static_cast<int>(w.meta[0]);
+  const bool uniform = w.meta[3] != 0ull;
+  const int p = blockIdx.x * kScanBlock + threadIdx.x;
+  const bool keep = p < n && a.valid[p] != 0;
+  const unsigned long long weight = keep ? weight_of(a.score[p]) : 0ull;
+  unsigned long long unused = 0ull;
+  const unsigned long long rank = block_exclusive_scan(keep ? 1ull : 0ull, s_scan, &unused);
+  const unsigned long long before = block_exclusive_scan(weight, s_scan, &unused);
+  if (keep) {
+    const unsigned long long k = w.tile_count[blockIdx.x] + rank;
+    a.kept[k] = p;
+    a.cdf[k] = uniform ? k + 1ull : w.tile_weight[blockIdx.x] + before + weight;
+  }
+}
+
+__global__ void __launch_bounds__(256) pf_resample_emit_kernel(const FilterArgs a, const WideScratch w) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w.meta[4] != 0ull) {
+    // _reset_filter (localiser.py:468-485): spread evenly along the centre line, heading along it, uniform scores
+    const int count = a.capacity;
+    if (idx >= count) return;
+    const int k = idx;
+    const double pos = (count > 1) ? static_cast<double>(k) * (static_cast<double>(a.m_centre - 3) / static_cast<double>(count - 1))
+                                   : 0.0;
+    const int at = static_cast<int>((k == count - 1 && count > 1) ? static_cast<double>(a.m_centre - 3) : pos);
+    const double x = a.centre[2 * at], y = a.centre[2 * at + 1];
+    const double yaw = atan2(a.centre[2 * (at + 1) + 1] - y, a.centre[2 * (at + 1)] - x);
+    a.states_out[3 * k] = static_cast<float>(x);
+    a.states_out[3 * k + 1] = static_cast<float>(y);
+    a.states_out[3 * k + 2] = static_cast<float>(yaw);
+    a.scores_out[k] = 1.0f / static_cast<float>(count);
+    return;
+  }
+  const int n_valid = static_cast<int>(w.meta[1]), n_new = static_cast<int>(w.meta[5]);
+  const unsigned long long wtotal = w.meta[2];
+  if (idx < n_valid) {   // kept particles first, in order
+    const int p = a.kept[idx];
+    a.states_out[3 * idx] = a.states_in[3 * p];
+    a.states_out[3 * idx + 1] = a.states_in[3 * p + 1];
+    a.states_out[3 * idx + 2] = a.states_in[3 * p + 2];
+    a.scores_out[idx] = a.scores_in[p];
+  }
+  if (idx < n_new) {   // top up: new particle j = kept[upper_bound(cdf, mulhi(r, total))] + noise
+    const int j = idx;
+    const uint32_t key[2] = {a.seed_lo, a.seed_hi};
+    const uint32_t c_pick[4] = {static_cast<uint32_t>(j), a.counter, kTagResample, 0u};
+    const uint32_t c_noise[4] = {static_cast<uint32_t>(j), a.counter, kTagResample, 1u};
+    uint32_t r[4], q[4];
+    acmpc::philox4x32_10(c_pick, key, r);
+    acmpc::philox4x32_10(c_noise, key, q);
+    const unsigned long long word = (static_cast<unsigned long long>(r[0]) << 32) | r[1];
+    const unsigned long long target = __umul64hi(word, wtotal);   // uniform in [0, total)
+    int lo = 0, hi = n_valid - 1;                                   // first k with cdf[k] > target
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (a.cdf[mid] > target) hi = mid; else lo = mid + 1;
+    }
+    const int p = a.kept[lo];
+    float z0, z1, z2, z3;
+    acmpc::box_muller(acmpc::uniform_open(q[0]), acmpc::uniform_open(q[1]), z0, z1);
+    acmpc::box_muller(acmpc::uniform_open(q[2]), acmpc::uniform_open(q[3]), z2, z3);
+    (void)z3;
+    const int k = n_valid + j;
+    a.states_out[3 * k] = static_cast<float>(static_cast<double>(a.states_in[3 * p]) + a.sigma_x * static_cast<double>(z0));
+    a.states_out[3 * k + 1] =
+        static_cast<float>(static_cast<double>(a.states_in[3 * p + 1]) + a.sigma_y * static_cast<double>(z1));
+    a.states_out[3 * k + 2] =
+        static_cast<float>(static_cast<double>(a.states_in[3 * p + 2]) + a.sigma_yaw * static_cast<double>(z2));
+    a.scores_out[k] = a.scores_in[p];
+  }
+}
+
+// The estimate of pf_estimate_kernel for many particles: partial sums per workgroup of kEstimateTile particles (float64, a
+// fixed order: thread, then the tree of the workgroup, then the workgroups in turn), the spread against the estimate in a
+// second launch, its maximum in a third.
+constexpr int kEstimateTile = 4096;
+
+__global__ void __launch_bounds__(kBlock) pf_estimate_partial_kernel(const float* states, const float* scores, const int* live,
+                                                                     double* partial /*[tiles][8]*/) {
+  __shared__ double s[7][kBlock];
+  const int tid = threadIdx.x;
+  const int P = live[0];
+  const int begin = blockIdx.x * kEstimateTile, end = min(begin + kEstimateTile, P);
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};   // sum(state * score) x 3, sum(score), sum(state) x 3
+  for (int p = begin + tid; p < end; p += kBlock) {
+    const double wgt = scores[p];
+    for (int c = 0; c < 3; ++c) {
+      const double v = static_cast<double>(states[3 * p + c]);
+      acc[c] += v * wgt;
+      acc[4 + c] += v;
+    }
+    acc[3] += wgt;
+  }
+  for (int c = 0; c < 7; ++c) s[c][tid] = acc[c];
+  __syncthreads();
+  for (int half = kBlock / 2; half > 0; half >>= 1) {
+    if (tid < half)
+      for (int c = 0; c < 7; ++c) s[c][tid] += s[c][tid + half];
+    __syncthreads();
+  }
+  if (tid < 7) partial[8 * blockIdx.x + tid] = s[tid][0];
+}
+
+__device__ __forceinline__ void estimate_from_partials(const double* partial, int tiles, int P, double est[3]) {
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < tiles; ++t)
+    for (int c = 0; c < 7; ++c) acc[c] += partial[8 * t + c];
+  for (int c = 0; c < 3; ++c) est[c] = acc[c] / acc[3];
+  if (est[0] != est[0] || est[1] != est[1] || est[2] != est[2])   // NaN: uniform weights
+    for (int c = 0; c < 3; ++c) est[c] = acc[4 + c] / static_cast<double>(P);
+}
+
+__global__ void __launch_bounds__(kBlock) pf_estimate_spread_kernel(const float* states, const int* live, const double* partial,
+                                                                    double* spread /*[tiles][2]*/) {
+  __shared__ double s[2][kBlock];
+  __shared__ double s_est[3];
+  const int tid = threadIdx.x;
+  const int P = live[0];
+  const int tiles = (P + kEstimateTile - 1) / kEstimateTile;
+  if (tid == 0) {
+    double est[3];
+    estimate_from_partials(partial, tiles, P, est);
+    for (int c = 0; c < 3; ++c) s_est[c] = est[c];
+  }
+  __syncthreads();
+  const double ex = s_est[0], ey = s_est[1], ez = s_est[2];
+  const int begin = blockIdx.x * kEstimateTile, end = min(begin + kEstimateTile, P);
+  double md = 0.0, ma = 0.0;
+  for (int p = begin + tid; p < end; p += kBlock) {
+    const double dx = states[3 * p] - ex, dy = states[3 * p + 1] - ey;
+    md = fmax(md, sqrt(dx * dx + dy * dy));
+    ma = fmax(ma, fabs(states[3 * p + 2] - ez));
+  }
+  s[0][tid] = md;
+  s[1][tid] = ma;
+  __syncthreads();
+  for (int half = kBlock / 2; half > 0; half >>= 1) {
+    if (tid < half) {
+      s[0][tid] = fmax(s[0][tid], s[0][tid + half]);
+      s[1][tid] = fmax(s[1][tid], s[1][tid + half]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    spread[2 * blockIdx.x] = s[0][0];
+    spread[2 * blockIdx.x + 1] = s[1][0];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) pf_estimate_final_kernel(const int* live, const double* partial, const double* spread,
+                                                                   double* out /*[5]*/, int* counts_out) {
+  __shared__ double s[2][kBlock];
+  const int tid = threadIdx.x;
+  const int P = live[0];
+  const int tiles = (P + kEstimateTile - 1) / kEstimateTile;
+  double md = 0.0, ma = 0.0;
+  for (int t = tid; t < tiles; t += kBlock) {
+    md = fmax(md, spread[2 * t]);
+    ma = fmax(ma, spread[2 * t + 1]);
+  }
+  s[0][tid] = md;
+  s[1][tid] = ma;
+  __syncthreads();
+  for (int half = kBlock / 2; half > 0; half >>= 1) {
+    if (tid < half) {
+      s[0][tid] = fmax(s[0][tid], s[0][tid + half]);
+      s[1][tid] = fmax(s[1][tid], s[1][tid + half]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double est[3];
+    estimate_from_partials(partial, tiles, P, est);
+    if (counts_out != nullptr)
+      for (int e = 0; e < 4; ++e) counts_out[e] = live[e];
+    out[0] = est[0];
+    out[1] = est[1];
+    out[2] = est[2];
+    out[3] = s[0][0];
+    out[4] = s[1][0];
+  }
+}
+
 // Localiser.step (localiser.py:41-77): delta = tyre_angle + N(0, sigma_yaw), speed = |velocity + N(0, sigma_v)| per
 // particle from Philox (counter = particle, step), then the float32 kinematic step of pf_advance_kernel
 __global__ void pf_step_kernel(float* states, const int* counts, float tyre_angle, float velocity, float sigma_yaw,
@@ -907,6 +1153,7 @@ struct acmpc_pf {
   acmpc_pf_params prm{};
   bool no_grid = false;   // ACMPC_PF_NO_GRID (A/B switch of the tests): read from the environment once, by acmpc_pf_create
   bool workgroup_score = false;   // ACMPC_PF_WORKGROUP_SCORE (likewise): pf_score_kernel<8> behind the grid search, as in rounds 2-5
+  bool narrow_filter = false;     // ACMPC_PF_NARROW_FILTER (likewise): the device-resident filter's one-workgroup kernels at any capacity
   int given_wave_slots[3] = {0, 0, 0};   // waves of pf_score_given_kernel's three forms the device holds at once (ensure_device)
   std::vector<double> h_track[3];
   double scale = 1.0;
@@ -951,6 +1198,8 @@ struct acmpc_pf {
   unsigned long long* f_cdf = nullptr;
   int* f_kept = nullptr;
   int* f_counts = nullptr;                  // [4] n_live, n_valid, was_reset
+  unsigned long long* f_wide = nullptr;     // capacity >= kWideFilter: [2 tiles + 6] scratch of the tiled resampling
+  double* f_partial = nullptr;              //   ... and of the tiled estimate: [tiles][8] sums, [tiles][2] spreads
   double* h_result = nullptr;               // pinned [8 doubles + 4 ints]
   mutable std::string err;
 };
@@ -1219,6 +1468,8 @@ int acmpc_pf_create(const acmpc_pf_params* params, const double* centre, int32_t
     h->no_grid = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
     value = std::getenv("ACMPC_PF_WORKGROUP_SCORE");
     h->workgroup_score = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
+    value = std::getenv("ACMPC_PF_NARROW_FILTER");
+    h->narrow_filter = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
     value = std::getenv("ACMPC_PF_NO_BLOCKS");
     h->no_blocks = value != nullptr && value[0] != '\0' && !(value[0] == '0' && value[1] == '\0');
   }
@@ -1269,6 +1520,8 @@ void acmpc_pf_destroy(acmpc_pf* h) {
     (void)hipFree(h->f_cdf);
     (void)hipFree(h->f_kept);
     (void)hipFree(h->f_counts);
+    (void)hipFree(h->f_wide);
+    (void)hipFree(h->f_partial);
     if (h->h_result != nullptr) (void)hipHostFree(h->h_result);
     if (h->stream != nullptr) (void)hipStreamDestroy(h->stream);
   }
@@ -1410,6 +1663,12 @@ int acmpc_pf_estimate(acmpc_pf* h, const float* states, const float* scores, int
 
 namespace {
 
+// the tiled resampling and estimate (pf_resample_tiles_kernel ...) for capacities one workgroup is too slow for; the plan
+// kernel holds a tile per thread, which bounds them at 2^20 particles.  ACMPC_PF_NARROW_FILTER=1: one workgroup always (A/B)
+bool wide_filter(const acmpc_pf* h) {
+  return h->prm.max_particles >= kWideFilter && h->prm.max_particles <= kScanBlock * kScanBlock && !h->narrow_filter;
+}
+
 int pf_ensure_filter(acmpc_pf* h) {
   if (h->filter_ready) return ACMPC_OK;
   const int rc = pf_ensure_device(h);
@@ -1423,6 +1682,11 @@ int pf_ensure_filter(acmpc_pf* h) {
   PF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->f_cdf), P * sizeof(unsigned long long)));
   PF_HIP(h, hipMalloc(&h->f_kept, P * sizeof(int)));
   PF_HIP(h, hipMalloc(&h->f_counts, 4 * sizeof(int)));
+  if (wide_filter(h)) {
+    const size_t tiles = (P + kScanBlock - 1) / kScanBlock, sums = (P + kEstimateTile - 1) / kEstimateTile;
+    PF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->f_wide), (2 * tiles + 6) * sizeof(unsigned long long)));
+    PF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->f_partial), sums * 10 * sizeof(double)));
+  }
   PF_HIP(h, hipMemset(h->f_counts, 0, 4 * sizeof(int)));
   PF_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_result), 8 * sizeof(double) + 4 * sizeof(int), hipHostMallocDefault));
   PF_HIP(h, hipStreamSynchronize(nullptr));
@@ -1577,14 +1841,35 @@ int acmpc_pf_filter_update(acmpc_pf* h, const float* obs_left, int32_t k_left, c
                      h->f_scores[h->f_cur], h->f_counts);
   PF_HIP(h, hipGetLastError());
   const FilterArgs f = filter_args(h, rs);
-  hipLaunchKernelGGL(pf_resample_kernel, dim3(1), dim3(kScanBlock), 0, s, f);
+  const bool wide = wide_filter(h);
+  if (wide) {
+    const int tiles = static_cast<int>((Pmax + kScanBlock - 1) / kScanBlock);
+    const WideScratch w{h->f_wide, h->f_wide + tiles, h->f_wide + 2 * tiles};
+    hipLaunchKernelGGL(pf_resample_tiles_kernel, dim3(tiles), dim3(kScanBlock), 0, s, f, w);
+    hipLaunchKernelGGL(pf_resample_plan_kernel, dim3(1), dim3(kScanBlock), 0, s, f, w, tiles);
+    hipLaunchKernelGGL(pf_resample_scatter_kernel, dim3(tiles), dim3(kScanBlock), 0, s, f, w);
+    hipLaunchKernelGGL(pf_resample_emit_kernel, dim3(static_cast<unsigned>((Pmax + 255) / 256)), dim3(256), 0, s, f, w);
+  } else {
+    hipLaunchKernelGGL(pf_resample_kernel, dim3(1), dim3(kScanBlock), 0, s, f);
+  }
   PF_HIP(h, hipGetLastError());
   h->f_cur = 1 - h->f_cur;
   double* res = h->h_result;
   // the estimate and the counts are written by the last kernel straight into the page-locked result block (posted writes
   // over the host link): no copy packets behind the update
-  hipLaunchKernelGGL(pf_estimate_kernel, dim3(1), dim3(kBlock), 0, s, h->f_states[h->f_cur], h->f_scores[h->f_cur], -1,
-                     res, h->f_counts, reinterpret_cast<int*>(res + 8));
+  if (wide) {
+    const int sums = static_cast<int>((Pmax + kEstimateTile - 1) / kEstimateTile);
+    double* spread = h->f_partial + static_cast<size_t>(sums) * 8;
+    hipLaunchKernelGGL(pf_estimate_partial_kernel, dim3(sums), dim3(kBlock), 0, s, h->f_states[h->f_cur], h->f_scores[h->f_cur],
+                       h->f_counts, h->f_partial);
+    hipLaunchKernelGGL(pf_estimate_spread_kernel, dim3(sums), dim3(kBlock), 0, s, h->f_states[h->f_cur], h->f_counts,
+                       h->f_partial, spread);
+    hipLaunchKernelGGL(pf_estimate_final_kernel, dim3(1), dim3(kBlock), 0, s, h->f_counts, h->f_partial, spread, res,
+                       reinterpret_cast<int*>(res + 8));
+  } else {
+    hipLaunchKernelGGL(pf_estimate_kernel, dim3(1), dim3(kBlock), 0, s, h->f_states[h->f_cur], h->f_scores[h->f_cur], -1,
+                       res, h->f_counts, reinterpret_cast<int*>(res + 8));
+  }
   PF_HIP(h, hipGetLastError());
   PF_HIP(h, hipStreamSynchronize(s));
   const int* counts = reinterpret_cast<const int*>(res + 8);

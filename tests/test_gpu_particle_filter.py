@@ -186,12 +186,13 @@ def _scene(golden, n, seed=21):
     return dict(centre=centre, left=left, right=right), states, obs, idx, heading
 
 
-@pytest.mark.parametrize("n,n_desired", [(300, 300), (5000, 6000), (300, 200)])
+@pytest.mark.parametrize("n,n_desired", [(300, 300), (5000, 6000), (300, 200), (20000, 24000)])
 def test_device_resampling_matches_its_restatement(golden, n, n_desired):
     """One update of the device-resident filter against the oracle's restatement of its counter-based resampling:
     the same particles kept in the same order, the SAME picked indices for every new particle (integer weights and
     prefix sums: exact), the noise to the accuracy of the device's fast float32 transcendentals, and the estimate of
-    the weighted mean."""
+    the weighted mean.  (24 000: the tiled kernels of capacities from 8 192 up - a launch per step over tiles of 1 024
+    particles instead of one workgroup for everything.)"""
     from acmpc_amd.particle_filter import DeviceParticleFilter, ParticleScorer
     track, states, obs, _, _ = _scene(golden, n)
     cfg = dict(LOCALISATION, n_particles=max(n, n_desired), n_converged_particles=n_desired,
@@ -221,6 +222,44 @@ def test_device_resampling_matches_its_restatement(golden, n, n_desired):
     np.testing.assert_allclose(out["estimate"], est, rtol=1e-9)
     np.testing.assert_allclose([out["max_distance"], out["max_angle"]], [max_d, max_a], rtol=1e-9)
     scorer.close()
+
+
+def test_the_tiled_filter_kernels_equal_the_one_workgroup_ones(golden, monkeypatch):
+    """Capacity 20 000: three updates of the device-resident filter through the tiled resampling and estimate
+    (pf_resample_tiles / plan / scatter / emit, pf_estimate_partial / spread / final) and through the one-workgroup kernels
+    (ACMPC_PF_NARROW_FILTER=1): the same particles and scores bit for bit - ranks, prefix sums and picks are integers - and
+    the same estimate to the order of its float64 sums; a reset (nothing near the track) likewise."""
+    from acmpc_amd.particle_filter import DeviceParticleFilter
+    n = 20000
+    track, states, obs, _, _ = _scene(golden, n)
+    cfg = dict(LOCALISATION, n_particles=n, n_converged_particles=15000, sampling_noise=dict(x=1.1, y=1.1, yaw=3.0),
+               control_noise=dict(velocity=0.25, yaw=2.0), convergence_criteria=dict(maximum_distance=50, maximum_angle=90))
+    runs = []
+    for narrow in (False, True):
+        if narrow:
+            monkeypatch.setenv("ACMPC_PF_NARROW_FILTER", "1")
+        pf = DeviceParticleFilter(cfg, track, seed=77)
+        pf.set_particles(states, np.full(n, 1.0 / n, dtype=np.float32))
+        seen = []
+        for k in range(3):
+            out = pf.update(obs)
+            seen.append((out, pf.particles()))
+            pf.step(0.01, 30.0, 0.05)
+        far = states.copy()
+        far[:, :2] += 5000.0
+        pf.set_particles(far, np.full(n, 1.0 / n, dtype=np.float32))
+        out = pf.update(obs)
+        assert out["was_reset"]
+        seen.append((out, pf.particles()))
+        runs.append(seen)
+    for (wide_out, (wide_states, wide_scores)), (narrow_out, (narrow_states, narrow_scores)) in zip(*runs):
+        np.testing.assert_array_equal(wide_states, narrow_states)
+        np.testing.assert_array_equal(wide_scores, narrow_scores)
+        assert wide_out["n_particles"] == narrow_out["n_particles"] and wide_out["n_valid"] == narrow_out["n_valid"]
+        assert wide_out["was_reset"] == narrow_out["was_reset"]
+        np.testing.assert_allclose(wide_out["estimate"], narrow_out["estimate"], rtol=1e-10)
+        np.testing.assert_allclose([wide_out["max_distance"], wide_out["max_angle"]],
+                                   [narrow_out["max_distance"], narrow_out["max_angle"]], rtol=1e-10)
 
 
 def test_device_filter_resets_when_too_few_particles_are_valid(golden):
