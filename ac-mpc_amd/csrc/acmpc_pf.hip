@@ -77,6 +77,7 @@ struct ScoreArgs {
   GridGeometry geometry;
   GridBlocks blocks;
   float inv_left_m, inv_right_m;   // 1.0f / left.m, 1.0f / right.m (pf_score_given_kernel: mod_u16)
+  float* publish;   // device-resident filter: the float32 score the reference publishes (_update_particle_scores), or nullptr
 };
 
 constexpr int kWaves = kBlock / 64;
@@ -444,6 +445,7 @@ __global__ void __launch_bounds__(kBlock) pf_score_kernel(const ScoreArgs a, con
     a.heading_offset[p] = heading;
     a.error[p] = error;
     a.score[p] = score;
+    if (a.publish != nullptr) a.publish[p] = static_cast<float>(score);
     a.valid[p] = (heading < a.thr_rotation && offset < a.thr_offset && error < a.thr_error) ? 1 : 0;
   }
 }
@@ -632,6 +634,7 @@ __global__ void __launch_bounds__(64) pf_score_given_kernel(const ScoreArgs a, c
     a.heading_offset[p] = heading;
     a.error[p] = error;
     a.score[p] = score;
+    if (a.publish != nullptr) a.publish[p] = static_cast<float>(score);
     a.valid[p] = (heading < a.thr_rotation && offset < a.thr_offset && error < a.thr_error) ? 1 : 0;
   }
 }
@@ -1139,11 +1142,6 @@ __global__ void pf_step_kernel(float* states, const int* counts, float tyre_angl
   states[3 * p + 2] += (v * tanf(delta) / wheelbase) * dt;
 }
 
-// float64 score -> the float32 score the reference publishes (_update_particle_scores), for the n live particles
-__global__ void pf_publish_scores_kernel(const double* score, float* scores, const int* counts) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < counts[0]) scores[p] = static_cast<float>(score[p]);
-}
 
 thread_local std::string g_pf_create_error;
 
@@ -1830,15 +1828,13 @@ int acmpc_pf_filter_update(acmpc_pf* h, const float* obs_left, int32_t k_left, c
   a.track_indices = reinterpret_cast<int32_t*>(h->d_down + 4 * pd);
   a.valid = reinterpret_cast<uint8_t*>(h->d_down + 4 * pd + Pmax * 3 * sizeof(int32_t));
   a.live = h->f_counts;   // the particle count is on the device
+  a.publish = h->f_scores[h->f_cur];   // (the scoring kernels write the float32 scores themselves: no launch for that)
   (void)hipGetLastError();
   {
     const int P = h->prm.max_particles;   // workgroups beyond the live count return at once
     PF_HIP(h, launch_nearest(h, a, P, s));
     launch_score(h, a, P, s);
   }
-  PF_HIP(h, hipGetLastError());
-  hipLaunchKernelGGL(pf_publish_scores_kernel, dim3((h->prm.max_particles + 255) / 256), dim3(256), 0, s, a.score,
-                     h->f_scores[h->f_cur], h->f_counts);
   PF_HIP(h, hipGetLastError());
   const FilterArgs f = filter_args(h, rs);
   const bool wide = wide_filter(h);
