@@ -281,6 +281,52 @@ def config5_host_pointer(workloads, Engine, device, poses=10000, N=4096, H=50, p
                     "from page-locked memory): never `value`"}
 
 
+def device_resident_filter(track, ticks=300):
+    """The localiser's whole update cycle with the particles LIVING on the GPU (`DeviceParticleFilter`: kinematic step with
+    control noise, scoring, exact integer inverse-CDF resampling, estimate - localiser.py:41-77,234-239,420-579; one host round
+    trip per update): a car driving along the centre line at 20 m/s, the true track limits seen from it plus noise as the
+    observation.  `update_us` includes the host's NumPy thinning of the observation (localiser.py:241-253, ~30 us)."""
+    from acmpc_amd.particle_filter import DeviceParticleFilter
+    centre, left, right = track["centre"], track["left"], track["right"]
+    M = len(centre)
+    tangent = np.roll(centre, -1, axis=0) - np.roll(centre, 1, axis=0)
+    heading = np.arctan2(tangent[:, 1], tangent[:, 0])
+    rng = np.random.default_rng(4)
+
+    def observe(limit, count, at, pose):
+        a = np.pi / 2 - pose[2]
+        rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        return ((limit[(at + np.arange(count)) % M] - pose[:2]) @ rot.T + rng.normal(0, 0.15, (count, 2))).astype(np.float32)
+
+    out = {}
+    for n in (500, 100000):
+        cfg = dict(n_particles=n, n_converged_particles=n, score_distribution=dict(mean=0, sigma=10),
+                   thresholds=dict(offset=10, rotation=90, minimum_particles=20, track_limit=20.0),
+                   sampling_noise=dict(x=1.1, y=1.1, yaw=3.0), control_noise=dict(velocity=0.25, yaw=2.0),
+                   convergence_criteria=dict(maximum_distance=50, maximum_angle=90))
+        pf = DeviceParticleFilter(cfg, dict(centre=centre, left=left, right=right), seed=3)
+        start = np.array([centre[0, 0], centre[0, 1], heading[0]])
+        pf.set_particles((start + rng.normal(0, [1.0, 1.0, 0.05], (n, 3))).astype(np.float32), np.full(n, 1.0 / n, dtype=np.float32))
+        t_step, t_update, resets = [], [], 0
+        for tick in range(ticks + 50):
+            pose = np.array([centre[tick % M, 0], centre[tick % M, 1], heading[tick % M]])
+            obs = {"left": observe(left, 230, tick % M, pose), "right": observe(right, 210, tick % M, pose)}
+            t0 = time.perf_counter()
+            pf.step(0.0, 20.0, 0.05)
+            t1 = time.perf_counter()
+            res = pf.update(obs)
+            t2 = time.perf_counter()
+            if tick >= 50:
+                t_step.append(t1 - t0)
+                t_update.append(t2 - t1)
+                resets += int(res["was_reset"])
+        out["particles_%d" % n] = {"step_us_p50": float(np.median(t_step) * 1e6), "update_us_p50": float(np.median(t_update) * 1e6),
+                                   "update_us_p99": float(np.percentile(t_update, 99) * 1e6), "resets": resets,
+                                   "resampling": "one workgroup" if n < 8192 else "tiled launches (capacity >= 8 192)"}
+        pf.scorer.close()
+    return out
+
+
 def particle_filter_block(workloads, iters=20):
     """the localiser's particle scoring (three nearest-point queries against the ~11.6 k-point map
     polylines, observation placement, score) through the host-pointer seam, at the reference's size (500 particles,
@@ -314,6 +360,7 @@ def particle_filter_block(workloads, iters=20):
                                                                       "pf_nearest_kernel in front of the scoring launch"))
         out["particles_%d" % P] = entry
     scorer.close()
+    out["device_resident_filter"] = device_resident_filter(track)
     # What bounds the kernels: kernel durations from the committed rocprofv3 summary of tools/bench_pf.py
     # (profiles/*_pf_kernel_stats.json, tools/profile_pf.sh) and - round 5 - the counters of the same command
     # (profiles/*_pf_sq_counters.json, tools/pmc_pf.sh): the cache LINES the kernel's vector loads ask the per-CU vector
@@ -369,7 +416,8 @@ SECONDARY_SCALARS = ("mode_T_window_2_5_frac_1M", "mode_T_window_2_5_frac_16M", 
                      "sampled_fused_16M_traj_per_s", "single_solve_us_p50", "config3_single_us_p50", "config4_share_us_p50",
                      "config5_us_p50", "config5_us_p99", "config5_pinned_us_p50", "config5_pinned_us_p99", "tick_ms_p50",
                      "tick_ms_p99", "tick_infeasible_solves", "tick_mode_T_ms_p50", "tick_mode_T_ms_p99",
-                     "tick_mode_T_window_2_5_ms_p50", "pf_update_us_500", "pf_update_us_100000")
+                     "tick_mode_T_window_2_5_ms_p50", "pf_update_us_500", "pf_update_us_100000", "pf_filter_update_us_500",
+                     "pf_filter_update_us_100000")
 
 
 def secondary_scalars(out):
@@ -412,6 +460,8 @@ def secondary_scalars(out):
         "tick_mode_T_window_2_5_ms_p50": out.get("closed_loop_replay_mode_T_window_2_5", {}).get("solve_ms_p50"),
         "pf_update_us_500": pf.get("particles_500", {}).get("update_us"),
         "pf_update_us_100000": pf.get("particles_100000", {}).get("update_us"),
+        "pf_filter_update_us_500": pf.get("device_resident_filter", {}).get("particles_500", {}).get("update_us_p50"),
+        "pf_filter_update_us_100000": pf.get("device_resident_filter", {}).get("particles_100000", {}).get("update_us_p50"),
     }
     assert set(scalars) == set(SECONDARY_SCALARS)
     return scalars
