@@ -146,6 +146,37 @@ def test_the_optimum_the_plan_is_measured_against_is_a_kkt_point(name):
     assert abs(f_tight - f_loose) <= 1e-4 * abs(f_tight)
 
 
+@pytest.mark.parametrize("name", ["corner entry r 8, monza", "corner entry r 7.5 after 60 m, nordschleife", "s-bend r 8, spa",
+                                  "hairpin r 9 (input box only), monza"])
+def test_a_third_party_solver_brackets_the_same_optimum(name):
+    """Independent of the restated OSQP: SciPy's generic constrained minimiser (trust-constr: an interior-point method, so its
+    answer meets the equality rows to 1e-15 and lies strictly inside the box) on the reference's QP.  A feasible point
+    cannot cost less than the optimum and the restated OSQP's iterate, infeasible by its tolerance, does not cost more (to 1e-4):
+    the two bracket it within 1.5 %; and the refined plan of `acmpc_lq_box_plan` - feasible as well - is within 2 % of SciPy's."""
+    from scipy import sparse
+    from scipy.optimize import Bounds, LinearConstraint, minimize
+    from acmpc_amd import _capi
+    track, coords, offset = _cases()[name]
+    p = _problem(track, coords, offset)
+    n = H - 1
+    qp = orc.control_qp(p["x0"], p["table"], p["cfg"], p["limits"])
+    n_eq = 3 * (n + 1)
+    P, q = qp["P_diag"], qp["q"]
+    rows, rhs = qp["A"][:n_eq], qp["l"][:n_eq]
+    lo, hi = qp["l"][n_eq:].copy(), qp["u"][n_eq:].copy()
+    lo[:3], hi[:3] = -np.inf, np.inf            # x_0's box rows dropped, as in _qp_tracking_optimum
+    found = minimize(lambda z: 0.5 * z @ (P * z) + q @ z, np.zeros(len(q)), jac=lambda z: P * z + q, hess=lambda z: sparse.diags(P),
+                     method="trust-constr", constraints=[LinearConstraint(sparse.csr_matrix(rows), rhs, rhs)], bounds=Bounds(lo, hi),
+                     options=dict(gtol=1e-9, xtol=1e-12, maxiter=5000, sparse_jacobian=True))
+    assert np.abs(rows @ found.x - rhs).max() < 1e-9 and (found.x >= lo - 1e-9).all() and (found.x <= hi + 1e-9).all()
+    weighted = P > 0
+    from_inside = found.fun + 0.5 * float(np.sum(q[weighted] ** 2 / P[weighted]))      # tracking cost, as J
+    from_outside = _qp_tracking_optimum(p)
+    assert from_outside <= from_inside * (1.0 + 1e-4) and (from_inside - from_outside) / from_inside <= 0.015, (from_inside, from_outside)
+    out = _capi.lq_box_plan(*_args(p, 60))
+    assert out["V"] <= 1e-8 and abs(out["J"] - from_inside) / from_inside <= 0.02, (out["J"], from_inside)
+
+
 @pytest.mark.parametrize("name,lq_excess_at_least", [("corner entry r 8, monza", 1.0),
                                                      ("corner entry r 7.5 after 60 m, nordschleife", 5.0),
                                                      ("s-bend r 8, spa", 0.0),

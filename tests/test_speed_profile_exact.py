@@ -85,6 +85,37 @@ def test_every_golden_problem(golden, golden_cases):
     assert solved >= len(golden_cases)             # (most problems of the fixture are feasible)
 
 
+def test_third_party_solvers_agree(golden, golden_cases):
+    """Independent of everything written here: SciPy's HiGHS maximising the sum of v over the REFERENCE-assembled rows returns
+    the same profile (the pointwise largest feasible one is the unique maximiser of any positive weighting) on every golden
+    problem, to 1e-9; and SciPy's generic constrained minimiser (trust-constr, an interior-point method) run on the QP itself
+    - 1/2 |v|^2 + q'v under the same rows - ends 1e-3 m/s from it with an objective that is not lower."""
+    from scipy.optimize import Bounds, LinearConstraint, linprog, minimize
+    from acmpc_amd import _capi
+    checked = 0
+    for key in golden_cases:
+        for tag in ("sp0_", "sp1_"):
+            A, l, u, q, n, ds = _golden_problem(golden, key, tag)
+            swept = _capi.speed_profile_exact(u[n - 1:], np.append(ds, 1.0), float(l[0]), float(u[0]), float(l[n - 1]))
+            if swept is None:
+                continue
+            D = A[:n - 1]
+            lp = linprog(-np.ones(n), A_ub=np.vstack([D, -D]), b_ub=np.concatenate([u[:n - 1], -l[:n - 1]]),
+                         bounds=list(zip(l[n - 1:], u[n - 1:])), method="highs")
+            assert lp.status == 0
+            np.testing.assert_allclose(lp.x, swept[0], rtol=0, atol=1e-9, err_msg=key + tag)
+            checked += 1
+    assert checked >= len(golden_cases)
+    for key in ("monza_H50_chicane_90", "nordschleife_H80_chicane_70"):
+        A, l, u, q, n, ds = _golden_problem(golden, key, "sp0_")
+        v = _capi.speed_profile_exact(u[n - 1:], np.append(ds, 1.0), float(l[0]), float(u[0]), float(l[n - 1]))[0]
+        objective = lambda x: 0.5 * x @ x + q @ x
+        found = minimize(objective, np.clip(0.5 * u[n - 1:], l[n - 1:], u[n - 1:]), jac=lambda x: x + q, hess=lambda x: np.eye(n),
+                         method="trust-constr", constraints=[LinearConstraint(A[:n - 1], l[:n - 1], u[:n - 1])],
+                         bounds=Bounds(l[n - 1:], u[n - 1:]), options=dict(gtol=1e-10, xtol=1e-12, maxiter=3000))
+        assert np.abs(found.x - v).max() < 1e-2 and objective(v) <= objective(found.x) + 1e-9
+
+
 def test_no_feasible_profile_lies_above_the_swept_one():
     """Solver-independent: the swept profile is feasible, and every feasible profile is below it in every coordinate - so it
     minimises |v - v_hi|^2 term by term.  Random problems; feasible points from random starts pushed into the set by the same
