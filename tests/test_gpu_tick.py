@@ -271,6 +271,35 @@ def test_the_exact_profile_is_the_default_and_hands_infeasible_problems_to_the_s
     eng.close()
 
 
+@pytest.mark.parametrize("H", [3, 9, 33, 64, 65, 66, 100, 129])
+def test_the_exact_profile_on_the_device_at_other_horizons(H):
+    """The scan of the exact speed profile on the device - an element per lane up to 64 waypoints (H <= 65), through the
+    workspace beyond - against the host's, bit for bit, on wiggly paths with random constraints: braking zones, acceleration
+    limits and the end velocity all active somewhere."""
+    from acmpc_amd import _capi
+    rng = np.random.default_rng(H)
+    n = H - 1
+    eng, _, _ = _engine(n)
+    held = 0
+    for trial in range(6):
+        y = np.linspace(0.0, 3.0 * n, H)
+        x = rng.uniform(2.0, 12.0) * np.sin(y / rng.uniform(8.0, 40.0)) + 0.002 * rng.uniform(-1, 1) * y ** 2
+        coords = np.stack([x - x[0], y, np.linspace(10, 6, H)], axis=1)
+        cons = dict(RACING["monza"]["speed_profile_constraints"], v_max=float(rng.uniform(20.0, 86.0)),
+                    a_min=-float(rng.uniform(0.3, 4.0)), a_max=float(rng.uniform(0.2, 3.0)), ay_max=float(rng.uniform(3.0, 9.0)),
+                    end_velocity=float(rng.uniform(9.0, 20.0)))
+        out = eng.control_tick(_tick(H, cons), coords, None)
+        table = out["table"]
+        ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
+                                         cons["end_velocity"])
+        swept = _capi.speed_profile_exact(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"])
+        assert swept is not None and out["info"][4] == 0 and out["info"][5] == 0
+        np.testing.assert_array_equal(table[6], swept[0])
+        held += int((table[6] < ceiling - 1e-9).any())
+    assert held > 0 or H < 9                                # rate rows are active in these problems
+    eng.close()
+
+
 def test_the_controller_takes_the_speed_profile_method_from_its_config():
     """`speed_profile_method` of the control config: "exact" (default) and "admm" drive the same laps - no solve rejected,
     reference speeds within the splitting's own tolerance band of each other - and are not the same numbers; the host
