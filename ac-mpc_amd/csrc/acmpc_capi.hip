@@ -140,7 +140,8 @@ struct acmpc_ctx {
   float* h_lq = nullptr;                // pinned [max_problems][max_steps][2]: the plans, read by the last round in place
   std::vector<double> tick_prev_table;  // what the previous acmpc_control_tick solved: its 7 x n table ...
   double tick_prev_x0[3] = {0.0, 0.0, 0.0};   // ... and its start state (Frenet)
-  std::vector<double> tick_lq_table;    // scratch: this tick's waypoints with the previous tick's speed profile
+  std::vector<double> tick_lq_table;    // scratch: this tick's waypoints with the speed profile the host plans with
+  std::vector<double> tick_lq_scratch;  // scratch: its ceiling and (unused) multipliers
   std::vector<double> tick_host_coords; // scratch: the H x 3 path of a map window, cut on the host for the plan
   int tick_prev_n = 0;                  // 0: nothing usable (first tick, or a tick that did not end with a finite plan)
   // lq_candidate = 2 (csrc/acmpc_lq_box.h): the splitting's iterate per problem, its factorisation scratch, what the last
@@ -1810,30 +1811,36 @@ int acmpc_control_tick(acmpc_ctx* c, const acmpc_tick* t, const double* coords, 
       }
       coords = c->tick_host_coords.data();
     }
-    // no previous tick to take a speed profile from (a handle's first tick, another horizon, a tick without a finite
-    // plan): with the path on the host the profile is solved HERE, once - the host statement of the prologue's QP
-    // (acmpc_velocity_ceiling + acmpc_speed_profile_qp, cold: a few hundred iterations of O(n), ~0.1 ms)
+    // The speed profile the plan is made with.  With the path on the host and the exact profile (qp_method 0) it is THIS
+    // tick's - the host statement of the prologue's own two passes (acmpc_velocity_ceiling + acmpc_speed_profile_exact, a
+    // microsecond) - on the host's waypoint table; where that does not apply (an infeasible profile; qp_method 1: the
+    // splitting is not run twice per tick) the previous tick's, and with no previous tick either (a handle's first, another
+    // horizon, a tick without a finite plan) the splitting, cold, once.
     const bool have_previous = c->tick_prev_n == n;
     if (!have_previous && coords == nullptr) return false;   // (no path on the host: nothing to plan for)
     if (coords == nullptr) return lq_plan_into(c, c->tick_prev_table.data(), n, c->tick_prev_x0, c->h_lq);
     c->tick_lq_table.resize(static_cast<size_t>(7) * n);
     if (acmpc_waypoint_table(coords, H, kEps, c->tick_lq_table.data()) != ACMPC_OK) return false;
-    if (!have_previous) {
-      std::vector<double> ceiling(static_cast<size_t>(n)), dual(static_cast<size_t>(2) * n);
+    {
+      c->tick_lq_scratch.resize(static_cast<size_t>(3) * n);
+      double* ceiling = c->tick_lq_scratch.data();
+      double* dual = ceiling + n;
       double* profile = c->tick_lq_table.data() + static_cast<size_t>(6) * n;
+      const double* spacing = c->tick_lq_table.data() + static_cast<size_t>(4) * n;
       int32_t iterations = 0;
       if (acmpc_velocity_ceiling(c->tick_lq_table.data() + static_cast<size_t>(3) * n, n, t->ay_max, t->ki_min, t->v_min,
-                                 t->v_max, t->localised, t->has_end_velocity, t->end_velocity, ceiling.data()) != ACMPC_OK ||
-          ((t->qp_method != 0 ||
-            acmpc_speed_profile_exact(ceiling.data(), c->tick_lq_table.data() + static_cast<size_t>(4) * n, n, t->a_min,
-                                      t->a_max, t->v_min, profile, dual.data()) != 0) &&
-           acmpc_speed_profile_qp(ceiling.data(), c->tick_lq_table.data() + static_cast<size_t>(4) * n, n, t->a_min, t->a_max,
-                                  t->v_min, t->qp_max_iter, t->qp_check_every, t->qp_eps_abs, t->qp_eps_rel, profile,
-                                  dual.data(), 0, &iterations) != 0))
+                                 t->v_max, t->localised, t->has_end_velocity, t->end_velocity, ceiling) != ACMPC_OK)
         return false;
-    } else {
-      std::memcpy(c->tick_lq_table.data() + static_cast<size_t>(6) * n, c->tick_prev_table.data() + static_cast<size_t>(6) * n,
-                  static_cast<size_t>(n) * sizeof(double));
+      const bool swept = t->qp_method == 0 &&
+                         acmpc_speed_profile_exact(ceiling, spacing, n, t->a_min, t->a_max, t->v_min, profile, dual) == 0;
+      if (!swept) {
+        if (have_previous) {
+          std::memcpy(profile, c->tick_prev_table.data() + static_cast<size_t>(6) * n, static_cast<size_t>(n) * sizeof(double));
+        } else if (acmpc_speed_profile_qp(ceiling, spacing, n, t->a_min, t->a_max, t->v_min, t->qp_max_iter, t->qp_check_every,
+                                          t->qp_eps_abs, t->qp_eps_rel, profile, dual, 0, &iterations) != 0) {
+          return false;
+        }
+      }
     }
     const double pose[3] = {lq_offset, 0.0, M_PI / 2.0};
     return lq_plan_into(c, c->tick_lq_table.data(), n, pose, c->h_lq, true);

@@ -91,13 +91,15 @@ typedef struct acmpc_params {
                             and clipped into the input box (csrc/acmpc_lq.h; host, float64).  acmpc_optimize plans for the
                             paths of acmpc_set_paths and the x0 it is given; acmpc_control_tick, whose table is built on
                             the device, plans on the host meanwhile for this tick's path (acmpc_waypoint_table of `coords`)
-                            and pose with the speed profile its PREVIOUS call solved.  With coords = NULL - the path cut
+                            and pose with this tick's speed profile as well (acmpc_velocity_ceiling +
+                            acmpc_speed_profile_exact on that table: the prologue's own two passes; with qp_method 1, or an
+                            infeasible profile, the one its PREVIOUS call solved).  With coords = NULL - the path cut
                             out of the map on the device - and a map index the host cuts the same window itself
                             (csrc/acmpc_prologue.h map_path_row: one statement for both sides); with a pose instead, whose
                             nearest map point the device searches, it plans for the previous call's problem as it was (none
-                            in a handle's first tick then).  A handle's first tick with a path on the host solves the
-                            speed profile once there (acmpc_velocity_ceiling + acmpc_speed_profile_qp) to plan with.  The
-                            argmin keeps the plan only when it wins.
+                            in a handle's first tick then).  A first tick under qp_method 1 solves the speed profile
+                            once on the host (acmpc_speed_profile_qp, cold) to plan with.  The argmin keeps the plan only
+                            when it wins.
                             2 = as 1, and where that plan is not already the QP's optimum - a control on the input box, or
                             state rows (corridor control.py:57-60, t >= 0.01 control.py:134) violated beyond the solver's
                             acceptance tolerance - it is refined against the QP WITH its box rows (csrc/acmpc_lq_box.h: the

@@ -72,9 +72,8 @@ def _tick(H, cons, N, rounds, offset, seed):
 def test_the_tick_equals_the_restated_solve(mode, window):
     """Three consecutive ticks of acmpc_control_tick (16 384 candidates x 2 rounds, the controller's shape): each record
     is the restated solve on the tables the device prologue built, warm-started from the tick before, with the LQ plan for
-    this tick's waypoints and pose and the PREVIOUS tick's speed profile as the last round's candidate 2 - in the first
-    tick (round 5) the profile the host solves once for it: acmpc_velocity_ceiling + the QP's exact optimum in two sweeps
-    (acmpc_speed_profile_exact, restated by the oracle)."""
+    this tick's waypoints, pose and speed profile (the host's statements of the prologue's steps: acmpc_velocity_ceiling +
+    the QP's exact optimum in two passes, acmpc_speed_profile_exact restated by the oracle) as the last round's candidate 2."""
     from acmpc_amd import Engine, _capi
     from acmpc_amd.mpc import waypoint_table
     H, N, rounds = 50, 16384, 2
@@ -86,7 +85,7 @@ def test_the_tick_equals_the_restated_solve(mode, window):
     eng = Engine(mode=mode, max_problems=1, max_candidates=N, max_steps=n, step_cost=cfg["step_cost"], r_term=cfg["r_term"],
                  final_cost=cfg["final_cost"], u_min=lo, u_max=hi, margin=lim.margin, wheelbase=lim.length, nn_window=window,
                  lq_candidate=True)
-    centre, previous, won = None, None, []
+    centre, won = None, []
     for j in range(3):
         y = np.linspace(0, 120, H)
         bend = (1.0, 1.0, 1.1)[j]   # the second tick sees the first one's path again, the third a tighter one
@@ -97,14 +96,11 @@ def test_the_tick_equals_the_restated_solve(mode, window):
         out = eng.control_tick(t, coords, centre)
         assert out["info"][4] == 0 and out["info"][7] == 0
         x0, u_ref, coef = eng.tick_device_tables(n)
-        # this tick's waypoints and pose; the previous tick's speed profile, or the one the host solves for a first tick
+        # this tick's waypoints, pose and speed profile - the host's statements of the prologue's steps
         table = waypoint_table(coords, 1e-12)
-        if previous is not None:
-            table[6] = previous[6]
-        else:
-            ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
-                                             cons["end_velocity"])
-            table[6] = orc.speed_profile_exact(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"])   # (feasible here)
+        ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
+                                         cons["end_velocity"])
+        table[6] = orc.speed_profile_exact(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"])   # (feasible here)
         frenet = orc.frenet_start(table, np.array([offset, 0.0, np.pi / 2]))
         plan = orc.lq_plan(table, frenet, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi)
         assert plan is not None
@@ -117,7 +113,6 @@ def test_the_tick_equals_the_restated_solve(mode, window):
         _record_equals(got, want, n)
         won.append(want["winners"][-1])
         centre = got["u"].copy()
-        previous = out["table"].copy()
     if mode == 0:
         # on the path whose speed profile it was planned with the LQ plan is the QP's optimum: it wins the FIRST tick's last
         # round (round 5: a first tick has a plan), and the second tick - the same path - starts from it as its centre, which
@@ -147,7 +142,7 @@ def test_the_tick_with_the_box_constrained_plan_equals_the_restated_solve(mode):
                  final_cost=cfg["final_cost"], u_min=lo, u_max=hi, margin=lim.margin, wheelbase=lim.length, nn_window=None,
                  lq_candidate=2, w_bound=w_bound)
     base = wl.corner_entry_path(8.0, 30.0, H)
-    centre, previous, state, ran = None, None, None, []
+    centre, state, ran = None, None, []
     for j in range(4):
         coords = np.array(base)
         coords[:, 1] -= (0.0, 0.0, 0.25, 0.5)[j]          # the car moves on along the straight
@@ -159,12 +154,9 @@ def test_the_tick_with_the_box_constrained_plan_equals_the_restated_solve(mode):
         stats = eng.lq_box_stats()
         x0, u_ref, coef = eng.tick_device_tables(n)
         table = waypoint_table(coords, 1e-12)
-        if previous is not None:
-            table[6] = previous[6]
-        else:
-            ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
-                                             cons["end_velocity"])
-            table[6] = orc.speed_profile_exact(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"])   # (feasible here)
+        ceiling = _capi.velocity_ceiling(table[3], cons["ay_max"], cons["ki_min"], cons["v_min"], cons["v_max"], False,
+                                         cons["end_velocity"])
+        table[6] = orc.speed_profile_exact(ceiling, table[4], cons["a_min"], cons["a_max"], cons["v_min"])   # (feasible here)
         frenet = orc.frenet_start(table, np.array([offset, 0.0, np.pi / 2]))
         restated = orc.lq_box_plan(table, frenet, cfg["step_cost"], cfg["r_term"], cfg["final_cost"], lo, hi, lim.margin, w_bound,
                                    40, state)
@@ -181,7 +173,6 @@ def test_the_tick_with_the_box_constrained_plan_equals_the_restated_solve(mode):
                    x=rec[4 + 2 * n:].reshape(n + 1, 3))
         _record_equals(got, want, n)
         centre = got["u"].copy()
-        previous = out["table"].copy()
     assert ran[0] >= 10 and all(k >= 1 for k in ran), ran       # cold: tens of iterations; warm: it confirms or continues
     eng.close()
 
